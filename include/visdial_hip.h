@@ -1,0 +1,142 @@
+/* visdial_hip.h -- C ABI of libvisdial_hip.so (MI355X / gfx950).
+ *
+ * The reference (batra-mlp-lab/visdial) is Lua/Torch7; its only native boundary is the
+ * LuaJIT-FFI call into THNN in model_utils/MaskSoftMax.lua:16-19,35-40.  Every arithmetic
+ * op on its training hot path lives in un-vendored Lua rocks (nn, rnn, cunn).  This header is
+ * the operator-level boundary that replaces those calls: each entry point names the reference
+ * module call it stands in for (file:line under /root/reference).  A host (LuaJIT ffi.cdef,
+ * Python ctypes, ...) composes them exactly as encoders/*.lua / decoders/*.lua compose nn
+ * modules; see INTEGRATION.md for the Lua-side binding.
+ *
+ * Conventions
+ *  - plain C types only; all pointers are DEVICE pointers unless the name says host.
+ *  - every function returns 0 on success, <0 on error (never throws / longjmps);
+ *    vd_last_error() returns a thread-local message.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue.
+ *  - caller owns every buffer; float buffers must be 16-byte aligned, row strides multiples of 4.
+ *  - fp32 throughout (IEEE, exact-fp32 MFMA); token ids are int32, 0 = padding; byte masks are uint8.
+ *  - LSTM weights follow nn.SeqLSTM: weight [(D+H) x 4H] = [Wx ; Wh], gate column order i,f,o,g;
+ *    nn.Linear weights are [out x in]; the embedding table is [(V+1) x E] with row 0 = pad (zero).
+ */
+#ifndef VISDIAL_HIP_H
+#define VISDIAL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VD_ACT_NONE 0
+#define VD_ACT_TANH 1
+
+/* ---- library ------------------------------------------------------------------------- */
+const char* vd_last_error(void);
+int vd_abi_version(void);
+int vd_device_count(int* count);
+int vd_set_device(int device);                 /* replaces cutorch.setDevice, train.lua:19 */
+int vd_device_info(int device, char* name256, char* arch256, int* num_cus, int64_t* hbm_bytes);
+int vd_malloc(void** ptr, int64_t bytes);      /* for hosts without a tensor library (Lua) */
+int vd_free(void* ptr);
+int vd_memset(void* ptr, int value, int64_t bytes, void* stream);
+int vd_memcpy_h2d(void* dst, const void* src_host, int64_t bytes, void* stream); /* :cuda() dataloader.lua:410-416 */
+int vd_memcpy_d2h(void* dst_host, const void* src, int64_t bytes, void* stream);
+int vd_memcpy_d2d(void* dst, const void* src, int64_t bytes, void* stream);
+int vd_stream_synchronize(void* stream);
+
+/* ---- dense contractions (nn.Linear / hoisted SeqLSTM input projection / weight grads) -- */
+/* C[MxN] (+)= act(A[MxK] * W[NxK]^T + bias)   -- nn.Linear:updateOutput (+nn.Tanh),
+ * e.g. encoders/mn-att-ques-im-hist.lua:64-65,77,88,106; also dX = dA * Wh^T style products. */
+int vd_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C,
+               int64_t ldc, int M, int N, int K, int act, int accumulate, void* stream);
+/* C[MxN] (+)= A[MxK] * B[KxN] + bias           -- x*Wx+b of nn.SeqLSTM (mn-att:27-41), nn.Linear:updateGradInput */
+int vd_gemm_nn(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
+               int64_t ldc, int M, int N, int K, int accumulate, void* stream);
+/* C[MxN] += A[KxM]^T * B[KxN]                  -- accGradParameters of nn.Linear / nn.SeqLSTM */
+int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
+                   int N, int K, void* stream);
+/* out[N] += column sums of X[MxN]              -- gradBias */
+int vd_colsum_acc(const float* X, int64_t ld, int M, int N, float* out, void* stream);
+
+/* ---- nn.SeqLSTM (Element-Research rnn; call sites mn-att:27-45, disc.lua:4-15, gen.lua:17-22,
+ *      lf-ques.lua:18-24, hre-ques-im-hist.lua:34,74,92) ---------------------------------------- */
+/* Recurrence over T steps, time-major.  The input projection (x_t*Wx + b) is supplied already
+ * computed: dense mode xproj[t] = xproj + t*x_tstride, row n at +n*x_ld ([N x 4H]); table mode
+ * (tok_gather != NULL, [T x N]): row = xproj + tok_gather[t,n]*x_ld (xproj = Emb*Wx+b, [V+1 x 4H]).
+ * tok_mask ([T x N] or NULL) implements :maskZero(): rows with token 0 get h = c = gates = 0.
+ * h0/c0 ([N x H] or both NULL = zeros) are userPrevOutput/userPrevCell (gen.lua:32-38).
+ * Outputs: gates [T x N x 4H] post-activation (i,f,o,g), h and c [T x N x H]. */
+int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const int32_t* tok_gather,
+                    const int32_t* tok_mask, const float* Wh, const float* h0, const float* c0, float* gates,
+                    float* h, float* c, int T, int N, int H, void* stream);
+/* Backward through time.  gates is overwritten IN PLACE by da (gradient w.r.t. the pre-activation
+ * gates, = gradient of xproj).  dh_seq [T x N x H] or NULL: gradient arriving at every h_t;
+ * dh_last [N x H] or NULL: extra gradient at h_{T-1} (nn.Select(1,-1)); dc_last or NULL:
+ * userNextGradCell (gen.lua:49).  dc_work [N x H] scratch, on return = dL/dc0 (userGradPrevCell);
+ * dh0 [N x H] or NULL receives dL/dh0 (userGradPrevOutput, gen.lua:50-58). */
+int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float* c0, const float* dh_seq,
+                     const float* dh_last, const float* dc_last, float* dc_work, float* dh0, int T, int N,
+                     int H, void* stream);
+
+/* ---- nn.LookupTableMaskZero / nn.Dropout / small glue ------------------------------------- */
+/* out[r,:] = emb[tok[r],:] * (mask ? mask*scale : 1)        mn-att:21,24-25; disc.lua:12 */
+int vd_embed_gather(const float* emb, const int32_t* tok, const uint8_t* mask, float* out, int64_t rows,
+                    int E, float scale, void* stream);
+/* demb[tok[r],:] += dx[r,:] * mask*scale                    LookupTable:accGradParameters */
+int vd_embed_scatter_acc(float* demb, const int32_t* tok, const uint8_t* mask, const float* dx, int64_t rows,
+                         int E, float scale, void* stream);
+/* counting sort of token ids (prepares the option-table gradient); offset int32[V+1],
+ * work int32[2V], perm int32[n] */
+int vd_token_sort(const int32_t* tok, int64_t n, int V, int32_t* offset, int32_t* work, int32_t* perm,
+                  void* stream);
+/* out[tok[r], 0:ncol] += X[r, 0:ncol] for all n rows */
+int vd_segment_rowsum_acc(const float* X, int64_t ldx, const int32_t* tok, const int32_t* perm, int64_t n,
+                          int ncol, float* out, int64_t ldo, void* stream);
+/* Bernoulli(1-p) keep-mask bytes from a counter-based generator (nn.Dropout noise) */
+int vd_dropout_mask(uint8_t* mask, int64_t n, uint64_t seed, float p, void* stream);
+/* y = x*mask*scale (nn.Dropout forward and backward) */
+int vd_dropout_apply(const float* x, const uint8_t* mask, float* y, int64_t n, float scale, void* stream);
+/* dx = dy*(1-y^2) (nn.Tanh:updateGradInput) */
+int vd_tanh_backward(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+/* c = alpha*a + beta*b (b may be NULL)  (nn.CAddTable and gradient fan-in) */
+int vd_axpby(const float* a, const float* b, float* c, int64_t n, float alpha, float beta, void* stream);
+
+/* ---- memory-network attention: nn.MM(false,true) -> nn.MaskSoftMax -> nn.MM
+ *      (mn-att:48-62; model_utils/MaskSoftMax.lua:5-46; mask from model.lua:280-294, 1 = hidden) */
+int vd_mn_attention_forward(const float* Q, const float* Hm, const uint8_t* mask, float* P, float* hAtt, int B,
+                            int R, int H, void* stream);
+int vd_mn_attention_backward(const float* Q, const float* Hm, const float* P, const float* dhAtt, float* dQ,
+                             float* dHm, int B, int R, int H, void* stream);
+
+/* ---- SAN image attention (mn-att:68-104).  pre = tanh(Linear(img)) per IMAGE [B*S2 x H];
+ *      mask1/mask2 = dropout keep-masks of img_tr / img_ques_common per ROUND (NULL in evaluate()) */
+int vd_img_common_forward(const float* pre, const uint8_t* mask1, const float* Wc, const float* bc,
+                          const float* qc, const uint8_t* mask2, float* iqc, int N, int R, int S2, int H, int Kc,
+                          float scale, void* stream);
+int vd_img_att_forward(const float* iqc, const float* wa, const float* ba, const float* pre,
+                       const uint8_t* mask1, const float* u0, float* p, float* u1, int N, int R, int S2, int H,
+                       int Kc, float scale, void* stream);
+int vd_img_att_backward(float* iqc_dz, const float* wa, const float* pre, const uint8_t* mask1,
+                        const uint8_t* mask2, const float* p, const float* datt, float* dwa, float* dba,
+                        float* dqc, int N, int R, int S2, int H, int Kc, float scale, void* stream);
+int vd_img_tr_backward(const float* dz, const float* Wc, const float* p, const float* datt,
+                       const uint8_t* mask1, float* dpre, int N, int R, int S2, int H, int Kc, float scale,
+                       void* stream);
+int vd_img_common_wgrad(const float* dz, const float* pre, const uint8_t* mask1, float* dWc, int N, int R,
+                        int S2, int H, int Kc, float scale, void* stream);
+
+/* ---- discriminative head: nn.MM + nn.Squeeze (disc.lua:22-29) + nn.CrossEntropyCriterion
+ *      (model.lua:37-38,330,334).  gt is 0-based here (the reference's answer_ind is 1-based). */
+int vd_score_ce(const float* optH, const float* enc, const int32_t* gt, float* scores, float* loss_rows,
+                float* dOptH, float* dEnc, int N, int O, int H, float gscale, void* stream);
+/* utils.computeRanks (utils.lua:106-128): 1-based descending-sort position of every option */
+int vd_ranks(const float* scores, int32_t* ranks, int N, int O, void* stream);
+
+/* ---- wrapperdW:clamp(-5,5) + adam (model.lua:96-99; model_utils/optim_updates.lua:62-91) ---- */
+int vd_clamp_adam(float* w, float* g, float* m, float* v, int64_t n, float gscale, float clip, float beta1,
+                  float beta2, float eps, float step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISDIAL_HIP_H */

@@ -1,0 +1,457 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  Never imported by the product path (visdial_amd/).
+
+PARITY UNPINNED: the reference (batra-mlp-lab/visdial) ships no tests, golden vectors or
+known-answer fixtures, its arithmetic lives in un-vendored Torch7 rocks (torch, nn, nngraph,
+Element-Research rnn @ git HEAD -- README.md:42-75) and no Lua/Torch7 runtime exists in the build
+container, so this restatement cannot be checked against the reference executable.  It is pinned
+instead by (a) an independent torch-autograd restatement of the same forward graphs
+(tests/test_oracle.py) and (b) central finite differences in fp64.
+
+Plain numpy restatement of the Visual-Dialog training step.  Each function cites the reference
+file:line it follows (paths under /root/reference); semantics of the un-vendored nn/rnn modules
+follow SURVEY.md Appendix A.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import numpy as np
+
+
+# ----------------------------------------------------------------------------- primitives
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def lookup(emb, tok):
+    """nn.LookupTableMaskZero (encoders/mn-att-ques-im-hist.lua:21): token 0 -> zero vector."""
+    out = emb[tok]
+    out = out * (tok != 0)[..., None]
+    return out
+
+
+def lookup_backward(demb, tok, dx):
+    """accGradParameters of the shared table: dense gradWeight accumulate (pads hit row 0)."""
+    np.add.at(demb, tok.reshape(-1), dx.reshape(-1, dx.shape[-1]))
+
+
+def dropout(x, mask, p):
+    """nn.Dropout in training mode with an explicit keep-mask (mask None = evaluate())."""
+    if mask is None:
+        return x
+    return x * mask * (1.0 / (1.0 - p))
+
+
+def linear(x, W, b):
+    """nn.Linear: y = x W^T + b, weight [out x in]."""
+    return x @ W.T + b
+
+
+def linear_backward(x, W, dy):
+    return dy @ W, dy.T @ x, dy.sum(0)
+
+
+# ----------------------------------------------------------------------------- nn.SeqLSTM
+def lstm_forward(x, W, b, tok_mask=None, h0=None, c0=None):
+    """nn.SeqLSTM forward (Element-Research rnn; reference call sites mn-att:27-45,
+    decoders/disc.lua:4-15).  x [T,N,D]; W [(D+H),4H] = [Wx;Wh]; gate order i,f,o,g.
+    tok_mask [T,N] int: maskZero() -- rows whose token is 0 get h=c=gates=0 at that step."""
+    T, N, D = x.shape
+    H = W.shape[1] // 4
+    Wx, Wh = W[:D], W[D:]
+    dt = x.dtype
+    h_all = np.zeros((T, N, H), dt)
+    c_all = np.zeros((T, N, H), dt)
+    gates = np.zeros((T, N, 4 * H), dt)
+    hp = np.zeros((N, H), dt) if h0 is None else h0
+    cp = np.zeros((N, H), dt) if c0 is None else c0
+    for t in range(T):
+        a = b + x[t] @ Wx + hp @ Wh
+        i, f, o = sigmoid(a[:, :H]), sigmoid(a[:, H:2 * H]), sigmoid(a[:, 2 * H:3 * H])
+        g = np.tanh(a[:, 3 * H:])
+        c = f * cp + i * g
+        h = o * np.tanh(c)
+        gt = np.concatenate([i, f, o, g], 1)
+        if tok_mask is not None:
+            keep = (tok_mask[t] != 0)[:, None].astype(dt)
+            h, c, gt = h * keep, c * keep, gt * keep
+        h_all[t], c_all[t], gates[t] = h, c, gt
+        hp, cp = h, c
+    return h_all, c_all, gates
+
+
+def lstm_backward(x, W, gates, h_all, c_all, dh_seq=None, dh_last=None, dc_last=None, h0=None, c0=None):
+    """nn.SeqLSTM backward.  Returns dx [T,N,D], dW, db, dh0, dc0."""
+    T, N, D = x.shape
+    H = W.shape[1] // 4
+    Wx, Wh = W[:D], W[D:]
+    dt = x.dtype
+    dW = np.zeros_like(W)
+    db = np.zeros(4 * H, dt)
+    dx = np.zeros_like(x)
+    dh_next = np.zeros((N, H), dt)
+    dc = np.zeros((N, H), dt) if dc_last is None else dc_last.copy()
+    for t in range(T - 1, -1, -1):
+        i, f, o, g = (gates[t][:, k * H:(k + 1) * H] for k in range(4))
+        dh = dh_next.copy()
+        if dh_seq is not None:
+            dh = dh + dh_seq[t]
+        if dh_last is not None and t == T - 1:
+            dh = dh + dh_last
+        tc = np.tanh(c_all[t])
+        cprev = c_all[t - 1] if t > 0 else (np.zeros((N, H), dt) if c0 is None else c0)
+        hprev = h_all[t - 1] if t > 0 else (np.zeros((N, H), dt) if h0 is None else h0)
+        dc = dc + dh * o * (1 - tc * tc)
+        da = np.concatenate([dc * g * i * (1 - i), dc * cprev * f * (1 - f), dh * tc * o * (1 - o),
+                             dc * i * (1 - g * g)], 1)
+        dx[t] = da @ Wx.T
+        dW[:D] += x[t].T @ da
+        dW[D:] += hprev.T @ da
+        db += da.sum(0)
+        dh_next = da @ Wh.T
+        dc = dc * f
+    return dx, dW, db, dh_next, dc
+
+
+# ----------------------------------------------------------------------------- memory attention
+def mn_attention_forward(q, h, mask):
+    """mn-att:48-62 + model_utils/MaskSoftMax.lua:5-21.  q,h [B,R,H]; mask [B,R,R] (1 = hidden)."""
+    s = np.einsum('bik,bjk->bij', q, h)
+    s = np.where(mask != 0, np.asarray(-9999999.0, s.dtype), s)
+    s = s - s.max(-1, keepdims=True)
+    e = np.exp(s)
+    p = e / e.sum(-1, keepdims=True)
+    return p, np.einsum('bij,bjk->bik', p, h)
+
+
+def mn_attention_backward(q, h, p, dhatt):
+    dp = np.einsum('bik,bjk->bij', dhatt, h)
+    ds = p * (dp - (p * dp).sum(-1, keepdims=True))      # MaskSoftMax.lua:23-41 (THNN softmax bwd)
+    dq = np.einsum('bij,bjk->bik', ds, h)
+    dh = np.einsum('bij,bik->bjk', p, dhatt) + np.einsum('bij,bik->bjk', ds, q)
+    return dq, dh
+
+
+# ----------------------------------------------------------------------------- head / metrics
+def cross_entropy(scores, gt):
+    """nn.CrossEntropyCriterion (model.lua:37-38): mean over rows; gt 0-based here."""
+    m = scores.max(1, keepdims=True)
+    lse = m[:, 0] + np.log(np.exp(scores - m).sum(1))
+    n = scores.shape[0]
+    loss_rows = lse - scores[np.arange(n), gt]
+    prob = np.exp(scores - lse[:, None])
+    dscores = prob.copy()
+    dscores[np.arange(n), gt] -= 1.0
+    return loss_rows.mean(), dscores / n, loss_rows
+
+
+def compute_ranks(scores, gt=None):
+    """utils.lua:106-128: 1-based position in the descending sort (ties: lower index first)."""
+    n, o = scores.shape
+    order = np.argsort(-scores, axis=1, kind='stable')
+    ranks = np.empty((n, o), np.int64)
+    ranks[np.arange(n)[:, None], order] = np.arange(1, o + 1)[None, :]
+    if gt is not None:
+        return ranks[np.arange(n), gt]
+    return ranks
+
+
+def process_ranks(ranks, num_options=100):
+    """utils.lua:131-160 (divides by the UNfiltered count; quirk D-12)."""
+    ranks = np.asarray(ranks, np.float64).reshape(-1)
+    num_ques = ranks.size
+    ranks = ranks[ranks > 0]
+    ranks = ranks[ranks <= num_options + 1]
+    return {
+        'numQues': num_ques,
+        'r@1': float((ranks <= 1).sum()) / num_ques,
+        'r@5': float((ranks <= 5).sum()) / num_ques,
+        'r@10': float((ranks <= 10).sum()) / num_ques,
+        'medianR': float(np.sort(ranks)[(ranks.size - 1) // 2]) if ranks.size else 0.0,  # torch.median = lower
+        'meanR': float(ranks.mean()) if ranks.size else 0.0,
+        'meanRR': float((1.0 / ranks).mean()) if ranks.size else 0.0,
+    }
+
+
+def clamp_adam(w, g, state, lr, clip=5.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    """model.lua:96-99 + model_utils/optim_updates.lua:62-91 (eps added to the uncorrected sqrt(v))."""
+    g = np.clip(g, -clip, clip)
+    if 'm' not in state:
+        state['t'] = 0
+        state['m'] = np.zeros_like(w)
+        state['v'] = np.zeros_like(w)
+    state['m'] = beta1 * state['m'] + (1 - beta1) * g
+    state['v'] = beta2 * state['v'] + (1 - beta2) * g * g
+    state['t'] += 1
+    t = state['t']
+    step = lr * np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+    return w - (step * state['m'] / (np.sqrt(state['v']) + eps)).astype(w.dtype), g
+
+
+# ----------------------------------------------------------------------------- parameters
+def param_spec(encoder, decoder, p):
+    """Flat parameter layout (name, shape) shared by construction with visdial_amd/params.py.
+    Tensors follow the reference modules: LSTM [(D+H) x 4H] + [4H], Linear [out x in] + [out],
+    shared embedding [(V+1) x E] (SURVEY.md App. B parameter list)."""
+    V, E, H = p['vocabSize'], p['embedSize'], p['rnnHiddenSize']
+    spec = [('embed', (V + 1, E), 'embed')]
+
+    def lstm(name, D):
+        spec.append((name + '.W', (D + H, 4 * H), 'lstm_w'))
+        spec.append((name + '.b', (4 * H,), 'lstm_b'))
+
+    def lin(name, i, o):
+        spec.append((name + '.W', (o, i), 'lin_w'))
+        spec.append((name + '.b', (o,), 'lin_b'))
+
+    if encoder == 'mn-att-ques-im-hist':
+        C, K = p['imgFeatureSize'], p.get('commonEmbeddingSize', 512)
+        lstm('hist1', E); lstm('hist2', H); lstm('ques1', E); lstm('ques2', H)
+        lin('mn1', H, H); lin('mn2', H, H)
+        lin('img_proj', C, H); lin('img_common', H, K); lin('ques_common', H, K); lin('att', K, 1)
+        lin('out', H, H)
+    elif encoder == 'lf-ques':
+        for l in range(p['numLayers']):
+            lstm('ques%d' % (l + 1), E if l == 0 else H)
+        lin('fuse', H, H)
+    elif encoder == 'lf-ques-im-hist':
+        for l in range(p['numLayers']):
+            lstm('ques%d' % (l + 1), E if l == 0 else H)
+        for l in range(p['numLayers']):
+            lstm('hist%d' % (l + 1), E if l == 0 else H)
+        lin('fuse', 2 * H + p['imgFeatureSize'], H)
+    elif encoder == 'hre-ques-im-hist':
+        for l in range(p['numLayers']):
+            lstm('hist%d' % (l + 1), E if l == 0 else H)
+        lin('img_embed', p['imgFeatureSize'], p['imgEmbedSize'])
+        for l in range(p['numLayers']):
+            lstm('ques%d' % (l + 1), (E + p['imgEmbedSize']) if l == 0 else H)
+        lstm('dialog', 2 * H)
+    else:
+        raise ValueError('oracle: encoder %s not restated yet' % encoder)
+    if decoder == 'disc':
+        lstm('opt', E)
+    elif decoder == 'gen':
+        for l in range(p['numLayers']):
+            lstm('dec%d' % (l + 1), E if l == 0 else H)
+        lin('vocab', H, V)
+    else:
+        raise ValueError(decoder)
+    return spec
+
+
+def init_params(encoder, decoder, p, seed=1234, dtype=np.float64):
+    """Library-default init (weight-init.lua is a no-op):
+    SeqLSTM weight ~ N(0, 1/sqrt(D+H)), bias 0 with forget gate 1; Linear U(+-1/sqrt(in));
+    LookupTable N(0,1) with the pad row zero."""
+    rng = np.random.RandomState(seed)
+    H = p['rnnHiddenSize']
+    out = {}
+    for name, shape, kind in param_spec(encoder, decoder, p):
+        if kind == 'embed':
+            w = rng.randn(*shape)
+            w[0] = 0
+        elif kind == 'lstm_w':
+            w = rng.randn(*shape) * (1.0 / np.sqrt(shape[0]))
+        elif kind == 'lstm_b':
+            w = np.zeros(shape)
+            w[H:2 * H] = 1.0
+        elif kind == 'lin_w':
+            s = 1.0 / np.sqrt(shape[1])
+            w = rng.uniform(-s, s, shape)
+        elif kind == 'lin_b':
+            s = 1.0 / np.sqrt(out[name[:-2] + '.W'].shape[1])
+            w = rng.uniform(-s, s, shape)
+        else:
+            raise AssertionError(kind)
+        out[name] = w.astype(dtype)
+    return out
+
+
+def flatten(params, spec):
+    return np.concatenate([params[e[0]].reshape(-1) for e in spec])
+
+
+def unflatten(vec, spec):
+    out, o = {}, 0
+    for e in spec:
+        n, s = e[0], e[1]
+        k = int(np.prod(s))
+        out[n] = vec[o:o + k].reshape(s)
+        o += k
+    return out
+
+
+# ----------------------------------------------------------------------------- model step
+def causal_mask(B, R):
+    """model.lua:280-294: mask[i][j] = 0 iff j <= i, tiled over the batch.  -> [B,R,R] uint8"""
+    m = (np.arange(R)[None, :] > np.arange(R)[:, None]).astype(np.uint8)
+    return np.broadcast_to(m, (B, R, R)).copy()
+
+
+def _two_layer_lstm_fwd(P, n1, n2, x, tok):
+    h1, c1, g1 = lstm_forward(x, P[n1 + '.W'], P[n1 + '.b'], tok)
+    h2, c2, g2 = lstm_forward(h1, P[n2 + '.W'], P[n2 + '.b'], tok)
+    return dict(x=x, h1=h1, c1=c1, g1=g1, h2=h2, c2=c2, g2=g2)
+
+
+def _two_layer_lstm_bwd(P, G, n1, n2, S, dlast):
+    dx2, dW2, db2, _, _ = lstm_backward(S['h1'], P[n2 + '.W'], S['g2'], S['h2'], S['c2'], dh_last=dlast)
+    dx1, dW1, db1, _, _ = lstm_backward(S['x'], P[n1 + '.W'], S['g1'], S['h1'], S['c1'], dh_seq=dx2)
+    G[n2 + '.W'] += dW2; G[n2 + '.b'] += db2
+    G[n1 + '.W'] += dW1; G[n1 + '.b'] += db1
+    return dx1
+
+
+def mnatt_encoder_forward(P, p, batch, drop):
+    """encoders/mn-att-ques-im-hist.lua:5-115 with inputs prepared as model.lua:249-294.
+    batch (dataloader.lua:324-339 keys): ques_fwd [B,R,Tq] int, hist [B,R,Th] int, img_feat [B,S,S,C].  drop: dict of keep-masks or None."""
+    B, R, Tq = batch['ques_fwd'].shape
+    Th = batch['hist'].shape[2]
+    H = p['rnnHiddenSize']
+    N = B * R
+    S2 = p['imgSpatialSize'] ** 2
+    d = (lambda k: None) if drop is None else (lambda k: drop[k])
+    qtok = batch['ques_fwd'].reshape(N, Tq).T        # model.lua:255-257 (time-major)
+    htok = batch['hist'].reshape(N, Th).T        # model.lua:275-277
+    st = {}
+    qx = dropout(lookup(P['embed'], qtok), d('q_emb'), 0.5)                 # mn-att:24
+    hx = dropout(lookup(P['embed'], htok), d('h_emb'), 0.5)                 # mn-att:25
+    st['hs'] = _two_layer_lstm_fwd(P, 'hist1', 'hist2', hx, htok)           # mn-att:27-35
+    st['qs'] = _two_layer_lstm_fwd(P, 'ques1', 'ques2', qx, qtok)           # mn-att:37-45
+    h3, q3 = st['hs']['h2'][-1], st['qs']['h2'][-1]
+    mask = causal_mask(B, R)
+    prob, hatt = mn_attention_forward(q3.reshape(B, R, H), h3.reshape(B, R, H), mask)   # mn-att:48-62
+    hatt = hatt.reshape(N, H)
+    hatt_d = dropout(hatt, d('hatt'), 0.5)
+    hattTr = np.tanh(linear(hatt_d, P['mn1.W'], P['mn1.b']))               # mn-att:64
+    s2 = hattTr + q3
+    qh2 = np.tanh(linear(s2, P['mn2.W'], P['mn2.b']))                       # mn-att:65
+    C = p['imgFeatureSize']
+    img = batch['img_feat'].reshape(B * S2, C)
+    pre = np.tanh(linear(img, P['img_proj.W'], P['img_proj.b']))            # mn-att:74-78 (per image)
+    pre_r = np.repeat(pre.reshape(B, 1, S2, H), R, 1).reshape(N, S2, H)     # model.lua:262-265 repeat
+    img_tr = dropout(pre_r, d('img_tr'), 0.5)
+    img_common = linear(img_tr.reshape(N * S2, H), P['img_common.W'], P['img_common.b']).reshape(N, S2, -1)  # :83-85
+    qc = linear(qh2, P['ques_common.W'], P['ques_common.b'])               # mn-att:88
+    t_iqc = np.tanh(img_common + qc[:, None, :])                            # mn-att:92
+    iqc = dropout(t_iqc, d('iqc'), 0.5)
+    score = (iqc @ P['att.W'][0]) + P['att.b'][0]                           # mn-att:93
+    score = score - score.max(1, keepdims=True)
+    e = np.exp(score)
+    patt = e / e.sum(1, keepdims=True)                                      # mn-att:94
+    att = np.einsum('ns,nsh->nh', patt, img_tr)                             # mn-att:97-99
+    u1 = att + qh2                                                          # mn-att:102
+    u1_d = dropout(u1, d('u'), 0.5)
+    enc_out = np.tanh(linear(u1_d, P['out.W'], P['out.b']))                 # mn-att:106
+    st.update(qtok=qtok, htok=htok, h3=h3, q3=q3, prob=prob, hatt_d=hatt_d, hattTr=hattTr, s2=s2, qh2=qh2, img=img,
+              pre=pre, img_tr=img_tr, t_iqc=t_iqc, iqc=iqc, patt=patt, u1_d=u1_d, enc_out=enc_out, qc=qc)
+    return enc_out, st
+
+
+def mnatt_encoder_backward(P, G, p, batch, drop, st, denc):
+    B, R, Tq = batch['ques_fwd'].shape
+    H = p['rnnHiddenSize']
+    N = B * R
+    S2 = p['imgSpatialSize'] ** 2
+    d = (lambda k: None) if drop is None else (lambda k: drop[k])
+
+    def dback(dy, key):
+        m = d(key)
+        return dy if m is None else dy * m * 2.0
+
+    dpre_o = denc * (1 - st['enc_out'] ** 2)
+    du1d, dW, db = linear_backward(st['u1_d'], P['out.W'], dpre_o)
+    G['out.W'] += dW; G['out.b'] += db
+    du1 = dback(du1d, 'u')
+    dqh2 = du1.copy()
+    datt = du1
+    img_tr, patt, iqc = st['img_tr'], st['patt'], st['iqc']
+    dp = np.einsum('nh,nsh->ns', datt, img_tr)
+    dimg_tr = patt[:, :, None] * datt[:, None, :]
+    dscore = patt * (dp - (patt * dp).sum(1, keepdims=True))
+    G['att.W'][0] += np.einsum('ns,nsk->k', dscore, iqc)
+    G['att.b'][0] += dscore.sum()
+    diqc = dscore[:, :, None] * P['att.W'][0][None, None, :]
+    dt_iqc = dback(diqc, 'iqc')
+    dz = dt_iqc * (1 - st['t_iqc'] ** 2)
+    dqc = dz.sum(1)
+    dzf = dz.reshape(N * S2, -1)
+    dimg_tr2, dW, db = linear_backward(img_tr.reshape(N * S2, H), P['img_common.W'], dzf)
+    G['img_common.W'] += dW; G['img_common.b'] += db
+    dimg_tr = dimg_tr + dimg_tr2.reshape(N, S2, H)
+    dpre_r = dback(dimg_tr, 'img_tr')
+    dpre = dpre_r.reshape(B, R, S2, H).sum(1).reshape(B * S2, H)
+    dpre_a = dpre * (1 - st['pre'] ** 2)
+    _, dW, db = linear_backward(st['img'], P['img_proj.W'], dpre_a)
+    G['img_proj.W'] += dW; G['img_proj.b'] += db
+    dq, dW, db = linear_backward(st['qh2'], P['ques_common.W'], dqc)
+    G['ques_common.W'] += dW; G['ques_common.b'] += db
+    dqh2 = dqh2 + dq
+    ds2p = dqh2 * (1 - st['qh2'] ** 2)
+    ds2, dW, db = linear_backward(st['s2'], P['mn2.W'], ds2p)
+    G['mn2.W'] += dW; G['mn2.b'] += db
+    dq3 = ds2.copy()
+    dhTr_p = ds2 * (1 - st['hattTr'] ** 2)
+    dhatt_d, dW, db = linear_backward(st['hatt_d'], P['mn1.W'], dhTr_p)
+    G['mn1.W'] += dW; G['mn1.b'] += db
+    dhatt = dback(dhatt_d, 'hatt')
+    dqv, dhv = mn_attention_backward(st['q3'].reshape(B, R, H), st['h3'].reshape(B, R, H), st['prob'],
+                                     dhatt.reshape(B, R, H))
+    dq3 = dq3 + dqv.reshape(N, H)
+    dh3 = dhv.reshape(N, H)
+    dqx = _two_layer_lstm_bwd(P, G, 'ques1', 'ques2', st['qs'], dq3)
+    dhx = _two_layer_lstm_bwd(P, G, 'hist1', 'hist2', st['hs'], dh3)
+    lookup_backward(G['embed'], st['qtok'], dback(dqx, 'q_emb'))
+    lookup_backward(G['embed'], st['htok'], dback(dhx, 'h_emb'))
+
+
+def disc_decoder_forward(P, p, options, enc_out):
+    """decoders/disc.lua:3-32: options [N,O,T] (left-aligned, trailing zeros, NO maskZero)."""
+    N, O, T = options.shape
+    otok = options.reshape(N * O, T).T
+    ox = lookup(P['embed'], otok)
+    h, c, g = lstm_forward(ox, P['opt.W'], P['opt.b'], None)
+    optH = h[-1].reshape(N, O, -1)
+    scores = np.einsum('noh,nh->no', optH, enc_out)
+    return scores, dict(otok=otok, ox=ox, h=h, c=c, g=g, optH=optH)
+
+
+def disc_decoder_backward(P, G, st, enc_out, dscores):
+    optH = st['optH']
+    N, O, H = optH.shape
+    doptH = dscores[:, :, None] * enc_out[:, None, :]
+    denc = np.einsum('no,noh->nh', dscores, optH)
+    dx, dW, db, _, _ = lstm_backward(st['ox'], P['opt.W'], st['g'], st['h'], st['c'], dh_last=doptH.reshape(N * O, H))
+    G['opt.W'] += dW; G['opt.b'] += db
+    lookup_backward(G['embed'], st['otok'], dx)
+    return denc
+
+
+def forward_backward(encoder, decoder, P, p, batch, drop=None, only_forward=False):
+    """Model:forwardBackward (model.lua:249-342) for the restated encoder/decoder pairs.
+    Returns dict(loss, scores, grads (dict, or None), enc_out)."""
+    if encoder != 'mn-att-ques-im-hist' or decoder != 'disc':
+        raise ValueError('oracle.forward_backward: %s + %s not restated yet' % (encoder, decoder))
+    P = dict(P)
+    P['embed'] = P['embed'].copy()
+    P['embed'][0] = 0          # LookupTableMaskZero zeroes the pad row on every forward
+    enc_out, st = mnatt_encoder_forward(P, p, batch, drop)
+    scores, dst = disc_decoder_forward(P, p, batch['options'], enc_out)
+    loss, dscores, loss_rows = cross_entropy(scores, batch['answer_ind'] - 1)   # answer_ind is 1-based (prepro.py:169)
+    out = dict(loss=loss, scores=scores, enc_out=enc_out, grads=None, loss_rows=loss_rows)
+    if only_forward:
+        return out
+    G = {k: np.zeros_like(v) for k, v in P.items()}
+    denc = disc_decoder_backward(P, G, dst, enc_out, dscores)
+    mnatt_encoder_backward(P, G, p, batch, drop, st, denc)
+    out['grads'] = G
+    return out
+
+
+def train_iteration(encoder, decoder, P, p, batch, drop, opt_state, lr):
+    """Model:trainIteration (model.lua:66-106) on explicit batch: fwd/bwd, clamp +-5, adam."""
+    spec = param_spec(encoder, decoder, p)
+    r = forward_backward(encoder, decoder, P, p, batch, drop)
+    w = flatten(P, spec)
+    g = flatten(r['grads'], spec)
+    w2, g2 = clamp_adam(w, g, opt_state, lr)
+    return unflatten(w2, spec), r

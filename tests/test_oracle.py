@@ -1,0 +1,143 @@
+"""Pins the numpy oracle (oracle/visdial_oracle.py) with an INDEPENDENT torch-autograd restatement of the
+same forward graph and with finite differences.  (The reference has no golden vectors -- SURVEY.md 8c.)"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import small_params
+from oracle import visdial_oracle as vo
+from visdial_amd.dataloader import SyntheticDataloader
+
+
+def make_drop(p, batch, rng):
+    B, R, Tq = batch['ques_fwd'].shape
+    Th = batch['hist'].shape[2]
+    N, H, E = B * R, p['rnnHiddenSize'], p['embedSize']
+    S2, K = p['imgSpatialSize'] ** 2, p['commonEmbeddingSize']
+    shp = dict(q_emb=(Tq, N, E), h_emb=(Th, N, E), hatt=(N, H), img_tr=(N, S2, H), iqc=(N, S2, K), u=(N, H))
+    return {k: (rng.rand(*s) > 0.5).astype(np.float64) for k, s in shp.items()}
+
+
+def torch_lstm(x, W, b, tok, H):
+    """independent restatement with torch ops + autograd"""
+    T, N, D = x.shape
+    h = torch.zeros(N, H, dtype=x.dtype)
+    c = torch.zeros(N, H, dtype=x.dtype)
+    hs = []
+    for t in range(T):
+        a = torch.addmm(b, torch.cat([x[t], h], 1), W)
+        i, f, o, g = a[:, :H].sigmoid(), a[:, H:2 * H].sigmoid(), a[:, 2 * H:3 * H].sigmoid(), a[:, 3 * H:].tanh()
+        c = f * c + i * g
+        h = o * c.tanh()
+        if tok is not None:
+            keep = (tok[t] != 0).to(x.dtype)[:, None]
+            h, c = h * keep, c * keep
+        hs.append(h)
+    return torch.stack(hs)
+
+
+def torch_forward(P, p, batch, drop):
+    F = torch.nn.functional
+    B, R, Tq = batch['ques_fwd'].shape
+    N, H = B * R, p['rnnHiddenSize']
+    S2 = p['imgSpatialSize'] ** 2
+    dm = {k: torch.from_numpy(v) for k, v in drop.items()} if drop else None
+    dr = (lambda x, k: x * dm[k] * 2.0) if drop else (lambda x, k: x)
+    emb = P['embed'] * torch.cat([torch.zeros(1, 1, dtype=torch.float64), torch.ones(P['embed'].shape[0] - 1, 1, dtype=torch.float64)])
+    qtok = torch.from_numpy(batch['ques_fwd'].reshape(N, -1).T.astype(np.int64))
+    htok = torch.from_numpy(batch['hist'].reshape(N, -1).T.astype(np.int64))
+    qx, hx = dr(emb[qtok], 'q_emb'), dr(emb[htok], 'h_emb')
+    h3 = torch_lstm(torch_lstm(hx, P['hist1.W'], P['hist1.b'], htok, H), P['hist2.W'], P['hist2.b'], htok, H)[-1]
+    q3 = torch_lstm(torch_lstm(qx, P['ques1.W'], P['ques1.b'], qtok, H), P['ques2.W'], P['ques2.b'], qtok, H)[-1]
+    qv, hv = q3.view(B, R, H), h3.view(B, R, H)
+    s = torch.bmm(qv, hv.transpose(1, 2))
+    mask = torch.triu(torch.ones(R, R, dtype=torch.bool), 1)
+    s = s.masked_fill(mask[None], -9999999.0)
+    hatt = torch.bmm(torch.softmax(s, -1), hv).reshape(N, H)
+    hattTr = torch.tanh(F.linear(dr(hatt, 'hatt'), P['mn1.W'], P['mn1.b']))
+    qh2 = torch.tanh(F.linear(hattTr + q3, P['mn2.W'], P['mn2.b']))
+    img = torch.from_numpy(batch['img_feat'].astype(np.float64)).reshape(B, S2, -1)
+    img = img[:, None].expand(B, R, S2, img.shape[-1]).reshape(N, S2, -1)      # model.lua:262-265
+    img_tr = dr(torch.tanh(F.linear(img, P['img_proj.W'], P['img_proj.b'])), 'img_tr')
+    ic = F.linear(img_tr, P['img_common.W'], P['img_common.b'])
+    qc = F.linear(qh2, P['ques_common.W'], P['ques_common.b'])
+    iqc = dr(torch.tanh(ic + qc[:, None, :]), 'iqc')
+    patt = torch.softmax(F.linear(iqc, P['att.W'], P['att.b']).squeeze(-1), 1)
+    u = torch.bmm(patt[:, None, :], img_tr).squeeze(1) + qh2
+    enc = torch.tanh(F.linear(dr(u, 'u'), P['out.W'], P['out.b']))
+    opt = batch['options']
+    O = opt.shape[1]
+    otok = torch.from_numpy(opt.reshape(N * O, -1).T.astype(np.int64))
+    oh = torch_lstm(emb[otok], P['opt.W'], P['opt.b'], None, H)[-1].view(N, O, H)
+    scores = torch.bmm(oh, enc[:, :, None]).squeeze(-1)
+    loss = F.cross_entropy(scores, torch.from_numpy(batch['answer_ind'].astype(np.int64)) - 1)
+    return loss, scores
+
+
+@pytest.mark.parametrize("use_drop", [False, True])
+def test_oracle_matches_torch_autograd(use_drop):
+    p = small_params()
+    dl = SyntheticDataloader(p, seed=7)
+    batch = dl.getTrainBatch(p)
+    P = vo.init_params(p['encoder'], p['decoder'], p, seed=3)
+    rng = np.random.RandomState(11)
+    drop = make_drop(p, batch, rng) if use_drop else None
+    r = vo.forward_backward(p['encoder'], p['decoder'], P, p, batch, drop)
+    Pt = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in P.items()}
+    loss, scores = torch_forward(Pt, p, batch, drop)
+    loss.backward()
+    assert abs(loss.item() - r['loss']) < 1e-10
+    np.testing.assert_allclose(scores.detach().numpy(), r['scores'], rtol=1e-9, atol=1e-10)
+    for k in P:
+        g_t = Pt[k].grad.numpy()
+        g_o = r['grads'][k]
+        if k == 'embed':
+            # the pad row: torch sees emb*0 (no grad); the reference's dense gradWeight accumulates pad
+            # gradients into row 0 -- compare the real rows only.
+            g_t, g_o = g_t[1:], g_o[1:]
+        np.testing.assert_allclose(g_o, g_t, rtol=1e-7, atol=1e-10, err_msg=k)
+
+
+def test_oracle_finite_difference():
+    p = small_params(batchSize=1, maxQuesCount=3, numOptions=4)
+    dl = SyntheticDataloader(p, seed=5)
+    batch = dl.getTrainBatch(p)
+    P = vo.init_params(p['encoder'], p['decoder'], p, seed=2)
+    r = vo.forward_backward(p['encoder'], p['decoder'], P, p, batch, None)
+    rng = np.random.RandomState(0)
+    eps = 1e-6
+    for name in ['hist1.W', 'ques2.b', 'mn1.W', 'img_proj.W', 'img_common.b', 'att.W', 'out.W', 'opt.W', 'embed']:
+        w = P[name]
+        for _ in range(3):
+            idx = tuple(rng.randint(0, s) for s in w.shape)
+            if name == 'embed' and idx[0] == 0:
+                continue
+            old = w[idx]
+            w[idx] = old + eps
+            lp = vo.forward_backward(p['encoder'], p['decoder'], P, p, batch, None, only_forward=True)['loss']
+            w[idx] = old - eps
+            lm = vo.forward_backward(p['encoder'], p['decoder'], P, p, batch, None, only_forward=True)['loss']
+            w[idx] = old
+            fd = (lp - lm) / (2 * eps)
+            assert abs(fd - r['grads'][name][idx]) < 1e-6 * max(1.0, abs(fd)), (name, idx, fd, r['grads'][name][idx])
+
+
+def test_ranks_and_metrics():
+    s = np.array([[0.1, 0.9, 0.5, 0.9], [3.0, 2.0, 1.0, 0.0]])
+    r = vo.compute_ranks(s)
+    assert r.tolist() == [[4, 1, 3, 2], [1, 2, 3, 4]]
+    assert vo.compute_ranks(s, np.array([2, 0])).tolist() == [3, 1]
+    m = vo.process_ranks(np.array([[1, 2], [6, 11]]))
+    assert m['r@1'] == 0.25 and m['r@5'] == 0.5 and m['r@10'] == 0.75
+    assert abs(m['meanRR'] - (1 + 0.5 + 1 / 6 + 1 / 11) / 4) < 1e-12
+
+
+def test_adam_matches_reference_formula():
+    rng = np.random.RandomState(0)
+    w = rng.randn(10); g = rng.randn(10) * 10
+    st = {}
+    w1, gc = vo.clamp_adam(w, g, st, 1e-3)
+    gc2 = np.clip(g, -5, 5)
+    m = 0.1 * gc2; v = 0.001 * gc2 * gc2
+    step = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    np.testing.assert_allclose(w1, w - step * m / (np.sqrt(v) + 1e-8), rtol=1e-12)

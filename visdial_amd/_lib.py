@@ -1,0 +1,91 @@
+"""ctypes binding of libvisdial_hip.so (the C ABI declared in include/visdial_hip.h).
+
+The library is the product: there is NO CPU fallback.  If the shared object is missing or a
+call fails this module raises -- it never routes to the oracle or to torch ops.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvisdial_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_int64
+_f = C.c_float
+_u64 = C.c_uint64
+
+# name -> argtypes  (return type is int unless listed in _RESTYPE)
+PROTOTYPES = {
+    "vd_last_error": [],
+    "vd_abi_version": [],
+    "vd_device_count": [C.POINTER(C.c_int)],
+    "vd_set_device": [_i],
+    "vd_device_info": [_i, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int64)],
+    "vd_malloc": [C.POINTER(C.c_void_p), _l],
+    "vd_free": [_p],
+    "vd_memset": [_p, _i, _l, _p],
+    "vd_memcpy_h2d": [_p, _p, _l, _p],
+    "vd_memcpy_d2h": [_p, _p, _l, _p],
+    "vd_memcpy_d2d": [_p, _p, _l, _p],
+    "vd_stream_synchronize": [_p],
+    "vd_gemm_nt": [_p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _i, _p],
+    "vd_gemm_nn": [_p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _p],
+    "vd_gemm_tn_acc": [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p],
+    "vd_colsum_acc": [_p, _l, _i, _i, _p, _p],
+    "vd_lstm_forward": [_p, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "vd_lstm_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "vd_embed_gather": [_p, _p, _p, _p, _l, _i, _f, _p],
+    "vd_embed_scatter_acc": [_p, _p, _p, _p, _l, _i, _f, _p],
+    "vd_token_sort": [_p, _l, _i, _p, _p, _p, _p],
+    "vd_segment_rowsum_acc": [_p, _l, _p, _p, _l, _i, _p, _l, _p],
+    "vd_dropout_mask": [_p, _l, _u64, _f, _p],
+    "vd_dropout_apply": [_p, _p, _p, _l, _f, _p],
+    "vd_tanh_backward": [_p, _p, _p, _l, _p],
+    "vd_axpby": [_p, _p, _p, _l, _f, _f, _p],
+    "vd_mn_attention_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "vd_mn_attention_backward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "vd_img_common_forward": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "vd_img_att_forward": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "vd_img_att_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "vd_img_tr_backward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "vd_img_common_wgrad": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "vd_score_ce": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
+    "vd_ranks": [_p, _p, _i, _i, _p],
+    "vd_clamp_adam": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _p],
+}
+_RESTYPE = {"vd_last_error": C.c_char_p}
+
+
+class VisdialHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VisdialHipError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Call an int-returning ABI function; raise VisdialHipError with vd_last_error() on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise VisdialHipError("%s failed (%d): %s" % (name, rc, lib.vd_last_error().decode()))
+    return rc

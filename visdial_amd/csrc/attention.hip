@@ -1,0 +1,410 @@
+// Memory-network attention over dialog history and the 1-hop SAN image attention of
+// encoders/mn-att-ques-im-hist.lua (reference lines 48-62 and 68-104), plus
+// model_utils/MaskSoftMax.lua semantics (mask byte 1 = hidden; hidden scores := -9999999).
+//
+// MI355X mapping:
+//  * memory attention: one workgroup per dialog; the R x R scores, the masked softmax and
+//    the weighted sums are wavefront reductions over H.
+//  * image attention: the per-round image tensor img_tr = dropout(tanh(Linear(img))) is
+//    NEVER materialised per round: the per-image pre-dropout map `pre` [B*S2 x H] stays
+//    L2/MALL-resident and the GEMM operand loader applies the per-round dropout mask
+//    (SURVEY.md H4).  img_common + ques_common + tanh + dropout run in the MFMA epilogue;
+//    score/softmax(196)/weighted-sum is one wave-reduction kernel per QA round (K7).
+#include "gemm_core.h"
+
+// =====================================================================================
+// Memory-network attention
+// =====================================================================================
+#define MN_MAX_R 16
+
+__global__ void __launch_bounds__(256)
+mn_att_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Hm, const uint8_t* __restrict__ mask,
+                  float* __restrict__ P, float* __restrict__ hAtt, int R, int H) {
+  __shared__ float S[MN_MAX_R * MN_MAX_R];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* q = Q + (long)b * R * H;
+  const float* h = Hm + (long)b * R * H;
+  for (int p = wave; p < R * R; p += 4) {
+    const int i = p / R, j = p % R;
+    float s = 0.f;
+    for (int k = lane; k < H; k += 64) s += q[i * H + k] * h[j * H + k];
+    s = wave_sum(s);
+    if (lane == 0) S[i * MN_MAX_R + j] = s;
+  }
+  __syncthreads();
+  if (tid < R) {
+    const int i = tid;
+    const uint8_t* mrow = mask + ((long)b * R + i) * R;
+    float mx = -INFINITY;
+    for (int j = 0; j < R; ++j) {
+      float v = mrow[j] ? -9999999.f : S[i * MN_MAX_R + j];
+      S[i * MN_MAX_R + j] = v;
+      mx = fmaxf(mx, v);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < R; ++j) {
+      const float e = expf(S[i * MN_MAX_R + j] - mx);
+      S[i * MN_MAX_R + j] = e;
+      sum += e;
+    }
+    const float inv = 1.f / sum;
+    for (int j = 0; j < R; ++j) {
+      const float pv = S[i * MN_MAX_R + j] * inv;
+      S[i * MN_MAX_R + j] = pv;
+      P[((long)b * R + i) * R + j] = pv;
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < R * H; idx += 256) {
+    const int i = idx / H, k = idx % H;
+    float a = 0.f;
+    for (int j = 0; j < R; ++j) a += S[i * MN_MAX_R + j] * h[j * H + k];
+    hAtt[(long)b * R * H + idx] = a;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+mn_att_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ Hm, const float* __restrict__ P,
+                  const float* __restrict__ dhAtt, float* __restrict__ dQ, float* __restrict__ dHm, int R,
+                  int H) {
+  __shared__ float Ps[MN_MAX_R * MN_MAX_R];
+  __shared__ float dS[MN_MAX_R * MN_MAX_R];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* q = Q + (long)b * R * H;
+  const float* h = Hm + (long)b * R * H;
+  const float* da = dhAtt + (long)b * R * H;
+  for (int p = wave; p < R * R; p += 4) {
+    const int i = p / R, j = p % R;
+    float s = 0.f;
+    for (int k = lane; k < H; k += 64) s += da[i * H + k] * h[j * H + k];
+    s = wave_sum(s);
+    if (lane == 0) {
+      dS[i * MN_MAX_R + j] = s;  // dP for now
+      Ps[i * MN_MAX_R + j] = P[((long)b * R + i) * R + j];
+    }
+  }
+  __syncthreads();
+  if (tid < R) {
+    const int i = tid;
+    float dot = 0.f;
+    for (int j = 0; j < R; ++j) dot += Ps[i * MN_MAX_R + j] * dS[i * MN_MAX_R + j];
+    for (int j = 0; j < R; ++j) dS[i * MN_MAX_R + j] = Ps[i * MN_MAX_R + j] * (dS[i * MN_MAX_R + j] - dot);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < R * H; idx += 256) {
+    const int i = idx / H, k = idx % H;  // i doubles as the fact index j for dHm
+    float aq = 0.f, ah = 0.f;
+    for (int j = 0; j < R; ++j) {
+      aq += dS[i * MN_MAX_R + j] * h[j * H + k];
+      ah += Ps[j * MN_MAX_R + i] * da[j * H + k] + dS[j * MN_MAX_R + i] * q[j * H + k];
+    }
+    dQ[(long)b * R * H + idx] = aq;
+    dHm[(long)b * R * H + idx] = ah;
+  }
+}
+
+// =====================================================================================
+// Image attention
+// =====================================================================================
+// Row (n, s) of the per-round image tensor, read from the per-image map with the round's
+// dropout mask applied on the fly.
+struct SrcImgDropRow {
+  static constexpr bool KMAJOR = false;
+  const float* pre;      // [Bi*S2 x H]
+  const uint8_t* mask;   // [N*S2 x H] or null
+  int H, S2, R;
+  float scale;
+  __device__ __forceinline__ float4 ld4(int row, int k) const {
+    const int n = row / S2, s = row - n * S2;
+    float4 v = *reinterpret_cast<const float4*>(pre + ((long)(n / R) * S2 + s) * H + k);
+    if (mask) {
+      const uint32_t m = *reinterpret_cast<const uint32_t*>(mask + (long)row * H + k);
+      v.x = (m & 0xff) ? v.x * scale : 0.f;
+      v.y = (m & 0xff00) ? v.y * scale : 0.f;
+      v.z = (m & 0xff0000) ? v.z * scale : 0.f;
+      v.w = (m & 0xff000000u) ? v.w * scale : 0.f;
+    }
+    return v;
+  }
+};
+// same tensor as a k-major operand: "r" runs over H (contiguous), "k" over rows (n, s).
+struct SrcImgDropK {
+  static constexpr bool KMAJOR = true;
+  const float* pre;
+  const uint8_t* mask;
+  int H, S2, R;
+  float scale;
+  __device__ __forceinline__ float4 ld4(int r, int row) const {
+    SrcImgDropRow s{pre, mask, H, S2, R, scale};
+    return s.ld4(row, r);
+  }
+};
+
+// iqc = dropout2( tanh( acc + bc[col] + qc[n, col] ) )
+struct EpiImgCommon {
+  float* iqc;            // [N*S2 x Kc]
+  const float* bc;       // [Kc]
+  const float* qc;       // [N x Kc]
+  const uint8_t* mask2;  // [N*S2 x Kc] or null
+  int S2;
+  float scale;
+  __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int col0, int lane, int M,
+                                             int N) const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = col0 + j * 32 + (lane & 31);
+      if (col >= N) continue;
+      const float bv = bc[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + mfma_row(r, lane);
+        if (row >= M) continue;
+        const int n = row / S2;
+        float v = tanhf(acc[j][r] + bv + qc[(long)n * N + col]);
+        if (mask2) v = mask2[(long)row * N + col] ? v * scale : 0.f;
+        iqc[(long)row * N + col] = v;
+      }
+    }
+  }
+};
+
+// d(pre)[image row, col] += (acc + p[row]*datt[n, col]) * mask1*scale   (sum over the R rounds)
+struct EpiImgTrBwd {
+  float* dpre;           // [Bi*S2 x H], atomically accumulated
+  const float* p;        // [N*S2]
+  const float* datt;     // [N x H]
+  const uint8_t* mask1;  // [N*S2 x H] or null
+  int S2, R;
+  float scale;
+  __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int col0, int lane, int M,
+                                             int N) const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = col0 + j * 32 + (lane & 31);
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + mfma_row(r, lane);
+        if (row >= M) continue;
+        const int n = row / S2, s = row - n * S2;
+        float v = acc[j][r] + p[row] * datt[(long)n * N + col];
+        if (mask1) v = mask1[(long)row * N + col] ? v * scale : 0.f;
+        unsafeAtomicAdd(dpre + ((long)(n / R) * S2 + s) * N + col, v);
+      }
+    }
+  }
+};
+
+// score + softmax over the S2 regions + weighted sum, one workgroup per QA round n:
+//   score[s] = <iqc[n,s,:], wa> + ba ; p = softmax(score) ; u1[n,:] = u0[n,:] + sum_s p[s]*img_tr[n,s,:]
+__global__ void __launch_bounds__(256)
+img_att_fwd_kernel(const float* __restrict__ iqc, const float* __restrict__ wa, const float* __restrict__ ba,
+                   const float* __restrict__ pre, const uint8_t* __restrict__ mask1,
+                   const float* __restrict__ u0, float* __restrict__ p_out, float* __restrict__ u1, int S2,
+                   int R, int H, int Kc, float scale) {
+  extern __shared__ float sc[];  // [S2]
+  __shared__ float red[8];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* iq = iqc + (long)n * S2 * Kc;
+  for (int s = wave; s < S2; s += 4) {
+    float a = 0.f;
+    for (int k = lane * 4; k < Kc; k += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(iq + (long)s * Kc + k);
+      const float4 w = *reinterpret_cast<const float4*>(wa + k);
+      a += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
+    }
+    a = wave_sum(a);
+    if (lane == 0) sc[s] = a + ba[0];
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int s = tid; s < S2; s += 256) mx = fmaxf(mx, sc[s]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int s = tid; s < S2; s += 256) {
+    const float e = expf(sc[s] - mx);
+    sc[s] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+  for (int s = tid; s < S2; s += 256) {
+    const float pv = sc[s] * inv;
+    sc[s] = pv;
+    p_out[(long)n * S2 + s] = pv;
+  }
+  __syncthreads();
+  const float* pr = pre + (long)(n / R) * S2 * H;
+  const uint8_t* m1 = mask1 ? mask1 + (long)n * S2 * H : nullptr;
+  for (int h = tid; h < H; h += 256) {
+    float a = 0.f;
+    for (int s = 0; s < S2; ++s) {
+      float v = pr[(long)s * H + h];
+      if (m1) v = m1[(long)s * H + h] ? v * scale : 0.f;
+      a += sc[s] * v;
+    }
+    u1[(long)n * H + h] = u0[(long)n * H + h] + a;
+  }
+}
+
+// backward of the kernel above + of the tanh/dropout epilogue.  Per QA round n:
+//   dp[s] = <datt[n,:], img_tr[n,s,:]> ; dscore = p*(dp - <p,dp>)
+//   dwa += sum_s dscore[s]*iqc[n,s,:] ; dba += sum_s dscore[s]
+//   dz[n,s,k] = dscore[s]*wa[k]*scale2*mask2*(1 - tanh^2)   (written over iqc in place)
+//   dqc[n,k] = sum_s dz[n,s,k]
+__global__ void __launch_bounds__(256)
+img_att_bwd_kernel(float* __restrict__ iqc, const float* __restrict__ wa, const float* __restrict__ pre,
+                   const uint8_t* __restrict__ mask1, const uint8_t* __restrict__ mask2,
+                   const float* __restrict__ p, const float* __restrict__ datt, float* __restrict__ dwa,
+                   float* __restrict__ dba, float* __restrict__ dqc, int S2, int R, int H, int Kc, float scale) {
+  extern __shared__ float sh[];  // dscore [S2]
+  __shared__ float red[4];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* pr = pre + (long)(n / R) * S2 * H;
+  const uint8_t* m1 = mask1 ? mask1 + (long)n * S2 * H : nullptr;
+  const float* da = datt + (long)n * H;
+  for (int s = wave; s < S2; s += 4) {
+    float a = 0.f;
+    for (int h = lane; h < H; h += 64) {
+      float v = pr[(long)s * H + h];
+      if (m1) v = m1[(long)s * H + h] ? v * scale : 0.f;
+      a += da[h] * v;
+    }
+    a = wave_sum(a);
+    if (lane == 0) sh[s] = a;
+  }
+  __syncthreads();
+  float dot = 0.f;
+  for (int s = tid; s < S2; s += 256) dot += p[(long)n * S2 + s] * sh[s];
+  dot = wave_sum(dot);
+  if (lane == 0) red[wave] = dot;
+  __syncthreads();
+  dot = red[0] + red[1] + red[2] + red[3];
+  float dsum = 0.f;
+  for (int s = tid; s < S2; s += 256) {
+    const float ds = p[(long)n * S2 + s] * (sh[s] - dot);
+    sh[s] = ds;
+    dsum += ds;
+  }
+  dsum = wave_sum(dsum);
+  if (lane == 0) unsafeAtomicAdd(dba, dsum);
+  __syncthreads();
+  float* iq = iqc + (long)n * S2 * Kc;
+  const uint8_t* m2 = mask2 ? mask2 + (long)n * S2 * Kc : nullptr;
+  const float inv_scale = m2 ? 1.f / scale : 1.f;
+  const float sc2 = m2 ? scale : 1.f;
+  for (int k = tid; k < Kc; k += 256) {
+    const float w = wa[k];
+    float aw = 0.f, aq = 0.f;
+    for (int s = 0; s < S2; ++s) {
+      const long o = (long)s * Kc + k;
+      const float y = iq[o];
+      const float ds = sh[s];
+      aw += ds * y;
+      float dz = 0.f;
+      if (!m2 || m2[o]) {
+        const float t = y * inv_scale;
+        dz = ds * w * sc2 * (1.f - t * t);
+      }
+      iq[o] = dz;
+      aq += dz;
+    }
+    unsafeAtomicAdd(dwa + k, aw);
+    dqc[(long)n * Kc + k] = aq;
+  }
+}
+
+using CfgBig = GemmCfg<4, 1, 4, 32>;
+
+extern "C" {
+
+int vd_mn_attention_forward(const float* Q, const float* Hm, const uint8_t* mask, float* P, float* hAtt, int B,
+                            int R, int H, void* stream) {
+  VD_CHECK_ARG(Q && Hm && mask && P && hAtt && B >= 0 && R >= 1 && R <= MN_MAX_R && H > 0,
+               "vd_mn_attention_forward: bad args (R=%d must be <= %d)", R, MN_MAX_R);
+  if (B == 0) return VD_OK;
+  hipLaunchKernelGGL(mn_att_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, Q, Hm, mask, P, hAtt, R, H);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+int vd_mn_attention_backward(const float* Q, const float* Hm, const float* P, const float* dhAtt, float* dQ,
+                             float* dHm, int B, int R, int H, void* stream) {
+  VD_CHECK_ARG(Q && Hm && P && dhAtt && dQ && dHm && B >= 0 && R >= 1 && R <= MN_MAX_R && H > 0,
+               "vd_mn_attention_backward: bad args");
+  if (B == 0) return VD_OK;
+  hipLaunchKernelGGL(mn_att_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, Q, Hm, P, dhAtt, dQ, dHm,
+                     R, H);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+// iqc[(n,s), :] = drop2(tanh(img_tr[(n,s), :] * Wc^T + bc + qc[n, :]))
+int vd_img_common_forward(const float* pre, const uint8_t* mask1, const float* Wc, const float* bc,
+                          const float* qc, const uint8_t* mask2, float* iqc, int N, int R, int S2, int H, int Kc,
+                          float scale, void* stream) {
+  VD_CHECK_ARG(pre && Wc && bc && qc && iqc && N >= 0 && R >= 1 && S2 >= 1 && H % 4 == 0 && Kc % 4 == 0,
+               "vd_img_common_forward: bad args");
+  SrcImgDropRow a{pre, mask1, H, S2, R, scale};
+  SrcRow b{Wc, H};
+  EpiImgCommon e{iqc, bc, qc, mask2, S2, scale};
+  return launch_gemm<CfgBig>(N * S2, Kc, H, 1, a, b, e, (hipStream_t)stream);
+}
+
+int vd_img_att_forward(const float* iqc, const float* wa, const float* ba, const float* pre,
+                       const uint8_t* mask1, const float* u0, float* p, float* u1, int N, int R, int S2, int H,
+                       int Kc, float scale, void* stream) {
+  VD_CHECK_ARG(iqc && wa && ba && pre && u0 && p && u1 && N >= 0 && Kc % 4 == 0, "vd_img_att_forward: bad args");
+  if (N == 0) return VD_OK;
+  hipLaunchKernelGGL(img_att_fwd_kernel, dim3(N), dim3(256), S2 * sizeof(float), (hipStream_t)stream, iqc, wa,
+                     ba, pre, mask1, u0, p, u1, S2, R, H, Kc, scale);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+// iqc is overwritten by dz.  dwa/dba are accumulated, dqc is written.
+int vd_img_att_backward(float* iqc_dz, const float* wa, const float* pre, const uint8_t* mask1,
+                        const uint8_t* mask2, const float* p, const float* datt, float* dwa, float* dba,
+                        float* dqc, int N, int R, int S2, int H, int Kc, float scale, void* stream) {
+  VD_CHECK_ARG(iqc_dz && wa && pre && p && datt && dwa && dba && dqc && N >= 0, "vd_img_att_backward: bad args");
+  if (N == 0) return VD_OK;
+  hipLaunchKernelGGL(img_att_bwd_kernel, dim3(N), dim3(256), S2 * sizeof(float), (hipStream_t)stream, iqc_dz,
+                     wa, pre, mask1, mask2, p, datt, dwa, dba, dqc, S2, R, H, Kc, scale);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+// dpre[(b,s), :] += sum_{rounds} (dz[(n,s), :] * Wc + p[n,s]*datt[n, :]) * mask1*scale
+int vd_img_tr_backward(const float* dz, const float* Wc, const float* p, const float* datt,
+                       const uint8_t* mask1, float* dpre, int N, int R, int S2, int H, int Kc, float scale,
+                       void* stream) {
+  VD_CHECK_ARG(dz && Wc && p && datt && dpre && N >= 0 && H % 4 == 0 && Kc % 4 == 0,
+               "vd_img_tr_backward: bad args");
+  SrcRow a{dz, Kc};
+  SrcK b{Wc, H};  // B[k][h] = Wc[k][h]
+  EpiImgTrBwd e{dpre, p, datt, mask1, S2, R, scale};
+  return launch_gemm<CfgBig>(N * S2, H, Kc, 1, a, b, e, (hipStream_t)stream);
+}
+
+// dWc[Kc x H] += dz^T * img_tr
+int vd_img_common_wgrad(const float* dz, const float* pre, const uint8_t* mask1, float* dWc, int N, int R,
+                        int S2, int H, int Kc, float scale, void* stream) {
+  VD_CHECK_ARG(dz && pre && dWc && N >= 0 && H % 4 == 0 && Kc % 4 == 0, "vd_img_common_wgrad: bad args");
+  if (N == 0) return VD_OK;
+  SrcK a{dz, Kc};
+  SrcImgDropK b{pre, mask1, H, S2, R, scale};
+  EpiAtomic<4> e{dWc, H};
+  const int K = N * S2;
+  const long tiles = (long)vd_cdiv(Kc, CfgBig::BM) * vd_cdiv(H, CfgBig::BN);
+  long splits = vd_cdiv(1024, tiles);
+  const long max_splits = vd_cdiv(K, 4 * CfgBig::BK);
+  if (splits > max_splits) splits = max_splits;
+  return launch_gemm<CfgBig>(Kc, H, K, (int)splits, a, b, e, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,323 @@
+// HBM-bound helper kernels: embedding gather / gradient scatter, dropout masks, small
+// pointwise glue, token counting-sort + segmented row sum (option-table gradient), and the
+// fused clamp + Adam update.  All are plain coalesced float4 / wave-per-row kernels.
+#include "common.h"
+
+// ------------------------------------------------------------------ dropout masks
+__device__ __forceinline__ uint32_t mix32(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return (uint32_t)x;
+}
+
+// mask[i] = 1 with probability (1-p).  Counter-based: (seed, i) -> bit, replayable.
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ mask, long n, uint64_t seed, float p) {
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const uint32_t thr = (uint32_t)(p * 16777216.0f);
+  uint8_t m[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t h = mix32(seed * 0x9E3779B97F4A7C15ULL + (uint64_t)(i4 + k));
+    m[k] = ((h >> 8) >= thr) ? 1 : 0;
+  }
+  if (i4 + 3 < n) {
+    *reinterpret_cast<uint32_t*>(mask + i4) = m[0] | (m[1] << 8) | (m[2] << 16) | ((uint32_t)m[3] << 24);
+  } else {
+    for (int k = 0; k < 4 && i4 + k < n; ++k) mask[i4 + k] = m[k];
+  }
+}
+
+// y = x * mask * scale   (nn.Dropout forward in training mode and its backward)
+__global__ void dropout_apply_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
+                                     float* __restrict__ y, long n, float scale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = mask[i] ? x[i] * scale : 0.f;
+}
+
+// dx = dy * (1 - y^2)
+__global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                float* __restrict__ dx, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float t = y[i];
+    dx[i] = dy[i] * (1.f - t * t);
+  }
+}
+
+// c = alpha*a + beta*b
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c,
+                             long n, float alpha, float beta) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) c[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+
+// ------------------------------------------------------------------ embedding
+// out[r, :] = Emb[tok[r], :] * (mask ? mask*scale : 1).  One thread per float4.
+// (nn.LookupTableMaskZero: token 0 -> table row 0, which the host keeps at zero.)
+__global__ void embed_gather_kernel(const float* __restrict__ emb, const int* __restrict__ tok,
+                                    const uint8_t* __restrict__ mask, float* __restrict__ out, long rows, int E,
+                                    float scale) {
+  const int e4 = E >> 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * e4) return;
+  const long r = idx / e4;
+  const int q = (int)(idx - r * e4);
+  float4 v = *reinterpret_cast<const float4*>(emb + (long)tok[r] * E + q * 4);
+  if (mask) {
+    const uint32_t m = *reinterpret_cast<const uint32_t*>(mask + r * E + q * 4);
+    v.x = (m & 0xff) ? v.x * scale : 0.f;
+    v.y = (m & 0xff00) ? v.y * scale : 0.f;
+    v.z = (m & 0xff0000) ? v.z * scale : 0.f;
+    v.w = (m & 0xff000000u) ? v.w * scale : 0.f;
+  }
+  *reinterpret_cast<float4*>(out + r * E + q * 4) = v;
+}
+
+// dEmb[tok[r], :] += dX[r, :] * mask * scale
+__global__ void embed_scatter_kernel(float* __restrict__ demb, const int* __restrict__ tok,
+                                     const uint8_t* __restrict__ mask, const float* __restrict__ dx, long rows,
+                                     int E, float scale) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * E) return;
+  const long r = idx / E;
+  const int e = (int)(idx - r * E);
+  float v = dx[idx];
+  if (mask) v = mask[idx] ? v * scale : 0.f;
+  if (v != 0.f) unsafeAtomicAdd(demb + (long)tok[r] * E + e, v);
+}
+
+// ------------------------------------------------------------------ token counting sort
+__global__ void tok_count_kernel(const int* __restrict__ tok, long n, int* __restrict__ count) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(count + tok[i], 1);
+}
+
+// exclusive scan of count[0..V) into offset[0..V]; cursor := offset.  Single block.
+__global__ void tok_scan_kernel(const int* __restrict__ count, int V, int* __restrict__ offset,
+                                int* __restrict__ cursor) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int per = (V + nt - 1) / nt;
+  const int b = tid * per, e = min(V, b + per);
+  int s = 0;
+  for (int i = b; i < e; ++i) s += count[i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < nt; ++i) {
+      const int t = part[i];
+      part[i] = run;
+      run += t;
+    }
+    offset[V] = run;
+  }
+  __syncthreads();
+  int run = part[tid];
+  for (int i = b; i < e; ++i) {
+    offset[i] = run;
+    cursor[i] = run;
+    run += count[i];
+  }
+}
+
+__global__ void tok_fill_kernel(const int* __restrict__ tok, long n, int* __restrict__ cursor,
+                                int* __restrict__ perm) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int p = atomicAdd(cursor + tok[i], 1);
+    perm[p] = (int)i;
+  }
+}
+
+// out[tok, :] += sum over rows r with tok[r] == tok of X[r, :].  perm lists the rows sorted by
+// token.  Each block walks CHUNK consecutive sorted rows, keeps the running sum of the current
+// token in registers (one float4 per thread per 1024 columns) and flushes with atomics when the
+// token changes, so a long run (the pad token) is split over many blocks.
+template <int CHUNK>
+__global__ void segment_rowsum_kernel(const float* __restrict__ X, long ldx, const int* __restrict__ tok,
+                                      const int* __restrict__ perm, long n, int ncol, float* __restrict__ out,
+                                      long ldo) {
+  const long p0 = (long)blockIdx.x * CHUNK;
+  if (p0 >= n) return;
+  const long p1 = min(n, p0 + CHUNK);
+  for (int c = threadIdx.x * 4; c < ncol; c += blockDim.x * 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cur = tok[perm[p0]];
+    for (long p = p0; p < p1; ++p) {
+      const int r = perm[p];
+      const int t = tok[r];
+      if (t != cur) {
+        float* o = out + (long)cur * ldo + c;
+        unsafeAtomicAdd(o, acc.x);
+        unsafeAtomicAdd(o + 1, acc.y);
+        unsafeAtomicAdd(o + 2, acc.z);
+        unsafeAtomicAdd(o + 3, acc.w);
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        cur = t;
+      }
+      const float4 v = *reinterpret_cast<const float4*>(X + (long)r * ldx + c);
+      acc.x += v.x;
+      acc.y += v.y;
+      acc.z += v.z;
+      acc.w += v.w;
+    }
+    float* o = out + (long)cur * ldo + c;
+    unsafeAtomicAdd(o, acc.x);
+    unsafeAtomicAdd(o + 1, acc.y);
+    unsafeAtomicAdd(o + 2, acc.z);
+    unsafeAtomicAdd(o + 3, acc.w);
+  }
+}
+
+// ------------------------------------------------------------------ clamp + Adam
+// model.lua:96-99 + model_utils/optim_updates.lua:62-91: g <- clamp(gscale*g, +-clip);
+// m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; w <- w - step * m / (sqrt(v) + eps)
+// (eps is added to the UNcorrected sqrt(v); step = lr*sqrt(1-b2^t)/(1-b1^t) from the host.)
+__global__ void clamp_adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, long n, float gscale, float clip, float b1, float b2,
+                                  float eps, float step) {
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 + 3 < n) {
+    float4 W = *reinterpret_cast<float4*>(w + i4), G = *reinterpret_cast<float4*>(g + i4);
+    float4 Mv = *reinterpret_cast<float4*>(m + i4), Vv = *reinterpret_cast<float4*>(v + i4);
+    float* Wp = &W.x;
+    float* Gp = &G.x;
+    float* Mp = &Mv.x;
+    float* Vp = &Vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gg = Gp[k] * gscale;
+      gg = fminf(fmaxf(gg, -clip), clip);
+      Gp[k] = gg;
+      Mp[k] = b1 * Mp[k] + (1.f - b1) * gg;
+      Vp[k] = b2 * Vp[k] + (1.f - b2) * gg * gg;
+      Wp[k] -= step * Mp[k] / (sqrtf(Vp[k]) + eps);
+    }
+    *reinterpret_cast<float4*>(w + i4) = W;
+    *reinterpret_cast<float4*>(g + i4) = G;
+    *reinterpret_cast<float4*>(m + i4) = Mv;
+    *reinterpret_cast<float4*>(v + i4) = Vv;
+  } else {
+    for (long i = i4; i < n; ++i) {
+      float gg = g[i] * gscale;
+      gg = fminf(fmaxf(gg, -clip), clip);
+      g[i] = gg;
+      m[i] = b1 * m[i] + (1.f - b1) * gg;
+      v[i] = b2 * v[i] + (1.f - b2) * gg * gg;
+      w[i] -= step * m[i] / (sqrtf(v[i]) + eps);
+    }
+  }
+}
+
+static inline dim3 grid1d(long n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+extern "C" {
+
+int vd_dropout_mask(uint8_t* mask, int64_t n, uint64_t seed, float p, void* stream) {
+  VD_CHECK_ARG(mask && n >= 0 && p >= 0.f && p < 1.f && ((uintptr_t)mask & 3) == 0, "vd_dropout_mask: bad args");
+  if (n == 0) return VD_OK;
+  hipLaunchKernelGGL(dropout_mask_kernel, grid1d((n + 3) / 4, 256), dim3(256), 0, (hipStream_t)stream, mask,
+                     (long)n, seed, p);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+int vd_dropout_apply(const float* x, const uint8_t* mask, float* y, int64_t n, float scale, void* stream) {
+  VD_CHECK_ARG(x && mask && y && n >= 0, "vd_dropout_apply: bad args");
+  if (n == 0) return VD_OK;
+  hipLaunchKernelGGL(dropout_apply_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, x, mask, y,
+                     (long)n, scale);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+int vd_tanh_backward(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+  VD_CHECK_ARG(dy && y && dx && n >= 0, "vd_tanh_backward: bad args");
+  if (n == 0) return VD_OK;
+  hipLaunchKernelGGL(tanh_bwd_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, dy, y, dx, (long)n);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+int vd_axpby(const float* a, const float* b, float* c, int64_t n, float alpha, float beta, void* stream) {
+  VD_CHECK_ARG(a && c && n >= 0, "vd_axpby: bad args");
+  if (n == 0) return VD_OK;
+  hipLaunchKernelGGL(axpby_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, a, b, c, (long)n, alpha,
+                     beta);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+int vd_embed_gather(const float* emb, const int32_t* tok, const uint8_t* mask, float* out, int64_t rows, int E,
+                    float scale, void* stream) {
+  VD_CHECK_ARG(emb && tok && out && rows >= 0 && E > 0 && E % 4 == 0, "vd_embed_gather: bad args (E=%d)", E);
+  if (rows == 0) return VD_OK;
+  hipLaunchKernelGGL(embed_gather_kernel, grid1d(rows * (E / 4), 256), dim3(256), 0, (hipStream_t)stream, emb,
+                     tok, mask, out, (long)rows, E, scale);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+int vd_embed_scatter_acc(float* demb, const int32_t* tok, const uint8_t* mask, const float* dx, int64_t rows,
+                         int E, float scale, void* stream) {
+  VD_CHECK_ARG(demb && tok && dx && rows >= 0 && E > 0, "vd_embed_scatter_acc: bad args");
+  if (rows == 0) return VD_OK;
+  hipLaunchKernelGGL(embed_scatter_kernel, grid1d(rows * E, 256), dim3(256), 0, (hipStream_t)stream, demb, tok,
+                     mask, dx, (long)rows, E, scale);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+// counting sort of n token ids in [0, V): perm = row indices ordered by token.
+// work = int32[2*V + 1] scratch (count, cursor); offset = int32[V+1].
+int vd_token_sort(const int32_t* tok, int64_t n, int V, int32_t* offset, int32_t* work, int32_t* perm,
+                  void* stream) {
+  VD_CHECK_ARG(tok && offset && work && perm && n >= 0 && V > 0, "vd_token_sort: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  int* count = work;
+  int* cursor = work + V;
+  VD_HIP(hipMemsetAsync(count, 0, sizeof(int) * V, s));
+  if (n > 0) {
+    hipLaunchKernelGGL(tok_count_kernel, grid1d(n, 256), dim3(256), 0, s, tok, (long)n, count);
+    VD_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(tok_scan_kernel, dim3(1), dim3(1024), 0, s, count, V, offset, cursor);
+  VD_LAUNCH_CHECK();
+  if (n > 0) {
+    hipLaunchKernelGGL(tok_fill_kernel, grid1d(n, 256), dim3(256), 0, s, tok, (long)n, cursor, perm);
+    VD_LAUNCH_CHECK();
+  }
+  return VD_OK;
+}
+
+// out[tok[r], 0:ncol] += X[r, 0:ncol] for all n rows (rows visited in perm order).
+int vd_segment_rowsum_acc(const float* X, int64_t ldx, const int32_t* tok, const int32_t* perm, int64_t n,
+                          int ncol, float* out, int64_t ldo, void* stream) {
+  VD_CHECK_ARG(X && tok && perm && out && n >= 0 && ncol > 0 && ncol % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0,
+               "vd_segment_rowsum_acc: bad args");
+  if (n == 0) return VD_OK;
+  constexpr int CHUNK = 32;
+  hipLaunchKernelGGL(segment_rowsum_kernel<CHUNK>, grid1d(n, CHUNK), dim3(256), 0, (hipStream_t)stream, X,
+                     (long)ldx, tok, perm, (long)n, ncol, out, (long)ldo);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+int vd_clamp_adam(float* w, float* g, float* m, float* v, int64_t n, float gscale, float clip, float beta1,
+                  float beta2, float eps, float step, void* stream) {
+  VD_CHECK_ARG(w && g && m && v && n >= 0, "vd_clamp_adam: bad args");
+  VD_CHECK_ARG((((uintptr_t)w | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+               "vd_clamp_adam: buffers must be 16-byte aligned");
+  if (n == 0) return VD_OK;
+  hipLaunchKernelGGL(clamp_adam_kernel, grid1d((n + 3) / 4, 256), dim3(256), 0, (hipStream_t)stream, w, g, m, v,
+                     (long)n, gscale, clip, beta1, beta2, eps, step);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,320 @@
+// fp32 MFMA GEMM core for gfx950 (CDNA4), written for 64-wide wavefronts.
+//
+//   C[M x N] = epilogue( A[M x K] * B[K x N] )
+//
+// * matrix op: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = 157 TF/chip).
+// * block = WM x WK waves.  Wave (wm, wk) owns a 32 x (NT*32) output strip and the
+//   wk-th KW-wide slice of every K tile (intra-block split-K for latency-bound
+//   small-M shapes; WK == 1 for the throughput shapes).
+// * both operands are staged global -> registers -> LDS as [row][k] (k contiguous,
+//   row stride BK+4 floats => conflict-free ds_read_b128 fragment reads).  LDS is
+//   double-buffered: one s_barrier per K tile, next tile's global loads are issued
+//   before the MFMA burst of the current one.
+// * k order inside each 8-wide chunk is permuted (lanes 0-31 take k0..k0+3, lanes
+//   32-63 take k0+4..k0+7) so that one ds_read_b128 feeds four MFMAs.
+// * sources are functors so operand fusion (dropout masks, per-image broadcast,
+//   LSTM gate-column interleave) happens in the loader instead of extra HBM passes.
+// * workgroup id -> tile mapping is XCD-aware (block b runs on XCD b % 8; every XCD
+//   gets a contiguous range of tiles so its private L2 sees a compact working set).
+#pragma once
+#include "common.h"
+
+template <int WM_, int WK_, int NT_, int KW_>
+struct GemmCfg {
+  static constexpr int WM = WM_, WK = WK_, NT = NT_, KW = KW_;
+  static constexpr int BM = WM * 32, BN = NT * 32, BK = WK * KW;
+  static constexpr int THREADS = WM * WK * 64;
+  static constexpr int STRIDE = BK + 4;  // floats
+  static constexpr int BUF_FLOATS = (BM + BN) * STRIDE;
+  static constexpr int STAGE_BYTES = 2 * BUF_FLOATS * 4;
+  static constexpr int RED_BYTES = (WK - 1) * WM * NT * 16 * 64 * 4;
+  static constexpr int LDS_BYTES = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
+  static constexpr int NA = (BM * BK / 4) / THREADS;
+  static constexpr int NB = (BN * BK / 4) / THREADS;
+  static_assert(KW % 8 == 0, "KW must be a multiple of 8");
+  static_assert((BM * BK / 4) % THREADS == 0 && NA >= 1, "A tile must split evenly");
+  static_assert((BN * BK / 4) % THREADS == 0 && NB >= 1, "B tile must split evenly");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// ---------------------------------------------------------------------------
+// Operand sources.  KMAJOR == false: element (r, k) lives at p[r*ld + k] and
+// ld4(r, k) returns k..k+3.  KMAJOR == true: element (r, k) lives at p[k*ld + r]
+// and ld4(r, k) returns r..r+3.
+// ---------------------------------------------------------------------------
+struct SrcRow {
+  static constexpr bool KMAJOR = false;
+  const float* p;
+  long ld;
+  __device__ __forceinline__ float4 ld4(int r, int k) const {
+    return *reinterpret_cast<const float4*>(p + (long)r * ld + k);
+  }
+};
+struct SrcK {
+  static constexpr bool KMAJOR = true;
+  const float* p;
+  long ld;
+  __device__ __forceinline__ float4 ld4(int r, int k) const {
+    return *reinterpret_cast<const float4*>(p + (long)k * ld + r);
+  }
+};
+// LSTM recurrent weight Wh [H x 4H] (gate order i,f,o,g) seen through "virtual"
+// columns vc = jb*128 + gate*32 + jj  ->  real column gate*H + jb*32 + jj, so one
+// wave strip holds all four gates of 32 hidden units.
+struct SrcKGate4 {
+  static constexpr bool KMAJOR = true;
+  const float* p;
+  long ld;
+  int H;
+  __device__ __forceinline__ float4 ld4(int vc, int k) const {
+    const int jb = vc >> 7, g = (vc >> 5) & 3, jj = vc & 31;
+    return *reinterpret_cast<const float4*>(p + (long)k * ld + g * H + jb * 32 + jj);
+  }
+};
+
+__device__ __forceinline__ int mfma_row(int r, int lane) {
+  return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+// XCD-aware bijective remap of the flat workgroup id (guide T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, li = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + li;
+}
+
+template <class Cfg, class ASrc, class BSrc, class Epi>
+__global__ void __launch_bounds__(Cfg::THREADS)
+gemm_f32_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, ASrc asrc, BSrc bsrc,
+                Epi epi) {
+  constexpr int WM = Cfg::WM, NT = Cfg::NT, KW = Cfg::KW;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
+  constexpr int THREADS = Cfg::THREADS, STR = Cfg::STRIDE;
+  constexpr int NA = Cfg::NA, NB = Cfg::NB;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wk = wave / WM;
+
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = wg % tiles_n;
+  const int tile_m = (wg / tiles_n) % tiles_m;
+  const int split = wg / (tiles_n * tiles_m);
+  const int row_base = tile_m * BM, col_base = tile_n * BN;
+  const int ks = split * kchunk;
+  const int ke = min(K, ks + kchunk);
+  const int nk = ke > ks ? (ke - ks + BK - 1) / BK : 0;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  float4 ra[NA], rb[NB];
+
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int f = tid + i * THREADS;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (!ASrc::KMAJOR) {
+        const int r = f / (BK / 4), kq = f % (BK / 4);
+        const int gr = row_base + r, gk = k0 + kq * 4;
+        if (gr < M && gk < ke) v = asrc.ld4(gr, gk);
+      } else {
+        const int klo = f & 7, g = f >> 3;
+        const int r4 = g % (BM / 4), kk = (g / (BM / 4)) * 8 + klo;
+        const int gr = row_base + r4 * 4, gk = k0 + kk;
+        if (gr < M && gk < ke) v = asrc.ld4(gr, gk);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int f = tid + i * THREADS;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (!BSrc::KMAJOR) {
+        const int r = f / (BK / 4), kq = f % (BK / 4);
+        const int gr = col_base + r, gk = k0 + kq * 4;
+        if (gr < N && gk < ke) v = bsrc.ld4(gr, gk);
+      } else {
+        const int klo = f & 7, g = f >> 3;
+        const int r4 = g % (BN / 4), kk = (g / (BN / 4)) * 8 + klo;
+        const int gr = col_base + r4 * 4, gk = k0 + kk;
+        if (gr < N && gk < ke) v = bsrc.ld4(gr, gk);
+      }
+      rb[i] = v;
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    float* sa = smem + buf * Cfg::BUF_FLOATS;
+    float* sb = sa + BM * STR;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int f = tid + i * THREADS;
+      if constexpr (!ASrc::KMAJOR) {
+        const int r = f / (BK / 4), kq = f % (BK / 4);
+        *reinterpret_cast<float4*>(sa + r * STR + kq * 4) = ra[i];
+      } else {
+        const int klo = f & 7, g = f >> 3;
+        const int r4 = g % (BM / 4), kk = (g / (BM / 4)) * 8 + klo;
+        float* d = sa + (r4 * 4) * STR + kk;
+        d[0] = ra[i].x;
+        d[STR] = ra[i].y;
+        d[2 * STR] = ra[i].z;
+        d[3 * STR] = ra[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int f = tid + i * THREADS;
+      if constexpr (!BSrc::KMAJOR) {
+        const int r = f / (BK / 4), kq = f % (BK / 4);
+        *reinterpret_cast<float4*>(sb + r * STR + kq * 4) = rb[i];
+      } else {
+        const int klo = f & 7, g = f >> 3;
+        const int r4 = g % (BN / 4), kk = (g / (BN / 4)) * 8 + klo;
+        float* d = sb + (r4 * 4) * STR + kk;
+        d[0] = rb[i].x;
+        d[STR] = rb[i].y;
+        d[2 * STR] = rb[i].z;
+        d[3 * STR] = rb[i].w;
+      }
+    }
+  };
+
+  if (nk > 0) {
+    load_tile(ks);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  const int frag_off = (lane & 31) * STR + wk * KW + (lane >> 5) * 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(ks + (kt + 1) * BK);
+    const float* sa = smem + cur * Cfg::BUF_FLOATS + (wm * 32) * STR + frag_off;
+    const float* sb = smem + cur * Cfg::BUF_FLOATS + BM * STR + frag_off;
+#pragma unroll
+    for (int kc = 0; kc < KW / 8; ++kc) {
+      const float4 a4 = *reinterpret_cast<const float4*>(sa + kc * 8);
+      float4 b4[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        b4[j] = *reinterpret_cast<const float4*>(sb + j * 32 * STR + kc * 8);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[j].x, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[j].y, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[j].z, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[j].w, acc[j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  if constexpr (Cfg::WK > 1) {
+    // intra-block split-K: waves wk>0 park their partial sums in LDS, wk==0 adds them.
+    float* red = smem;
+    if (wk > 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          red[((((wk - 1) * WM + wm) * NT + j) * 16 + r) * 64 + lane] = acc[j][r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int w = 0; w < Cfg::WK - 1; ++w)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] += red[(((w * WM + wm) * NT + j) * 16 + r) * 64 + lane];
+  }
+
+  epi(acc, row_base + wm * 32, col_base, lane, M, N);
+}
+
+// ---------------------------------------------------------------------------
+// Generic epilogues
+// ---------------------------------------------------------------------------
+enum { VD_ACT_NONE = 0, VD_ACT_TANH = 1 };
+
+// C = act(acc + bias[col]) (or C += ...).  One block owns each C element (no split-K).
+template <int NT>
+struct EpiStore {
+  float* C;
+  long ldc;
+  const float* bias;  // nullable
+  int act;
+  int accumulate;
+  __device__ __forceinline__ void operator()(const f32x16 (&acc)[NT], int row0, int col0, int lane, int M,
+                                             int N) const {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = col0 + j * 32 + (lane & 31);
+      if (col >= N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + mfma_row(r, lane);
+        if (row >= M) continue;
+        float v = acc[j][r] + bv;
+        if (act == VD_ACT_TANH) v = tanhf(v);
+        float* d = C + (long)row * ldc + col;
+        if (accumulate) v += *d;
+        *d = v;
+      }
+    }
+  }
+};
+
+// C += acc with hardware float atomics (split-K partial sums into a gradient buffer).
+template <int NT>
+struct EpiAtomic {
+  float* C;
+  long ldc;
+  __device__ __forceinline__ void operator()(const f32x16 (&acc)[NT], int row0, int col0, int lane, int M,
+                                             int N) const {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = col0 + j * 32 + (lane & 31);
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + mfma_row(r, lane);
+        if (row >= M) continue;
+        unsafeAtomicAdd(C + (long)row * ldc + col, acc[j][r]);
+      }
+    }
+  }
+};
+
+// host-side launcher
+template <class Cfg, class ASrc, class BSrc, class Epi>
+static int launch_gemm(int M, int N, int K, int splits, ASrc a, BSrc b, Epi e, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return VD_OK;
+  const int tiles_m = vd_cdiv(M, Cfg::BM), tiles_n = vd_cdiv(N, Cfg::BN);
+  if (splits < 1) splits = 1;
+  int kchunk = K > 0 ? vd_cdiv(vd_cdiv(K, splits), Cfg::BK) * Cfg::BK : Cfg::BK;
+  if (K > 0) splits = vd_cdiv(K, kchunk);
+  else splits = 1;
+  auto kern = gemm_f32_kernel<Cfg, ASrc, BSrc, Epi>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               Cfg::LDS_BYTES));
+    attr_set = true;
+  }
+  const int grid = tiles_m * tiles_n * splits;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, M, N, K, kchunk, tiles_m,
+                     tiles_n, a, b, e);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}

@@ -1,0 +1,110 @@
+// C-ABI entry points for the plain (non-recurrent) fp32 MFMA GEMMs: the Linear layers
+// of the encoders (nn.Linear y = x*W^T + b, weight [out x in]), the
+// hoisted LSTM input projections, and every weight-gradient contraction.
+#include "gemm_core.h"
+
+using CfgBig = GemmCfg<4, 1, 4, 32>;    // 128 x 128 tile
+using CfgSmall = GemmCfg<1, 4, 1, 32>;  // 32 x 32 tile, 4-way intra-block split-K (latency shapes)
+
+static inline bool use_small(int M, int N) {
+  return (long)vd_cdiv(M, CfgBig::BM) * vd_cdiv(N, CfgBig::BN) < 48;
+}
+
+static int check_align(const void* p, long ld, const char* what) {
+  if (((uintptr_t)p & 15) != 0 || (ld & 3) != 0) {
+    vd_set_error("%s: pointer must be 16-byte aligned and leading dimension a multiple of 4 (ld=%ld)", what, ld);
+    return VD_ERR_ARG;
+  }
+  return VD_OK;
+}
+
+// column sums: out[col] += sum_rows X[row][col]
+__global__ void colsum_kernel(const float* __restrict__ X, long ld, int M, int N, int rows_per_block,
+                              float* __restrict__ out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N) return;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
+    s0 += X[(long)r * ld + col];
+    s1 += X[(long)(r + 1) * ld + col];
+    s2 += X[(long)(r + 2) * ld + col];
+    s3 += X[(long)(r + 3) * ld + col];
+  }
+  for (; r < r1; ++r) s0 += X[(long)r * ld + col];
+  unsafeAtomicAdd(out + col, (s0 + s1) + (s2 + s3));
+}
+
+extern "C" {
+
+// C[M x N] (+)= act(A[M x K] * W[N x K]^T + bias)
+int vd_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C,
+               int64_t ldc, int M, int N, int K, int act, int accumulate, void* stream) {
+  VD_CHECK_ARG(A && W && C && M >= 0 && N >= 0 && K >= 0 && K % 4 == 0, "vd_gemm_nt: bad args M=%d N=%d K=%d", M,
+               N, K);
+  if (int rc = check_align(A, lda, "vd_gemm_nt A")) return rc;
+  if (int rc = check_align(W, ldw, "vd_gemm_nt W")) return rc;
+  SrcRow a{A, lda}, b{W, ldw};
+  hipStream_t s = (hipStream_t)stream;
+  if (use_small(M, N)) {
+    EpiStore<1> e{C, ldc, bias, act, accumulate};
+    return launch_gemm<CfgSmall>(M, N, K, 1, a, b, e, s);
+  }
+  EpiStore<4> e{C, ldc, bias, act, accumulate};
+  return launch_gemm<CfgBig>(M, N, K, 1, a, b, e, s);
+}
+
+// C[M x N] (+)= A[M x K] * B[K x N] + bias
+int vd_gemm_nn(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
+               int64_t ldc, int M, int N, int K, int accumulate, void* stream) {
+  VD_CHECK_ARG(A && B && C && M >= 0 && N >= 0 && K >= 0 && K % 4 == 0 && N % 4 == 0,
+               "vd_gemm_nn: bad args M=%d N=%d K=%d", M, N, K);
+  if (int rc = check_align(A, lda, "vd_gemm_nn A")) return rc;
+  if (int rc = check_align(B, ldb, "vd_gemm_nn B")) return rc;
+  SrcRow a{A, lda};
+  SrcK b{B, ldb};
+  hipStream_t s = (hipStream_t)stream;
+  if (use_small(M, N)) {
+    EpiStore<1> e{C, ldc, bias, VD_ACT_NONE, accumulate};
+    return launch_gemm<CfgSmall>(M, N, K, 1, a, b, e, s);
+  }
+  EpiStore<4> e{C, ldc, bias, VD_ACT_NONE, accumulate};
+  return launch_gemm<CfgBig>(M, N, K, 1, a, b, e, s);
+}
+
+// C[M x N] += A[K x M]^T * B[K x N]   (weight gradients; split-K with float atomics)
+int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
+                   int N, int K, void* stream) {
+  VD_CHECK_ARG(A && B && C && M >= 0 && N >= 0 && K >= 0 && M % 4 == 0 && N % 4 == 0,
+               "vd_gemm_tn_acc: bad args M=%d N=%d K=%d", M, N, K);
+  if (int rc = check_align(A, lda, "vd_gemm_tn_acc A")) return rc;
+  if (int rc = check_align(B, ldb, "vd_gemm_tn_acc B")) return rc;
+  if (K == 0) return VD_OK;
+  SrcK a{A, lda}, b{B, ldb};
+  EpiAtomic<4> e{C, ldc};
+  const long tiles = (long)vd_cdiv(M, CfgBig::BM) * vd_cdiv(N, CfgBig::BN);
+  long splits = vd_cdiv(1024, tiles);
+  const long max_splits = vd_cdiv(K, 4 * CfgBig::BK);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  return launch_gemm<CfgBig>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
+}
+
+// out[N] += column sums of X[M x N]  (bias gradients)
+int vd_colsum_acc(const float* X, int64_t ld, int M, int N, float* out, void* stream) {
+  VD_CHECK_ARG(X && out && M >= 0 && N >= 0, "vd_colsum_acc: bad args");
+  if (M == 0 || N == 0) return VD_OK;
+  const int cb = vd_cdiv(N, 256);
+  int rb = vd_cdiv(1024, cb);
+  int rows_per_block = vd_cdiv(M, rb);
+  if (rows_per_block < 16) rows_per_block = 16;
+  rb = vd_cdiv(M, rows_per_block);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cb, rb), dim3(256), 0, (hipStream_t)stream, X, ld, M, N,
+                     rows_per_block, out);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+}  // extern "C"

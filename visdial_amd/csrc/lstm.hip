@@ -1,0 +1,193 @@
+// Fused SeqLSTM timestep kernels (forward + backward) and the sequence drivers.
+//
+// Semantics restated from Element-Research rnn `nn.SeqLSTM` as used by the reference
+// (encoders/mn-att-ques-im-hist.lua:27-45, decoders/disc.lua:4-15, decoders/gen.lua:17-22;
+// SURVEY.md App. A1): weight [(D+H) x 4H] with gate column order i,f,o,g; per step
+//   a = b + x_t*Wx + h_{t-1}*Wh ; i,f,o = sigmoid ; g = tanh ; c = f*c_prev + i*g ; h = o*tanh(c)
+// maskZero(): rows whose step input is all-zero (<=> token id 0) get h = c = gates = 0.
+//
+// MI355X mapping: the input projection x_t*Wx + b is hoisted out of the recurrence
+// (one batched GEMM, or a gather from the [V+1 x 4H] table Emb*Wx+b for the option
+// LSTM), so a timestep is ONE kernel: h_{t-1}[N x H] * Wh[H x 4H] on fp32 MFMA with
+// the gate columns interleaved so each wave strip holds i,f,o,g of 32 hidden units,
+// and the whole cell update (+ mask) runs in the epilogue on the accumulator registers.
+#include "gemm_core.h"
+
+// ---------------------------------------------------------------------------
+// forward epilogue: acc[g] = (h_prev*Wh)[row, g*H + j]
+// ---------------------------------------------------------------------------
+struct EpiLstmFwd {
+  const float* xproj;  // dense: [N x 4H] rows (ld = xld); table mode: table base [V+1 x 4H]
+  long xld;
+  const int* tok_gather;  // nullable; if set, x row = xproj + tok_gather[row]*xld
+  const int* tok_mask;    // nullable; row is masked (zero state) when tok_mask[row] == 0
+  const float* c_prev;    // nullable -> zeros
+  float* gates;           // [N x 4H] post-activation i,f,o,g
+  float* c_out;           // [N x H]
+  float* h_out;           // [N x H]
+  int H;
+  __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int vcol0, int lane, int M,
+                                             int /*Nv*/) const {
+    const int j = (vcol0 >> 7) * 32 + (lane & 31);
+    if (j >= H) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + mfma_row(r, lane);
+      if (row >= M) continue;
+      const float* xr = xproj + (tok_gather ? (long)tok_gather[row] : (long)row) * xld;
+      float gi, gf, go, gg, c, h;
+      if (tok_mask && tok_mask[row] == 0) {
+        gi = gf = go = gg = c = h = 0.f;
+      } else {
+        gi = vd_sigmoid(acc[0][r] + xr[j]);
+        gf = vd_sigmoid(acc[1][r] + xr[H + j]);
+        go = vd_sigmoid(acc[2][r] + xr[2 * H + j]);
+        gg = tanhf(acc[3][r] + xr[3 * H + j]);
+        const float cp = c_prev ? c_prev[(long)row * H + j] : 0.f;
+        c = gf * cp + gi * gg;
+        h = go * tanhf(c);
+      }
+      float* gr = gates + (long)row * 4 * H;
+      gr[j] = gi;
+      gr[H + j] = gf;
+      gr[2 * H + j] = go;
+      gr[3 * H + j] = gg;
+      c_out[(long)row * H + j] = c;
+      h_out[(long)row * H + j] = h;
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// backward epilogue: acc = (da_{t+1} * Wh^T)[row, j]  (zero at the last step)
+//   dh = acc + dh_a + dh_b ; tc = tanh(c_t)
+//   dc = dc_next + dh*o*(1-tc^2)
+//   da_i = dc*g*i(1-i) ; da_f = dc*c_prev*f(1-f) ; da_o = dh*tc*o(1-o) ; da_g = dc*i*(1-g^2)
+//   dc_next <- dc*f
+// da_t overwrites the saved gates of step t in place.
+// ---------------------------------------------------------------------------
+template <int NT>
+struct EpiLstmBwd {
+  const float* dh_a;  // nullable [N x H]
+  const float* dh_b;  // nullable [N x H]
+  float* gates;       // [N x 4H] in: gates_t, out: da_t
+  const float* c_t;   // [N x H]
+  const float* c_prev;  // nullable -> zeros
+  float* dc;            // [N x H] in: dc_next (ignored when dc_first), out: dc for step t-1
+  int dc_first;
+  int H;
+  __device__ __forceinline__ void operator()(const f32x16 (&acc)[NT], int row0, int col0, int lane, int M,
+                                             int N) const {
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      const int j = col0 + jt * 32 + (lane & 31);
+      if (j >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + mfma_row(r, lane);
+        if (row >= M) continue;
+        const long o = (long)row * H + j;
+        float dh = acc[jt][r];
+        if (dh_a) dh += dh_a[o];
+        if (dh_b) dh += dh_b[o];
+        float* gr = gates + (long)row * 4 * H;
+        const float gi = gr[j], gf = gr[H + j], go = gr[2 * H + j], gg = gr[3 * H + j];
+        const float tc = tanhf(c_t[o]);
+        const float cp = c_prev ? c_prev[o] : 0.f;
+        float dcv = dc_first ? 0.f : dc[o];
+        dcv += dh * go * (1.f - tc * tc);
+        gr[j] = dcv * gg * gi * (1.f - gi);
+        gr[H + j] = dcv * cp * gf * (1.f - gf);
+        gr[2 * H + j] = dh * tc * go * (1.f - go);
+        gr[3 * H + j] = dcv * gi * (1.f - gg * gg);
+        dc[o] = dcv * gf;
+      }
+    }
+  }
+};
+
+using CfgBig = GemmCfg<4, 1, 4, 32>;     // 128 x 128 tile, throughput shapes
+using CfgFwdSmall = GemmCfg<1, 4, 4, 16>;  // 32 x (32 j x 4 gates), 4-way intra-block split-K
+using CfgBwdSmall = GemmCfg<1, 4, 1, 32>;  // 32 x 32 tile, 4-way intra-block split-K
+
+static int lstm_step_fwd(const float* h_prev, const float* Wh, int N, int H, int K, const EpiLstmFwd& epi,
+                         hipStream_t s) {
+  SrcRow a{h_prev, H};
+  SrcKGate4 b{Wh, 4L * H, H};
+  if (N >= 2048)
+    return launch_gemm<CfgBig>(N, 4 * H, K, 1, a, b, epi, s);
+  return launch_gemm<CfgFwdSmall>(N, 4 * H, K, 1, a, b, epi, s);
+}
+
+static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, int K, const float* dh_a,
+                         const float* dh_b, float* gates, const float* c_t, const float* c_prev, float* dc,
+                         int dc_first, hipStream_t s) {
+  SrcRow a{da_next, 4L * H};
+  SrcRow b{Wh, 4L * H};  // B[k][n] = Wh[n][k]
+  if (N >= 2048) {
+    EpiLstmBwd<4> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
+    return launch_gemm<CfgBig>(N, H, K, 1, a, b, e, s);
+  }
+  EpiLstmBwd<1> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
+  return launch_gemm<CfgBwdSmall>(N, H, K, 1, a, b, e, s);
+}
+
+extern "C" {
+
+// see include/visdial_hip.h
+int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const int32_t* tok_gather,
+                    const int32_t* tok_mask, const float* Wh, const float* h0, const float* c0, float* gates,
+                    float* h, float* c, int T, int N, int H, void* stream) {
+  VD_CHECK_ARG(T >= 0 && N >= 0 && H > 0 && H % 32 == 0, "vd_lstm_forward: bad dims T=%d N=%d H=%d", T, N, H);
+  VD_CHECK_ARG(xproj && Wh && gates && h && c, "vd_lstm_forward: null pointer");
+  VD_CHECK_ARG((h0 == nullptr) == (c0 == nullptr), "vd_lstm_forward: h0 and c0 must both be set or both null");
+  VD_CHECK_ARG(x_ld % 4 == 0, "vd_lstm_forward: x_ld must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  const long NH = (long)N * H;
+  for (int t = 0; t < T; ++t) {
+    const float* hp = t ? h + (t - 1) * NH : h0;
+    const float* cp = t ? c + (t - 1) * NH : c0;
+    EpiLstmFwd e;
+    e.xproj = xproj + (long)t * x_tstride;
+    e.xld = x_ld;
+    e.tok_gather = tok_gather ? tok_gather + (long)t * N : nullptr;
+    e.tok_mask = tok_mask ? tok_mask + (long)t * N : nullptr;
+    e.c_prev = cp;
+    e.gates = gates + (long)t * 4 * NH;
+    e.c_out = c + t * NH;
+    e.h_out = h + t * NH;
+    e.H = H;
+    int rc = lstm_step_fwd(hp, Wh, N, H, hp ? H : 0, e, s);
+    if (rc) return rc;
+  }
+  return VD_OK;
+}
+
+int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float* c0, const float* dh_seq,
+                     const float* dh_last, const float* dc_last, float* dc_work, float* dh0, int T, int N,
+                     int H, void* stream) {
+  VD_CHECK_ARG(T >= 1 && N >= 0 && H > 0 && H % 32 == 0, "vd_lstm_backward: bad dims T=%d N=%d H=%d", T, N, H);
+  VD_CHECK_ARG(Wh && gates && c && dc_work, "vd_lstm_backward: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const long NH = (long)N * H;
+  if (dc_last) VD_HIP(hipMemcpyAsync(dc_work, dc_last, NH * sizeof(float), hipMemcpyDeviceToDevice, s));
+  for (int t = T - 1; t >= 0; --t) {
+    const bool last = (t == T - 1);
+    const float* da_next = last ? nullptr : gates + (long)(t + 1) * 4 * NH;
+    int rc = lstm_step_bwd(da_next, Wh, N, H, last ? 0 : 4 * H, dh_seq ? dh_seq + t * NH : nullptr,
+                           last ? dh_last : nullptr, gates + (long)t * 4 * NH, c + t * NH,
+                           t ? c + (t - 1) * NH : c0, dc_work, (last && !dc_last) ? 1 : 0, s);
+    if (rc) return rc;
+  }
+  if (dh0) {
+    // gradient w.r.t. the initial hidden state: da_0 * Wh^T (dc_work already holds dL/dc0)
+    SrcRow a{gates, 4L * H};
+    SrcRow b{Wh, 4L * H};
+    EpiStore<4> e{dh0, H, nullptr, VD_ACT_NONE, 0};
+    int rc = launch_gemm<CfgBig>(N, H, 4 * H, 1, a, b, e, s);
+    if (rc) return rc;
+  }
+  return VD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+"""Thin torch-tensor wrappers over the C ABI (include/visdial_hip.h).
+
+torch is plumbing only here: it owns device memory and the current HIP stream; every
+computation is a call into libvisdial_hip.so.  All tensors must be contiguous CUDA(HIP)
+tensors of the documented dtype (float32 / int32 / uint8).
+"""
+import torch
+
+from . import _lib
+
+call = _lib.call
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t, dtype=None):
+    if t is None:
+        return None
+    assert t.is_cuda, "device tensor expected"
+    assert t.is_contiguous(), "contiguous tensor expected"
+    if dtype is not None:
+        assert t.dtype == dtype, "expected %s got %s" % (dtype, t.dtype)
+    return t.data_ptr()
+
+
+F32, I32, U8 = torch.float32, torch.int32, torch.uint8
+
+
+# ---------------------------------------------------------------- dense contractions
+def gemm_nt(A, W, C_out, bias=None, act=0, accumulate=False, M=None, N=None, K=None, lda=None, ldw=None, ldc=None):
+    """C[MxN] (+)= act(A[MxK] @ W[NxK].T + bias)"""
+    M = A.shape[0] if M is None else M
+    K = A.shape[1] if K is None else K
+    N = W.shape[0] if N is None else N
+    call("vd_gemm_nt", _p(A, F32), lda or A.stride(0), _p(W, F32), ldw or W.stride(0), _p(bias, F32), _p(C_out, F32),
+         ldc or C_out.stride(0), M, N, K, act, int(accumulate), _stream())
+    return C_out
+
+
+def gemm_nn(A, B, C_out, bias=None, accumulate=False, M=None, N=None, K=None, lda=None, ldb=None, ldc=None):
+    """C[MxN] (+)= A[MxK] @ B[KxN] + bias"""
+    M = A.shape[0] if M is None else M
+    K = A.shape[1] if K is None else K
+    N = B.shape[1] if N is None else N
+    call("vd_gemm_nn", _p(A, F32), lda or A.stride(0), _p(B, F32), ldb or B.stride(0), _p(bias, F32), _p(C_out, F32),
+         ldc or C_out.stride(0), M, N, K, int(accumulate), _stream())
+    return C_out
+
+
+def gemm_tn_acc(A, B, C_acc, M=None, N=None, K=None, lda=None, ldb=None, ldc=None):
+    """C[MxN] += A[KxM].T @ B[KxN]"""
+    K = A.shape[0] if K is None else K
+    M = A.shape[1] if M is None else M
+    N = B.shape[1] if N is None else N
+    call("vd_gemm_tn_acc", _p(A, F32), lda or A.stride(0), _p(B, F32), ldb or B.stride(0), _p(C_acc, F32),
+         ldc or C_acc.stride(0), M, N, K, _stream())
+    return C_acc
+
+
+def colsum_acc(X, out, M=None, N=None, ld=None):
+    M = X.shape[0] if M is None else M
+    N = X.shape[1] if N is None else N
+    call("vd_colsum_acc", _p(X, F32), ld or X.stride(0), M, N, _p(out, F32), _stream())
+    return out
+
+
+# ---------------------------------------------------------------- LSTM
+def lstm_forward(xproj, Wh, gates, h, c, T, N, H, x_tstride, x_ld, tok_gather=None, tok_mask=None, h0=None, c0=None):
+    call("vd_lstm_forward", _p(xproj, F32), x_tstride, x_ld, _p(tok_gather, I32), _p(tok_mask, I32), _p(Wh, F32),
+         _p(h0, F32), _p(c0, F32), _p(gates, F32), _p(h, F32), _p(c, F32), T, N, H, _stream())
+
+
+def lstm_backward(Wh, gates, c, dc_work, T, N, H, c0=None, dh_seq=None, dh_last=None, dc_last=None, dh0=None):
+    call("vd_lstm_backward", _p(Wh, F32), _p(gates, F32), _p(c, F32), _p(c0, F32), _p(dh_seq, F32), _p(dh_last, F32),
+         _p(dc_last, F32), _p(dc_work, F32), _p(dh0, F32), T, N, H, _stream())
+
+
+# ---------------------------------------------------------------- embedding / dropout / glue
+def embed_gather(emb, tok, out, mask=None, scale=1.0):
+    rows = tok.numel()
+    call("vd_embed_gather", _p(emb, F32), _p(tok, I32), _p(mask, U8), _p(out, F32), rows, emb.shape[1], float(scale),
+         _stream())
+    return out
+
+
+def embed_scatter_acc(demb, tok, dx, mask=None, scale=1.0):
+    rows = tok.numel()
+    call("vd_embed_scatter_acc", _p(demb, F32), _p(tok, I32), _p(mask, U8), _p(dx, F32), rows, demb.shape[1],
+         float(scale), _stream())
+
+
+def token_sort(tok, V, offset, work, perm):
+    call("vd_token_sort", _p(tok, I32), tok.numel(), V, _p(offset, I32), _p(work, I32), _p(perm, I32), _stream())
+
+
+def segment_rowsum_acc(X, tok, perm, out, ncol=None):
+    ncol = X.shape[1] if ncol is None else ncol
+    call("vd_segment_rowsum_acc", _p(X, F32), X.stride(0), _p(tok, I32), _p(perm, I32), tok.numel(), ncol,
+         _p(out, F32), out.stride(0), _stream())
+
+
+def dropout_mask(mask, seed, p):
+    call("vd_dropout_mask", _p(mask, U8), mask.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), _stream())
+    return mask
+
+
+def dropout_apply(x, mask, y, scale):
+    call("vd_dropout_apply", _p(x, F32), _p(mask, U8), _p(y, F32), x.numel(), float(scale), _stream())
+    return y
+
+
+def tanh_backward(dy, y, dx):
+    call("vd_tanh_backward", _p(dy, F32), _p(y, F32), _p(dx, F32), y.numel(), _stream())
+    return dx
+
+
+def axpby(a, b, c, alpha=1.0, beta=1.0):
+    call("vd_axpby", _p(a, F32), _p(b, F32), _p(c, F32), a.numel(), float(alpha), float(beta), _stream())
+    return c
+
+
+# ---------------------------------------------------------------- attention
+def mn_attention_forward(Q, Hm, mask, P, hAtt, B, R, H):
+    call("vd_mn_attention_forward", _p(Q, F32), _p(Hm, F32), _p(mask, U8), _p(P, F32), _p(hAtt, F32), B, R, H,
+         _stream())
+
+
+def mn_attention_backward(Q, Hm, P, dhAtt, dQ, dHm, B, R, H):
+    call("vd_mn_attention_backward", _p(Q, F32), _p(Hm, F32), _p(P, F32), _p(dhAtt, F32), _p(dQ, F32), _p(dHm, F32),
+         B, R, H, _stream())
+
+
+def img_common_forward(pre, mask1, Wc, bc, qc, mask2, iqc, N, R, S2, H, Kc, scale):
+    call("vd_img_common_forward", _p(pre, F32), _p(mask1, U8), _p(Wc, F32), _p(bc, F32), _p(qc, F32), _p(mask2, U8),
+         _p(iqc, F32), N, R, S2, H, Kc, float(scale), _stream())
+
+
+def img_att_forward(iqc, wa, ba, pre, mask1, u0, p, u1, N, R, S2, H, Kc, scale):
+    call("vd_img_att_forward", _p(iqc, F32), _p(wa, F32), _p(ba, F32), _p(pre, F32), _p(mask1, U8), _p(u0, F32),
+         _p(p, F32), _p(u1, F32), N, R, S2, H, Kc, float(scale), _stream())
+
+
+def img_att_backward(iqc_dz, wa, pre, mask1, mask2, p, datt, dwa, dba, dqc, N, R, S2, H, Kc, scale):
+    call("vd_img_att_backward", _p(iqc_dz, F32), _p(wa, F32), _p(pre, F32), _p(mask1, U8), _p(mask2, U8), _p(p, F32),
+         _p(datt, F32), _p(dwa, F32), _p(dba, F32), _p(dqc, F32), N, R, S2, H, Kc, float(scale), _stream())
+
+
+def img_tr_backward(dz, Wc, p, datt, mask1, dpre, N, R, S2, H, Kc, scale):
+    call("vd_img_tr_backward", _p(dz, F32), _p(Wc, F32), _p(p, F32), _p(datt, F32), _p(mask1, U8), _p(dpre, F32), N, R,
+         S2, H, Kc, float(scale), _stream())
+
+
+def img_common_wgrad(dz, pre, mask1, dWc, N, R, S2, H, Kc, scale):
+    call("vd_img_common_wgrad", _p(dz, F32), _p(pre, F32), _p(mask1, U8), _p(dWc, F32), N, R, S2, H, Kc, float(scale),
+         _stream())
+
+
+# ---------------------------------------------------------------- head / optimiser
+def score_ce(optH, enc, scores, N, O, H, gt=None, loss_rows=None, dOptH=None, dEnc=None, gscale=1.0):
+    call("vd_score_ce", _p(optH, F32), _p(enc, F32), _p(gt, I32), _p(scores, F32), _p(loss_rows, F32), _p(dOptH, F32),
+         _p(dEnc, F32), N, O, H, float(gscale), _stream())
+
+
+def ranks(scores, out, N, O):
+    call("vd_ranks", _p(scores, F32), _p(out, I32), N, O, _stream())
+    return out
+
+
+def clamp_adam(w, g, m, v, step, gscale=1.0, clip=5.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    call("vd_clamp_adam", _p(w, F32), _p(g, F32), _p(m, F32), _p(v, F32), w.numel(), float(gscale), float(clip),
+         float(beta1), float(beta2), float(eps), float(step), _stream())
