@@ -78,7 +78,8 @@ def lstm_forward(x, W, b, tok_mask=None, h0=None, c0=None):
     return h_all, c_all, gates
 
 
-def lstm_backward(x, W, gates, h_all, c_all, dh_seq=None, dh_last=None, dc_last=None, h0=None, c0=None):
+def lstm_backward(x, W, gates, h_all, c_all, dh_seq=None, dh_last=None, dc_last=None, h0=None, c0=None,
+                  return_da=False):
     """nn.SeqLSTM backward.  Returns dx [T,N,D], dW, db, dh0, dc0."""
     T, N, D = x.shape
     H = W.shape[1] // 4
@@ -89,6 +90,7 @@ def lstm_backward(x, W, gates, h_all, c_all, dh_seq=None, dh_last=None, dc_last=
     dx = np.zeros_like(x)
     dh_next = np.zeros((N, H), dt)
     dc = np.zeros((N, H), dt) if dc_last is None else dc_last.copy()
+    da_all = np.zeros_like(gates)
     for t in range(T - 1, -1, -1):
         i, f, o, g = (gates[t][:, k * H:(k + 1) * H] for k in range(4))
         dh = dh_next.copy()
@@ -102,12 +104,15 @@ def lstm_backward(x, W, gates, h_all, c_all, dh_seq=None, dh_last=None, dc_last=
         dc = dc + dh * o * (1 - tc * tc)
         da = np.concatenate([dc * g * i * (1 - i), dc * cprev * f * (1 - f), dh * tc * o * (1 - o),
                              dc * i * (1 - g * g)], 1)
+        da_all[t] = da
         dx[t] = da @ Wx.T
         dW[:D] += x[t].T @ da
         dW[D:] += hprev.T @ da
         db += da.sum(0)
         dh_next = da @ Wh.T
         dc = dc * f
+    if return_da:
+        return dx, dW, db, dh_next, dc, da_all
     return dx, dW, db, dh_next, dc
 
 

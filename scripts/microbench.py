@@ -1,0 +1,109 @@
+"""Kernel micro-benchmarks at the headline shapes (mn-att-ques-im-hist + disc, B=20):
+prints achieved TFLOP/s (fp32 MFMA peak 157.3) or GB/s per kernel family."""
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from visdial_amd import ops
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters  # ms
+
+
+def main():
+    dev = "cuda"
+    T, N, H, E, V = 20, 20000, 512, 300, 11322
+    g = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    Wh = rnd(H, 4 * H) * 0.04
+    table = rnd(V + 1, 4 * H) * 0.1
+    tok = torch.randint(0, V + 1, (T, N), device=dev, dtype=torch.int32, generator=g)
+    gates = torch.empty(T, N, 4 * H, device=dev)
+    h = torch.empty(T, N, H, device=dev)
+    c = torch.empty(T, N, H, device=dev)
+    dcw = torch.empty(N, H, device=dev)
+    dh_last = rnd(N, H)
+
+    ms = timeit(lambda: ops.lstm_forward(table, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok))
+    fl = 2.0 * N * H * 4 * H * (T - 1)
+    print("option LSTM fwd  T=20 N=20000: %.2f ms  %.1f TFLOP/s (recurrent GEMM only)" % (ms, fl / ms / 1e9))
+
+    def bwd():
+        ops.lstm_backward(Wh, gates, c, dcw, T, N, H, dh_last=dh_last)
+    ms = timeit(bwd, iters=3, warm=1)
+    print("option LSTM bwd  T=20 N=20000: %.2f ms  %.1f TFLOP/s" % (ms, fl / ms / 1e9))
+
+    dWh = torch.zeros(H, 4 * H, device=dev)
+    hh = h.view(T * N, H)
+    gg = gates.view(T * N, 4 * H)
+    K = (T - 1) * N
+    ms = timeit(lambda: ops.gemm_tn_acc(hh, gg[N:], dWh, M=H, N=4 * H, K=K), iters=3, warm=1)
+    print("dWh tn_acc K=%d: %.2f ms  %.1f TFLOP/s" % (K, ms, 2.0 * H * 4 * H * K / ms / 1e9))
+
+    # encoder-sized recurrent steps (latency-bound)
+    Ns, Ts = 200, 40
+    toks = torch.randint(1, V, (Ts, Ns), device=dev, dtype=torch.int32, generator=g)
+    xp = rnd(Ts, Ns, 4 * H)
+    gs = torch.empty(Ts, Ns, 4 * H, device=dev)
+    hs = torch.empty(Ts, Ns, H, device=dev)
+    cs = torch.empty(Ts, Ns, H, device=dev)
+    ms = timeit(lambda: ops.lstm_forward(xp, Wh, gs, hs, cs, Ts, Ns, H, Ns * 4 * H, 4 * H, tok_mask=toks), iters=10)
+    print("encoder LSTM fwd T=40 N=200: %.3f ms  (%.1f us/step)" % (ms, ms * 1e3 / Ts))
+    dcs = torch.empty(Ns, H, device=dev)
+    dl = rnd(Ns, H)
+    ms = timeit(lambda: ops.lstm_backward(Wh, gs, cs, dcs, Ts, Ns, H, dh_last=dl), iters=10)
+    print("encoder LSTM bwd T=40 N=200: %.3f ms  (%.1f us/step)" % (ms, ms * 1e3 / Ts))
+
+    # image-attention GEMM with fused loader/epilogue
+    B, R, S2, Kc = 20, 10, 196, 512
+    Nn = B * R
+    pre = torch.tanh(rnd(B * S2, H))
+    m1 = torch.randint(0, 2, (Nn * S2, H), device=dev, dtype=torch.uint8, generator=g)
+    m2 = torch.randint(0, 2, (Nn * S2, Kc), device=dev, dtype=torch.uint8, generator=g)
+    Wc, bc, qc = rnd(Kc, H) * 0.04, rnd(Kc), rnd(Nn, Kc)
+    iqc = torch.empty(Nn * S2, Kc, device=dev)
+    ms = timeit(lambda: ops.img_common_forward(pre, m1, Wc, bc, qc, m2, iqc, Nn, R, S2, H, Kc, 2.0))
+    print("img_common fwd [39200x512x512]: %.3f ms  %.1f TFLOP/s" % (ms, 2.0 * Nn * S2 * H * Kc / ms / 1e9))
+
+    # plain GEMMs
+    A = rnd(8000, E)
+    Wx = rnd(E, 4 * H)
+    bx = rnd(4 * H)
+    out = torch.empty(8000, 4 * H, device=dev)
+    ms = timeit(lambda: ops.gemm_nn(A, Wx, out, bias=bx))
+    print("xproj nn [8000x2048x300]: %.3f ms  %.1f TFLOP/s" % (ms, 2.0 * 8000 * 2048 * 300 / ms / 1e9))
+    A2, W2, o2 = rnd(200, H), rnd(H, H), torch.empty(200, H, device=dev)
+    ms = timeit(lambda: ops.gemm_nt(A2, W2, o2, act=1), iters=20)
+    print("linear nt [200x512x512]: %.1f us" % (ms * 1e3))
+
+    # Adam
+    n = 14166821
+    w, gr, m, v = (torch.zeros(n, device=dev) for _ in range(4))
+    ms = timeit(lambda: ops.clamp_adam(w, gr, m, v, 1e-3), iters=10)
+    print("clamp+adam n=%d: %.3f ms  %.0f GB/s" % (n, ms, 28.0 * n / ms / 1e6))
+    # option-table gradient: token sort + segmented row sum
+    tokf = tok.view(-1)
+    offset = torch.empty(V + 2, dtype=torch.int32, device=dev)
+    work = torch.empty(2 * (V + 1), dtype=torch.int32, device=dev)
+    perm = torch.empty(T * N, dtype=torch.int32, device=dev)
+    ms = timeit(lambda: ops.token_sort(tokf, V + 1, offset, work, perm))
+    print("token sort n=%d: %.3f ms" % (T * N, ms))
+    dtab = torch.zeros(V + 1, 4 * H, device=dev)
+    ms = timeit(lambda: ops.segment_rowsum_acc(gg, tokf, perm, dtab), iters=3, warm=1)
+    print("segment rowsum [400000x2048]: %.3f ms  %.0f GB/s" % (ms, 4.0 * T * N * 4 * H / ms / 1e6))
+
+
+if __name__ == "__main__":
+    main()

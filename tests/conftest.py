@@ -17,7 +17,8 @@ def small_params(**kw):
     p = dict(encoder='mn-att-ques-im-hist', decoder='disc', vocabSize=50, embedSize=12, rnnHiddenSize=32,
              numLayers=2, dropout=0.5, imgFeatureSize=16, imgEmbedSize=12, imgSpatialSize=3,
              commonEmbeddingSize=32, numAttentionLayers=1, maxQuesCount=4, maxQuesLen=6, maxAnsLen=5,
-             maxHistoryLenPerRound=8, numOptions=7, batchSize=2, imgNorm=0, learningRate=1e-3)
+             maxHistoryLenPerRound=8, numOptions=7, batchSize=2, imgNorm=0, learningRate=1e-3,
+             lrDecayRate=0.9997592083, minLRate=5e-5)
     p.update(kw)
     return p
 

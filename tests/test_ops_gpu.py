@@ -1,0 +1,324 @@
+"""Operator-level parity: every C-ABI entry point (called through ctypes on device buffers) against
+the numpy oracle on seeded inputs.  fp32 tolerance: rel-L2 <= 1e-5 for single ops (north_star: 1e-4
+end-to-end); integer outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import visdial_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from visdial_amd import ops as o
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def relerr(got, ref):
+    got = got.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(got) else np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    return float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
+
+
+def f32(rng, *shape):
+    return rng.randn(*shape).astype(np.float32)
+
+
+# asymmetric operands everywhere (guide: symmetric inputs hide transposes)
+@pytest.mark.parametrize("M,N,K", [(200, 512, 512), (3920, 512, 512), (260, 300, 300), (33, 40, 4), (1, 512, 2048),
+                                   (5000, 2048, 300)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_gemm_nt(ops, M, N, K, act):
+    rng = np.random.RandomState(M + N + K)
+    A, W, b = f32(rng, M, K), f32(rng, N, K) * 0.1, f32(rng, N)
+    C = torch.zeros(M, N, device="cuda")
+    ops.gemm_nt(dev(A), dev(W), C, bias=dev(b), act=act)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + b
+    if act:
+        ref = np.tanh(ref)
+    assert relerr(C, ref) < 1e-5
+    C0 = f32(rng, M, N)
+    Cd = dev(C0)
+    ops.gemm_nt(dev(A), dev(W), Cd, bias=None, act=0, accumulate=True)
+    assert relerr(Cd, C0 + A.astype(np.float64) @ W.astype(np.float64).T) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(8000, 2048, 300), (200, 2048, 512), (130, 300, 2048), (51, 2048, 12), (4000, 512, 512)])
+def test_gemm_nn(ops, M, N, K):
+    rng = np.random.RandomState(M + N + K + 1)
+    A, B, b = f32(rng, M, K), f32(rng, K, N) * 0.1, f32(rng, N)
+    C = torch.zeros(M, N, device="cuda")
+    ops.gemm_nn(dev(A), dev(B), C, bias=dev(b))
+    assert relerr(C, A.astype(np.float64) @ B.astype(np.float64) + b) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 2048, 8000), (512, 512, 200), (300, 2048, 11323), (512, 2048, 40000), (12, 128, 37)])
+def test_gemm_tn_acc(ops, M, N, K):
+    rng = np.random.RandomState(M + N + K + 2)
+    A, B = f32(rng, K, M), f32(rng, K, N) * 0.1
+    C0 = f32(rng, M, N)
+    C = dev(C0)
+    ops.gemm_tn_acc(dev(A), dev(B), C)
+    assert relerr(C, C0 + A.astype(np.float64).T @ B.astype(np.float64)) < 1e-5
+
+
+def test_colsum(ops):
+    rng = np.random.RandomState(0)
+    X = f32(rng, 8001, 2048)
+    out0 = f32(rng, 2048)
+    out = dev(out0)
+    ops.colsum_acc(dev(X), out)
+    assert relerr(out, out0 + X.astype(np.float64).sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("T,N,H,masked,table", [(5, 200, 64, True, False), (4, 2500, 64, False, True),
+                                                (3, 2100, 512, True, False), (6, 37, 32, True, False)])
+def test_lstm_forward_backward(ops, T, N, H, masked, table):
+    rng = np.random.RandomState(T * 1000 + N + H)
+    D = 20
+    V = 30
+    emb = f32(rng, V + 1, D)
+    emb[0] = 0
+    tok = rng.randint(0, V + 1, size=(T, N)).astype(np.int32)
+    if masked:   # right-aligned: leading pads
+        lens = rng.randint(0, T + 1, size=N)
+        for n in range(N):
+            tok[:T - lens[n], n] = 0
+            tok[T - lens[n]:, n] = np.maximum(tok[T - lens[n]:, n], 1)
+    x = emb[tok]
+    W = (f32(rng, D + H, 4 * H) / np.sqrt(D + H)).astype(np.float32)
+    b = f32(rng, 4 * H) * 0.1
+    h_ref, c_ref, g_ref = vo.lstm_forward(x.astype(np.float64), W.astype(np.float64), b.astype(np.float64),
+                                          tok if masked else None)
+    Wh = dev(W[D:])
+    gates = torch.empty(T, N, 4 * H, device="cuda")
+    h = torch.empty(T, N, H, device="cuda")
+    c = torch.empty(T, N, H, device="cuda")
+    tok_d = dev(tok)
+    if table:
+        tab = (emb.astype(np.float64) @ W[:D].astype(np.float64) + b).astype(np.float32)
+        ops.lstm_forward(dev(tab), Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok_d,
+                         tok_mask=tok_d if masked else None)
+    else:
+        xp = (x.reshape(T * N, D).astype(np.float64) @ W[:D].astype(np.float64) + b).astype(np.float32)
+        ops.lstm_forward(dev(xp), Wh, gates, h, c, T, N, H, N * 4 * H, 4 * H, tok_mask=tok_d if masked else None)
+    torch.cuda.synchronize()
+    assert relerr(h, h_ref) < 1e-5 and relerr(c, c_ref) < 1e-5 and relerr(gates, g_ref) < 1e-5
+
+    dh_seq = f32(rng, T, N, H)
+    dh_last = f32(rng, N, H)
+    _, _, _, dh0_ref, dc0_ref, da_ref = vo.lstm_backward(
+        x.astype(np.float64), W.astype(np.float64), g_ref, h_ref, c_ref, dh_seq=dh_seq.astype(np.float64),
+        dh_last=dh_last.astype(np.float64), return_da=True)
+    # feed the device its own forward state (already checked above)
+    dc_work = torch.empty(N, H, device="cuda")
+    dh0 = torch.empty(N, H, device="cuda")
+    ops.lstm_backward(Wh, gates, c, dc_work, T, N, H, dh_seq=dev(dh_seq), dh_last=dev(dh_last), dh0=dh0)
+    torch.cuda.synchronize()
+    assert relerr(gates, da_ref) < 2e-5
+    assert relerr(dc_work, dc0_ref) < 2e-5
+    assert relerr(dh0, dh0_ref) < 2e-5
+
+
+def test_embed_gather_scatter(ops):
+    rng = np.random.RandomState(1)
+    V, E, rows = 40, 300, 1234
+    emb = f32(rng, V + 1, E)
+    emb[0] = 0
+    tok = rng.randint(0, V + 1, size=rows).astype(np.int32)
+    mask = (rng.rand(rows, E) > 0.5).astype(np.uint8)
+    out = torch.empty(rows, E, device="cuda")
+    ops.embed_gather(dev(emb), dev(tok), out, mask=dev(mask), scale=2.0)
+    np.testing.assert_array_equal(out.cpu().numpy(), emb[tok] * mask * 2.0)
+    ops.embed_gather(dev(emb), dev(tok), out)
+    np.testing.assert_array_equal(out.cpu().numpy(), emb[tok])
+    dx = f32(rng, rows, E)
+    demb = torch.zeros(V + 1, E, device="cuda")
+    ops.embed_scatter_acc(demb, dev(tok), dev(dx), mask=dev(mask), scale=2.0)
+    ref = np.zeros((V + 1, E))
+    vo.lookup_backward(ref, tok, dx.astype(np.float64) * mask * 2.0)
+    assert relerr(demb, ref) < 1e-5
+
+
+def test_token_sort_and_segment_sum(ops):
+    rng = np.random.RandomState(2)
+    V1, n, ncol = 57, 5000, 256
+    tok = rng.randint(0, V1, size=n).astype(np.int32)
+    tok[rng.rand(n) < 0.5] = 0     # a dominant pad token
+    offset = torch.empty(V1 + 1, dtype=torch.int32, device="cuda")
+    work = torch.empty(2 * V1, dtype=torch.int32, device="cuda")
+    perm = torch.empty(n, dtype=torch.int32, device="cuda")
+    tok_d = dev(tok)
+    ops.token_sort(tok_d, V1, offset, work, perm)
+    pm = perm.cpu().numpy()
+    assert sorted(pm.tolist()) == list(range(n))                       # a permutation
+    assert np.all(np.diff(tok[pm]) >= 0)                               # sortedness
+    np.testing.assert_array_equal(offset.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(tok, minlength=V1))]))
+    X = f32(rng, n, ncol)
+    out = torch.zeros(V1, ncol, device="cuda")
+    ops.segment_rowsum_acc(dev(X), tok_d, perm, out)
+    ref = np.zeros((V1, ncol))
+    np.add.at(ref, tok, X.astype(np.float64))
+    assert relerr(out, ref) < 1e-5
+
+
+def test_dropout_and_glue(ops):
+    n = 1000003
+    mask = torch.empty(n + 1, dtype=torch.uint8, device="cuda")[:n]
+    ops.dropout_mask(mask, 1234, 0.5)
+    m = mask.cpu().numpy()
+    assert set(np.unique(m).tolist()) <= {0, 1} and abs(m.mean() - 0.5) < 5e-3
+    m2 = torch.empty_like(mask)
+    ops.dropout_mask(m2, 1234, 0.5)
+    assert torch.equal(mask, m2)                                        # replayable
+    ops.dropout_mask(m2, 1235, 0.5)
+    assert not torch.equal(mask, m2)
+    rng = np.random.RandomState(3)
+    x, y = f32(rng, 4097), f32(rng, 4097)
+    mk = (rng.rand(4097) > 0.5).astype(np.uint8)
+    out = torch.empty(4097, device="cuda")
+    ops.dropout_apply(dev(x), dev(mk), out, 2.0)
+    np.testing.assert_array_equal(out.cpu().numpy(), x * mk * 2.0)
+    t = np.tanh(x)
+    ops.tanh_backward(dev(y), dev(t), out)
+    np.testing.assert_allclose(out.cpu().numpy(), y * (1 - t * t), rtol=1e-6, atol=1e-7)
+    ops.axpby(dev(x), dev(y), out, 0.5, -2.0)
+    np.testing.assert_allclose(out.cpu().numpy(), 0.5 * x - 2.0 * y, rtol=1e-6)
+
+
+def test_mn_attention(ops):
+    rng = np.random.RandomState(4)
+    B, R, H = 7, 10, 512
+    q, h = f32(rng, B, R, H) * 0.2, f32(rng, B, R, H) * 0.2
+    mask = vo.causal_mask(B, R)
+    p_ref, hatt_ref = vo.mn_attention_forward(q.astype(np.float64), h.astype(np.float64), mask)
+    P = torch.empty(B, R, R, device="cuda")
+    hatt = torch.empty(B, R, H, device="cuda")
+    ops.mn_attention_forward(dev(q), dev(h), dev(mask), P, hatt, B, R, H)
+    assert relerr(P, p_ref) < 1e-5 and relerr(hatt, hatt_ref) < 1e-5
+    assert float(P.cpu().numpy()[:, 0, 1:].max()) == 0.0               # hidden facts get exactly zero
+    dh = f32(rng, B, R, H)
+    dq_ref, dh_ref = vo.mn_attention_backward(q.astype(np.float64), h.astype(np.float64), p_ref, dh.astype(np.float64))
+    dQ = torch.empty(B, R, H, device="cuda")
+    dH = torch.empty(B, R, H, device="cuda")
+    ops.mn_attention_backward(dev(q), dev(h), P, dev(dh), dQ, dH, B, R, H)
+    assert relerr(dQ, dq_ref) < 1e-5 and relerr(dH, dh_ref) < 1e-5
+
+
+@pytest.mark.parametrize("use_drop", [False, True])
+def test_image_attention(ops, use_drop):
+    rng = np.random.RandomState(5)
+    B, R, S2, H, Kc = 3, 4, 49, 64, 96
+    N = B * R
+    pre = np.tanh(f32(rng, B * S2, H))
+    m1 = (rng.rand(N * S2, H) > 0.5).astype(np.uint8) if use_drop else None
+    m2 = (rng.rand(N * S2, Kc) > 0.5).astype(np.uint8) if use_drop else None
+    Wc, bc = f32(rng, Kc, H) * 0.1, f32(rng, Kc) * 0.1
+    qc = f32(rng, N, Kc) * 0.5
+    wa, ba = f32(rng, Kc) * 0.3, f32(rng, 1)
+    u0 = f32(rng, N, H)
+    sc = 2.0 if use_drop else 1.0
+    d64 = np.float64
+    img_tr = np.repeat(pre.reshape(B, 1, S2, H), R, 1).reshape(N * S2, H).astype(d64)
+    if use_drop:
+        img_tr = img_tr * m1 * 2.0
+    t_iqc = np.tanh(img_tr @ Wc.astype(d64).T + bc + np.repeat(qc.astype(d64), S2, 0))
+    iqc_ref = t_iqc * m2 * 2.0 if use_drop else t_iqc
+    score = (iqc_ref @ wa.astype(d64) + ba[0]).reshape(N, S2)
+    e = np.exp(score - score.max(1, keepdims=True))
+    p_ref = e / e.sum(1, keepdims=True)
+    att = np.einsum('ns,nsh->nh', p_ref, img_tr.reshape(N, S2, H))
+    u1_ref = att + u0
+
+    pre_d, m1_d, m2_d = dev(pre), (dev(m1) if use_drop else None), (dev(m2) if use_drop else None)
+    iqc = torch.empty(N * S2, Kc, device="cuda")
+    ops.img_common_forward(pre_d, m1_d, dev(Wc), dev(bc), dev(qc), m2_d, iqc, N, R, S2, H, Kc, sc)
+    assert relerr(iqc, iqc_ref) < 1e-5
+    p = torch.empty(N, S2, device="cuda")
+    u1 = torch.empty(N, H, device="cuda")
+    ops.img_att_forward(iqc, dev(wa), dev(ba), pre_d, m1_d, dev(u0), p, u1, N, R, S2, H, Kc, sc)
+    assert relerr(p, p_ref) < 1e-5 and relerr(u1, u1_ref) < 1e-5
+
+    datt = f32(rng, N, H)
+    dp = np.einsum('nh,nsh->ns', datt.astype(d64), img_tr.reshape(N, S2, H))
+    dscore = p_ref * (dp - (p_ref * dp).sum(1, keepdims=True))
+    dwa_ref = np.einsum('ns,nsk->k', dscore, iqc_ref.reshape(N, S2, Kc))
+    diqc = dscore[:, :, None] * wa.astype(d64)[None, None, :]
+    dz_ref = (diqc * (m2.reshape(N, S2, Kc) * 2.0 if use_drop else 1.0)) * (1 - t_iqc.reshape(N, S2, Kc) ** 2)
+    dqc_ref = dz_ref.sum(1)
+    dwa = torch.zeros(Kc, device="cuda")
+    dba = torch.zeros(1, device="cuda")
+    dqc = torch.empty(N, Kc, device="cuda")
+    ops.img_att_backward(iqc, dev(wa), pre_d, m1_d, m2_d, p, dev(datt), dwa, dba, dqc, N, R, S2, H, Kc, sc)
+    assert relerr(iqc, dz_ref.reshape(N * S2, Kc)) < 1e-5
+    assert relerr(dwa, dwa_ref) < 1e-5 and relerr(dqc, dqc_ref) < 1e-5
+    assert abs(float(dba.item()) - dscore.sum()) < 1e-4
+    dimg = p_ref[:, :, None] * datt.astype(d64)[:, None, :] + (dz_ref.reshape(N * S2, Kc) @ Wc.astype(d64)).reshape(N, S2, H)
+    if use_drop:
+        dimg = dimg * m1.reshape(N, S2, H) * 2.0
+    dpre_ref = dimg.reshape(B, R, S2, H).sum(1).reshape(B * S2, H)
+    dpre = torch.zeros(B * S2, H, device="cuda")
+    ops.img_tr_backward(iqc, dev(Wc), p, dev(datt), m1_d, dpre, N, R, S2, H, Kc, sc)
+    assert relerr(dpre, dpre_ref) < 1e-5
+    dWc = torch.zeros(Kc, H, device="cuda")
+    ops.img_common_wgrad(iqc, pre_d, m1_d, dWc, N, R, S2, H, Kc, sc)
+    assert relerr(dWc, dz_ref.reshape(N * S2, Kc).T @ img_tr) < 1e-5
+
+
+def test_score_ce_and_ranks(ops):
+    rng = np.random.RandomState(6)
+    N, O, H = 23, 100, 512
+    optH, enc = f32(rng, N, O, H) * 0.2, f32(rng, N, H) * 0.2
+    gt = rng.randint(0, O, size=N).astype(np.int32)
+    s_ref = np.einsum('noh,nh->no', optH.astype(np.float64), enc.astype(np.float64))
+    loss_ref, ds_ref, rows_ref = vo.cross_entropy(s_ref, gt)
+    scores = torch.empty(N, O, device="cuda")
+    rows = torch.empty(N, device="cuda")
+    dO = torch.empty(N, O, H, device="cuda")
+    dE = torch.empty(N, H, device="cuda")
+    ops.score_ce(dev(optH), dev(enc), scores, N, O, H, gt=dev(gt), loss_rows=rows, dOptH=dO, dEnc=dE, gscale=1.0 / N)
+    assert relerr(scores, s_ref) < 1e-5 and relerr(rows, rows_ref) < 1e-5
+    assert abs(float(rows.mean().item()) - loss_ref) < 1e-5
+    assert relerr(dO, ds_ref[:, :, None] * enc.astype(np.float64)[:, None, :]) < 1e-5
+    assert relerr(dE, np.einsum('no,noh->nh', ds_ref, optH.astype(np.float64))) < 1e-5
+    # ranks: bit-exact against the oracle on the DEVICE scores (incl. forced ties)
+    sc = scores.clone()
+    sc[0, 5] = sc[0, 9]
+    sc[1, :] = 0.25
+    rk = torch.empty(N, O, dtype=torch.int32, device="cuda")
+    ops.ranks(sc, rk, N, O)
+    np.testing.assert_array_equal(rk.cpu().numpy(), vo.compute_ranks(sc.cpu().numpy()))
+
+
+def test_clamp_adam(ops):
+    rng = np.random.RandomState(7)
+    n = 100003
+    w, g = f32(rng, n), f32(rng, n) * 4
+    wd, gd = dev(w), dev(g)
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    st = {}
+    wr = w.astype(np.float64)
+    lr = 1e-3
+    for t in range(1, 4):
+        step = lr * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        ops.clamp_adam(wd, gd, m, v, step)
+        wr, gc = vo.clamp_adam(wr, g.astype(np.float64), st, lr)
+        gd.copy_(dev(g))
+    assert relerr(wd, wr) < 1e-6
+    assert relerr(m, st["m"]) < 5e-5 and relerr(v, st["v"]) < 5e-5
+
+
+def test_error_reporting(ops):
+    from visdial_amd import _lib
+    with pytest.raises(_lib.VisdialHipError):
+        A = torch.zeros(4, 6, device="cuda")
+        ops.gemm_nt(A, A, torch.zeros(4, 4, device="cuda"), K=6)       # K % 4 != 0 -> rejected loudly

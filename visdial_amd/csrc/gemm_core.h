@@ -17,6 +17,8 @@
 // * workgroup id -> tile mapping is XCD-aware (block b runs on XCD b % 8; every XCD
 //   gets a contiguous range of tiles so its private L2 sees a compact working set).
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 template <int WM_, int WK_, int NT_, int KW_>
@@ -86,8 +88,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 template <class Cfg, class ASrc, class BSrc, class Epi>
 __global__ void __launch_bounds__(Cfg::THREADS)
-gemm_f32_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, ASrc asrc, BSrc bsrc,
-                Epi epi) {
+gemm_f32_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, int rotate, ASrc asrc,
+                BSrc bsrc, Epi epi) {
   constexpr int WM = Cfg::WM, NT = Cfg::NT, KW = Cfg::KW;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
   constexpr int THREADS = Cfg::THREADS, STR = Cfg::STRIDE;
@@ -186,8 +188,16 @@ gemm_f32_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, ASrc 
     }
   };
 
+  // K-tile rotation: co-resident blocks start at different K offsets so that power-of-two
+  // row strides do not funnel every block's loads into the same L2/HBM channel at once.
+  const int rot = (rotate && nk > 1) ? (tile_m * 5 + tile_n * 3 + split) % nk : 0;
+  auto ktile = [&](int kt) {
+    int t = kt + rot;
+    if (t >= nk) t -= nk;
+    return ks + t * BK;
+  };
   if (nk > 0) {
-    load_tile(ks);
+    load_tile(ktile(0));
     store_tile(0);
   }
   __syncthreads();
@@ -195,7 +205,7 @@ gemm_f32_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, ASrc 
   const int frag_off = (lane & 31) * STR + wk * KW + (lane >> 5) * 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(ks + (kt + 1) * BK);
+    if (kt + 1 < nk) load_tile(ktile(kt + 1));
     const float* sa = smem + cur * Cfg::BUF_FLOATS + (wm * 32) * STR + frag_off;
     const float* sb = smem + cur * Cfg::BUF_FLOATS + BM * STR + frag_off;
 #pragma unroll
@@ -313,8 +323,13 @@ static int launch_gemm(int M, int N, int K, int splits, ASrc a, BSrc b, Epi e, h
     attr_set = true;
   }
   const int grid = tiles_m * tiles_n * splits;
+  static int rotate = -1;
+  if (rotate < 0) {
+    const char* ev = getenv("VD_GEMM_ROTATE");
+    rotate = ev ? atoi(ev) : 1;
+  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, M, N, K, kchunk, tiles_m,
-                     tiles_n, a, b, e);
+                     tiles_n, rotate, a, b, e);
   VD_LAUNCH_CHECK();
   return VD_OK;
 }

@@ -1,0 +1,84 @@
+"""Discriminative decoder: counterpart of decoders/disc.lua:3-38.
+
+The reference builds 100 weight-shared (embed -> SeqLSTM(batchfirst, no maskZero) -> last step)
+clones under nn.Concat(2) and scores them against the encoder output with nn.MM.  Here the 100
+clones ARE one batch of N*100 option sequences: the option LSTM runs as a single [N*O x H] x
+[H x 4H] fp32-MFMA recurrence whose input projection is gathered from the table Emb*Wx+b
+(exact: no dropout on option embeddings, disc.lua:12-14), and scoring + cross-entropy + their
+gradients are one wave-reduction kernel.
+"""
+import torch
+
+from .. import ops
+
+
+def declare(params, spec):
+    spec.lstm('opt', params['embedSize'], params['rnnHiddenSize'])       # disc.lua:4
+
+
+class Decoder(object):
+    def __init__(self, params, enc, fp, ws, drop):
+        self.p, self.fp, self.ws = params, fp, ws
+        self.E, self.H, self.V = params['embedSize'], params['rnnHiddenSize'], params['vocabSize']
+        self.emb, self.demb = enc.wordEmbed[1], enc.wordEmbed[2]         # shared table (disc.lua:12)
+        W, dW = fp.w['opt.W'], fp.g['opt.W']
+        self.Wx, self.Wh, self.b = W[:self.E], W[self.E:], fp.w['opt.b']
+        self.dWx, self.dWh, self.db = dW[:self.E], dW[self.E:], fp.g['opt.b']
+
+    def forward(self, inputs):
+        """inputs = {options [To x N*O] int32 time-major, encOut [N x H]} -> scores [N x O]"""
+        otok, enc_out = inputs
+        ws, H, V = self.ws, self.H, self.V
+        To, NO = otok.shape
+        N = enc_out.shape[0]
+        O = NO // N
+        self.To, self.NO, self.N, self.O = To, NO, N, O
+        self.table = ws.get('opt.table', (V + 1, 4 * H))
+        ops.gemm_nn(self.emb, self.Wx, self.table, bias=self.b, M=V + 1, N=4 * H, K=self.E)
+        self.gates = ws.get('opt.gates', (To, NO, 4 * H))
+        self.h = ws.get('opt.h', (To, NO, H))
+        self.c = ws.get('opt.c', (To, NO, H))
+        t0 = ops.prof_begin('opt_lstm_fwd_step')
+        ops.lstm_forward(self.table, self.Wh, self.gates, self.h, self.c, To, NO, H, 0, 4 * H, tok_gather=otok)
+        ops.prof_end('opt_lstm_fwd_step', t0, To)
+        self.optH = self.h[To - 1]
+        self.output = ws.get('opt.scores', (N, O))
+        return self.output          # filled by the criterion call (scores + loss are one kernel)
+
+    def backward(self, inputs, d_optH):
+        """d_optH [N*O x H] from the fused score/CE kernel.  Accumulates option-LSTM and embedding grads."""
+        otok, enc_out = inputs
+        ws, H, V, To, NO = self.ws, self.H, self.V, self.To, self.NO
+        dc = ws.get('opt.dc', (NO, H))
+        t0 = ops.prof_begin('opt_lstm_bwd_step')
+        ops.lstm_backward(self.Wh, self.gates, self.c, dc, To, NO, H, dh_last=d_optH)
+        ops.prof_end('opt_lstm_bwd_step', t0, To)
+        da = self.gates.view(To * NO, 4 * H)
+        if To > 1:
+            t0 = ops.prof_begin('opt_lstm_dWh')
+            ops.gemm_tn_acc(self.h.view(To * NO, H), da[NO:], self.dWh, M=H, N=4 * H, K=(To - 1) * NO)
+            ops.prof_end('opt_lstm_dWh', t0, 1)
+        # gradient of the gathered table: counting-sort the tokens, segmented row sums
+        tokf = otok.view(-1)
+        offset = ws.get('opt.sort_off', (V + 2,), torch.int32)
+        work = ws.get('opt.sort_work', (2 * (V + 1),), torch.int32)
+        perm = ws.get('opt.sort_perm', (To * NO,), torch.int32)
+        ops.token_sort(tokf, V + 1, offset, work, perm)
+        dtab = ws.get('opt.dtable', (V + 1, 4 * H))
+        dtab.zero_()
+        ops.segment_rowsum_acc(da, tokf, perm, dtab)
+        ops.colsum_acc(dtab, self.db, M=V + 1, N=4 * H)
+        ops.gemm_tn_acc(self.emb, dtab, self.dWx, M=self.E, N=4 * H, K=V + 1)
+        ops.gemm_nt(dtab, self.Wx, self.demb, accumulate=True, M=V + 1, N=self.E, K=4 * H)
+
+
+def model(params, enc, fp, ws, drop):
+    return Decoder(params, enc, fp, ws, drop)
+
+
+def forwardConnect(enc, dec, encOut, seqLen):      # disc.lua:35 -- no-op
+    pass
+
+
+def backwardConnect(enc, dec):                     # disc.lua:38 -- no-op
+    pass

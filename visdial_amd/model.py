@@ -1,0 +1,246 @@
+"""`Model` -- the step driver, counterpart of the reference's model.lua (class Model, :8-615).
+
+Same public surface: Model(params), :trainIteration(dataloader), :forwardBackward(batch,
+onlyForward, encOutOnly), :retrieve / :predict / :retrieveBatch, fields wrapperW / wrapperdW /
+optims.  Encoder and decoder are resolved by plug-in file name (model.lua:19-26).  Every tensor
+op is a launch into libvisdial_hip.so; this file only prepares inputs and orders the launches.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import decoders, encoders, ops, utils
+from .nn import DropoutState, Workspace
+from .params import FlatParams, ParamSpec, init_host
+
+
+class Wrapper(object):
+    """Stands in for `nn.Sequential():add(enc):add(dec)` (model.lua:42): mode switches,
+    zeroGradParameters, getParameters."""
+
+    def __init__(self, model):
+        self._m = model
+
+    def training(self):
+        self._m.drop.training = True
+
+    def evaluate(self):
+        self._m.drop.training = False
+
+    def zeroGradParameters(self):
+        self._m.fp.dW.zero_()
+
+    def getParameters(self):
+        return self._m.fp.W, self._m.fp.dW
+
+    def get(self, i):
+        return self._m.encoder if i == 1 else self._m.decoder
+
+
+class Model(object):
+    def __init__(self, params, dist_group=None):
+        self.params = params
+        if not torch.cuda.is_available():
+            raise RuntimeError("visdial_amd.Model needs an MI355X (HIP device); there is no CPU path")
+        gpuid = int(params.get('gpuid', 0))
+        self.device = torch.device('cuda', gpuid)
+        torch.cuda.set_device(self.device)
+        self.dist_group = dist_group           # torch.distributed process group (RCCL) or None
+        self.world = 1
+        if dist_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(dist_group)
+
+        # build the model - encoder, decoder (model.lua:19-26)
+        self.encFile = encoders.load(params['encoder'])
+        self.decFile = decoders.load(params['decoder'])
+        spec = ParamSpec()
+        spec.embed('embed', params['vocabSize'] + 1, params['embedSize'])
+        self.encFile.declare(params, spec)
+        self.decFile.declare(params, spec)
+        self.fp = FlatParams(spec, self.device)
+        self.fp.load_host(init_host(spec, params['rnnHiddenSize'], int(params.get('seed', 1234))))
+        self.ws = Workspace(self.device)
+        self.drop = DropoutState(self.ws, seed=int(params.get('seed', 1234)) + 7919 * int(params.get('rank', 0)))
+        self.encoder = self.encFile.model(params, self.fp, self.ws, self.drop)
+        self.decoder = self.decFile.model(params, self.encoder, self.fp, self.ws, self.drop)
+        # decoder hooks (model.lua:28-29)
+        self.forwardConnect = self.decFile.forwardConnect
+        self.backwardConnect = self.decFile.backwardConnect
+        self.decoderConnect = getattr(self.decFile, 'decoderConnect', None)
+        self.wrapper = Wrapper(self)
+        self.wrapperW, self.wrapperdW = self.wrapper.getParameters()     # model.lua:55
+        self.wrapper.training()                                          # model.lua:57
+        # optimiser state (model.lua:60-61; optim_updates.lua:68-77)
+        self.optims = {'learningRate': float(params['learningRate']), 't': 0}
+        self.adam_m = torch.zeros_like(self.wrapperW)
+        self.adam_v = torch.zeros_like(self.wrapperW)
+        self.runningLoss = 0.0
+        self._mask_cache = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _dev(self, a, dtype):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(self.device, non_blocking=False)
+
+    def _causal_mask(self, B):
+        """model.lua:280-294: mask[i][j] = 0 iff j <= i, tiled over the batch ([N x R] bytes)."""
+        R = int(self.params['maxQuesCount'])
+        m = self._mask_cache.get(B)
+        if m is None:
+            base = (np.arange(R)[None, :] > np.arange(R)[:, None]).astype(np.uint8)
+            m = self._dev(np.tile(base, (B, 1)), np.uint8)
+            self._mask_cache[B] = m
+        return m
+
+    def prepare_inputs(self, batch):
+        """Input re-layout of model.lua:255-294 (+ the :cuda() copies of dataloader.lua:410-475):
+        time-major token matrices, per-image feature map, causal mask."""
+        p = self.params
+        inputs = []
+        q = batch['ques_fwd']
+        B = q.shape[0]
+        inputs.append(self._dev(q.reshape(-1, q.shape[2]).T, np.int32))             # [Tq x N]
+        if p.get('useIm'):
+            f = batch['img_feat']
+            if 'att' in p['encoder']:
+                f = f.reshape(-1, f.shape[-1])                                        # [B*S2 x C]
+            inputs.append(self._dev(f, np.float32))
+        if p.get('useHistory'):
+            h = batch['hist']
+            inputs.append(self._dev(h.reshape(-1, h.shape[2]).T, np.int32))          # [Th x N]
+        if 'mn' in p['encoder']:
+            inputs.append(self._causal_mask(B))
+        dec_in = {}
+        if p['decoder'] == 'disc':
+            o = batch['options']
+            dec_in['options'] = self._dev(o.reshape(-1, o.shape[2]).T, np.int32)     # [To x N*O]
+            if 'answer_ind' in batch:
+                dec_in['gt'] = self._dev(np.asarray(batch['answer_ind']).reshape(-1) - 1, np.int32)   # 0-based
+        else:
+            for k in ('answer_in', 'answer_out'):
+                a = batch[k]
+                dec_in[k] = self._dev(a.reshape(-1, a.shape[2]).T, np.int32)
+        return inputs, dec_in
+
+    # ------------------------------------------------------------------ training
+    def trainIteration(self, dataloader):
+        """model.lua:66-106"""
+        self.wrapper.zeroGradParameters()
+        batch = dataloader.getTrainBatch(self.params)
+        curLoss = self.forwardBackward(batch)
+        if self.params['decoder'] == 'gen':
+            numTokens = float((batch['answer_out'] > 0).sum())
+            cur = curLoss / numTokens
+        else:
+            cur = curLoss
+        self.runningLoss = 0.95 * self.runningLoss + 0.05 * cur if self.runningLoss > 0 else cur
+        self.update()
+        return curLoss
+
+    def update(self):
+        """[all-reduce] -> clamp(-5, 5) -> adam -> lr decay (model.lua:96-105)."""
+        gscale = 1.0
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.wrapperdW, group=self.dist_group)       # RCCL sum over xGMI
+            gscale = 1.0 / self.world
+        o = self.optims
+        o['t'] += 1
+        t = o['t']
+        step = o['learningRate'] * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
+        ops.clamp_adam(self.wrapperW, self.wrapperdW, self.adam_m, self.adam_v, step, gscale=gscale, clip=5.0)
+        if o['learningRate'] > self.params.get('minLRate', 5e-5):
+            o['learningRate'] *= self.params.get('lrDecayRate', 0.9997592083)
+        self.drop.next_step()
+
+    def forwardBackward(self, batch, onlyForward=False, encOutOnly=False, prepared=None):
+        """model.lua:249-342.  Returns curLoss (python float)."""
+        inputs, dec_in = prepared if prepared is not None else self.prepare_inputs(batch)
+        # LookupTableMaskZero zeroes the pad row on every forward
+        self.fp.w['embed'][0].zero_()
+        encOut = self.encoder.forward(inputs)
+        self.forwardConnect(self.encoder, self.decoder, encOut, inputs[0].shape[0])
+        if encOutOnly:
+            return encOut
+        if self.params['decoder'] == 'disc':
+            d_in = (dec_in['options'], encOut)
+            scores = self.decoder.forward(d_in)
+            N, O, H = self.decoder.N, self.decoder.O, self.decoder.H
+            loss_rows = self.ws.get('crit.loss_rows', (N,))
+            if onlyForward:
+                ops.score_ce(self.decoder.optH, encOut, scores, N, O, H, gt=dec_in['gt'], loss_rows=loss_rows)
+            else:
+                d_optH = self.ws.get('crit.d_optH', (N * O, H))
+                d_enc = self.ws.get('crit.d_enc', (N, H))
+                # CrossEntropyCriterion forward+backward and nn.MM backward in one kernel (model.lua:330-335)
+                ops.score_ce(self.decoder.optH, encOut, scores, N, O, H, gt=dec_in['gt'], loss_rows=loss_rows,
+                             dOptH=d_optH, dEnc=d_enc, gscale=1.0 / N)
+                self.decoder.backward(d_in, d_optH)
+                self.encoder.backward(inputs, d_enc)                                  # model.lua:337
+            curLoss = float(loss_rows.cpu().numpy().astype(np.float64).mean())
+            return curLoss
+        return self.decoder.forward_backward_gen(self, inputs, dec_in, encOut, onlyForward)
+
+    # ------------------------------------------------------------------ retrieval (model.lua:142-246,344-430)
+    def retrieveBatch(self, batch):
+        inputs, dec_in = self.prepare_inputs(batch)
+        self.fp.w['embed'][0].zero_()
+        encOut = self.encoder.forward(inputs)
+        if self.params['decoder'] != 'disc':
+            raise NotImplementedError("gen-decoder retrieval (computeLhood, model.lua:392-420) is not built yet")
+        scores = self.decoder.forward((dec_in['options'], encOut))
+        N, O, H = self.decoder.N, self.decoder.O, self.decoder.H
+        ops.score_ce(self.decoder.optH, encOut, scores, N, O, H)
+        gt = dec_in.get('gt') if self.params.get('useGt') else None
+        return utils.computeRanks(scores, gt, self.ws)
+
+    def retrieve(self, dataloader, dtype):
+        """model.lua:142-189: ground-truth ranks + metrics."""
+        self.wrapper.evaluate()
+        self.params['useGt'] = True
+        n = dataloader.numThreads[dtype]
+        R = int(self.params['maxQuesCount'])
+        ranks = np.zeros((n, R))
+        start = 1
+        while start <= n:
+            batch, nxt = dataloader.getTestBatch(start, self.params, dtype)
+            ranks[start - 1:nxt - 1] = self.retrieveBatch(batch).reshape(-1, R)
+            start = nxt
+        metrics = utils.processRanks(ranks)
+        self.wrapper.training()
+        records = [{'image_id': i, 'round_id': r + 1, 'ranks': ranks[i, r]} for i in range(n) for r in range(R)]
+        return metrics, records
+
+    def predict(self, dataloader, dtype):
+        """model.lua:192-246: all 100 ranks per round."""
+        self.wrapper.evaluate()
+        self.params['useGt'] = False
+        n = dataloader.numThreads[dtype]
+        R = int(self.params['maxQuesCount'])
+        O = int(self.params.get('numOptions', 100))
+        ranks = np.zeros((n, R, O))
+        start = 1
+        while start <= n:
+            batch, nxt = dataloader.getTestBatch(start, self.params, dtype)
+            ranks[start - 1:nxt - 1] = self.retrieveBatch(batch).reshape(-1, R, O)
+            start = nxt
+        self.wrapper.training()
+        return [{'image_id': i, 'round_id': r + 1, 'ranks': ranks[i, r].tolist()} for i in range(n) for r in range(R)]
+
+    # ------------------------------------------------------------------ test / checkpoint helpers
+    def get_parameters_dict(self):
+        return self.fp.to_host('w')
+
+    def get_gradients_dict(self):
+        return self.fp.to_host('g')
+
+    def set_parameters_dict(self, d):
+        self.fp.load_host(d)
+
+    def set_dropout_masks(self, masks):
+        """Pin nn.Dropout noise (dict name -> uint8 numpy array) for parity runs; None = generator."""
+        if masks is None:
+            self.drop.external = None
+        else:
+            self.drop.external = {k: self._dev(v.reshape(-1), np.uint8) for k, v in masks.items()}

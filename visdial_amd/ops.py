@@ -27,6 +27,35 @@ def _p(t, dtype=None):
 
 F32, I32, U8 = torch.float32, torch.int32, torch.uint8
 
+# ---------------------------------------------------------------- live kernel-family timing (bench.py)
+# HIP events recorded on the launch stream (torch's current stream) around a group of launches.
+PROFILE = None   # None = off; dict tag -> list of (start_event, end_event, n_launches)
+
+
+def prof_begin(tag):
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def prof_end(tag, start, n_launches=1):
+    if PROFILE is None or start is None:
+        return
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    PROFILE.setdefault(tag, []).append((start, e, n_launches))
+
+
+def prof_summary():
+    """tag -> (total_ms, n_launches).  Call after torch.cuda.synchronize()."""
+    out = {}
+    for tag, evs in (PROFILE or {}).items():
+        ms = sum(a.elapsed_time(b) for a, b, _ in evs)
+        out[tag] = (ms, sum(n for _, _, n in evs))
+    return out
+
 
 # ---------------------------------------------------------------- dense contractions
 def gemm_nt(A, W, C_out, bias=None, act=0, accumulate=False, M=None, N=None, K=None, lda=None, ldw=None, ldc=None):

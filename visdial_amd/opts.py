@@ -1,0 +1,74 @@
+"""Command-line options: same flag names and defaults as the reference's opts.lua:5-40, plus the
+derived capability flags it infers from the encoder NAME (opts.lua:54-67)."""
+import argparse
+import time
+
+# (flag, default, help) -- opts.lua:5-40
+OPTIONS = [
+    ('inputImg', 'data/data_img.h5', 'HDF5 file with image features'),
+    ('inputQues', 'data/visdial_data.h5', 'HDF5 file with preprocessed questions'),
+    ('inputJson', 'data/visdial_params.json', 'JSON file with info and vocab'),
+    ('savePath', 'checkpoints/', 'Path to save checkpoints'),
+    ('saveIter', 2, 'Save model checkpoint after every saveIter epochs'),
+    ('encoder', 'lf-ques-hist', 'Name of the encoder to use'),
+    ('decoder', 'gen', 'Name of the decoder to use (gen/disc)'),
+    ('imgNorm', 1, 'normalize the image feature. 1=yes, 0=no'),
+    ('imgEmbedSize', 300, 'Size of the multimodal embedding'),
+    ('imgFeatureSize', 4096, 'Channel size of the image feature'),
+    ('imgSpatialSize', 14, 'Spatial size of image features (for attention-based encoders)'),
+    ('embedSize', 300, 'Size of input word embeddings'),
+    ('rnnHiddenSize', 512, 'Size of the LSTM state'),
+    ('maxHistoryLen', 60, 'Maximum history to consider when using concatenated QA pairs'),
+    ('numLayers', 2, 'Number of layers in LSTM'),
+    ('commonEmbeddingSize', 512, 'Common embedding size in MN-ATT-QIH'),
+    ('numAttentionLayers', 1, 'No. of attention hops in MN-ATT-QIH'),
+    ('loadPath', '', 'Checkpoint path to load from'),
+    ('batchSize', 40, 'Batch size (number of threads)'),
+    ('learningRate', 1e-3, 'Learning rate'),
+    ('weightInit', 'xavier', 'Weight initialization strategy (accepted and ignored, as in the reference)'),
+    ('dropout', 0.5, 'Dropout'),
+    ('numEpochs', 100, 'Epochs'),
+    ('LRateDecay', 10, 'unused (as in the reference)'),
+    ('lrDecayRate', 0.9997592083, 'Decay for learning rate'),
+    ('minLRate', 5e-5, 'Minimum learning rate'),
+    ('gpuid', 0, 'GPU id to use'),
+    ('backend', 'cudnn', 'accepted for CLI compatibility; ignored'),
+]
+
+
+def derive(opt):
+    """opts.lua:54-67: capabilities come from substrings of the encoder file name."""
+    enc = opt['encoder']
+    opt['useHistory'] = 'hist' in enc
+    opt['useIm'] = 'im' in enc
+    opt['concatHistory'] = 'lf' in enc
+    if 'att' in enc:
+        if opt.get('inputImg') == 'data/data_img.h5':
+            opt['inputImg'] = 'data/data_img_pool5.h5'
+        opt['imgNorm'] = 0
+    return opt
+
+
+def default_params(**overrides):
+    opt = {k: v for k, v, _ in OPTIONS}
+    # sizes the reference copies from the dataloader (train.lua:55-59)
+    opt.update(vocabSize=11322, maxQuesCount=10, maxQuesLen=20, maxAnsLen=20, numOptions=100)
+    opt.update(overrides)
+    return derive(opt)
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser(description='Train the Visual Dialog model')
+    for k, v, h in OPTIONS:
+        ap.add_argument('-' + k, '--' + k, type=type(v), default=v, help=h)
+    # synthetic-data knobs (no HDF5 offline)
+    ap.add_argument('--vocabSize', type=int, default=11322)
+    ap.add_argument('--numTrainThreads', type=int, default=2000)
+    ap.add_argument('--maxIters', type=int, default=0, help='stop after this many iterations (0 = numEpochs)')
+    opt = vars(ap.parse_args(argv))
+    opt.update(maxQuesCount=10, maxQuesLen=20, maxAnsLen=20, numOptions=100)
+    if opt['savePath'] == 'checkpoints/':
+        t = time.localtime()
+        opt['savePath'] = 'checkpoints/model-%d-%d-%d-%d:%d:%d-%s-%s/' % (
+            t.tm_mon, t.tm_mday, t.tm_year, t.tm_hour, t.tm_min, t.tm_sec, opt['encoder'], opt['decoder'])
+    return derive(opt)
