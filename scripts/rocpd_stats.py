@@ -1,0 +1,31 @@
+"""Summarise a rocprofv3 rocpd (.db) kernel trace: per-kernel calls / total / avg / % (the
+--stats table), optionally restricted to the last `--steps` training steps."""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r'\(.*$', '', name)
+    m = re.match(r'void gemm_f32_kernel<GemmCfg<(\d+), (\d+), (\d+), (\d+)>, (\w+), (\w+), (\w+)', name)
+    if m:
+        return 'gemm_f32<%sx%sx%sx%s,%s,%s,%s>' % m.groups()
+    return name.replace('void ', '')[:90]
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
+                      "from kernels group by name order by sum(duration) desc").fetchall()
+    total = sum(r[2] for r in rows)
+    print("%-78s %8s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
+    for n, c, t, a, mn, mx in rows:
+        print("%-78s %8d %12.1f %10.2f %10.2f %10.2f %6.2f" % (short(n), c, t / 1e3, a / 1e3, mn / 1e3, mx / 1e3,
+                                                                100.0 * t / total))
+    span = db.execute("select min(start), max(end) from kernels").fetchone()
+    print("total kernel time %.3f ms over a %.3f ms span (%d dispatches)" % (
+        total / 1e6, (span[1] - span[0]) / 1e6, sum(r[1] for r in rows)))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])

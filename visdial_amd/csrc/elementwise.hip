@@ -91,9 +91,30 @@ __global__ void embed_scatter_kernel(float* __restrict__ demb, const int* __rest
 }
 
 // ------------------------------------------------------------------ token counting sort
+// Wave-aggregated atomics: lanes holding the same token as the wave's first active lane are
+// counted with one atomic (the pad token dominates option batches: ~50% of all ids are 0).
+__device__ __forceinline__ int wave_agg_atomic_inc(int* base, int tok, bool active) {
+  // returns this lane's slot (old counter value + rank among equal-token lanes)
+  int result = 0;
+  unsigned long long todo = __ballot(active);
+  const int lane = threadIdx.x & 63;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int ltok = __shfl(tok, leader, 64);
+    const unsigned long long same = __ballot(active && tok == ltok) & todo;
+    int basev = 0;
+    if (lane == leader) basev = atomicAdd(base + ltok, __popcll(same));
+    basev = __shfl(basev, leader, 64);
+    if ((same >> lane) & 1ULL) result = basev + __popcll(same & ((1ULL << lane) - 1ULL));
+    todo &= ~same;
+  }
+  return result;
+}
+
 __global__ void tok_count_kernel(const int* __restrict__ tok, long n, int* __restrict__ count) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) atomicAdd(count + tok[i], 1);
+  const bool active = i < n;
+  wave_agg_atomic_inc(count, active ? tok[i] : 0, active);
 }
 
 // exclusive scan of count[0..V) into offset[0..V]; cursor := offset.  Single block.
@@ -128,10 +149,9 @@ __global__ void tok_scan_kernel(const int* __restrict__ count, int V, int* __res
 __global__ void tok_fill_kernel(const int* __restrict__ tok, long n, int* __restrict__ cursor,
                                 int* __restrict__ perm) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const int p = atomicAdd(cursor + tok[i], 1);
-    perm[p] = (int)i;
-  }
+  const bool active = i < n;
+  const int p = wave_agg_atomic_inc(cursor, active ? tok[i] : 0, active);
+  if (active) perm[p] = (int)i;
 }
 
 // out[tok, :] += sum over rows r with tok[r] == tok of X[r, :].  perm lists the rows sorted by

@@ -21,15 +21,15 @@
 
 #include "common.h"
 
-template <int WM_, int WK_, int NT_, int KW_>
+template <int WM_, int WK_, int NT_, int KW_, int DB_ = 1, int MINW_ = 1>
 struct GemmCfg {
-  static constexpr int WM = WM_, WK = WK_, NT = NT_, KW = KW_;
+  static constexpr int WM = WM_, WK = WK_, NT = NT_, KW = KW_, DB = DB_, MINW = MINW_;
   static constexpr int BM = WM * 32, BN = NT * 32, BK = WK * KW;
   static constexpr int THREADS = WM * WK * 64;
   static constexpr int STRIDE = BK + 4;  // floats
   static constexpr int BUF_FLOATS = (BM + BN) * STRIDE;
-  static constexpr int STAGE_BYTES = 2 * BUF_FLOATS * 4;
-  static constexpr int RED_BYTES = (WK - 1) * WM * NT * 16 * 64 * 4;
+  static constexpr int STAGE_BYTES = (DB ? 2 : 1) * BUF_FLOATS * 4;
+  static constexpr int RED_BYTES = (WK - 1) * WM * 16 * 64 * 4;  // one 32x32 tile per parked wave at a time
   static constexpr int LDS_BYTES = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
   static constexpr int NA = (BM * BK / 4) / THREADS;
   static constexpr int NB = (BN * BK / 4) / THREADS;
@@ -87,7 +87,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 template <class Cfg, class ASrc, class BSrc, class Epi>
-__global__ void __launch_bounds__(Cfg::THREADS)
+__global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW)
 gemm_f32_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, int rotate, ASrc asrc,
                 BSrc bsrc, Epi epi) {
   constexpr int WM = Cfg::WM, NT = Cfg::NT, KW = Cfg::KW;
@@ -196,18 +196,10 @@ gemm_f32_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, int r
     if (t >= nk) t -= nk;
     return ks + t * BK;
   };
-  if (nk > 0) {
-    load_tile(ktile(0));
-    store_tile(0);
-  }
-  __syncthreads();
-
   const int frag_off = (lane & 31) * STR + wk * KW + (lane >> 5) * 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(ktile(kt + 1));
-    const float* sa = smem + cur * Cfg::BUF_FLOATS + (wm * 32) * STR + frag_off;
-    const float* sb = smem + cur * Cfg::BUF_FLOATS + BM * STR + frag_off;
+  auto mfma_tile = [&](int buf) {
+    const float* sa = smem + buf * Cfg::BUF_FLOATS + (wm * 32) * STR + frag_off;
+    const float* sb = smem + buf * Cfg::BUF_FLOATS + BM * STR + frag_off;
 #pragma unroll
     for (int kc = 0; kc < KW / 8; ++kc) {
       const float4 a4 = *reinterpret_cast<const float4*>(sa + kc * 8);
@@ -224,28 +216,55 @@ gemm_f32_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, int r
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[j].w, acc[j], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tile(cur ^ 1);
+  };
+
+  if constexpr (Cfg::DB) {
+    // two LDS buffers, one barrier per K tile
+    if (nk > 0) {
+      load_tile(ktile(0));
+      store_tile(0);
+    }
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) load_tile(ktile(kt + 1));
+      mfma_tile(cur);
+      if (kt + 1 < nk) store_tile(cur ^ 1);
+      __syncthreads();
+    }
+  } else {
+    // one LDS buffer (half the LDS => more co-resident workgroups), two barriers per K tile;
+    // the next tile's global loads stay in flight in registers across the MFMA burst
+    if (nk > 0) load_tile(ktile(0));
+    for (int kt = 0; kt < nk; ++kt) {
+      store_tile(0);
+      __syncthreads();
+      if (kt + 1 < nk) load_tile(ktile(kt + 1));
+      mfma_tile(0);
+      __syncthreads();
+    }
   }
 
   if constexpr (Cfg::WK > 1) {
-    // intra-block split-K: waves wk>0 park their partial sums in LDS, wk==0 adds them.
+    // intra-block split-K: waves wk>0 park their partial sums in LDS one 32x32 tile at a time
+    // (keeps the scratch at 4 KB per parked wave), wk==0 adds them.
     float* red = smem;
-    if (wk > 0) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NT; ++j) {
+      __syncthreads();
+      if (wk > 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          red[((((wk - 1) * WM + wm) * NT + j) * 16 + r) * 64 + lane] = acc[j][r];
+        for (int r = 0; r < 16; ++r) red[(((wk - 1) * WM + wm) * 16 + r) * 64 + lane] = acc[j][r];
+      }
+      __syncthreads();
+      if (wk == 0) {
+#pragma unroll
+        for (int w = 0; w < Cfg::WK - 1; ++w)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][r] += red[((w * WM + wm) * 16 + r) * 64 + lane];
+      }
     }
-    __syncthreads();
     if (wk > 0) return;
-#pragma unroll
-    for (int w = 0; w < Cfg::WK - 1; ++w)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] += red[(((w * WM + wm) * NT + j) * 16 + r) * 64 + lane];
   }
 
   epi(acc, row_base + wm * 32, col_base, lane, M, N);

@@ -3,8 +3,9 @@
 // hoisted LSTM input projections, and every weight-gradient contraction.
 #include "gemm_core.h"
 
-using CfgBig = GemmCfg<4, 1, 4, 32>;    // 128 x 128 tile
-using CfgSmall = GemmCfg<1, 4, 1, 32>;  // 32 x 32 tile, 4-way intra-block split-K (latency shapes)
+using CfgBigDB = GemmCfg<4, 1, 4, 32>;        // 128 x 128 tile, double-buffered LDS (long K loops: weight grads)
+using CfgBig = GemmCfg<4, 1, 4, 32, 0, 3>;    // 128 x 128 tile, single LDS buffer, 3 workgroups / CU (short K loops)
+using CfgSmall = GemmCfg<1, 4, 1, 32, 0, 3>;  // 32 x 32 tile, 4-way intra-block split-K (latency shapes)
 
 static inline bool use_small(int M, int N) {
   return (long)vd_cdiv(M, CfgBig::BM) * vd_cdiv(N, CfgBig::BN) < 48;
@@ -89,7 +90,7 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
   const long max_splits = vd_cdiv(K, 4 * CfgBig::BK);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  return launch_gemm<CfgBig>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
+  return launch_gemm<CfgBigDB>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
 }
 
 // out[N] += column sums of X[M x N]  (bias gradients)

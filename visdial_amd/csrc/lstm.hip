@@ -106,16 +106,29 @@ struct EpiLstmBwd {
   }
 };
 
-using CfgBig = GemmCfg<4, 1, 4, 32>;     // 128 x 128 tile, throughput shapes
-using CfgFwdSmall = GemmCfg<1, 4, 4, 16>;  // 32 x (32 j x 4 gates), 4-way intra-block split-K
-using CfgBwdSmall = GemmCfg<1, 4, 1, 32>;  // 32 x 32 tile, 4-way intra-block split-K
+using CfgBig = GemmCfg<4, 1, 4, 32>;     // 128 x 128 tile, throughput shapes (double-buffered LDS, 2 WG/CU)
+using CfgBigSB = GemmCfg<4, 1, 4, 32, 0, 3>;   // same tile, single LDS buffer, 3 WG/CU
+using CfgHalfSB = GemmCfg<4, 1, 2, 32, 0, 3>;  // 128 x 64 tile, single LDS buffer, 3 WG/CU
+using CfgHalfDB = GemmCfg<4, 1, 2, 32, 1, 3>;  // 128 x 64 tile, double buffer (55 KB), 2 WG/CU
+// latency shapes (N ~ 200 rows): 4-way intra-block split-K.  Single LDS buffer and <= 152 VGPRs so one
+// of these workgroups fits into the footprint a retiring throughput-shape workgroup frees (they run
+// concurrently on other streams).
+using CfgFwdSmall = GemmCfg<1, 4, 4, 8, 0, 3>;   // 32 x (32 j x 4 gates), BK = 32, 23 KB LDS
+using CfgBwdSmall = GemmCfg<1, 4, 1, 32, 0, 3>;  // 32 x 32 tile, BK = 128, 33.8 KB LDS
 
 static int lstm_step_fwd(const float* h_prev, const float* Wh, int N, int H, int K, const EpiLstmFwd& epi,
                          hipStream_t s) {
   SrcRow a{h_prev, H};
   SrcKGate4 b{Wh, 4L * H, H};
-  if (N >= 2048)
+  if (N >= 2048) {
+    static int cfg = -1;
+    if (cfg < 0) {
+      const char* ev = getenv("VD_LSTM_FWD_CFG");
+      cfg = ev ? atoi(ev) : 1;
+    }
+    if (cfg == 1) return launch_gemm<CfgBigSB>(N, 4 * H, K, 1, a, b, epi, s);
     return launch_gemm<CfgBig>(N, 4 * H, K, 1, a, b, epi, s);
+  }
   return launch_gemm<CfgFwdSmall>(N, 4 * H, K, 1, a, b, epi, s);
 }
 
@@ -125,7 +138,18 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
   SrcRow a{da_next, 4L * H};
   SrcRow b{Wh, 4L * H};  // B[k][n] = Wh[n][k]
   if (N >= 2048) {
+    static int cfg = -1;
+    if (cfg < 0) {
+      const char* ev = getenv("VD_LSTM_BWD_CFG");
+      cfg = ev ? atoi(ev) : 2;
+    }
+    if (cfg == 2 || cfg == 3) {
+      EpiLstmBwd<2> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
+      if (cfg == 2) return launch_gemm<CfgHalfSB>(N, H, K, 1, a, b, e, s);
+      return launch_gemm<CfgHalfDB>(N, H, K, 1, a, b, e, s);
+    }
     EpiLstmBwd<4> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
+    if (cfg == 1) return launch_gemm<CfgBigSB>(N, H, K, 1, a, b, e, s);
     return launch_gemm<CfgBig>(N, H, K, 1, a, b, e, s);
   }
   EpiLstmBwd<1> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};

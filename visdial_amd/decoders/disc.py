@@ -46,7 +46,9 @@ class Decoder(object):
         return self.output          # filled by the criterion call (scores + loss are one kernel)
 
     def backward(self, inputs, d_optH):
-        """d_optH [N*O x H] from the fused score/CE kernel.  Accumulates option-LSTM and embedding grads."""
+        """d_optH [N*O x H] from the fused score/CE kernel.  Accumulates the option-LSTM gradients and
+        leaves the gradient of the gathered table in self.dtab; the shared embedding gradient is added
+        by backward_embed() (kept separate so the host can order it after the encoder's scatters)."""
         otok, enc_out = inputs
         ws, H, V, To, NO = self.ws, self.H, self.V, self.To, self.NO
         dc = ws.get('opt.dc', (NO, H))
@@ -69,7 +71,12 @@ class Decoder(object):
         ops.segment_rowsum_acc(da, tokf, perm, dtab)
         ops.colsum_acc(dtab, self.db, M=V + 1, N=4 * H)
         ops.gemm_tn_acc(self.emb, dtab, self.dWx, M=self.E, N=4 * H, K=V + 1)
-        ops.gemm_nt(dtab, self.Wx, self.demb, accumulate=True, M=V + 1, N=self.E, K=4 * H)
+        self.dtab = dtab
+
+    def backward_embed(self):
+        """dEmb += dTable * Wx^T.  Non-atomic read-modify-write of the SHARED embedding gradient: must be
+        ordered after every other writer of that buffer (the encoder's atomic scatters)."""
+        ops.gemm_nt(self.dtab, self.Wx, self.demb, accumulate=True, M=self.V + 1, N=self.E, K=4 * self.H)
 
 
 def model(params, enc, fp, ws, drop):

@@ -7,7 +7,7 @@ Inputs (order of the reference's input table, model.lua:255-294):
 Like the reference this encoder hard-codes two LSTM layers per branch and dropout 0.5 (mn-att:24-41).
 """
 from .. import ops
-from ..nn import SeqLSTM, Linear, dropout_forward, dropout_backward
+from ..nn import SeqLSTM, Linear, StreamPool, dropout_forward, dropout_backward
 
 P_DROP = 0.5
 SCALE = 1.0 / (1.0 - P_DROP)
@@ -28,8 +28,9 @@ def declare(params, spec):
 
 
 class Encoder(object):
-    def __init__(self, params, fp, ws, drop):
+    def __init__(self, params, fp, ws, drop, streams=None):
         self.p, self.fp, self.ws, self.drop = params, fp, ws, drop
+        self.streams = streams if streams is not None else StreamPool(None, enabled=False)
         E, H = params['embedSize'], params['rnnHiddenSize']
         self.E, self.H = E, H
         self.C, self.K = params['imgFeatureSize'], params.get('commonEmbeddingSize', 512)
@@ -59,14 +60,25 @@ class Encoder(object):
         dx, _, _ = l1.backward(dh_seq=dh1.view(T, N, self.H))
         ops.embed_scatter_acc(self.fp.g['embed'], tok, dx, mask=m, scale=SCALE)
 
+    def output_buffer(self, inputs):
+        """the tensor forward() will return (lets the host enqueue consumers' launches first)"""
+        return self.ws.get('out.y', (inputs[0].shape[1], self.H))
+
     def forward(self, inputs):
         ques, img, hist, mask = inputs
         ws, H, K, S2, R = self.ws, self.H, self.K, self.S2, self.R
         Tq, N = ques.shape
         B = N // R
         self.inputs, self.N, self.B = inputs, N, B
-        self.h3, self.m_h = self._branch_fwd('h', hist, self.hist1, self.hist2)
+        # history branch || question branch || per-image projection (independent launch chains)
+        with self.streams.fork('hist'):
+            self.h3, self.m_h = self._branch_fwd('h', hist, self.hist1, self.hist2)
+        with self.streams.fork('img'):
+            self.pre = self.img_proj.forward(img, B * S2, tanh=True)            # mn-att:74-78 (pre-dropout)
+            self.m1 = self.drop.mask('img_tr', N * S2 * H, P_DROP)
+            self.m2 = self.drop.mask('iqc', N * S2 * K, P_DROP)
         self.q3, self.m_q = self._branch_fwd('q', ques, self.ques1, self.ques2)
+        self.streams.join('hist')
         # memory attention over the R history facts of each dialog (mn-att:48-62)
         self.prob = ws.get('mn.prob', (N, R))
         self.hatt = ws.get('mn.hatt', (N, H))
@@ -78,9 +90,7 @@ class Encoder(object):
         qh2 = self.mn2.forward(s2, N, tanh=True)                                # mn-att:65
         self.qh2 = qh2
         # image attention (mn-att:68-104); `pre` is per image, dropout masks are per round
-        self.pre = self.img_proj.forward(img, B * S2, tanh=True)                # mn-att:74-78 (pre-dropout)
-        self.m1 = self.drop.mask('img_tr', N * S2 * H, P_DROP)
-        self.m2 = self.drop.mask('iqc', N * S2 * K, P_DROP)
+        self.streams.join('img')
         sc = SCALE if self.m1 is not None else 1.0
         self.sc = sc
         qc = self.ques_common.forward(qh2, N)                                   # mn-att:88
@@ -121,10 +131,12 @@ class Encoder(object):
         dh3 = ws.get('mn.dh', (N, H))
         ops.mn_attention_backward(self.q3, self.h3, self.prob, dhatt, dq_att, dh3, B, R, H)
         dq3 = ops.axpby(dq_att, ds2, ws.get('mn.dq3', (N, H)), 1.0, 1.0)
+        with self.streams.fork('hist'):
+            self._branch_bwd(hist, self.hist1, self.hist2, dh3, self.m_h)
         self._branch_bwd(ques, self.ques1, self.ques2, dq3, self.m_q)
-        self._branch_bwd(hist, self.hist1, self.hist2, dh3, self.m_h)
+        self.streams.join('hist')
         return None
 
 
-def model(params, fp, ws, drop):
-    return Encoder(params, fp, ws, drop)
+def model(params, fp, ws, drop, streams=None):
+    return Encoder(params, fp, ws, drop, streams)

@@ -10,8 +10,10 @@ import math
 import numpy as np
 import torch
 
+import os
+
 from . import decoders, encoders, ops, utils
-from .nn import DropoutState, Workspace
+from .nn import DropoutState, StreamPool, Workspace
 from .params import FlatParams, ParamSpec, init_host
 
 
@@ -63,7 +65,8 @@ class Model(object):
         self.fp.load_host(init_host(spec, params['rnnHiddenSize'], int(params.get('seed', 1234))))
         self.ws = Workspace(self.device)
         self.drop = DropoutState(self.ws, seed=int(params.get('seed', 1234)) + 7919 * int(params.get('rank', 0)))
-        self.encoder = self.encFile.model(params, self.fp, self.ws, self.drop)
+        self.streams = StreamPool(self.device, enabled=os.environ.get('VD_STREAMS', '1') != '0')
+        self.encoder = self.encFile.model(params, self.fp, self.ws, self.drop, self.streams)
         self.decoder = self.decFile.model(params, self.encoder, self.fp, self.ws, self.drop)
         # decoder hooks (model.lua:28-29)
         self.forwardConnect = self.decFile.forwardConnect
@@ -159,28 +162,53 @@ class Model(object):
         inputs, dec_in = prepared if prepared is not None else self.prepare_inputs(batch)
         # LookupTableMaskZero zeroes the pad row on every forward
         self.fp.w['embed'][0].zero_()
+        if self.params['decoder'] == 'disc' and not encOutOnly:
+            return self._forwardBackward_disc(inputs, dec_in, onlyForward)
         encOut = self.encoder.forward(inputs)
         self.forwardConnect(self.encoder, self.decoder, encOut, inputs[0].shape[0])
         if encOutOnly:
             return encOut
-        if self.params['decoder'] == 'disc':
-            d_in = (dec_in['options'], encOut)
-            scores = self.decoder.forward(d_in)
-            N, O, H = self.decoder.N, self.decoder.O, self.decoder.H
-            loss_rows = self.ws.get('crit.loss_rows', (N,))
-            if onlyForward:
-                ops.score_ce(self.decoder.optH, encOut, scores, N, O, H, gt=dec_in['gt'], loss_rows=loss_rows)
-            else:
-                d_optH = self.ws.get('crit.d_optH', (N * O, H))
-                d_enc = self.ws.get('crit.d_enc', (N, H))
-                # CrossEntropyCriterion forward+backward and nn.MM backward in one kernel (model.lua:330-335)
-                ops.score_ce(self.decoder.optH, encOut, scores, N, O, H, gt=dec_in['gt'], loss_rows=loss_rows,
-                             dOptH=d_optH, dEnc=d_enc, gscale=1.0 / N)
-                self.decoder.backward(d_in, d_optH)
-                self.encoder.backward(inputs, d_enc)                                  # model.lua:337
-            curLoss = float(loss_rows.cpu().numpy().astype(np.float64).mean())
-            return curLoss
         return self.decoder.forward_backward_gen(self, inputs, dec_in, encOut, onlyForward)
+
+    def _forwardBackward_disc(self, inputs, dec_in, onlyForward):
+        """disc branch of model.lua:326-338.  The encoder (latency-bound chains) runs on a side stream
+        concurrently with the option LSTM (throughput-bound) in both directions."""
+        st = self.streams
+        # Enqueue order matters: the option LSTM is a handful of big launches, the encoder ~200 small
+        # ones -- the big chain goes to the main stream first so the GPU is busy while the host is
+        # still enqueueing the encoder on the side streams.
+        enc_out_buf = self.encoder.output_buffer(inputs)
+        d_in = (dec_in['options'], enc_out_buf)
+        start = torch.cuda.Event()
+        start.record()
+        scores = self.decoder.forward(d_in)
+        with st.fork('enc', after=start):
+            encOut = self.encoder.forward(inputs)
+        assert encOut.data_ptr() == enc_out_buf.data_ptr()
+        self.forwardConnect(self.encoder, self.decoder, encOut, inputs[0].shape[0])
+        st.join('enc')
+        N, O, H = self.decoder.N, self.decoder.O, self.decoder.H
+        loss_rows = self.ws.get('crit.loss_rows', (N,))
+        if onlyForward:
+            ops.score_ce(self.decoder.optH, encOut, scores, N, O, H, gt=dec_in['gt'], loss_rows=loss_rows)
+        else:
+            d_optH = self.ws.get('crit.d_optH', (N * O, H))
+            d_enc = self.ws.get('crit.d_enc', (N, H))
+            # CrossEntropyCriterion forward+backward and nn.MM backward in one kernel (model.lua:330-335)
+            ops.score_ce(self.decoder.optH, encOut, scores, N, O, H, gt=dec_in['gt'], loss_rows=loss_rows,
+                         dOptH=d_optH, dEnc=d_enc, gscale=1.0 / N)
+            self._ce_event = torch.cuda.Event()
+            self._ce_event.record()
+            self.decoder.backward(d_in, d_optH)                                   # model.lua:335 (main stream)
+            with st.fork('enc', after=self._ce_done()):
+                self.encoder.backward(inputs, d_enc)                              # model.lua:337
+            st.join('enc')
+            self.decoder.backward_embed()
+        curLoss = float(loss_rows.cpu().numpy().astype(np.float64).mean())
+        return curLoss
+
+    def _ce_done(self):
+        return self._ce_event
 
     # ------------------------------------------------------------------ retrieval (model.lua:142-246,344-430)
     def retrieveBatch(self, batch):

@@ -35,6 +35,54 @@ class Workspace(object):
         return sum(b.numel() * b.element_size() for b in self.bufs.values())
 
 
+class StreamPool(object):
+    """Fork/join helper over HIP streams (torch only provides the stream/event handles).
+
+    The step has three independent launch chains -- history LSTMs, question LSTMs (both
+    latency-bound, ~120 dependent ~30 us launches) and the option LSTM (throughput-bound, all CUs)
+    -- so they are enqueued on separate streams and the hardware dispatcher interleaves the small
+    chains under the big MFMA kernels.  Side streams get high priority so their short kernels are
+    dispatched as soon as a CU has room."""
+
+    def __init__(self, device, enabled=True):
+        self.enabled = enabled
+        self.device = device
+        self.side = {}
+
+    def get(self, name):
+        s = self.side.get(name)
+        if s is None:
+            s = torch.cuda.Stream(device=self.device, priority=-1)
+            self.side[name] = s
+        return s
+
+    def fork(self, name, after=None):
+        """Return a context manager that makes `name` the current stream, ordered after everything
+        already enqueued on the current stream (or, with `after`, only after that recorded event).
+        Disabled pool: a no-op context."""
+        if not self.enabled:
+            return _NullCtx()
+        s = self.get(name)
+        if after is not None:
+            s.wait_event(after)
+        else:
+            s.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(s)
+
+    def join(self, name):
+        """Make the current stream wait for everything enqueued on `name`."""
+        if self.enabled:
+            torch.cuda.current_stream().wait_stream(self.get(name))
+
+
+class _NullCtx(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class DropoutState(object):
     """nn.Dropout noise.  training + no external masks: keep-masks come from the on-device
     counter-based generator (fresh seed per call site per step); `external` (dict name -> uint8
