@@ -43,6 +43,10 @@ int vd_memcpy_h2d(void* dst, const void* src_host, int64_t bytes, void* stream);
 int vd_memcpy_d2h(void* dst_host, const void* src, int64_t bytes, void* stream);
 int vd_memcpy_d2d(void* dst, const void* src, int64_t bytes, void* stream);
 int vd_stream_synchronize(void* stream);
+/* strided 2-D device copy of rows x cols floats (nn.JoinTable / nn.Narrow on column blocks,
+ * encoders/lf-ques-im-hist.lua:49-55) */
+int vd_copy_2d(float* dst, int64_t dst_ld, const float* src, int64_t src_ld, int64_t rows, int64_t cols,
+               void* stream);
 
 /* ---- dense contractions (nn.Linear / hoisted SeqLSTM input projection / weight grads) -- */
 /* C[MxN] (+)= act(A[MxK] * W[NxK]^T + bias)   -- nn.Linear:updateOutput (+nn.Tanh),
@@ -85,6 +89,11 @@ int vd_embed_gather(const float* emb, const int32_t* tok, const uint8_t* mask, f
 /* demb[tok[r],:] += dx[r,:] * mask*scale                    LookupTable:accGradParameters */
 int vd_embed_scatter_acc(float* demb, const int32_t* tok, const uint8_t* mask, const float* dx, int64_t rows,
                          int E, float scale, void* stream);
+/* nn.MaskTime (model_utils/MaskTime.lua:12-40): out[t,n,:] = tok[t,n] != 0 ? feat[n,:] : 0, and its
+ * backward dfeat[n,:] = sum_t (tok[t,n] != 0) * dout[t,n,:]   (encoders/hre-ques-im-hist.lua:50-53) */
+int vd_mask_time_forward(const float* feat, const int32_t* tok, float* out, int T, int N, int D, void* stream);
+int vd_mask_time_backward(const float* dout, const int32_t* tok, float* dfeat, int T, int N, int D,
+                          void* stream);
 /* counting sort of token ids (prepares the option-table gradient); offset int32[V+1],
  * work int32[2V], perm int32[n] */
 int vd_token_sort(const int32_t* tok, int64_t n, int V, int32_t* offset, int32_t* work, int32_t* perm,
@@ -129,6 +138,13 @@ int vd_img_common_wgrad(const float* dz, const float* pre, const uint8_t* mask1,
  *      (model.lua:37-38,330,334).  gt is 0-based here (the reference's answer_ind is 1-based). */
 int vd_score_ce(const float* optH, const float* enc, const int32_t* gt, float* scores, float* loss_rows,
                 float* dOptH, float* dEnc, int N, int O, int H, float gscale, void* stream);
+/* generative head: nn.Sequencer(nn.MaskZero(nn.LogSoftMax(),1)) (decoders/gen.lua:24) +
+ * SequencerCriterion(MaskZeroCriterion(ClassNLLCriterion, sizeAverage=false)) (model.lua:33-36).
+ * logits [rows x ld] (V valid columns, ld = V rounded up to 4), tok_in/target int32[rows] (1-based
+ * vocabulary ids, 0 = pad).  loss_rows[r] = -log p(target); with write_grad the row is overwritten
+ * by d loss / d logits (softmax - onehot, zero rows at pads). */
+int vd_logsoftmax_nll(float* logits, int64_t ld, int64_t rows, int V, const int32_t* tok_in,
+                      const int32_t* target, float* loss_rows, int write_grad, void* stream);
 /* utils.computeRanks (utils.lua:106-128): 1-based descending-sort position of every option */
 int vd_ranks(const float* scores, int32_t* ranks, int N, int O, void* stream);
 

@@ -431,23 +431,212 @@ def disc_decoder_backward(P, G, st, enc_out, dscores):
     return denc
 
 
+# ----------------------------------------------------------------------------- lf / hre encoders
+def _stack_fwd(P, names, x, tok, h0s=None, c0s=None):
+    """numLayers x SeqLSTM(maskZero) (encoders/lf-ques.lua:17-24)."""
+    states = []
+    for i, nm in enumerate(names):
+        h0 = None if h0s is None else h0s[i]
+        c0 = None if c0s is None else c0s[i]
+        h, c, g = lstm_forward(x, P[nm + '.W'], P[nm + '.b'], tok, h0, c0)
+        states.append(dict(x=x, h=h, c=c, g=g, h0=h0, c0=c0))
+        x = h
+    return states
+
+
+def _stack_bwd(P, G, names, states, dh_last_top=None, dh_seq_top=None, dh_last=None, dc_last=None):
+    """dh_last / dc_last: optional per-layer lists (gradPrevOutput / userNextGradCell, gen.lua:49-51).
+    Returns (dx of the bottom layer, [dh0 per layer], [dc0 per layer])."""
+    L = len(names)
+    dseq = dh_seq_top
+    dh0s, dc0s = [None] * L, [None] * L
+    for i in range(L - 1, -1, -1):
+        st = states[i]
+        dl = dh_last_top if i == L - 1 else None
+        if dh_last is not None and dh_last[i] is not None:
+            dl = dh_last[i] if dl is None else dl + dh_last[i]
+        dcl = None if dc_last is None else dc_last[i]
+        dx, dW, db, dh0, dc0 = lstm_backward(st['x'], P[names[i] + '.W'], st['g'], st['h'], st['c'], dh_seq=dseq,
+                                             dh_last=dl, dc_last=dcl, h0=st['h0'], c0=st['c0'])
+        G[names[i] + '.W'] += dW
+        G[names[i] + '.b'] += db
+        dh0s[i], dc0s[i] = dh0, dc0
+        dseq = dx
+    return dx, dh0s, dc0s
+
+
+def _layer_names(prefix, p):
+    return ['%s%d' % (prefix, l + 1) for l in range(p['numLayers'])]
+
+
+def _tm(a):
+    """[B,R,T] -> time-major [T, N] (model.lua:255-257)"""
+    return a.reshape(-1, a.shape[2]).T
+
+
+def _img_rep(batch, R):
+    f = batch['img_feat']
+    return np.repeat(f, R, axis=0)                      # model.lua:267-269
+
+
+def encoder_forward(encoder, P, p, batch, drop):
+    if encoder == 'mn-att-ques-im-hist':
+        return mnatt_encoder_forward(P, p, batch, drop)
+    d = (lambda k: None) if drop is None else (lambda k: drop[k])
+    pd = p.get('dropout', 0.5)
+    H = p['rnnHiddenSize']
+    qtok = _tm(batch['ques_fwd'])
+    st = dict(qtok=qtok)
+    if encoder == 'lf-ques':                                            # encoders/lf-ques.lua:3-36
+        st['qs'] = _stack_fwd(P, _layer_names('ques', p), lookup(P['embed'], qtok), qtok)
+        st['cat'] = dropout(st['qs'][-1]['h'][-1], d('fuse'), pd)
+        st['out'] = np.tanh(linear(st['cat'], P['fuse.W'], P['fuse.b']))
+    elif encoder == 'lf-ques-im-hist':                                  # encoders/lf-ques-im-hist.lua:3-62
+        htok = _tm(batch['hist'])
+        st['htok'] = htok
+        st['qs'] = _stack_fwd(P, _layer_names('ques', p), lookup(P['embed'], qtok), qtok)
+        st['hs'] = _stack_fwd(P, _layer_names('hist', p), lookup(P['embed'], htok), htok)
+        cat = np.concatenate([st['qs'][-1]['h'][-1], _img_rep(batch, p['maxQuesCount']), st['hs'][-1]['h'][-1]], 1)
+        st['cat'] = dropout(cat, d('fuse'), pd)
+        st['out'] = np.tanh(linear(st['cat'], P['fuse.W'], P['fuse.b']))
+    elif encoder == 'hre-ques-im-hist':                                 # encoders/hre-ques-im-hist.lua:5-97
+        htok = _tm(batch['hist'])
+        st['htok'] = htok
+        R = p['maxQuesCount']
+        N = qtok.shape[1]
+        B = N // R
+        st['hs'] = _stack_fwd(P, _layer_names('hist', p), lookup(P['embed'], htok), htok)
+        st['img_rep'] = _img_rep(batch, R)
+        imgE = linear(st['img_rep'], P['img_embed.W'], P['img_embed.b'])                     # :43-48
+        keep = (qtok != 0)[:, :, None].astype(imgE.dtype)
+        st['keep'] = keep
+        xi = imgE[None, :, :] * keep                                                         # MaskTime.lua:12-29
+        x = np.concatenate([lookup(P['embed'], qtok), xi], 2)                                # JoinTable(-1) :68
+        st['qs'] = _stack_fwd(P, _layer_names('ques', p), x, qtok)
+        j = np.concatenate([st['qs'][-1]['h'][-1], st['hs'][-1]['h'][-1]], 1)                # :85
+        dx = j.reshape(B, R, 2 * H).transpose(1, 0, 2)                                       # :88-89
+        st['ds'] = _stack_fwd(P, ['dialog'], np.ascontiguousarray(dx), None)                 # :90 (no maskZero)
+        st['out'] = st['ds'][0]['h'].transpose(1, 0, 2).reshape(N, H)                        # :91-92
+    else:
+        raise ValueError('oracle: encoder %s not restated yet' % encoder)
+    return st['out'], st
+
+
+def encoder_backward(encoder, P, G, p, batch, drop, st, denc, dec_dh0=None, dec_dc0=None):
+    """dec_dh0 / dec_dc0: per-layer gradients handed back by the gen decoder (gen.lua:45-60)."""
+    if encoder == 'mn-att-ques-im-hist':
+        return mnatt_encoder_backward(P, G, p, batch, drop, st, denc)
+    d = (lambda k: None) if drop is None else (lambda k: drop[k])
+    pd = p.get('dropout', 0.5)
+    H = p['rnnHiddenSize']
+    L = p['numLayers']
+    dh_last = dc_last = None
+    if dec_dh0 is not None:
+        dh_last = [dec_dh0[i] if i != L - 1 else None for i in range(L)]     # gradPrevOutput, ii ~= top
+        dc_last = list(dec_dc0)                                              # userNextGradCell
+    if encoder in ('lf-ques', 'lf-ques-im-hist'):
+        dpre = denc * (1 - st['out'] ** 2)
+        dcat, dW, db = linear_backward(st['cat'], P['fuse.W'], dpre)
+        G['fuse.W'] += dW; G['fuse.b'] += db
+        m = d('fuse')
+        if m is not None:
+            dcat = dcat * m * (1.0 / (1.0 - pd))
+        dq = dcat[:, :H]
+        dx, _, _ = _stack_bwd(P, G, _layer_names('ques', p), st['qs'], dh_last_top=dq, dh_last=dh_last, dc_last=dc_last)
+        lookup_backward(G['embed'], st['qtok'], dx)
+        if encoder == 'lf-ques-im-hist':
+            dh = dcat[:, -H:]
+            dx, _, _ = _stack_bwd(P, G, _layer_names('hist', p), st['hs'], dh_last_top=dh)
+            lookup_backward(G['embed'], st['htok'], dx)
+    elif encoder == 'hre-ques-im-hist':
+        R = p['maxQuesCount']
+        N = denc.shape[0]
+        B = N // R
+        E = p['embedSize']
+        g = np.ascontiguousarray(denc.reshape(B, R, H).transpose(1, 0, 2))
+        dj, _, _ = _stack_bwd(P, G, ['dialog'], st['ds'], dh_seq_top=g)
+        dj = dj.transpose(1, 0, 2).reshape(N, 2 * H)
+        dx, _, _ = _stack_bwd(P, G, _layer_names('ques', p), st['qs'], dh_last_top=dj[:, :H], dh_last=dh_last,
+                              dc_last=dc_last)
+        lookup_backward(G['embed'], st['qtok'], dx[:, :, :E])
+        dimgE = (dx[:, :, E:] * st['keep']).sum(0)                                           # MaskTime.lua:31-40
+        _, dW, db = linear_backward(st['img_rep'], P['img_embed.W'], dimgE)
+        G['img_embed.W'] += dW; G['img_embed.b'] += db
+        dx, _, _ = _stack_bwd(P, G, _layer_names('hist', p), st['hs'], dh_last_top=dj[:, H:])
+        lookup_backward(G['embed'], st['htok'], dx)
+
+
+def gen_decoder_forward(P, p, batch, enc_out, enc_state):
+    """decoders/gen.lua:3-42 + criterion of model.lua:32-36,306-314."""
+    L = p['numLayers']
+    ain, aout = _tm(batch['answer_in']), _tm(batch['answer_out'])
+    N = ain.shape[1]
+    h0s, c0s = [None] * L, [None] * L
+    qs = enc_state.get('qs') if isinstance(enc_state.get('qs'), list) else None   # Sequential encoders expose rnnLayers
+    if qs is not None:
+        for i in range(L):
+            h0s[i], c0s[i] = qs[i]['h'][-1], qs[i]['c'][-1]                        # gen.lua:32-35
+        h0s[L - 1] = enc_out                                                       # gen.lua:38
+    else:
+        h0s[L - 1] = enc_out                                                       # gen.lua:40
+        c0s[L - 1] = np.zeros_like(enc_out)
+    ds = _stack_fwd(P, _layer_names('dec', p), lookup(P['embed'], ain), ain, h0s, c0s)
+    h = ds[-1]['h']
+    logits = h @ P['vocab.W'].T + P['vocab.b']
+    m = logits.max(-1, keepdims=True)
+    lse = m[..., 0] + np.log(np.exp(logits - m).sum(-1))
+    keep = (ain != 0)
+    tgt = np.where(keep, aout - 1, 0)
+    T, _ = ain.shape
+    picked = logits[np.arange(T)[:, None], np.arange(N)[None, :], tgt]
+    loss = float(((lse - picked) * keep).sum())
+    dlogits = np.exp(logits - lse[..., None])
+    dlogits[np.arange(T)[:, None], np.arange(N)[None, :], tgt] -= 1.0
+    dlogits = dlogits * keep[..., None]
+    return loss, dict(ds=ds, h=h, dlogits=dlogits, ain=ain, shared=qs is not None)
+
+
+def gen_decoder_backward(P, G, p, st):
+    L = p['numLayers']
+    h, dl = st['h'], st['dlogits']
+    T, N, H = h.shape
+    G['vocab.W'] += dl.reshape(T * N, -1).T @ h.reshape(T * N, H)
+    G['vocab.b'] += dl.reshape(T * N, -1).sum(0)
+    dh = dl @ P['vocab.W']
+    dx, dh0s, dc0s = _stack_bwd(P, G, _layer_names('dec', p), st['ds'], dh_seq_top=dh)
+    lookup_backward(G['embed'], st['ain'], dx)
+    denc = dh0s[L - 1]                                                            # gen.lua:56 / :58
+    if st['shared']:
+        return denc, dh0s, dc0s
+    return denc, None, None
+
+
 def forward_backward(encoder, decoder, P, p, batch, drop=None, only_forward=False):
-    """Model:forwardBackward (model.lua:249-342) for the restated encoder/decoder pairs.
-    Returns dict(loss, scores, grads (dict, or None), enc_out)."""
-    if encoder != 'mn-att-ques-im-hist' or decoder != 'disc':
-        raise ValueError('oracle.forward_backward: %s + %s not restated yet' % (encoder, decoder))
+    """Model:forwardBackward (model.lua:249-342).  Returns dict(loss, scores, grads, enc_out)."""
     P = dict(P)
     P['embed'] = P['embed'].copy()
     P['embed'][0] = 0          # LookupTableMaskZero zeroes the pad row on every forward
-    enc_out, st = mnatt_encoder_forward(P, p, batch, drop)
-    scores, dst = disc_decoder_forward(P, p, batch['options'], enc_out)
-    loss, dscores, loss_rows = cross_entropy(scores, batch['answer_ind'] - 1)   # answer_ind is 1-based (prepro.py:169)
-    out = dict(loss=loss, scores=scores, enc_out=enc_out, grads=None, loss_rows=loss_rows)
-    if only_forward:
-        return out
-    G = {k: np.zeros_like(v) for k, v in P.items()}
-    denc = disc_decoder_backward(P, G, dst, enc_out, dscores)
-    mnatt_encoder_backward(P, G, p, batch, drop, st, denc)
+    enc_out, st = encoder_forward(encoder, P, p, batch, drop)
+    out = dict(enc_out=enc_out, grads=None, scores=None)
+    if decoder == 'disc':
+        scores, dst = disc_decoder_forward(P, p, batch['options'], enc_out)
+        loss, dscores, loss_rows = cross_entropy(scores, batch['answer_ind'] - 1)   # answer_ind is 1-based (prepro.py:169)
+        out.update(loss=loss, scores=scores, loss_rows=loss_rows)
+        if only_forward:
+            return out
+        G = {k: np.zeros_like(v) for k, v in P.items()}
+        denc = disc_decoder_backward(P, G, dst, enc_out, dscores)
+        encoder_backward(encoder, P, G, p, batch, drop, st, denc)
+    elif decoder == 'gen':
+        loss, gst = gen_decoder_forward(P, p, batch, enc_out, st)
+        out.update(loss=loss)
+        if only_forward:
+            return out
+        G = {k: np.zeros_like(v) for k, v in P.items()}
+        denc, dh0s, dc0s = gen_decoder_backward(P, G, p, gst)
+        encoder_backward(encoder, P, G, p, batch, drop, st, denc, dh0s, dc0s)
+    else:
+        raise ValueError(decoder)
     out['grads'] = G
     return out
 

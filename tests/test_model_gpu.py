@@ -123,3 +123,57 @@ def test_train_iterations_reduce_loss(gpu):
     for _ in range(30):
         l = model.trainIteration(Fixed())
     assert np.isfinite(l) and l < l0
+
+
+# ----------------------------------------------------------------------------------------------------
+# lf-ques(+im-hist) + gen, hre-ques-im-hist + disc (and cross pairs)
+WIDE = {
+    'tiny': dict(imgNorm=1, dropout=0.3, imgFeatureSize=16),
+    'mid': dict(imgNorm=1, dropout=0.5, vocabSize=203, embedSize=300, rnnHiddenSize=512, imgFeatureSize=4096,
+                imgEmbedSize=300, maxQuesCount=10, batchSize=2, numOptions=100, maxQuesLen=20, maxAnsLen=20,
+                maxHistoryLenPerRound=40, maxHistoryLen=12),
+}
+
+
+def fuse_masks(p, batch, rng):
+    enc = p['encoder']
+    if enc not in ('lf-ques', 'lf-ques-im-hist'):
+        return None
+    N = batch['ques_fwd'].shape[0] * batch['ques_fwd'].shape[1]
+    D = p['rnnHiddenSize'] if enc == 'lf-ques' else 2 * p['rnnHiddenSize'] + p['imgFeatureSize']
+    return {'fuse': (rng.rand(N, D) > p['dropout']).astype(np.uint8)}
+
+
+@pytest.mark.parametrize("enc,dec", [('lf-ques', 'gen'), ('lf-ques-im-hist', 'gen'), ('hre-ques-im-hist', 'disc'),
+                                     ('hre-ques-im-hist', 'gen'), ('lf-ques-im-hist', 'disc'),
+                                     ('mn-att-ques-im-hist', 'gen')])
+@pytest.mark.parametrize("case", ['tiny', 'mid'])
+def test_widened_pairs_match_oracle(gpu, enc, dec, case):
+    from visdial_amd.model import Model
+    kw = dict(WIDE[case])
+    if 'att' in enc:
+        kw.update(imgFeatureSize=32 if case == 'tiny' else 512, imgSpatialSize=3 if case == 'tiny' else 7)
+    p = derive(small_params(encoder=enc, decoder=dec, **kw))
+    dl = SyntheticDataloader(p, seed=21)
+    batch = dl.getTrainBatch(p)
+    model = Model(p)
+    masks = fuse_masks(p, batch, np.random.RandomState(8))
+    if masks is not None:
+        model.set_dropout_masks(masks)
+    else:
+        model.wrapper.evaluate()
+    P0 = {k: v.astype(np.float64) for k, v in model.get_parameters_dict().items()}
+    model.wrapper.zeroGradParameters()
+    loss = model.forwardBackward(batch)
+    drop = {k: v.astype(np.float64) for k, v in masks.items()} if masks else None
+    ref = vo.forward_backward(enc, dec, P0, p, batch, drop)
+    assert abs(loss - ref['loss']) < 1e-4 * max(1.0, abs(ref['loss']))
+    g = model.get_gradients_dict()
+    gnorm = max(np.abs(v).max() for v in ref['grads'].values())
+    bad = [(rel(g[k], ref['grads'][k]), k) for k in ref['grads']
+           if rel(g[k], ref['grads'][k]) >= 1e-4 and np.abs(g[k] - ref['grads'][k]).max() >= 1e-6 * max(1.0, gnorm)]
+    assert not bad, bad
+    # forward-only (Model:evaluate path, model.lua:128) must give the same loss and leave gradients alone
+    before = model.wrapperdW.clone()
+    loss2 = model.forwardBackward(batch, onlyForward=True)
+    assert abs(loss2 - loss) < 1e-5 * max(1.0, abs(loss)) and torch.equal(before, model.wrapperdW)

@@ -141,3 +141,114 @@ def test_adam_matches_reference_formula():
     m = 0.1 * gc2; v = 0.001 * gc2 * gc2
     step = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
     np.testing.assert_allclose(w1, w - step * m / (np.sqrt(v) + 1e-8), rtol=1e-12)
+
+
+# ----------------------------------------------------------------------------------------------------
+# widening rows a10 / a11: lf-ques, lf-ques-im-hist, hre-ques-im-hist encoders and the gen decoder
+def torch_lstm2(x, W, b, tok, H, h0=None, c0=None):
+    T, N, D = x.shape
+    h = torch.zeros(N, H, dtype=x.dtype) if h0 is None else h0
+    c = torch.zeros(N, H, dtype=x.dtype) if c0 is None else c0
+    hs, cs = [], []
+    for t in range(T):
+        a = torch.addmm(b, torch.cat([x[t], h], 1), W)
+        i, f, o, g = a[:, :H].sigmoid(), a[:, H:2 * H].sigmoid(), a[:, 2 * H:3 * H].sigmoid(), a[:, 3 * H:].tanh()
+        c = f * c + i * g
+        h = o * c.tanh()
+        if tok is not None:
+            keep = (tok[t] != 0).to(x.dtype)[:, None]
+            h, c = h * keep, c * keep
+        hs.append(h)
+        cs.append(c)
+    return torch.stack(hs), torch.stack(cs)
+
+
+def torch_generic_forward(enc, dec, P, p, batch, drop):
+    F = torch.nn.functional
+    H, L, R = p['rnnHiddenSize'], p['numLayers'], p['maxQuesCount']
+    f64 = torch.float64
+    emb = P['embed'] * torch.cat([torch.zeros(1, 1, dtype=f64), torch.ones(P['embed'].shape[0] - 1, 1, dtype=f64)])
+    tm = lambda a: torch.from_numpy(a.reshape(-1, a.shape[2]).T.astype(np.int64))
+    dr = (lambda x, k: x * torch.from_numpy(drop[k]) * (1.0 / (1.0 - p['dropout']))) if drop else (lambda x, k: x)
+    qtok = tm(batch['ques_fwd'])
+    N = qtok.shape[1]
+    B = N // R
+
+    def stack(prefix, x, tok):
+        st = []
+        for l in range(L):
+            h, c = torch_lstm2(x, P['%s%d.W' % (prefix, l + 1)], P['%s%d.b' % (prefix, l + 1)], tok, H)
+            st.append((h, c))
+            x = h
+        return st
+    img = torch.from_numpy(batch['img_feat'].astype(np.float64)).repeat_interleave(R, 0) if 'img_feat' in batch else None
+    if enc == 'lf-ques':
+        qs = stack('ques', emb[qtok], qtok)
+        enc_out = torch.tanh(F.linear(dr(qs[-1][0][-1], 'fuse'), P['fuse.W'], P['fuse.b']))
+    elif enc == 'lf-ques-im-hist':
+        htok = tm(batch['hist'])
+        qs = stack('ques', emb[qtok], qtok)
+        hs = stack('hist', emb[htok], htok)
+        cat = torch.cat([qs[-1][0][-1], img, hs[-1][0][-1]], 1)
+        enc_out = torch.tanh(F.linear(dr(cat, 'fuse'), P['fuse.W'], P['fuse.b']))
+    elif enc == 'hre-ques-im-hist':
+        htok = tm(batch['hist'])
+        hs = stack('hist', emb[htok], htok)
+        imgE = F.linear(img, P['img_embed.W'], P['img_embed.b'])
+        xi = imgE[None].expand(qtok.shape[0], N, imgE.shape[1]) * (qtok != 0).to(f64)[:, :, None]
+        qs = stack('ques', torch.cat([emb[qtok], xi], 2), qtok)
+        j = torch.cat([qs[-1][0][-1], hs[-1][0][-1]], 1).view(B, R, 2 * H).transpose(0, 1)
+        dh, _ = torch_lstm2(j, P['dialog.W'], P['dialog.b'], None, H)
+        enc_out = dh.transpose(0, 1).reshape(N, H)
+    else:
+        raise ValueError(enc)
+    if dec == 'disc':
+        opt = batch['options']
+        O = opt.shape[1]
+        otok = torch.from_numpy(opt.reshape(N * O, -1).T.astype(np.int64))
+        oh, _ = torch_lstm2(emb[otok], P['opt.W'], P['opt.b'], None, H)
+        scores = torch.bmm(oh[-1].view(N, O, H), enc_out[:, :, None]).squeeze(-1)
+        return F.cross_entropy(scores, torch.from_numpy(batch['answer_ind'].astype(np.int64)) - 1)
+    ain, aout = tm(batch['answer_in']), tm(batch['answer_out'])
+    x = emb[ain]
+    for l in range(L):
+        h0, c0 = qs[l][0][-1], qs[l][1][-1]
+        if l == L - 1:
+            h0 = enc_out
+        x, _ = torch_lstm2(x, P['dec%d.W' % (l + 1)], P['dec%d.b' % (l + 1)], ain, H, h0, c0)
+    logp = F.log_softmax(F.linear(x, P['vocab.W'], P['vocab.b']), -1)
+    keep = (ain != 0)
+    tgt = torch.where(keep, aout - 1, torch.zeros_like(aout))
+    nll = -logp.gather(2, tgt[:, :, None]).squeeze(-1)
+    return (nll * keep.to(f64)).sum()
+
+
+def fuse_masks(p, batch, enc, rng):
+    if enc not in ('lf-ques', 'lf-ques-im-hist'):
+        return None
+    N = batch['ques_fwd'].shape[0] * batch['ques_fwd'].shape[1]
+    D = p['rnnHiddenSize'] if enc == 'lf-ques' else 2 * p['rnnHiddenSize'] + p['imgFeatureSize']
+    return {'fuse': (rng.rand(N, D) > p['dropout']).astype(np.float64)}
+
+
+@pytest.mark.parametrize("enc,dec", [('lf-ques', 'gen'), ('lf-ques-im-hist', 'gen'), ('hre-ques-im-hist', 'disc'),
+                                     ('hre-ques-im-hist', 'gen'), ('lf-ques', 'disc')])
+@pytest.mark.parametrize("use_drop", [False, True])
+def test_oracle_widening_matches_torch_autograd(enc, dec, use_drop):
+    from visdial_amd.opts import derive
+    p = derive(small_params(encoder=enc, decoder=dec, imgNorm=1, dropout=0.3))
+    dl = SyntheticDataloader(p, seed=9)
+    batch = dl.getTrainBatch(p)
+    P = vo.init_params(enc, dec, p, seed=4)
+    drop = fuse_masks(p, batch, enc, np.random.RandomState(2)) if use_drop else None
+    r = vo.forward_backward(enc, dec, P, p, batch, drop)
+    Pt = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in P.items()}
+    loss = torch_generic_forward(enc, dec, Pt, p, batch, drop)
+    loss.backward()
+    assert abs(loss.item() - r['loss']) < 1e-9 * max(1.0, abs(r['loss']))
+    for k in P:
+        g_t = Pt[k].grad.numpy() if Pt[k].grad is not None else np.zeros_like(P[k])
+        g_o = r['grads'][k]
+        if k == 'embed':
+            g_t, g_o = g_t[1:], g_o[1:]
+        np.testing.assert_allclose(g_o, g_t, rtol=1e-7, atol=1e-9, err_msg=k)

@@ -77,6 +77,16 @@ int vd_memcpy_d2d(void* dst, const void* src, int64_t bytes, void* stream) {
   return VD_OK;
 }
 
+// strided 2-D device copy: `rows` rows of `cols` floats (nn.JoinTable / nn.Narrow on column blocks)
+int vd_copy_2d(float* dst, int64_t dst_ld, const float* src, int64_t src_ld, int64_t rows, int64_t cols,
+               void* stream) {
+  VD_CHECK_ARG(dst && src && rows >= 0 && cols >= 0 && dst_ld >= cols && src_ld >= cols, "vd_copy_2d: bad args");
+  if (rows == 0 || cols == 0) return VD_OK;
+  VD_HIP(hipMemcpy2DAsync(dst, (size_t)dst_ld * 4, src, (size_t)src_ld * 4, (size_t)cols * 4, (size_t)rows,
+                          hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return VD_OK;
+}
+
 int vd_stream_synchronize(void* stream) {
   VD_HIP(hipStreamSynchronize((hipStream_t)stream));
   return VD_OK;

@@ -90,6 +90,31 @@ __global__ void embed_scatter_kernel(float* __restrict__ demb, const int* __rest
   if (v != 0.f) unsafeAtomicAdd(demb + (long)tok[r] * E + e, v);
 }
 
+// ------------------------------------------------------------------ MaskTime (model_utils/MaskTime.lua:12-40)
+// forward: out[t, n, :] = tok[t, n] != 0 ? feat[n, :] : 0      (replicate over time, zero at pads)
+__global__ void mask_time_fwd_kernel(const float* __restrict__ feat, const int* __restrict__ tok,
+                                     float* __restrict__ out, int T, int N, int D) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)T * N * D;
+  if (idx >= total) return;
+  const long tn = idx / D;
+  const int d = (int)(idx - tn * D);
+  const int n = (int)(tn % N);
+  out[idx] = tok[tn] != 0 ? feat[(long)n * D + d] : 0.f;
+}
+// backward: dfeat[n, :] = sum_t (tok[t, n] != 0) * dout[t, n, :]
+__global__ void mask_time_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ tok,
+                                     float* __restrict__ dfeat, int T, int N, int D) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)N * D) return;
+  const int n = (int)(idx / D);
+  const int d = (int)(idx - (long)n * D);
+  float s = 0.f;
+  for (int t = 0; t < T; ++t)
+    if (tok[(long)t * N + n] != 0) s += dout[((long)t * N + n) * D + d];
+  dfeat[idx] = s;
+}
+
 // ------------------------------------------------------------------ token counting sort
 // Wave-aggregated atomics: lanes holding the same token as the wave's first active lane are
 // counted with one atomic (the pad token dominates option batches: ~50% of all ids are 0).
@@ -269,6 +294,26 @@ int vd_axpby(const float* a, const float* b, float* c, int64_t n, float alpha, f
   if (n == 0) return VD_OK;
   hipLaunchKernelGGL(axpby_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, a, b, c, (long)n, alpha,
                      beta);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+int vd_mask_time_forward(const float* feat, const int32_t* tok, float* out, int T, int N, int D, void* stream) {
+  VD_CHECK_ARG(feat && tok && out && T >= 0 && N >= 0 && D > 0, "vd_mask_time_forward: bad args");
+  const long total = (long)T * N * D;
+  if (total == 0) return VD_OK;
+  hipLaunchKernelGGL(mask_time_fwd_kernel, grid1d(total, 256), dim3(256), 0, (hipStream_t)stream, feat, tok, out,
+                     T, N, D);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+int vd_mask_time_backward(const float* dout, const int32_t* tok, float* dfeat, int T, int N, int D,
+                          void* stream) {
+  VD_CHECK_ARG(dout && tok && dfeat && T >= 0 && N >= 0 && D > 0, "vd_mask_time_backward: bad args");
+  if ((long)N * D == 0) return VD_OK;
+  hipLaunchKernelGGL(mask_time_bwd_kernel, grid1d((long)N * D, 256), dim3(256), 0, (hipStream_t)stream, dout,
+                     tok, dfeat, T, N, D);
   VD_LAUNCH_CHECK();
   return VD_OK;
 }

@@ -60,7 +60,9 @@ int vd_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const f
 // C[M x N] (+)= A[M x K] * B[K x N] + bias
 int vd_gemm_nn(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
                int64_t ldc, int M, int N, int K, int accumulate, void* stream) {
-  VD_CHECK_ARG(A && B && C && M >= 0 && N >= 0 && K >= 0 && K % 4 == 0 && N % 4 == 0,
+  // K need not be a multiple of 4 when every A row is padded to one (lda >= ceil4(K), pad columns finite):
+  // the float4 that straddles K multiplies pad values by zero-filled B rows.
+  VD_CHECK_ARG(A && B && C && M >= 0 && N >= 0 && K >= 0 && (K % 4 == 0 || lda >= (K + 3) / 4 * 4) && N % 4 == 0,
                "vd_gemm_nn: bad args M=%d N=%d K=%d", M, N, K);
   if (int rc = check_align(A, lda, "vd_gemm_nn A")) return rc;
   if (int rc = check_align(B, ldb, "vd_gemm_nn B")) return rc;
@@ -78,7 +80,9 @@ int vd_gemm_nn(const float* A, int64_t lda, const float* B, int64_t ldb, const f
 // C[M x N] += A[K x M]^T * B[K x N]   (weight gradients; split-K with float atomics)
 int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
                    int N, int K, void* stream) {
-  VD_CHECK_ARG(A && B && C && M >= 0 && N >= 0 && K >= 0 && M % 4 == 0 && N % 4 == 0,
+  // M (resp. N) need not be a multiple of 4 when the rows of A (resp. B) are padded to one.
+  VD_CHECK_ARG(A && B && C && M >= 0 && N >= 0 && K >= 0 && (M % 4 == 0 || lda >= (M + 3) / 4 * 4) &&
+                   (N % 4 == 0 || ldb >= (N + 3) / 4 * 4),
                "vd_gemm_tn_acc: bad args M=%d N=%d K=%d", M, N, K);
   if (int rc = check_align(A, lda, "vd_gemm_tn_acc A")) return rc;
   if (int rc = check_align(B, ldb, "vd_gemm_tn_acc B")) return rc;

@@ -78,7 +78,57 @@ ranks_kernel(const float* __restrict__ scores, int* __restrict__ ranks, int O) {
   ranks[(long)n * O + o] = r;
 }
 
+// Generative head, per (t, n) row of logits [rows x ld] (V valid columns):
+//   nn.Sequencer(nn.MaskZero(nn.LogSoftMax(), 1)) + SequencerCriterion(MaskZeroCriterion(ClassNLL(sum)))
+//   (decoders/gen.lua:23-24, model.lua:33-36): rows whose decoder input token is 0 contribute nothing.
+//   loss_rows[r] = logsumexp(logits[r]) - logits[r, target-1]   (target ids are 1-based vocabulary ids)
+//   logits[r, :] <- (softmax - onehot) (the gradient, unscaled: sizeAverage = false), zeros for pad rows.
+__global__ void __launch_bounds__(256)
+logsoftmax_nll_kernel(float* __restrict__ logits, long ld, int V, const int* __restrict__ tok_in,
+                      const int* __restrict__ target, float* __restrict__ loss_rows, int write_grad) {
+  __shared__ float red[8];
+  const long r = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* row = logits + r * ld;
+  if (write_grad && tid < ld - V) row[V + tid] = 0.f;  // keep the alignment pad columns finite (K-padding rule)
+  if (tok_in[r] == 0) {
+    if (tid == 0) loss_rows[r] = 0.f;
+    if (write_grad)
+      for (int c = tid; c < V; c += 256) row[c] = 0.f;
+    return;
+  }
+  float mx = -INFINITY;
+  for (int c = tid; c < V; c += 256) mx = fmaxf(mx, row[c]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int c = tid; c < V; c += 256) sum += expf(row[c] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float lse = mx + logf(red[4] + red[5] + red[6] + red[7]);
+  const int tgt = target[r] - 1;
+  if (tid == 0) loss_rows[r] = lse - row[tgt];
+  if (write_grad) {
+    __syncthreads();
+    for (int c = tid; c < V; c += 256) row[c] = expf(row[c] - lse) - (c == tgt ? 1.f : 0.f);
+  }
+}
+
 extern "C" {
+
+int vd_logsoftmax_nll(float* logits, int64_t ld, int64_t rows, int V, const int32_t* tok_in,
+                      const int32_t* target, float* loss_rows, int write_grad, void* stream) {
+  VD_CHECK_ARG(logits && tok_in && target && loss_rows && rows >= 0 && V >= 1 && ld >= V,
+               "vd_logsoftmax_nll: bad args");
+  if (rows == 0) return VD_OK;
+  hipLaunchKernelGGL(logsoftmax_nll_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits,
+                     (long)ld, V, tok_in, target, loss_rows, write_grad);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
 
 // gt: 0-based ground-truth option per round, or null for scores only.
 // dOptH/dEnc: null for forward-only.  gscale = 1/N_global (CrossEntropyCriterion sizeAverage).

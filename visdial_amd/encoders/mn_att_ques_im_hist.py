@@ -7,7 +7,7 @@ Inputs (order of the reference's input table, model.lua:255-294):
 Like the reference this encoder hard-codes two LSTM layers per branch and dropout 0.5 (mn-att:24-41).
 """
 from .. import ops
-from ..nn import SeqLSTM, Linear, StreamPool, dropout_forward, dropout_backward
+from ..nn import SeqLSTM, Linear, StreamPool, dropout_forward, dropout_backward, lstm_stack_backward
 
 P_DROP = 0.5
 SCALE = 1.0 / (1.0 - P_DROP)
@@ -55,9 +55,7 @@ class Encoder(object):
         return h2[T - 1], m
 
     def _branch_bwd(self, tok, l1, l2, dlast, m):
-        dh1, _, _ = l2.backward(dh_last=dlast)
-        T, N = tok.shape
-        dx, _, _ = l1.backward(dh_seq=dh1.view(T, N, self.H))
+        dx = lstm_stack_backward([l1, l2], dh_last_top=dlast)[0]
         ops.embed_scatter_acc(self.fp.g['embed'], tok, dx, mask=m, scale=SCALE)
 
     def output_buffer(self, inputs):

@@ -112,52 +112,118 @@ class DropoutState(object):
 
 class SeqLSTM(object):
     """nn.SeqLSTM(D, H) [:maskZero()] -- forward/backward over a whole time-major sequence.
-    Saved state (gates, h, c) lives in the workspace under `key`."""
 
-    def __init__(self, fp, name, D, H, ws, key=None):
+    The input may arrive as several column blocks (`part_dims`): x*Wx is then the sum of the
+    per-block products against the matching row blocks of Wx, which is how nn.JoinTable(-1) in front
+    of an LSTM (encoders/hre-ques-im-hist.lua:66-68,85-92) is folded away without a concat copy.
+    State hand-off fields carry the reference's names (rnn SeqLSTM, used by decoders/gen.lua:30-60):
+    userPrevOutput / userPrevCell (h0, c0), userNextGradCell (dc at the last step), gradPrevOutput
+    (extra dh at the last step); after backward userGradPrevOutput / userGradPrevCell (dh0, dc0).
+    Saved state (gates, h, c) lives in the workspace under `key`: `.output` = h, `.cell` = c."""
+
+    def __init__(self, fp, name, D, H, ws, key=None, part_dims=None):
         self.D, self.H = D, H
+        self.part_dims = list(part_dims) if part_dims else [D]
+        assert sum(self.part_dims) == D
         self.W, self.b = fp.w[name + '.W'], fp.w[name + '.b']
         self.dW, self.db = fp.g[name + '.W'], fp.g[name + '.b']
         self.Wx, self.Wh = self.W[:D], self.W[D:]
         self.dWx, self.dWh = self.dW[:D], self.dW[D:]
         self.ws = ws
         self.key = key or name
+        self.userPrevOutput = self.userPrevCell = None
+        self.userNextGradCell = self.gradPrevOutput = None
+        self.userGradPrevOutput = self.userGradPrevCell = None
 
-    def forward(self, x, T, N, tok_mask=None, h0=None, c0=None):
-        """x: [T*N, D] dense input rows (time-major).  Returns h [T, N, H]."""
+    def _wx_blocks(self, W):
+        out, o = [], 0
+        for d in self.part_dims:
+            out.append(W[o:o + d])
+            o += d
+        return out
+
+    def forward(self, x, T, N, tok_mask=None):
+        """x: [T*N, D] dense input rows (time-major), or a list of column blocks.  Returns h [T, N, H]."""
         H, k = self.H, self.key
-        self.T, self.N, self.x, self.tok_mask, self.h0, self.c0 = T, N, x, tok_mask, h0, c0
+        xs = list(x) if isinstance(x, (list, tuple)) else [x]
+        assert len(xs) == len(self.part_dims)
+        h0, c0 = self.userPrevOutput, self.userPrevCell
+        self.userPrevOutput = self.userPrevCell = None          # consumed once (rnn semantics)
+        if h0 is not None and c0 is None:
+            c0 = self.ws.get(k + '.c0zero', (N, H))
+            c0.zero_()
+        if c0 is not None and h0 is None:
+            h0 = self.ws.get(k + '.h0zero', (N, H))
+            h0.zero_()
+        self.T, self.N, self.xs, self.tok_mask, self.h0, self.c0 = T, N, xs, tok_mask, h0, c0
         self.gates = self.ws.get(k + '.gates', (T, N, 4 * H))
         self.h = self.ws.get(k + '.h', (T, N, H))
         self.c = self.ws.get(k + '.c', (T, N, H))
+        self.output, self.cell = self.h, self.c
         g2 = self.gates.view(T * N, 4 * H)
         # hoisted input projection, written straight into the gates buffer (the step kernel reads
         # and overwrites each element from the same thread, so the recurrence runs in place)
-        ops.gemm_nn(x, self.Wx, g2, bias=self.b, M=T * N, N=4 * H, K=self.D)
+        for i, (xi, wi, d) in enumerate(zip(xs, self._wx_blocks(self.Wx), self.part_dims)):
+            ops.gemm_nn(xi, wi, g2, bias=self.b if i == 0 else None, accumulate=(i > 0), M=T * N, N=4 * H, K=d)
         ops.lstm_forward(g2, self.Wh, self.gates, self.h, self.c, T, N, H, N * 4 * H, 4 * H, tok_mask=tok_mask,
                          h0=h0, c0=c0)
         return self.h
 
-    def backward(self, dh_seq=None, dh_last=None, dc_last=None, need_dx=True, need_dh0=False):
-        """Returns (dx [T*N, D] or None, dh0 or None, dc0).  Accumulates dW, db."""
+    def backward(self, dh_seq=None, dh_last=None, need_dx=True):
+        """Returns the list of dx blocks ([T*N, d_i]; None where not requested).  Accumulates dW, db and
+        sets userGradPrevOutput / userGradPrevCell."""
         T, N, H, k = self.T, self.N, self.H, self.key
+        if self.gradPrevOutput is not None:
+            if dh_last is None:
+                dh_last = self.gradPrevOutput
+            else:
+                dh_last = ops.axpby(dh_last, self.gradPrevOutput, self.ws.get(k + '.dhl', (N, H)), 1.0, 1.0)
+        dc_last = self.userNextGradCell
+        self.gradPrevOutput = self.userNextGradCell = None
         dc = self.ws.get(k + '.dc', (N, H))
-        dh0 = self.ws.get(k + '.dh0', (N, H)) if need_dh0 else None
+        dh0 = self.ws.get(k + '.dh0', (N, H)) if self.h0 is not None else None
         ops.lstm_backward(self.Wh, self.gates, self.c, dc, T, N, H, c0=self.c0, dh_seq=dh_seq, dh_last=dh_last,
                           dc_last=dc_last, dh0=dh0)
+        self.userGradPrevOutput, self.userGradPrevCell = dh0, (dc if self.h0 is not None else None)
         da = self.gates.view(T * N, 4 * H)
         h2 = self.h.view(T * N, H)
         if T > 1:
             ops.gemm_tn_acc(h2, da[N:], self.dWh, M=H, N=4 * H, K=(T - 1) * N)
         if self.h0 is not None:
             ops.gemm_tn_acc(self.h0, da, self.dWh, M=H, N=4 * H, K=N)
-        ops.gemm_tn_acc(self.x, da, self.dWx, M=self.D, N=4 * H, K=T * N)
         ops.colsum_acc(da, self.db, M=T * N, N=4 * H)
-        dx = None
-        if need_dx:
-            dx = self.ws.get(k + '.dx', (T * N, self.D))
-            ops.gemm_nt(da, self.Wx, dx, M=T * N, N=self.D, K=4 * H)
-        return dx, dh0, dc
+        need = need_dx if isinstance(need_dx, (list, tuple)) else [need_dx] * len(self.xs)
+        dxs = []
+        for i, (xi, wi, dwi, d) in enumerate(zip(self.xs, self._wx_blocks(self.Wx), self._wx_blocks(self.dWx),
+                                                self.part_dims)):
+            ops.gemm_tn_acc(xi, da, dwi, M=d, N=4 * H, K=T * N)
+            if need[i]:
+                dx = self.ws.get('%s.dx%d' % (k, i), (T * N, d))
+                ops.gemm_nt(da, wi, dx, M=T * N, N=d, K=4 * H)
+                dxs.append(dx)
+            else:
+                dxs.append(None)
+        return dxs
+
+
+def lstm_stack_forward(layers, x, T, N, tok_mask):
+    """numLayers x SeqLSTM(maskZero) as in encoders/lf-ques.lua:18-24.  Returns the top layer's h."""
+    h = layers[0].forward(x, T, N, tok_mask)
+    for l in layers[1:]:
+        h = l.forward(h.view(T * N, l.D), T, N, tok_mask)
+    return h
+
+
+def lstm_stack_backward(layers, dh_last_top=None, dh_seq_top=None, need_dx=True):
+    """Backward through the stack; returns the bottom layer's dx blocks."""
+    dseq = dh_seq_top
+    for i in range(len(layers) - 1, -1, -1):
+        l = layers[i]
+        top = (i == len(layers) - 1)
+        dxs = l.backward(dh_seq=dseq, dh_last=dh_last_top if top else None, need_dx=need_dx if i == 0 else True)
+        if i > 0:
+            dseq = dxs[0].view(l.T, l.N, layers[i - 1].H)
+    return dxs
 
 
 class Linear(object):

@@ -200,3 +200,26 @@ def ranks(scores, out, N, O):
 def clamp_adam(w, g, m, v, step, gscale=1.0, clip=5.0, beta1=0.9, beta2=0.999, eps=1e-8):
     call("vd_clamp_adam", _p(w, F32), _p(g, F32), _p(m, F32), _p(v, F32), w.numel(), float(gscale), float(clip),
          float(beta1), float(beta2), float(eps), float(step), _stream())
+
+
+# ---------------------------------------------------------------- widening: gen head, MaskTime, column copies
+def logsoftmax_nll(logits, V, tok_in, target, loss_rows, write_grad=True):
+    rows = tok_in.numel()
+    call("vd_logsoftmax_nll", _p(logits, F32), logits.stride(0), rows, V, _p(tok_in, I32), _p(target, I32),
+         _p(loss_rows, F32), int(write_grad), _stream())
+
+
+def mask_time_forward(feat, tok, out, T, N, D):
+    call("vd_mask_time_forward", _p(feat, F32), _p(tok, I32), _p(out, F32), T, N, D, _stream())
+    return out
+
+
+def mask_time_backward(dout, tok, dfeat, T, N, D):
+    call("vd_mask_time_backward", _p(dout, F32), _p(tok, I32), _p(dfeat, F32), T, N, D, _stream())
+    return dfeat
+
+
+def copy_2d(dst, dst_ld, src, src_ld, rows, cols, dst_off=0, src_off=0):
+    """copy a [rows x cols] column block; offsets are in floats from the tensor base"""
+    assert dst.is_cuda and src.is_cuda and dst.dtype == F32 and src.dtype == F32
+    call("vd_copy_2d", dst.data_ptr() + 4 * dst_off, dst_ld, src.data_ptr() + 4 * src_off, src_ld, rows, cols, _stream())
