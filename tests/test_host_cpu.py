@@ -1,0 +1,169 @@
+"""CPU-only checks (-m "not gpu"): the C-ABI library loads and exports every symbol the header declares,
+host logic (flags, batch layout, metrics), and the data-parallel reduction with gloo, world_size 2."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, small_params
+from oracle import visdial_oracle as vo
+
+
+def test_library_exports_every_declared_symbol():
+    """no compute calls here (no GPU): load the .so, compare its symbols with include/visdial_hip.h"""
+    from visdial_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, 'include', 'visdial_hip.h')).read()
+    declared = set(re.findall(r'\b(vd_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 40
+    for name in sorted(declared):
+        assert hasattr(lib, name), "library does not export %s" % name
+    assert declared == set(_lib.PROTOTYPES), (declared ^ set(_lib.PROTOTYPES))
+    assert lib.vd_abi_version() == 1
+    assert isinstance(lib.vd_last_error(), bytes)
+
+
+def test_product_path_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'visdial_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('the oracle', '').replace('# oracle', ''), (dirpath, f)
+
+
+def test_model_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from visdial_amd.model import Model
+    from visdial_amd.opts import derive
+    with pytest.raises(RuntimeError):
+        Model(derive(small_params()))
+
+
+def test_opts_defaults_and_derived_flags():
+    from visdial_amd import opts
+    o = opts.default_params()
+    assert o['batchSize'] == 40 and o['learningRate'] == 1e-3 and o['lrDecayRate'] == 0.9997592083      # opts.lua:33-38
+    assert o['encoder'] == 'lf-ques-hist' and o['decoder'] == 'gen' and o['rnnHiddenSize'] == 512
+    assert o['useHistory'] and not o['useIm'] and o['concatHistory']                                    # opts.lua:54-59
+    a = opts.default_params(encoder='mn-att-ques-im-hist')
+    assert a['useIm'] and a['useHistory'] and not a['concatHistory']
+    assert a['imgNorm'] == 0 and a['inputImg'] == 'data/data_img_pool5.h5'                              # opts.lua:61-67
+    p = opts.parse(['-encoder', 'hre-ques-im-hist', '-decoder', 'disc', '-batchSize', '20'])
+    assert p['encoder'] == 'hre-ques-im-hist' and p['batchSize'] == 20 and 'hre-ques-im-hist-disc' in p['savePath']
+
+
+def test_plugin_registry_knows_every_reference_file():
+    from visdial_amd import encoders, decoders
+    ref = ['hre-ques-hist', 'hre-ques-im-hist', 'hrea-ques-im-hist', 'lf-att-ques-im-hist', 'lf-ques-hist',
+           'lf-ques-im-hist', 'lf-ques-im', 'lf-ques', 'mn-att-ques-im-hist', 'mn-ques-hist', 'mn-ques-im-hist']
+    assert sorted(encoders.NAMES) == sorted(ref) and decoders.NAMES == ['disc', 'gen']
+    for n in ('lf-ques', 'lf-ques-im-hist', 'hre-ques-im-hist', 'mn-att-ques-im-hist'):
+        m = encoders.load(n)
+        assert hasattr(m, 'model') and hasattr(m, 'declare')
+    with pytest.raises(ValueError):
+        encoders.load('no-such-encoder')
+    for n in ('disc', 'gen'):
+        m = decoders.load(n)
+        assert all(hasattr(m, f) for f in ('model', 'forwardConnect', 'backwardConnect'))
+    assert hasattr(decoders.load('gen'), 'decoderConnect') and not hasattr(decoders.load('disc'), 'decoderConnect')
+
+
+def test_synthetic_batch_layout_matches_dataloader_contract():
+    from visdial_amd.dataloader import SyntheticDataloader
+    from visdial_amd.opts import derive
+    p = derive(small_params(batchSize=3, maxQuesCount=5, numOptions=9))
+    b = SyntheticDataloader(p, seed=0).getTrainBatch(p)
+    q, h, o = b['ques_fwd'], b['hist'], b['options']
+    assert q.shape[:2] == (3, 5) and h.shape[:2] == (3, 5) and o.shape[:2] == (15, 9)
+    for seq in q.reshape(-1, q.shape[2]):                       # right-aligned: zeros only on the left
+        nz = np.nonzero(seq)[0]
+        assert len(nz) and (seq[nz[0]:] != 0).all()
+    assert (q.reshape(-1, q.shape[2])[:, 0] != 0).any()         # trimmed to the batch maximum
+    for seq in o.reshape(-1, o.shape[2]):                       # options left-aligned, trailing zeros
+        nz = np.nonzero(seq)[0]
+        assert len(nz) and (seq[:nz[-1] + 1] != 0).all()
+    assert b['answer_ind'].min() >= 1 and b['answer_ind'].max() <= 9            # 1-based (prepro.py:169)
+    assert b['img_feat'].shape == (3, 3, 3, 16) and (b['img_feat'] >= 0).all()
+    g = derive(small_params(encoder='lf-ques-im-hist', decoder='gen', imgNorm=1))
+    bg = SyntheticDataloader(g, seed=0).getTrainBatch(g)
+    ai, ao = bg['answer_in'], bg['answer_out']
+    assert ai.shape == ao.shape and (ai[:, :, 0] == g['vocabSize'] - 1).all()   # <START> first
+    assert ((ai != 0) == (ao != 0)).all()                                         # same pad pattern
+    np.testing.assert_allclose(np.linalg.norm(bg['img_feat'], axis=1), 1.0, rtol=1e-5)   # imgNorm (dataloader.lua:64-68)
+
+
+def test_process_ranks_matches_oracle():
+    from visdial_amd import utils
+    rng = np.random.RandomState(0)
+    ranks = rng.randint(1, 101, size=(50, 10)).astype(np.float64)
+    a, b = utils.processRanks(ranks, verbose=False), vo.process_ranks(ranks)
+    for k in b:
+        assert a[k] == b[k]
+
+
+def test_shard_dialogs_partition():
+    from visdial_amd.parallel import shard_dialogs
+    for n, w in ((20, 8), (160, 8), (7, 3), (5, 1)):
+        spans = [shard_dialogs(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import numpy as np, torch, torch.distributed as dist
+from conftest import small_params
+from oracle import visdial_oracle as vo
+from visdial_amd.dataloader import SyntheticDataloader
+from visdial_amd.opts import derive
+from visdial_amd.parallel import reduce_gradients, shard_dialogs
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=int(sys.argv[1]), world_size=2)
+rank = dist.get_rank()
+p = derive(small_params(batchSize=4))
+full = SyntheticDataloader(p, seed=123).getTrainBatch(p)          # the same global batch on both ranks
+lo, hi = shard_dialogs(4, rank, 2)
+R, O = p['maxQuesCount'], p['numOptions']
+mine = {'ques_fwd': full['ques_fwd'][lo:hi], 'hist': full['hist'][lo:hi], 'img_feat': full['img_feat'][lo:hi],
+        'options': full['options'][lo * R:hi * R], 'answer_ind': full['answer_ind'][lo * R:hi * R]}
+P = vo.init_params(p['encoder'], p['decoder'], p, seed=1)
+spec = vo.param_spec(p['encoder'], p['decoder'], p)
+r = vo.forward_backward(p['encoder'], p['decoder'], P, p, mine, None)
+flat = torch.from_numpy(vo.flatten(r['grads'], spec).copy())
+gscale, _ = reduce_gradients(flat)                                  # gloo all-reduce (RCCL on the GPU box)
+w_dp, _ = vo.clamp_adam(vo.flatten(P, spec), flat.numpy() * gscale, {}, 1e-3)
+if rank == 0:
+    big = vo.forward_backward(p['encoder'], p['decoder'], P, p, full, None)
+    w_big, _ = vo.clamp_adam(vo.flatten(P, spec), vo.flatten(big['grads'], spec), {}, 1e-3)
+    np.testing.assert_allclose(flat.numpy() * gscale, vo.flatten(big['grads'], spec), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(w_dp, w_big, rtol=0, atol=1e-12)
+    print("DP_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_step_equals_big_batch_step_gloo(tmp_path):
+    """2 ranks x 2 dialogs (gloo) == 1 rank x 4 dialogs: averaged gradient and post-Adam weights."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "dp_worker.py"
+    script.write_text(DP_WORKER % dict(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "DP_OK" in outs[0]

@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""train.py -- counterpart of the reference's train.lua (same flags: visdial_amd/opts.py <-> opts.lua).
+
+  python train.py -encoder mn-att-ques-im-hist -decoder disc -imgFeatureSize 512 -batchSize 20 --maxIters 300
+
+Data is synthetic with the reference dataloader's exact layout (no VisDial HDF5/JSON offline).
+Loop, logging line, lr schedule, checkpoint cadence and resume semantics follow train.lua:76-121:
+resume restores weights + learning rate only (not the Adam moments, not the iteration counter)."""
+import math
+import os
+import time
+
+import numpy as np
+import torch
+
+from visdial_amd import opts
+from visdial_amd.dataloader import SyntheticDataloader
+from visdial_amd.model import Model
+
+
+def main():
+    opt = opts.parse()
+    print(opt)
+    np.random.seed(1234)                                         # train.lua:12
+    saved = None
+    if opt['loadPath']:
+        saved = torch.load(opt['loadPath'], weights_only=False)   # train.lua:32-42
+        mp = saved['modelParams']
+        mp['gpuid'], mp['batchSize'] = opt['gpuid'], opt['batchSize']
+        for k in ('numEpochs', 'maxIters', 'savePath', 'saveIter', 'numTrainThreads'):
+            mp[k] = opt[k]
+        opt = mp
+    dataloader = SyntheticDataloader(opt, seed=1234, num_threads=opt['numTrainThreads'])
+    for k in ('vocabSize', 'maxQuesCount', 'maxQuesLen', 'maxAnsLen'):   # train.lua:55-59
+        opt[k] = getattr(dataloader, k)
+    opt['numTrainThreads'] = dataloader.numTrainThreads
+    os.makedirs(opt['savePath'], exist_ok=True)
+    opt['numIterPerEpoch'] = int(math.ceil(opt['numTrainThreads'] / float(opt['batchSize'])))
+    print('\n%d iter per epoch.' % opt['numIterPerEpoch'])
+    model = Model(opt)
+    if saved is not None:                                        # train.lua:78-81
+        model.wrapperW.copy_(saved['modelW'].to(model.wrapperW.device))
+        model.optims['learningRate'] = saved['optims']['learningRate']
+    print('Training..')
+    total = opt['numEpochs'] * opt['numIterPerEpoch']
+    if opt.get('maxIters'):
+        total = min(total, opt['maxIters'])
+    t0 = time.time()
+    for it in range(1, total + 1):
+        model.trainIteration(dataloader)
+        if it % (opt['saveIter'] * opt['numIterPerEpoch']) == 0:      # train.lua:95-102
+            ep = it // opt['numIterPerEpoch']
+            torch.save({'modelW': model.wrapperW.cpu(), 'optims': dict(model.optims), 'modelParams': opt},
+                       os.path.join(opt['savePath'], 'model_epoch_%d.pt' % ep))
+        if it % 100 == 0:                                            # train.lua:108-115
+            torch.cuda.synchronize()
+            rounds = 100 * opt['batchSize'] * opt['maxQuesCount']
+            print('[%s][Epoch:%.02f][Iter:%d][Loss:%.05f][lr:%f][%.0f QA-rounds/s]' % (
+                time.ctime(), it / float(opt['numIterPerEpoch']), it, model.runningLoss,
+                model.optims['learningRate'], rounds / (time.time() - t0)))
+            t0 = time.time()
+    torch.save({'modelW': model.wrapperW.float().cpu(), 'modelParams': opt, 'optims': dict(model.optims)},
+               os.path.join(opt['savePath'], 'model_final.pt'))     # train.lua:120-121
+
+
+if __name__ == '__main__':
+    main()

@@ -145,9 +145,8 @@ class Model(object):
         """[all-reduce] -> clamp(-5, 5) -> adam -> lr decay (model.lua:96-105)."""
         gscale = 1.0
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.wrapperdW, group=self.dist_group)       # RCCL sum over xGMI
-            gscale = 1.0 / self.world
+            from .parallel import reduce_gradients
+            gscale, _ = reduce_gradients(self.wrapperdW, self.dist_group)   # RCCL sum over xGMI
         o = self.optims
         o['t'] += 1
         t = o['t']
