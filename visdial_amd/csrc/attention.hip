@@ -320,7 +320,7 @@ img_att_bwd_kernel(float* __restrict__ iqc, const float* __restrict__ wa, const 
 }
 
 using CfgBigDB = GemmCfg<4, 1, 4, 32>;
-using CfgBig = GemmCfg<4, 1, 4, 32, 0, 3>;
+using CfgBig = GemmCfg<4, 1, 4, 16, 0, 3>;
 
 extern "C" {
 
@@ -405,7 +405,7 @@ int vd_img_common_wgrad(const float* dz, const float* pre, const uint8_t* mask1,
   long splits = vd_cdiv(1024, tiles);
   const long max_splits = vd_cdiv(K, 4 * CfgBig::BK);
   if (splits > max_splits) splits = max_splits;
-  return launch_gemm<CfgBigDB>(Kc, H, K, (int)splits, a, b, e, (hipStream_t)stream);
+  return launch_gemm<CfgBig>(Kc, H, K, (int)splits, a, b, e, (hipStream_t)stream);
 }
 
 }  // extern "C"

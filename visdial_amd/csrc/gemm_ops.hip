@@ -4,7 +4,7 @@
 #include "gemm_core.h"
 
 using CfgBigDB = GemmCfg<4, 1, 4, 32>;        // 128 x 128 tile, double-buffered LDS (long K loops: weight grads)
-using CfgBig = GemmCfg<4, 1, 4, 32, 0, 3>;    // 128 x 128 tile, single LDS buffer, 3 workgroups / CU (short K loops)
+using CfgBig = GemmCfg<4, 1, 4, 16, 0, 3>;    // 128 x 128 tile, BK = 16, single LDS buffer, 3 workgroups / CU
 using CfgSmall = GemmCfg<1, 4, 1, 32, 0, 3>;  // 32 x 32 tile, 4-way intra-block split-K (latency shapes)
 
 static inline bool use_small(int M, int N) {
@@ -94,6 +94,11 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
   const long max_splits = vd_cdiv(K, 4 * CfgBig::BK);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
+  static const int cfg = getenv("VD_TN_CFG") ? atoi(getenv("VD_TN_CFG")) : 2;
+  if (cfg == 1) return launch_gemm<CfgBig>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
+  if (cfg == 2) return launch_gemm<GemmCfg<4, 1, 4, 16, 0, 3>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
+  if (cfg == 3) return launch_gemm<GemmCfg<4, 1, 4, 16, 0, 4>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
+  if (cfg == 4) return launch_gemm<GemmCfg<4, 1, 4, 16, 1, 3>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
   return launch_gemm<CfgBigDB>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
 }
 

@@ -42,10 +42,10 @@ struct EpiLstmFwd {
         gi = vd_sigmoid(acc[0][r] + xr[j]);
         gf = vd_sigmoid(acc[1][r] + xr[H + j]);
         go = vd_sigmoid(acc[2][r] + xr[2 * H + j]);
-        gg = tanhf(acc[3][r] + xr[3 * H + j]);
+        gg = vd_tanh(acc[3][r] + xr[3 * H + j]);
         const float cp = c_prev ? c_prev[(long)row * H + j] : 0.f;
         c = gf * cp + gi * gg;
-        h = go * tanhf(c);
+        h = go * vd_tanh(c);
       }
       float* gr = gates + (long)row * 4 * H;
       gr[j] = gi;
@@ -92,7 +92,7 @@ struct EpiLstmBwd {
         if (dh_b) dh += dh_b[o];
         float* gr = gates + (long)row * 4 * H;
         const float gi = gr[j], gf = gr[H + j], go = gr[2 * H + j], gg = gr[3 * H + j];
-        const float tc = tanhf(c_t[o]);
+        const float tc = vd_tanh(c_t[o]);
         const float cp = c_prev ? c_prev[o] : 0.f;
         float dcv = dc_first ? 0.f : dc[o];
         dcv += dh * go * (1.f - tc * tc);
@@ -106,28 +106,58 @@ struct EpiLstmBwd {
   }
 };
 
-using CfgBig = GemmCfg<4, 1, 4, 32>;     // 128 x 128 tile, throughput shapes (double-buffered LDS, 2 WG/CU)
-using CfgBigSB = GemmCfg<4, 1, 4, 32, 0, 3>;   // same tile, single LDS buffer, 3 WG/CU
-using CfgHalfSB = GemmCfg<4, 1, 2, 32, 0, 3>;  // 128 x 64 tile, single LDS buffer, 3 WG/CU
-using CfgHalfDB = GemmCfg<4, 1, 2, 32, 1, 3>;  // 128 x 64 tile, double buffer (55 KB), 2 WG/CU
+// throughput shapes (option LSTM: N = 20 000 rows).  Defaults chosen by on-device sweeps
+// (scripts/microbench.py, profiles/r01_config_sweep.txt): forward = 128x128 tile, BK = 16, single LDS
+// buffer, 3 workgroups/CU (99 TF); backward = 128x64 tile (1 256 half-size workgroups balance 256 CUs),
+// BK = 16, single buffer, 4 workgroups/CU (102 TF).
+// VD_LSTM_FWD_CFG / VD_LSTM_BWD_CFG select the alternatives for A/B runs.
+using CfgF0 = GemmCfg<4, 1, 4, 32, 1, 1>;  // double-buffered, 2 WG/CU
+using CfgF1 = GemmCfg<4, 1, 4, 32, 0, 3>;  // default
+using CfgF2 = GemmCfg<8, 1, 4, 32, 0, 4>;  // 256x128 tile, 512 threads, 2 WG/CU
+using CfgF3 = GemmCfg<4, 1, 4, 64, 0, 2>;  // BK = 64, 2 WG/CU
+using CfgF4 = GemmCfg<4, 1, 4, 16, 0, 3>;  // BK = 16
+using CfgF5 = GemmCfg<4, 1, 4, 16, 0, 4>;
+using CfgF6 = GemmCfg<4, 1, 4, 8, 0, 4>;
+using CfgF7 = GemmCfg<4, 1, 4, 8, 0, 3>;
+using CfgF8 = GemmCfg<4, 1, 4, 16, 1, 3>;
+using CfgB0 = GemmCfg<4, 1, 4, 32, 1, 1>;
+using CfgB1 = GemmCfg<4, 1, 4, 32, 0, 3>;
+using CfgB2 = GemmCfg<4, 1, 2, 32, 0, 3>;  // default
+using CfgB3 = GemmCfg<4, 1, 2, 32, 1, 3>;
+using CfgB4 = GemmCfg<4, 1, 2, 32, 0, 4>;  // 4 WG/CU
+using CfgB5 = GemmCfg<4, 1, 2, 64, 0, 3>;  // BK = 64
+using CfgB6 = GemmCfg<8, 1, 2, 32, 0, 4>;  // 256x64 tile
+using CfgB7 = GemmCfg<4, 1, 2, 16, 0, 4>;
+using CfgB8 = GemmCfg<4, 1, 2, 16, 0, 3>;
+using CfgB10 = GemmCfg<4, 1, 4, 16, 0, 3>;
 // latency shapes (N ~ 200 rows): 4-way intra-block split-K.  Single LDS buffer and <= 152 VGPRs so one
 // of these workgroups fits into the footprint a retiring throughput-shape workgroup frees (they run
 // concurrently on other streams).
 using CfgFwdSmall = GemmCfg<1, 4, 4, 8, 0, 3>;   // 32 x (32 j x 4 gates), BK = 32, 23 KB LDS
 using CfgBwdSmall = GemmCfg<1, 4, 1, 32, 0, 3>;  // 32 x 32 tile, BK = 128, 33.8 KB LDS
 
+static int env_int(const char* name, int dflt) {
+  const char* ev = getenv(name);
+  return ev ? atoi(ev) : dflt;
+}
+
 static int lstm_step_fwd(const float* h_prev, const float* Wh, int N, int H, int K, const EpiLstmFwd& epi,
                          hipStream_t s) {
   SrcRow a{h_prev, H};
   SrcKGate4 b{Wh, 4L * H, H};
   if (N >= 2048) {
-    static int cfg = -1;
-    if (cfg < 0) {
-      const char* ev = getenv("VD_LSTM_FWD_CFG");
-      cfg = ev ? atoi(ev) : 1;
+    static const int cfg = env_int("VD_LSTM_FWD_CFG", 4);
+    switch (cfg) {
+      case 0: return launch_gemm<CfgF0>(N, 4 * H, K, 1, a, b, epi, s);
+      case 2: return launch_gemm<CfgF2>(N, 4 * H, K, 1, a, b, epi, s);
+      case 3: return launch_gemm<CfgF3>(N, 4 * H, K, 1, a, b, epi, s);
+      case 4: return launch_gemm<CfgF4>(N, 4 * H, K, 1, a, b, epi, s);
+      case 5: return launch_gemm<CfgF5>(N, 4 * H, K, 1, a, b, epi, s);
+      case 6: return launch_gemm<CfgF6>(N, 4 * H, K, 1, a, b, epi, s);
+      case 7: return launch_gemm<CfgF7>(N, 4 * H, K, 1, a, b, epi, s);
+      case 8: return launch_gemm<CfgF8>(N, 4 * H, K, 1, a, b, epi, s);
+      default: return launch_gemm<CfgF1>(N, 4 * H, K, 1, a, b, epi, s);
     }
-    if (cfg == 1) return launch_gemm<CfgBigSB>(N, 4 * H, K, 1, a, b, epi, s);
-    return launch_gemm<CfgBig>(N, 4 * H, K, 1, a, b, epi, s);
   }
   return launch_gemm<CfgFwdSmall>(N, 4 * H, K, 1, a, b, epi, s);
 }
@@ -138,19 +168,21 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
   SrcRow a{da_next, 4L * H};
   SrcRow b{Wh, 4L * H};  // B[k][n] = Wh[n][k]
   if (N >= 2048) {
-    static int cfg = -1;
-    if (cfg < 0) {
-      const char* ev = getenv("VD_LSTM_BWD_CFG");
-      cfg = ev ? atoi(ev) : 2;
+    static const int cfg = env_int("VD_LSTM_BWD_CFG", 7);
+    EpiLstmBwd<4> e4{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
+    EpiLstmBwd<2> e2{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
+    switch (cfg) {
+      case 0: return launch_gemm<CfgB0>(N, H, K, 1, a, b, e4, s);
+      case 1: return launch_gemm<CfgB1>(N, H, K, 1, a, b, e4, s);
+      case 3: return launch_gemm<CfgB3>(N, H, K, 1, a, b, e2, s);
+      case 4: return launch_gemm<CfgB4>(N, H, K, 1, a, b, e2, s);
+      case 5: return launch_gemm<CfgB5>(N, H, K, 1, a, b, e2, s);
+      case 6: return launch_gemm<CfgB6>(N, H, K, 1, a, b, e2, s);
+      case 7: return launch_gemm<CfgB7>(N, H, K, 1, a, b, e2, s);
+      case 8: return launch_gemm<CfgB8>(N, H, K, 1, a, b, e2, s);
+      case 10: return launch_gemm<CfgB10>(N, H, K, 1, a, b, e4, s);
+      default: return launch_gemm<CfgB2>(N, H, K, 1, a, b, e2, s);
     }
-    if (cfg == 2 || cfg == 3) {
-      EpiLstmBwd<2> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
-      if (cfg == 2) return launch_gemm<CfgHalfSB>(N, H, K, 1, a, b, e, s);
-      return launch_gemm<CfgHalfDB>(N, H, K, 1, a, b, e, s);
-    }
-    EpiLstmBwd<4> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
-    if (cfg == 1) return launch_gemm<CfgBigSB>(N, H, K, 1, a, b, e, s);
-    return launch_gemm<CfgBig>(N, H, K, 1, a, b, e, s);
   }
   EpiLstmBwd<1> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
   return launch_gemm<CfgBwdSmall>(N, H, K, 1, a, b, e, s);
@@ -208,7 +240,7 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
     SrcRow a{gates, 4L * H};
     SrcRow b{Wh, 4L * H};
     EpiStore<4> e{dh0, H, nullptr, VD_ACT_NONE, 0};
-    int rc = launch_gemm<CfgBig>(N, H, 4 * H, 1, a, b, e, s);
+    int rc = launch_gemm<CfgB1>(N, H, 4 * H, 1, a, b, e, s);
     if (rc) return rc;
   }
   return VD_OK;
