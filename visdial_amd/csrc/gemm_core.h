@@ -98,6 +98,11 @@ gemm_f32_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, int r
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wk = wave / WM;
+  // Latency shapes (intra-block split-K configs) are the short dependent launches of the encoder
+  // recurrences; they share CUs with throughput-shape workgroups of other streams.  Raising their wave
+  // priority lets them win MFMA/VALU issue arbitration on the SIMD (priority outranks age), so a step
+  // runs at near-isolated speed while the big workgroups fill the remaining issue slots.
+  if constexpr (Cfg::WK > 1) __builtin_amdgcn_s_setprio(3);
 
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = wg % tiles_n;

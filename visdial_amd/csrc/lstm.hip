@@ -133,8 +133,10 @@ using CfgB10 = GemmCfg<4, 1, 4, 16, 0, 3>;
 // latency shapes (N ~ 200 rows): 4-way intra-block split-K.  Single LDS buffer and <= 152 VGPRs so one
 // of these workgroups fits into the footprint a retiring throughput-shape workgroup frees (they run
 // concurrently on other streams).
-using CfgFwdSmall = GemmCfg<1, 4, 4, 8, 0, 3>;   // 32 x (32 j x 4 gates), BK = 32, 23 KB LDS
-using CfgBwdSmall = GemmCfg<1, 4, 1, 32, 0, 3>;  // 32 x 32 tile, BK = 128, 33.8 KB LDS
+using CfgFwdSmallA = GemmCfg<1, 4, 4, 8, 0, 3>;   // 32 x (32 j x 4 gates), BK = 32, 23 KB LDS
+using CfgFwdSmallB = GemmCfg<1, 4, 4, 16, 0, 3>;  // BK = 64, 43.5 KB LDS, half the dependent K iterations
+using CfgBwdSmallA = GemmCfg<1, 4, 1, 32, 0, 3>;  // 32 x 32 tile, BK = 128, 33.8 KB LDS
+using CfgBwdSmallB = GemmCfg<1, 4, 1, 64, 0, 3>;  // BK = 256, 66.6 KB LDS
 
 static int env_int(const char* name, int dflt) {
   const char* ev = getenv(name);
@@ -159,7 +161,9 @@ static int lstm_step_fwd(const float* h_prev, const float* Wh, int N, int H, int
       default: return launch_gemm<CfgF1>(N, 4 * H, K, 1, a, b, epi, s);
     }
   }
-  return launch_gemm<CfgFwdSmall>(N, 4 * H, K, 1, a, b, epi, s);
+  static const int scfg = env_int("VD_LSTM_FWD_SMALL", 0);
+  if (scfg == 0) return launch_gemm<CfgFwdSmallA>(N, 4 * H, K, 1, a, b, epi, s);
+  return launch_gemm<CfgFwdSmallB>(N, 4 * H, K, 1, a, b, epi, s);
 }
 
 static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, int K, const float* dh_a,
@@ -168,7 +172,7 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
   SrcRow a{da_next, 4L * H};
   SrcRow b{Wh, 4L * H};  // B[k][n] = Wh[n][k]
   if (N >= 2048) {
-    static const int cfg = env_int("VD_LSTM_BWD_CFG", 7);
+    static const int cfg = env_int("VD_LSTM_BWD_CFG", 8);
     EpiLstmBwd<4> e4{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
     EpiLstmBwd<2> e2{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
     switch (cfg) {
@@ -185,7 +189,9 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
     }
   }
   EpiLstmBwd<1> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
-  return launch_gemm<CfgBwdSmall>(N, H, K, 1, a, b, e, s);
+  static const int scfg = env_int("VD_LSTM_BWD_SMALL", 0);
+  if (scfg == 0) return launch_gemm<CfgBwdSmallA>(N, H, K, 1, a, b, e, s);
+  return launch_gemm<CfgBwdSmallB>(N, H, K, 1, a, b, e, s);
 }
 
 extern "C" {
