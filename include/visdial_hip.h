@@ -82,6 +82,34 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
                      const float* dh_last, const float* dc_last, float* dc_work, float* dh0, int T, int N,
                      int H, void* stream);
 
+/* Two stacked nn.SeqLSTM layers (the pattern of every encoder branch: mn-att:27-45, lf-ques.lua:17-24)
+ * advanced as a skewed wavefront, up to 2 independent stacks per call (history + question branches):
+ * tick tau launches ONE grouped kernel doing L1 step tau, the layer-2 input projection of step tau-1
+ * and L2 step tau-2 of every stack, so a T-step stack costs T+2 launches instead of 2T.
+ * Forward: gates1 must hold x*Wx1+b1 on entry (vd_gemm_nn); outputs as vd_lstm_forward for both layers.
+ * Backward: gates1/gates2 are overwritten by da1/da2; dh_last2 [N x H] is the gradient at the top
+ * layer's last step; dh1_seq [T x N x H], dc1, dc2 [N x H] are scratch.  Weight gradients are then
+ * formed by the caller with vd_gemm_tn_acc / vd_colsum_acc exactly as for vd_lstm_backward. */
+typedef struct {
+  int T, N;
+  const int32_t* tok_mask;               /* [T x N] or NULL (maskZero) */
+  const float *Wh1, *Wx2, *b2, *Wh2;
+  float *gates1, *h1, *c1, *gates2, *h2, *c2;
+} vd_lstm2_fwd_t;
+typedef struct {
+  int T, N;
+  const float *Wh1, *Wx2, *Wh2;
+  float* gates1;
+  const float* c1;
+  float* gates2;
+  const float* c2;
+  const float* dh_last2;
+  float* dh1_seq;
+  float *dc1, *dc2;
+} vd_lstm2_bwd_t;
+int vd_lstm2_forward(const vd_lstm2_fwd_t* stacks, int nstacks, int H, void* stream);
+int vd_lstm2_backward(const vd_lstm2_bwd_t* stacks, int nstacks, int H, void* stream);
+
 /* ---- nn.LookupTableMaskZero / nn.Dropout / small glue ------------------------------------- */
 /* out[r,:] = emb[tok[r],:] * (mask ? mask*scale : 1)        mn-att:21,24-25; disc.lua:12 */
 int vd_embed_gather(const float* emb, const int32_t* tok, const uint8_t* mask, float* out, int64_t rows,

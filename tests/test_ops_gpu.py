@@ -322,3 +322,45 @@ def test_error_reporting(ops):
     with pytest.raises(_lib.VisdialHipError):
         A = torch.zeros(4, 6, device="cuda")
         ops.gemm_nt(A, A, torch.zeros(4, 4, device="cuda"), K=6)       # K % 4 != 0 -> rejected loudly
+
+
+def test_lstm2_wavefront_matches_oracle(ops):
+    """two stacks (T=7 and T=4) x two layers through the grouped skewed-wavefront drivers"""
+    rng = np.random.RandomState(11)
+    H, D, V = 64, 20, 30
+    stacks = []
+    for T, N in ((7, 70), (4, 70)):
+        emb = f32(rng, V + 1, D); emb[0] = 0
+        tok = rng.randint(1, V + 1, size=(T, N)).astype(np.int32)
+        lens = rng.randint(0, T + 1, size=N)
+        for n in range(N):
+            tok[:T - lens[n], n] = 0
+        W1 = (f32(rng, D + H, 4 * H) / np.sqrt(D + H)).astype(np.float32); b1 = f32(rng, 4 * H) * 0.1
+        W2 = (f32(rng, 2 * H, 4 * H) / np.sqrt(2 * H)).astype(np.float32); b2 = f32(rng, 4 * H) * 0.1
+        x = emb[tok]
+        d = np.float64
+        h1, c1, g1 = vo.lstm_forward(x.astype(d), W1.astype(d), b1.astype(d), tok)
+        h2, c2, g2 = vo.lstm_forward(h1, W2.astype(d), b2.astype(d), tok)
+        dlast = f32(rng, N, H)
+        dx2, dW2, db2, _, _, da2 = vo.lstm_backward(h1, W2.astype(d), g2, h2, c2, dh_last=dlast.astype(d), return_da=True)
+        dx1, dW1, db1, _, _, da1 = vo.lstm_backward(x.astype(d), W1.astype(d), g1, h1, c1, dh_seq=dx2, return_da=True)
+        t = lambda *s: torch.empty(*s, device="cuda")
+        dev_st = dict(T=T, N=N, tok_mask=dev(tok), Wh1=dev(W1[D:]), Wx2=dev(W2[:H]), b2=dev(b2), Wh2=dev(W2[H:]),
+                      gates1=dev((x.reshape(T * N, D).astype(d) @ W1[:D].astype(d) + b1).astype(np.float32).reshape(T, N, 4 * H)),
+                      h1=t(T, N, H), c1=t(T, N, H), gates2=t(T, N, 4 * H), h2=t(T, N, H), c2=t(T, N, H))
+        stacks.append((dev_st, dict(h1=h1, h2=h2, c2=c2, g1=g1, g2=g2, da1=da1, da2=da2, dlast=dlast)))
+    ops.lstm2_forward([s for s, _ in stacks], H)
+    torch.cuda.synchronize()
+    for s, r in stacks:
+        assert relerr(s['h1'], r['h1']) < 1e-5 and relerr(s['h2'], r['h2']) < 1e-5
+        assert relerr(s['gates1'], r['g1']) < 1e-5 and relerr(s['gates2'], r['g2']) < 1e-5 and relerr(s['c2'], r['c2']) < 1e-5
+    bw = []
+    for s, r in stacks:
+        T, N = s['T'], s['N']
+        bw.append(dict(T=T, N=N, Wh1=s['Wh1'], Wx2=s['Wx2'], Wh2=s['Wh2'], gates1=s['gates1'], c1=s['c1'],
+                       gates2=s['gates2'], c2=s['c2'], dh_last2=dev(r['dlast']), dh1_seq=torch.empty(T, N, H, device="cuda"),
+                       dc1=torch.empty(N, H, device="cuda"), dc2=torch.empty(N, H, device="cuda")))
+    ops.lstm2_backward(bw, H)
+    torch.cuda.synchronize()
+    for s, r in stacks:
+        assert relerr(s['gates2'], r['da2']) < 2e-5 and relerr(s['gates1'], r['da1']) < 2e-5

@@ -86,31 +86,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + li;
 }
 
+// One workgroup's tile: C[row_base.., col_base..] over K range [ks, ke).  Shared by the plain and the
+// grouped kernels.
 template <class Cfg, class ASrc, class BSrc, class Epi>
-__global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW)
-gemm_f32_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, int rotate, ASrc asrc,
-                BSrc bsrc, Epi epi) {
+__device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row_base, int col_base, int rot_seed,
+                                           const ASrc& asrc, const BSrc& bsrc, const Epi& epi, float* smem) {
   constexpr int WM = Cfg::WM, NT = Cfg::NT, KW = Cfg::KW;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
   constexpr int THREADS = Cfg::THREADS, STR = Cfg::STRIDE;
   constexpr int NA = Cfg::NA, NB = Cfg::NB;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wk = wave / WM;
-  // Latency shapes (intra-block split-K configs) are the short dependent launches of the encoder
-  // recurrences; they share CUs with throughput-shape workgroups of other streams.  Raising their wave
-  // priority lets them win MFMA/VALU issue arbitration on the SIMD (priority outranks age), so a step
-  // runs at near-isolated speed while the big workgroups fill the remaining issue slots.
-  if constexpr (Cfg::WK > 1) __builtin_amdgcn_s_setprio(3);
-
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = wg % tiles_n;
-  const int tile_m = (wg / tiles_n) % tiles_m;
-  const int split = wg / (tiles_n * tiles_m);
-  const int row_base = tile_m * BM, col_base = tile_n * BN;
-  const int ks = split * kchunk;
-  const int ke = min(K, ks + kchunk);
   const int nk = ke > ks ? (ke - ks + BK - 1) / BK : 0;
 
   f32x16 acc[NT];
@@ -195,7 +181,7 @@ gemm_f32_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, int r
 
   // K-tile rotation: co-resident blocks start at different K offsets so that power-of-two
   // row strides do not funnel every block's loads into the same L2/HBM channel at once.
-  const int rot = (rotate && nk > 1) ? (tile_m * 5 + tile_n * 3 + split) % nk : 0;
+  const int rot = (rot_seed >= 0 && nk > 1) ? rot_seed % nk : 0;
   auto ktile = [&](int kt) {
     int t = kt + rot;
     if (t >= nk) t -= nk;
@@ -273,6 +259,74 @@ gemm_f32_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, int r
   }
 
   epi(acc, row_base + wm * 32, col_base, lane, M, N);
+}
+
+template <class Cfg, class ASrc, class BSrc, class Epi>
+__global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW)
+gemm_f32_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, int rotate, ASrc asrc,
+                BSrc bsrc, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // Latency shapes (intra-block split-K configs) are the short dependent launches of the encoder
+  // recurrences; they share CUs with throughput-shape workgroups of other streams.  Raising their wave
+  // priority lets them win MFMA/VALU issue arbitration on the SIMD (priority outranks age).
+  if constexpr (Cfg::WK > 1) __builtin_amdgcn_s_setprio(3);
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = wg % tiles_n;
+  const int tile_m = (wg / tiles_n) % tiles_m;
+  const int split = wg / (tiles_n * tiles_m);
+  const int ks = split * kchunk;
+  const int ke = min(K, ks + kchunk);
+  gemm_block<Cfg>(M, N, ks, ke, tile_m * Cfg::BM, tile_n * Cfg::BN, rotate ? tile_m * 5 + tile_n * 3 + split : -1,
+                  asrc, bsrc, epi, smem);
+}
+
+// ---------------------------------------------------------------------------
+// Grouped launch: up to MAXP independent problems (same tile config and functor types, different
+// pointers / dims) in ONE launch -- used to advance several recurrences by one tick per launch.
+// ---------------------------------------------------------------------------
+template <class Prob, int MAXP>
+struct GroupArgs {
+  Prob p[MAXP];
+  int tile_start[MAXP + 1];
+  int nprob;
+};
+
+template <class Cfg, class Prob, int MAXP>
+__global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW)
+gemm_f32_grouped_kernel(GroupArgs<Prob, MAXP> g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if constexpr (Cfg::WK > 1) __builtin_amdgcn_s_setprio(3);
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < MAXP; ++i)
+    if (i < g.nprob && wg >= g.tile_start[i]) pi = i;
+  const Prob& P = g.p[pi];
+  const int t = wg - g.tile_start[pi];
+  const int tile_n = t % P.tiles_n, tile_m = t / P.tiles_n;
+  gemm_block<Cfg>(P.M, P.N, 0, P.K, tile_m * Cfg::BM, tile_n * Cfg::BN, -1, P.a, P.b, P.e, smem);
+}
+
+template <class Cfg, class Prob, int MAXP>
+static int launch_grouped(GroupArgs<Prob, MAXP>& g, hipStream_t stream) {
+  int total = 0;
+  for (int i = 0; i < g.nprob; ++i) {
+    g.p[i].tiles_n = vd_cdiv(g.p[i].N, Cfg::BN);
+    g.tile_start[i] = total;
+    total += vd_cdiv(g.p[i].M, Cfg::BM) * g.p[i].tiles_n;
+  }
+  g.tile_start[g.nprob] = total;
+  if (total == 0) return VD_OK;
+  auto kern = gemm_f32_grouped_kernel<Cfg, Prob, MAXP>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               Cfg::LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(total), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, g);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -194,6 +194,84 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
   return launch_gemm<CfgBwdSmallB>(N, H, K, 1, a, b, e, s);
 }
 
+// ---------------------------------------------------------------------------
+// Two-layer stacks advanced as a skewed wavefront, several stacks per launch.
+//
+// The encoder recurrences (history / question, 2 x SeqLSTM each) are chains of ~30 us dependent
+// launches.  Tick tau runs, for every stack, THREE independent sub-problems in one grouped launch:
+//   forward :  L1 step tau | X2 = h1[tau-1]*Wx2 + b2 | L2 step tau-2
+//   backward:  L2 step t   | dh1[t+1] = da2[t+1]*Wx2^T | L1 step t+2      (t = T-1-tau)
+// so a T-step, 2-layer stack needs T+2 launches instead of 2T, all sub-problems keep K = H (4H in
+// backward), and history + question stacks share the launches.
+// ---------------------------------------------------------------------------
+struct SrcKSel {
+  static constexpr bool KMAJOR = true;
+  const float* p;
+  long ld;
+  int H;
+  int gate4;
+  __device__ __forceinline__ float4 ld4(int vc, int k) const {
+    int col = vc;
+    if (gate4) {
+      const int jb = vc >> 7, g = (vc >> 5) & 3, jj = vc & 31;
+      col = g * H + jb * 32 + jj;
+    }
+    return *reinterpret_cast<const float4*>(p + (long)k * ld + col);
+  }
+};
+struct EpiTickFwd {
+  int kind;  // 0 = LSTM cell update, 1 = plain store (+bias)
+  EpiLstmFwd f;
+  EpiStore<4> s;
+  __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int col0, int lane, int M,
+                                             int N) const {
+    if (kind == 0) f(acc, row0, col0, lane, M, N);
+    else s(acc, row0, col0, lane, M, N);
+  }
+};
+struct TickFwdProb {
+  int M, N, K, tiles_n;
+  SrcRow a;
+  SrcKSel b;
+  EpiTickFwd e;
+};
+struct EpiTickBwd {
+  int kind;
+  EpiLstmBwd<1> f;
+  EpiStore<1> s;
+  __device__ __forceinline__ void operator()(const f32x16 (&acc)[1], int row0, int col0, int lane, int M,
+                                             int N) const {
+    if (kind == 0) f(acc, row0, col0, lane, M, N);
+    else s(acc, row0, col0, lane, M, N);
+  }
+};
+struct TickBwdProb {
+  int M, N, K, tiles_n;
+  SrcRow a;
+  SrcRow b;
+  EpiTickBwd e;
+};
+
+struct vd_lstm2_fwd_t {
+  int T, N;
+  const int32_t* tok_mask;
+  const float *Wh1, *Wx2, *b2, *Wh2;
+  float *gates1, *h1, *c1, *gates2, *h2, *c2;
+};
+struct vd_lstm2_bwd_t {
+  int T, N;
+  const float *Wh1, *Wx2, *Wh2;
+  float* gates1;
+  const float* c1;
+  float* gates2;
+  const float* c2;
+  const float* dh_last2;
+  float* dh1_seq;
+  float *dc1, *dc2;
+};
+
+#define VD_MAX_STACKS 2
+
 extern "C" {
 
 // see include/visdial_hip.h
@@ -248,6 +326,111 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
     EpiStore<4> e{dh0, H, nullptr, VD_ACT_NONE, 0};
     int rc = launch_gemm<CfgB1>(N, H, 4 * H, 1, a, b, e, s);
     if (rc) return rc;
+  }
+  return VD_OK;
+}
+
+int vd_lstm2_forward(const vd_lstm2_fwd_t* st, int nstacks, int H, void* stream) {
+  VD_CHECK_ARG(st && nstacks >= 1 && nstacks <= VD_MAX_STACKS && H > 0 && H % 32 == 0,
+               "vd_lstm2_forward: bad args (nstacks=%d, max %d)", nstacks, VD_MAX_STACKS);
+  int Tmax = 0;
+  for (int s = 0; s < nstacks; ++s) {
+    VD_CHECK_ARG(st[s].T >= 1 && st[s].N >= 1 && st[s].Wh1 && st[s].Wx2 && st[s].b2 && st[s].Wh2 && st[s].gates1 &&
+                     st[s].h1 && st[s].c1 && st[s].gates2 && st[s].h2 && st[s].c2,
+                 "vd_lstm2_forward: stack %d has null/empty fields", s);
+    Tmax = st[s].T > Tmax ? st[s].T : Tmax;
+  }
+  for (int tau = 0; tau < Tmax + 2; ++tau) {
+    GroupArgs<TickFwdProb, 3 * VD_MAX_STACKS> g;
+    g.nprob = 0;
+    for (int s = 0; s < nstacks; ++s) {
+      const vd_lstm2_fwd_t& S = st[s];
+      const long NH = (long)S.N * H;
+      for (int layer = 1; layer <= 2; ++layer) {  // cell updates: L1 at t = tau, L2 at t = tau - 2
+        const int t = layer == 1 ? tau : tau - 2;
+        if (t < 0 || t >= S.T) continue;
+        float* gates = layer == 1 ? S.gates1 : S.gates2;
+        float* h = layer == 1 ? S.h1 : S.h2;
+        float* c = layer == 1 ? S.c1 : S.c2;
+        TickFwdProb& P = g.p[g.nprob++];
+        P.M = S.N; P.N = 4 * H; P.K = t ? H : 0;
+        P.a = SrcRow{t ? h + (t - 1) * NH : h, H};
+        P.b = SrcKSel{layer == 1 ? S.Wh1 : S.Wh2, 4L * H, H, 1};
+        P.e.kind = 0;
+        P.e.f.xproj = gates + (long)t * 4 * NH; P.e.f.xld = 4L * H;
+        P.e.f.tok_gather = nullptr;
+        P.e.f.tok_mask = S.tok_mask ? S.tok_mask + (long)t * S.N : nullptr;
+        P.e.f.c_prev = t ? c + (t - 1) * NH : nullptr;
+        P.e.f.gates = gates + (long)t * 4 * NH; P.e.f.c_out = c + t * NH; P.e.f.h_out = h + t * NH; P.e.f.H = H;
+        P.e.s = EpiStore<4>{nullptr, 0, nullptr, 0, 0};
+      }
+      const int t = tau - 1;  // layer-2 input projection of step t
+      if (t >= 0 && t < S.T) {
+        TickFwdProb& P = g.p[g.nprob++];
+        P.M = S.N; P.N = 4 * H; P.K = H;
+        P.a = SrcRow{S.h1 + t * NH, H};
+        P.b = SrcKSel{S.Wx2, 4L * H, H, 0};
+        P.e.kind = 1;
+        P.e.s = EpiStore<4>{S.gates2 + (long)t * 4 * NH, 4L * H, S.b2, VD_ACT_NONE, 0};
+        P.e.f = EpiLstmFwd{nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, H};
+      }
+    }
+    if (g.nprob == 0) continue;
+    if (int rc = launch_grouped<CfgFwdSmallA>(g, (hipStream_t)stream)) return rc;
+  }
+  return VD_OK;
+}
+
+int vd_lstm2_backward(const vd_lstm2_bwd_t* st, int nstacks, int H, void* stream) {
+  VD_CHECK_ARG(st && nstacks >= 1 && nstacks <= VD_MAX_STACKS && H > 0 && H % 32 == 0,
+               "vd_lstm2_backward: bad args (nstacks=%d, max %d)", nstacks, VD_MAX_STACKS);
+  int Tmax = 0;
+  for (int s = 0; s < nstacks; ++s) {
+    VD_CHECK_ARG(st[s].T >= 1 && st[s].N >= 1 && st[s].Wh1 && st[s].Wx2 && st[s].Wh2 && st[s].gates1 && st[s].c1 &&
+                     st[s].gates2 && st[s].c2 && st[s].dh_last2 && st[s].dh1_seq && st[s].dc1 && st[s].dc2,
+                 "vd_lstm2_backward: stack %d has null/empty fields", s);
+    Tmax = st[s].T > Tmax ? st[s].T : Tmax;
+  }
+  for (int tau = 0; tau < Tmax + 2; ++tau) {
+    GroupArgs<TickBwdProb, 3 * VD_MAX_STACKS> g;
+    g.nprob = 0;
+    for (int s = 0; s < nstacks; ++s) {
+      const vd_lstm2_bwd_t& S = st[s];
+      const long NH = (long)S.N * H;
+      for (int layer = 2; layer >= 1; --layer) {  // cell backward: L2 at t = T-1-tau, L1 at t = T+1-tau
+        const int t = layer == 2 ? S.T - 1 - tau : S.T + 1 - tau;
+        if (t < 0 || t >= S.T) continue;
+        float* gates = layer == 2 ? S.gates2 : S.gates1;
+        const float* c = layer == 2 ? S.c2 : S.c1;
+        const bool last = (t == S.T - 1);
+        TickBwdProb& P = g.p[g.nprob++];
+        P.M = S.N; P.N = H; P.K = last ? 0 : 4 * H;
+        P.a = SrcRow{last ? gates : gates + (long)(t + 1) * 4 * NH, 4L * H};
+        P.b = SrcRow{layer == 2 ? S.Wh2 : S.Wh1, 4L * H};
+        P.e.kind = 0;
+        P.e.f.dh_a = layer == 2 ? (last ? S.dh_last2 : nullptr) : S.dh1_seq + t * NH;
+        P.e.f.dh_b = nullptr;
+        P.e.f.gates = gates + (long)t * 4 * NH;
+        P.e.f.c_t = c + t * NH;
+        P.e.f.c_prev = t ? c + (t - 1) * NH : nullptr;
+        P.e.f.dc = layer == 2 ? S.dc2 : S.dc1;
+        P.e.f.dc_first = last ? 1 : 0;
+        P.e.f.H = H;
+        P.e.s = EpiStore<1>{nullptr, 0, nullptr, 0, 0};
+      }
+      const int t = S.T - tau;  // dh1[t] = da2[t] * Wx2^T
+      if (t >= 0 && t < S.T) {
+        TickBwdProb& P = g.p[g.nprob++];
+        P.M = S.N; P.N = H; P.K = 4 * H;
+        P.a = SrcRow{S.gates2 + (long)t * 4 * NH, 4L * H};
+        P.b = SrcRow{S.Wx2, 4L * H};
+        P.e.kind = 1;
+        P.e.s = EpiStore<1>{S.dh1_seq + t * NH, H, nullptr, VD_ACT_NONE, 0};
+        P.e.f = EpiLstmBwd<1>{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, H};
+      }
+    }
+    if (g.nprob == 0) continue;
+    if (int rc = launch_grouped<CfgBwdSmallA>(g, (hipStream_t)stream)) return rc;
   }
   return VD_OK;
 }

@@ -7,7 +7,10 @@ Inputs (order of the reference's input table, model.lua:255-294):
 Like the reference this encoder hard-codes two LSTM layers per branch and dropout 0.5 (mn-att:24-41).
 """
 from .. import ops
-from ..nn import SeqLSTM, Linear, StreamPool, dropout_forward, dropout_backward, lstm_stack_backward
+import os
+
+from ..nn import (SeqLSTM, Linear, StreamPool, dropout_forward, dropout_backward, lstm_stack_backward,
+                  lstm2_bundle_forward, lstm2_bundle_backward)
 
 P_DROP = 0.5
 SCALE = 1.0 / (1.0 - P_DROP)
@@ -44,12 +47,17 @@ class Encoder(object):
         self.ques_common = Linear(fp, 'ques_common', H, self.K, ws)
         self.out = Linear(fp, 'out', H, H, ws)
 
-    # -- one text branch: embed -> dropout -> 2 x SeqLSTM(maskZero) -> last step (mn-att:24-45)
-    def _branch_fwd(self, name, tok, l1, l2):
+    def _embed(self, name, tok):
         T, N = tok.shape
         m = self.drop.mask(name + '_emb', T * N * self.E, P_DROP)
         x = self.ws.get(name + '.x', (T * N, self.E))
         ops.embed_gather(self.fp.w['embed'], tok, x, mask=m, scale=SCALE)
+        return x, m
+
+    # -- one text branch: embed -> dropout -> 2 x SeqLSTM(maskZero) -> last step (mn-att:24-45)
+    def _branch_fwd(self, name, tok, l1, l2):
+        T, N = tok.shape
+        x, m = self._embed(name, tok)
         h1 = l1.forward(x, T, N, tok_mask=tok)
         h2 = l2.forward(h1.view(T * N, self.H), T, N, tok_mask=tok)
         return h2[T - 1], m
@@ -69,14 +77,25 @@ class Encoder(object):
         B = N // R
         self.inputs, self.N, self.B = inputs, N, B
         # history branch || question branch || per-image projection (independent launch chains)
-        with self.streams.fork('hist'):
-            self.h3, self.m_h = self._branch_fwd('h', hist, self.hist1, self.hist2)
+        fused = os.environ.get('VD_LSTM2', '1') != '0'
+        if not fused:
+            with self.streams.fork('hist'):
+                self.h3, self.m_h = self._branch_fwd('h', hist, self.hist1, self.hist2)
         with self.streams.fork('img'):
             self.pre = self.img_proj.forward(img, B * S2, tanh=True)            # mn-att:74-78 (pre-dropout)
             self.m1 = self.drop.mask('img_tr', N * S2 * H, P_DROP)
             self.m2 = self.drop.mask('iqc', N * S2 * K, P_DROP)
-        self.q3, self.m_q = self._branch_fwd('q', ques, self.ques1, self.ques2)
-        self.streams.join('hist')
+        if fused:
+            # both two-layer stacks advance together: one grouped launch per wavefront tick
+            hx, self.m_h = self._embed('h', hist)
+            qx, self.m_q = self._embed('q', ques)
+            hT, qT = hist.shape[0], ques.shape[0]
+            hh, qh = lstm2_bundle_forward([(self.hist1, self.hist2, hx, hT, N, hist),
+                                           (self.ques1, self.ques2, qx, qT, N, ques)])
+            self.h3, self.q3 = hh[hT - 1], qh[qT - 1]
+        else:
+            self.q3, self.m_q = self._branch_fwd('q', ques, self.ques1, self.ques2)
+            self.streams.join('hist')
         # memory attention over the R history facts of each dialog (mn-att:48-62)
         self.prob = ws.get('mn.prob', (N, R))
         self.hatt = ws.get('mn.hatt', (N, H))
@@ -129,6 +148,11 @@ class Encoder(object):
         dh3 = ws.get('mn.dh', (N, H))
         ops.mn_attention_backward(self.q3, self.h3, self.prob, dhatt, dq_att, dh3, B, R, H)
         dq3 = ops.axpby(dq_att, ds2, ws.get('mn.dq3', (N, H)), 1.0, 1.0)
+        if os.environ.get('VD_LSTM2', '1') != '0':
+            dhx, dqx = lstm2_bundle_backward([(self.hist1, self.hist2, dh3), (self.ques1, self.ques2, dq3)])
+            ops.embed_scatter_acc(self.fp.g['embed'], hist, dhx, mask=self.m_h, scale=SCALE)
+            ops.embed_scatter_acc(self.fp.g['embed'], ques, dqx, mask=self.m_q, scale=SCALE)
+            return None
         with self.streams.fork('hist'):
             self._branch_bwd(hist, self.hist1, self.hist2, dh3, self.m_h)
         self._branch_bwd(ques, self.ques1, self.ques2, dq3, self.m_q)

@@ -185,6 +185,11 @@ class SeqLSTM(object):
         ops.lstm_backward(self.Wh, self.gates, self.c, dc, T, N, H, c0=self.c0, dh_seq=dh_seq, dh_last=dh_last,
                           dc_last=dc_last, dh0=dh0)
         self.userGradPrevOutput, self.userGradPrevCell = dh0, (dc if self.h0 is not None else None)
+        return self.param_grads(need_dx)
+
+    def param_grads(self, need_dx=True):
+        """Weight/bias gradients and input gradients from da (held in the gates buffer after BPTT)."""
+        T, N, H, k = self.T, self.N, self.H, self.key
         da = self.gates.view(T * N, 4 * H)
         h2 = self.h.view(T * N, H)
         if T > 1:
@@ -204,6 +209,49 @@ class SeqLSTM(object):
             else:
                 dxs.append(None)
         return dxs
+
+
+def lstm2_bundle_forward(bundle):
+    """bundle: list of (l1, l2, x, T, N, tok_mask) -- two-layer maskZero stacks advanced together as a
+    skewed wavefront (vd_lstm2_forward): one grouped launch per tick for ALL stacks.  Returns the top
+    layers' h tensors.  Fills the same saved-state fields SeqLSTM.forward does."""
+    H = bundle[0][0].H
+    descs = []
+    for l1, l2, x, T, N, tok in bundle:
+        assert l1.H == H and l2.H == H and l2.D == H and len(l1.part_dims) == 1
+        for l, xs in ((l1, [x]), (l2, None)):
+            l.T, l.N, l.tok_mask, l.h0, l.c0 = T, N, tok, None, None
+            l.gates = l.ws.get(l.key + '.gates', (T, N, 4 * H))
+            l.h = l.ws.get(l.key + '.h', (T, N, H))
+            l.c = l.ws.get(l.key + '.c', (T, N, H))
+            l.output, l.cell = l.h, l.c
+            l.userPrevOutput = l.userPrevCell = None
+        l1.xs = [x]
+        l2.xs = [l1.h.view(T * N, H)]
+        ops.gemm_nn(x, l1.Wx, l1.gates.view(T * N, 4 * H), bias=l1.b, M=T * N, N=4 * H, K=l1.D)
+        descs.append(dict(T=T, N=N, tok_mask=tok, Wh1=l1.Wh, Wx2=l2.Wx, b2=l2.b, Wh2=l2.Wh, gates1=l1.gates, h1=l1.h,
+                          c1=l1.c, gates2=l2.gates, h2=l2.h, c2=l2.c))
+    ops.lstm2_forward(descs, H)
+    return [b[1].h for b in bundle]
+
+
+def lstm2_bundle_backward(bundle):
+    """bundle: list of (l1, l2, dh_last_top).  Runs the fused two-layer BPTT for all stacks, then the
+    weight-gradient contractions per layer.  Returns the bottom layers' dx ([T*N, D])."""
+    H = bundle[0][0].H
+    descs = []
+    for l1, l2, dlast in bundle:
+        T, N = l1.T, l1.N
+        ws = l1.ws
+        descs.append(dict(T=T, N=N, Wh1=l1.Wh, Wx2=l2.Wx, Wh2=l2.Wh, gates1=l1.gates, c1=l1.c, gates2=l2.gates,
+                          c2=l2.c, dh_last2=dlast, dh1_seq=ws.get(l1.key + '.dhseq', (T, N, H)),
+                          dc1=ws.get(l1.key + '.dc', (N, H)), dc2=ws.get(l2.key + '.dc', (N, H))))
+    ops.lstm2_backward(descs, H)
+    out = []
+    for l1, l2, _ in bundle:
+        l2.param_grads(need_dx=False)
+        out.append(l1.param_grads(need_dx=True)[0])
+    return out
 
 
 def lstm_stack_forward(layers, x, T, N, tok_mask):

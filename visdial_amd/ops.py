@@ -223,3 +223,25 @@ def copy_2d(dst, dst_ld, src, src_ld, rows, cols, dst_off=0, src_off=0):
     """copy a [rows x cols] column block; offsets are in floats from the tensor base"""
     assert dst.is_cuda and src.is_cuda and dst.dtype == F32 and src.dtype == F32
     call("vd_copy_2d", dst.data_ptr() + 4 * dst_off, dst_ld, src.data_ptr() + 4 * src_off, src_ld, rows, cols, _stream())
+
+
+def lstm2_forward(stacks, H):
+    """stacks: list of dicts with the vd_lstm2_fwd_t fields (tensors)."""
+    arr = (_lib.Lstm2Fwd * len(stacks))()
+    for a, s in zip(arr, stacks):
+        a.T, a.N = s['T'], s['N']
+        a.tok_mask = _p(s.get('tok_mask'), I32)
+        for k in ('Wh1', 'Wx2', 'b2', 'Wh2', 'gates1', 'h1', 'c1', 'gates2', 'h2', 'c2'):
+            setattr(a, k, _p(s[k], F32))
+    import ctypes
+    call("vd_lstm2_forward", ctypes.cast(arr, ctypes.c_void_p), len(stacks), H, _stream())
+
+
+def lstm2_backward(stacks, H):
+    arr = (_lib.Lstm2Bwd * len(stacks))()
+    for a, s in zip(arr, stacks):
+        a.T, a.N = s['T'], s['N']
+        for k in ('Wh1', 'Wx2', 'Wh2', 'gates1', 'c1', 'gates2', 'c2', 'dh_last2', 'dh1_seq', 'dc1', 'dc2'):
+            setattr(a, k, _p(s[k], F32))
+    import ctypes
+    call("vd_lstm2_backward", ctypes.cast(arr, ctypes.c_void_p), len(stacks), H, _stream())
