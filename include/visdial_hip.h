@@ -145,6 +145,18 @@ int vd_mn_attention_forward(const float* Q, const float* Hm, const uint8_t* mask
 int vd_mn_attention_backward(const float* Q, const float* Hm, const float* P, const float* dhAtt, float* dQ,
                              float* dHm, int B, int R, int H, void* stream);
 
+/* history attention of encoders/hrea-ques-im-hist.lua:83-131 (Linear(H,1) scores, Replicate+CAddTable,
+ * model_utils/MaskFuture.lua, model_utils/ReplaceZero.lua(-inf), SoftMax, CMulTable+Sum):
+ * sq, sh [B*R] scores; Hm [B x R x H]; P [B x R x R]; att [B x R x H] */
+int vd_hrea_attention_forward(const float* sq, const float* sh, const float* Hm, float* P, float* att, int B, int R,
+                              int H, void* stream);
+int vd_hrea_attention_backward(const float* Hm, const float* P, const float* datt, float* dsq, float* dsh,
+                               float* dHm, int B, int R, int H, void* stream);
+/* nn.Linear(H, 1) (hrea:83-85): out[n] = <x[n,:], w> + b; backward accumulates dw, db and writes dx */
+int vd_rowdot_forward(const float* x, const float* w, const float* bias, float* out, int N, int H, void* stream);
+int vd_rowdot_backward(const float* x, const float* w, const float* dout, float* dw, float* db, float* dx, int N,
+                       int H, void* stream);
+
 /* ---- SAN image attention (mn-att:68-104).  pre = tanh(Linear(img)) per IMAGE [B*S2 x H];
  *      mask1/mask2 = dropout keep-masks of img_tr / img_ques_common per ROUND (NULL in evaluate()) */
 int vd_img_common_forward(const float* pre, const uint8_t* mask1, const float* Wc, const float* bc,

@@ -213,22 +213,34 @@ def param_spec(encoder, decoder, p):
         lin('mn1', H, H); lin('mn2', H, H)
         lin('img_proj', C, H); lin('img_common', H, K); lin('ques_common', H, K); lin('att', K, 1)
         lin('out', H, H)
-    elif encoder == 'lf-ques':
+    elif encoder in ('mn-ques-hist', 'mn-ques-im-hist'):
+        lstm('hist1', E); lstm('hist2', H); lstm('ques1', E); lstm('ques2', H)
+        if encoder == 'mn-ques-im-hist':
+            lin('qi', p['imgFeatureSize'] + H, H)
+        lin('mn1', H, H); lin('mn2', H, H)
+    elif encoder == 'lf-att-ques-im-hist':
+        C, K = p['imgFeatureSize'], p.get('commonEmbeddingSize', 512)
+        lstm('hist1', E); lstm('hist2', H); lstm('ques1', E); lstm('ques2', H)
+        lin('qh', 2 * H, H)
+        lin('img_proj', C, H); lin('img_common', H, K); lin('ques_common', H, K); lin('att', K, 1)
+        lin('out', H, H)
+    elif encoder in ('lf-ques', 'lf-ques-im', 'lf-ques-hist', 'lf-ques-im-hist'):
         for l in range(p['numLayers']):
             lstm('ques%d' % (l + 1), E if l == 0 else H)
-        lin('fuse', H, H)
-    elif encoder == 'lf-ques-im-hist':
-        for l in range(p['numLayers']):
-            lstm('ques%d' % (l + 1), E if l == 0 else H)
-        for l in range(p['numLayers']):
-            lstm('hist%d' % (l + 1), E if l == 0 else H)
-        lin('fuse', 2 * H + p['imgFeatureSize'], H)
-    elif encoder == 'hre-ques-im-hist':
+        if 'hist' in encoder:
+            for l in range(p['numLayers']):
+                lstm('hist%d' % (l + 1), E if l == 0 else H)
+        lin('fuse', H * (2 if 'hist' in encoder else 1) + (p['imgFeatureSize'] if 'im' in encoder else 0), H)
+    elif encoder in ('hre-ques-hist', 'hre-ques-im-hist', 'hrea-ques-im-hist'):
+        DI = p['imgEmbedSize'] if 'im' in encoder else 0
         for l in range(p['numLayers']):
             lstm('hist%d' % (l + 1), E if l == 0 else H)
-        lin('img_embed', p['imgFeatureSize'], p['imgEmbedSize'])
+        if DI:
+            lin('img_embed', p['imgFeatureSize'], DI)
         for l in range(p['numLayers']):
-            lstm('ques%d' % (l + 1), (E + p['imgEmbedSize']) if l == 0 else H)
+            lstm('ques%d' % (l + 1), (E + DI) if l == 0 else H)
+        if encoder.startswith('hrea'):
+            lin('att_q', H, 1); lin('att_h', H, 1)
         lstm('dialog', 2 * H)
     else:
         raise ValueError('oracle: encoder %s not restated yet' % encoder)
@@ -306,68 +318,67 @@ def _two_layer_lstm_bwd(P, G, n1, n2, S, dlast):
     return dx1
 
 
-def mnatt_encoder_forward(P, p, batch, drop):
-    """encoders/mn-att-ques-im-hist.lua:5-115 with inputs prepared as model.lua:249-294.
-    batch (dataloader.lua:324-339 keys): ques_fwd [B,R,Tq] int, hist [B,R,Th] int, img_feat [B,S,S,C].  drop: dict of keep-masks or None."""
-    B, R, Tq = batch['ques_fwd'].shape
-    Th = batch['hist'].shape[2]
-    H = p['rnnHiddenSize']
-    N = B * R
+def _mn_block_fwd(P, query, h3, B, R, d):
+    """memory attention + the two Linear+Tanh of mn-att:48-65 / mn-ques-hist.lua:43-58.
+    query [N,H] is q3 (mn-ques-hist, mn-att) or qi_proj (mn-ques-im-hist)."""
+    N, H = query.shape
+    prob, hatt = mn_attention_forward(query.reshape(B, R, H), h3.reshape(B, R, H), causal_mask(B, R))
+    hatt_d = dropout(hatt.reshape(N, H), d('hatt'), 0.5)
+    hattTr = np.tanh(linear(hatt_d, P['mn1.W'], P['mn1.b']))
+    s2 = hattTr + query
+    qh2 = np.tanh(linear(s2, P['mn2.W'], P['mn2.b']))
+    return qh2, dict(query=query, h3=h3, prob=prob, hatt_d=hatt_d, hattTr=hattTr, s2=s2, qh2=qh2, B=B, R=R)
+
+
+def _mn_block_bwd(P, G, st, dqh2, dback):
+    N, H = st['query'].shape
+    B, R = st['B'], st['R']
+    ds2p = dqh2 * (1 - st['qh2'] ** 2)
+    ds2, dW, db = linear_backward(st['s2'], P['mn2.W'], ds2p)
+    G['mn2.W'] += dW; G['mn2.b'] += db
+    dhTr_p = ds2 * (1 - st['hattTr'] ** 2)
+    dhatt_d, dW, db = linear_backward(st['hatt_d'], P['mn1.W'], dhTr_p)
+    G['mn1.W'] += dW; G['mn1.b'] += db
+    dhatt = dback(dhatt_d, 'hatt')
+    dqv, dhv = mn_attention_backward(st['query'].reshape(B, R, H), st['h3'].reshape(B, R, H), st['prob'],
+                                     dhatt.reshape(B, R, H))
+    return ds2 + dqv.reshape(N, H), dhv.reshape(N, H)
+
+
+def _san_block_fwd(P, p, batch, u0, R, d):
+    """1-hop SAN image attention + output layer (mn-att:68-106 / lf-att-ques-im-hist.lua:45-86)."""
+    N, H = u0.shape
+    B = N // R
     S2 = p['imgSpatialSize'] ** 2
-    d = (lambda k: None) if drop is None else (lambda k: drop[k])
-    qtok = batch['ques_fwd'].reshape(N, Tq).T        # model.lua:255-257 (time-major)
-    htok = batch['hist'].reshape(N, Th).T        # model.lua:275-277
-    st = {}
-    qx = dropout(lookup(P['embed'], qtok), d('q_emb'), 0.5)                 # mn-att:24
-    hx = dropout(lookup(P['embed'], htok), d('h_emb'), 0.5)                 # mn-att:25
-    st['hs'] = _two_layer_lstm_fwd(P, 'hist1', 'hist2', hx, htok)           # mn-att:27-35
-    st['qs'] = _two_layer_lstm_fwd(P, 'ques1', 'ques2', qx, qtok)           # mn-att:37-45
-    h3, q3 = st['hs']['h2'][-1], st['qs']['h2'][-1]
-    mask = causal_mask(B, R)
-    prob, hatt = mn_attention_forward(q3.reshape(B, R, H), h3.reshape(B, R, H), mask)   # mn-att:48-62
-    hatt = hatt.reshape(N, H)
-    hatt_d = dropout(hatt, d('hatt'), 0.5)
-    hattTr = np.tanh(linear(hatt_d, P['mn1.W'], P['mn1.b']))               # mn-att:64
-    s2 = hattTr + q3
-    qh2 = np.tanh(linear(s2, P['mn2.W'], P['mn2.b']))                       # mn-att:65
-    C = p['imgFeatureSize']
-    img = batch['img_feat'].reshape(B * S2, C)
-    pre = np.tanh(linear(img, P['img_proj.W'], P['img_proj.b']))            # mn-att:74-78 (per image)
+    img = batch['img_feat'].reshape(B * S2, p['imgFeatureSize'])
+    pre = np.tanh(linear(img, P['img_proj.W'], P['img_proj.b']))            # per image
     pre_r = np.repeat(pre.reshape(B, 1, S2, H), R, 1).reshape(N, S2, H)     # model.lua:262-265 repeat
     img_tr = dropout(pre_r, d('img_tr'), 0.5)
-    img_common = linear(img_tr.reshape(N * S2, H), P['img_common.W'], P['img_common.b']).reshape(N, S2, -1)  # :83-85
-    qc = linear(qh2, P['ques_common.W'], P['ques_common.b'])               # mn-att:88
-    t_iqc = np.tanh(img_common + qc[:, None, :])                            # mn-att:92
+    img_common = linear(img_tr.reshape(N * S2, H), P['img_common.W'], P['img_common.b']).reshape(N, S2, -1)
+    qc = linear(u0, P['ques_common.W'], P['ques_common.b'])
+    t_iqc = np.tanh(img_common + qc[:, None, :])
     iqc = dropout(t_iqc, d('iqc'), 0.5)
-    score = (iqc @ P['att.W'][0]) + P['att.b'][0]                           # mn-att:93
+    score = (iqc @ P['att.W'][0]) + P['att.b'][0]
     score = score - score.max(1, keepdims=True)
     e = np.exp(score)
-    patt = e / e.sum(1, keepdims=True)                                      # mn-att:94
-    att = np.einsum('ns,nsh->nh', patt, img_tr)                             # mn-att:97-99
-    u1 = att + qh2                                                          # mn-att:102
+    patt = e / e.sum(1, keepdims=True)
+    att = np.einsum('ns,nsh->nh', patt, img_tr)
+    u1 = att + u0
     u1_d = dropout(u1, d('u'), 0.5)
-    enc_out = np.tanh(linear(u1_d, P['out.W'], P['out.b']))                 # mn-att:106
-    st.update(qtok=qtok, htok=htok, h3=h3, q3=q3, prob=prob, hatt_d=hatt_d, hattTr=hattTr, s2=s2, qh2=qh2, img=img,
-              pre=pre, img_tr=img_tr, t_iqc=t_iqc, iqc=iqc, patt=patt, u1_d=u1_d, enc_out=enc_out, qc=qc)
-    return enc_out, st
+    out = np.tanh(linear(u1_d, P['out.W'], P['out.b']))
+    return out, dict(u0=u0, img=img, pre=pre, img_tr=img_tr, t_iqc=t_iqc, iqc=iqc, patt=patt, u1_d=u1_d, out=out, R=R)
 
 
-def mnatt_encoder_backward(P, G, p, batch, drop, st, denc):
-    B, R, Tq = batch['ques_fwd'].shape
-    H = p['rnnHiddenSize']
-    N = B * R
+def _san_block_bwd(P, G, p, st, denc, dback):
+    N, H = st['u0'].shape
+    R = st['R']
+    B = N // R
     S2 = p['imgSpatialSize'] ** 2
-    d = (lambda k: None) if drop is None else (lambda k: drop[k])
-
-    def dback(dy, key):
-        m = d(key)
-        return dy if m is None else dy * m * 2.0
-
-    dpre_o = denc * (1 - st['enc_out'] ** 2)
+    dpre_o = denc * (1 - st['out'] ** 2)
     du1d, dW, db = linear_backward(st['u1_d'], P['out.W'], dpre_o)
     G['out.W'] += dW; G['out.b'] += db
     du1 = dback(du1d, 'u')
-    dqh2 = du1.copy()
+    du0 = du1.copy()
     datt = du1
     img_tr, patt, iqc = st['img_tr'], st['patt'], st['iqc']
     dp = np.einsum('nh,nsh->ns', datt, img_tr)
@@ -376,37 +387,86 @@ def mnatt_encoder_backward(P, G, p, batch, drop, st, denc):
     G['att.W'][0] += np.einsum('ns,nsk->k', dscore, iqc)
     G['att.b'][0] += dscore.sum()
     diqc = dscore[:, :, None] * P['att.W'][0][None, None, :]
-    dt_iqc = dback(diqc, 'iqc')
-    dz = dt_iqc * (1 - st['t_iqc'] ** 2)
+    dz = dback(diqc, 'iqc') * (1 - st['t_iqc'] ** 2)
     dqc = dz.sum(1)
-    dzf = dz.reshape(N * S2, -1)
-    dimg_tr2, dW, db = linear_backward(img_tr.reshape(N * S2, H), P['img_common.W'], dzf)
+    dimg_tr2, dW, db = linear_backward(img_tr.reshape(N * S2, H), P['img_common.W'], dz.reshape(N * S2, -1))
     G['img_common.W'] += dW; G['img_common.b'] += db
     dimg_tr = dimg_tr + dimg_tr2.reshape(N, S2, H)
-    dpre_r = dback(dimg_tr, 'img_tr')
-    dpre = dpre_r.reshape(B, R, S2, H).sum(1).reshape(B * S2, H)
+    dpre = dback(dimg_tr, 'img_tr').reshape(B, R, S2, H).sum(1).reshape(B * S2, H)
     dpre_a = dpre * (1 - st['pre'] ** 2)
     _, dW, db = linear_backward(st['img'], P['img_proj.W'], dpre_a)
     G['img_proj.W'] += dW; G['img_proj.b'] += db
-    dq, dW, db = linear_backward(st['qh2'], P['ques_common.W'], dqc)
+    dq, dW, db = linear_backward(st['u0'], P['ques_common.W'], dqc)
     G['ques_common.W'] += dW; G['ques_common.b'] += db
-    dqh2 = dqh2 + dq
-    ds2p = dqh2 * (1 - st['qh2'] ** 2)
-    ds2, dW, db = linear_backward(st['s2'], P['mn2.W'], ds2p)
-    G['mn2.W'] += dW; G['mn2.b'] += db
-    dq3 = ds2.copy()
-    dhTr_p = ds2 * (1 - st['hattTr'] ** 2)
-    dhatt_d, dW, db = linear_backward(st['hatt_d'], P['mn1.W'], dhTr_p)
-    G['mn1.W'] += dW; G['mn1.b'] += db
-    dhatt = dback(dhatt_d, 'hatt')
-    dqv, dhv = mn_attention_backward(st['q3'].reshape(B, R, H), st['h3'].reshape(B, R, H), st['prob'],
-                                     dhatt.reshape(B, R, H))
-    dq3 = dq3 + dqv.reshape(N, H)
-    dh3 = dhv.reshape(N, H)
+    return du0 + dq
+
+
+GRAPH_ENCODERS = ('mn-ques-hist', 'mn-ques-im-hist', 'mn-att-ques-im-hist', 'lf-att-ques-im-hist')
+
+
+def graph_encoder_forward(encoder, P, p, batch, drop):
+    """the four nngraph encoders: two text branches (embed -> Dropout(0.5) -> 2 x SeqLSTM(maskZero), hard-coded
+    in every file, e.g. mn-att:24-45) followed by memory attention and/or SAN image attention."""
+    B, R, Tq = batch['ques_fwd'].shape
+    N = B * R
+    H = p['rnnHiddenSize']
+    d = (lambda k: None) if drop is None else (lambda k: drop[k])
+    qtok, htok = _tm(batch['ques_fwd']), _tm(batch['hist'])
+    st = dict(qtok=qtok, htok=htok)
+    st['hs'] = _two_layer_lstm_fwd(P, 'hist1', 'hist2', dropout(lookup(P['embed'], htok), d('h_emb'), 0.5), htok)
+    st['qs'] = _two_layer_lstm_fwd(P, 'ques1', 'ques2', dropout(lookup(P['embed'], qtok), d('q_emb'), 0.5), qtok)
+    h3, q3 = st['hs']['h2'][-1], st['qs']['h2'][-1]
+    if encoder == 'lf-att-ques-im-hist':                                   # lf-att:43
+        st['cat'] = np.concatenate([q3, h3], 1)
+        st['qh'] = np.tanh(linear(st['cat'], P['qh.W'], P['qh.b']))
+        u = st['qh']
+    else:
+        query = q3
+        if encoder == 'mn-ques-im-hist':                                   # mn-ques-im-hist.lua:47-48
+            st['qi'] = np.concatenate([q3, _img_rep(batch, R)], 1)
+            st['qi_proj'] = np.tanh(linear(st['qi'], P['qi.W'], P['qi.b']))
+            query = st['qi_proj']
+        u, st['mn'] = _mn_block_fwd(P, query, h3, B, R, d)
+    if 'att' in encoder:
+        out, st['san'] = _san_block_fwd(P, p, batch, u, R, d)
+    else:
+        out = u
+    st['enc_out'] = out
+    return out, st
+
+
+def graph_encoder_backward(encoder, P, G, p, batch, drop, st, denc):
+    H = p['rnnHiddenSize']
+    d = (lambda k: None) if drop is None else (lambda k: drop[k])
+
+    def dback(dy, key):
+        m = d(key)
+        return dy if m is None else dy * m * 2.0
+    du = _san_block_bwd(P, G, p, st['san'], denc, dback) if 'att' in encoder else denc
+    if encoder == 'lf-att-ques-im-hist':
+        dcat, dW, db = linear_backward(st['cat'], P['qh.W'], du * (1 - st['qh'] ** 2))
+        G['qh.W'] += dW; G['qh.b'] += db
+        dq3, dh3 = dcat[:, :H], dcat[:, H:]
+    else:
+        dquery, dh3 = _mn_block_bwd(P, G, st['mn'], du, dback)
+        if encoder == 'mn-ques-im-hist':
+            dqi, dW, db = linear_backward(st['qi'], P['qi.W'], dquery * (1 - st['qi_proj'] ** 2))
+            G['qi.W'] += dW; G['qi.b'] += db
+            dq3 = dqi[:, :H]
+        else:
+            dq3 = dquery
     dqx = _two_layer_lstm_bwd(P, G, 'ques1', 'ques2', st['qs'], dq3)
     dhx = _two_layer_lstm_bwd(P, G, 'hist1', 'hist2', st['hs'], dh3)
     lookup_backward(G['embed'], st['qtok'], dback(dqx, 'q_emb'))
     lookup_backward(G['embed'], st['htok'], dback(dhx, 'h_emb'))
+
+
+def mnatt_encoder_forward(P, p, batch, drop):
+    return graph_encoder_forward('mn-att-ques-im-hist', P, p, batch, drop)
+
+
+def mnatt_encoder_backward(P, G, p, batch, drop, st, denc):
+    return graph_encoder_backward('mn-att-ques-im-hist', P, G, p, batch, drop, st, denc)
 
 
 def disc_decoder_forward(P, p, options, enc_out):
@@ -480,43 +540,63 @@ def _img_rep(batch, R):
 
 
 def encoder_forward(encoder, P, p, batch, drop):
-    if encoder == 'mn-att-ques-im-hist':
-        return mnatt_encoder_forward(P, p, batch, drop)
+    if encoder in GRAPH_ENCODERS:
+        return graph_encoder_forward(encoder, P, p, batch, drop)
     d = (lambda k: None) if drop is None else (lambda k: drop[k])
     pd = p.get('dropout', 0.5)
     H = p['rnnHiddenSize']
     qtok = _tm(batch['ques_fwd'])
     st = dict(qtok=qtok)
-    if encoder == 'lf-ques':                                            # encoders/lf-ques.lua:3-36
+    if encoder in ('lf-ques', 'lf-ques-im', 'lf-ques-hist', 'lf-ques-im-hist'):
+        # encoders/lf-ques.lua:3-36, lf-ques-im.lua, lf-ques-hist.lua, lf-ques-im-hist.lua:3-62
         st['qs'] = _stack_fwd(P, _layer_names('ques', p), lookup(P['embed'], qtok), qtok)
-        st['cat'] = dropout(st['qs'][-1]['h'][-1], d('fuse'), pd)
+        parts = [st['qs'][-1]['h'][-1]]
+        if 'im' in encoder:
+            parts.append(_img_rep(batch, p['maxQuesCount']))
+        if 'hist' in encoder:
+            htok = _tm(batch['hist'])
+            st['htok'] = htok
+            st['hs'] = _stack_fwd(P, _layer_names('hist', p), lookup(P['embed'], htok), htok)
+            parts.append(st['hs'][-1]['h'][-1])
+        st['cat'] = dropout(np.concatenate(parts, 1), d('fuse'), pd)
         st['out'] = np.tanh(linear(st['cat'], P['fuse.W'], P['fuse.b']))
-    elif encoder == 'lf-ques-im-hist':                                  # encoders/lf-ques-im-hist.lua:3-62
-        htok = _tm(batch['hist'])
-        st['htok'] = htok
-        st['qs'] = _stack_fwd(P, _layer_names('ques', p), lookup(P['embed'], qtok), qtok)
-        st['hs'] = _stack_fwd(P, _layer_names('hist', p), lookup(P['embed'], htok), htok)
-        cat = np.concatenate([st['qs'][-1]['h'][-1], _img_rep(batch, p['maxQuesCount']), st['hs'][-1]['h'][-1]], 1)
-        st['cat'] = dropout(cat, d('fuse'), pd)
-        st['out'] = np.tanh(linear(st['cat'], P['fuse.W'], P['fuse.b']))
-    elif encoder == 'hre-ques-im-hist':                                 # encoders/hre-ques-im-hist.lua:5-97
+    elif encoder in ('hre-ques-hist', 'hre-ques-im-hist', 'hrea-ques-im-hist'):
+        # encoders/hre-ques-hist.lua, hre-ques-im-hist.lua:5-97, hrea-ques-im-hist.lua
         htok = _tm(batch['hist'])
         st['htok'] = htok
         R = p['maxQuesCount']
         N = qtok.shape[1]
         B = N // R
         st['hs'] = _stack_fwd(P, _layer_names('hist', p), lookup(P['embed'], htok), htok)
-        st['img_rep'] = _img_rep(batch, R)
-        imgE = linear(st['img_rep'], P['img_embed.W'], P['img_embed.b'])                     # :43-48
-        keep = (qtok != 0)[:, :, None].astype(imgE.dtype)
-        st['keep'] = keep
-        xi = imgE[None, :, :] * keep                                                         # MaskTime.lua:12-29
-        x = np.concatenate([lookup(P['embed'], qtok), xi], 2)                                # JoinTable(-1) :68
+        x = lookup(P['embed'], qtok)
+        if 'im' in encoder:
+            st['img_in'] = _img_rep(batch, R)
+            if encoder.startswith('hrea'):
+                st['img_in'] = dropout(st['img_in'], d('img'), 0.5)                              # hrea:47
+            imgE = linear(st['img_in'], P['img_embed.W'], P['img_embed.b'])                      # hre:43-48
+            st['keep'] = (qtok != 0)[:, :, None].astype(imgE.dtype)
+            x = np.concatenate([x, imgE[None, :, :] * st['keep']], 2)                           # MaskTime + JoinTable(-1)
         st['qs'] = _stack_fwd(P, _layer_names('ques', p), x, qtok)
-        j = np.concatenate([st['qs'][-1]['h'][-1], st['hs'][-1]['h'][-1]], 1)                # :85
-        dx = j.reshape(B, R, 2 * H).transpose(1, 0, 2)                                       # :88-89
-        st['ds'] = _stack_fwd(P, ['dialog'], np.ascontiguousarray(dx), None)                 # :90 (no maskZero)
-        st['out'] = st['ds'][0]['h'].transpose(1, 0, 2).reshape(N, H)                        # :91-92
+        q, h = st['qs'][-1]['h'][-1], st['hs'][-1]['h'][-1]
+        first = q
+        if encoder.startswith('hrea'):                                                           # hrea:83-131
+            sq = linear(q, P['att_q.W'], P['att_q.b']).reshape(B, R)
+            sh = linear(h, P['att_h.W'], P['att_h.b']).reshape(B, R)
+            A = sq[:, :, None] + sh[:, None, :]                                                  # Replicate + CAddTable
+            A = np.where(np.triu(np.ones((R, R), bool), 1)[None], 0.0, A)                        # MaskFuture
+            A = np.where(A == 0, -np.inf, A)                                                     # ReplaceZero(-inf)
+            A = A - A.max(-1, keepdims=True)
+            e = np.exp(A)
+            Pm = e / e.sum(-1, keepdims=True)
+            hv = h.reshape(B, R, H)
+            att = np.einsum('bij,bjk->bik', Pm, hv).reshape(N, H)                                # CMul + Sum(3)
+            st.update(P_att=Pm, q=q, h=h)
+            j = np.concatenate([att, q], 1)                                                      # concat4: {att, ques}
+        else:
+            j = np.concatenate([q, h], 1)
+        dx = j.reshape(B, R, 2 * H).transpose(1, 0, 2)
+        st['ds'] = _stack_fwd(P, ['dialog'], np.ascontiguousarray(dx), None)
+        st['out'] = st['ds'][0]['h'].transpose(1, 0, 2).reshape(N, H)
     else:
         raise ValueError('oracle: encoder %s not restated yet' % encoder)
     return st['out'], st
@@ -524,8 +604,8 @@ def encoder_forward(encoder, P, p, batch, drop):
 
 def encoder_backward(encoder, P, G, p, batch, drop, st, denc, dec_dh0=None, dec_dc0=None):
     """dec_dh0 / dec_dc0: per-layer gradients handed back by the gen decoder (gen.lua:45-60)."""
-    if encoder == 'mn-att-ques-im-hist':
-        return mnatt_encoder_backward(P, G, p, batch, drop, st, denc)
+    if encoder in GRAPH_ENCODERS:
+        return graph_encoder_backward(encoder, P, G, p, batch, drop, st, denc)
     d = (lambda k: None) if drop is None else (lambda k: drop[k])
     pd = p.get('dropout', 0.5)
     H = p['rnnHiddenSize']
@@ -534,7 +614,7 @@ def encoder_backward(encoder, P, G, p, batch, drop, st, denc, dec_dh0=None, dec_
     if dec_dh0 is not None:
         dh_last = [dec_dh0[i] if i != L - 1 else None for i in range(L)]     # gradPrevOutput, ii ~= top
         dc_last = list(dec_dc0)                                              # userNextGradCell
-    if encoder in ('lf-ques', 'lf-ques-im-hist'):
+    if encoder in ('lf-ques', 'lf-ques-im', 'lf-ques-hist', 'lf-ques-im-hist'):
         dpre = denc * (1 - st['out'] ** 2)
         dcat, dW, db = linear_backward(st['cat'], P['fuse.W'], dpre)
         G['fuse.W'] += dW; G['fuse.b'] += db
@@ -544,11 +624,11 @@ def encoder_backward(encoder, P, G, p, batch, drop, st, denc, dec_dh0=None, dec_
         dq = dcat[:, :H]
         dx, _, _ = _stack_bwd(P, G, _layer_names('ques', p), st['qs'], dh_last_top=dq, dh_last=dh_last, dc_last=dc_last)
         lookup_backward(G['embed'], st['qtok'], dx)
-        if encoder == 'lf-ques-im-hist':
+        if 'hist' in encoder:
             dh = dcat[:, -H:]
             dx, _, _ = _stack_bwd(P, G, _layer_names('hist', p), st['hs'], dh_last_top=dh)
             lookup_backward(G['embed'], st['htok'], dx)
-    elif encoder == 'hre-ques-im-hist':
+    elif encoder in ('hre-ques-hist', 'hre-ques-im-hist', 'hrea-ques-im-hist'):
         R = p['maxQuesCount']
         N = denc.shape[0]
         B = N // R
@@ -556,13 +636,27 @@ def encoder_backward(encoder, P, G, p, batch, drop, st, denc, dec_dh0=None, dec_
         g = np.ascontiguousarray(denc.reshape(B, R, H).transpose(1, 0, 2))
         dj, _, _ = _stack_bwd(P, G, ['dialog'], st['ds'], dh_seq_top=g)
         dj = dj.transpose(1, 0, 2).reshape(N, 2 * H)
-        dx, _, _ = _stack_bwd(P, G, _layer_names('ques', p), st['qs'], dh_last_top=dj[:, :H], dh_last=dh_last,
-                              dc_last=dc_last)
+        if encoder.startswith('hrea'):
+            datt, dq = dj[:, :H].reshape(B, R, H), dj[:, H:].copy()
+            Pm, hv = st['P_att'], st['h'].reshape(B, R, H)
+            dP = np.einsum('bik,bjk->bij', datt, hv)
+            dA = Pm * (dP - (Pm * dP).sum(-1, keepdims=True))
+            dh = np.einsum('bij,bik->bjk', Pm, datt).reshape(N, H)
+            dsq, dsh = dA.sum(2).reshape(N, 1), dA.sum(1).reshape(N, 1)
+            dq_, dW, db = linear_backward(st['q'], P['att_q.W'], dsq)
+            G['att_q.W'] += dW; G['att_q.b'] += db
+            dh_, dW, db = linear_backward(st['h'], P['att_h.W'], dsh)
+            G['att_h.W'] += dW; G['att_h.b'] += db
+            dq, dh = dq + dq_, dh + dh_
+        else:
+            dq, dh = dj[:, :H], dj[:, H:]
+        dx, _, _ = _stack_bwd(P, G, _layer_names('ques', p), st['qs'], dh_last_top=dq, dh_last=dh_last, dc_last=dc_last)
         lookup_backward(G['embed'], st['qtok'], dx[:, :, :E])
-        dimgE = (dx[:, :, E:] * st['keep']).sum(0)                                           # MaskTime.lua:31-40
-        _, dW, db = linear_backward(st['img_rep'], P['img_embed.W'], dimgE)
-        G['img_embed.W'] += dW; G['img_embed.b'] += db
-        dx, _, _ = _stack_bwd(P, G, _layer_names('hist', p), st['hs'], dh_last_top=dj[:, H:])
+        if 'im' in encoder:
+            dimgE = (dx[:, :, E:] * st['keep']).sum(0)                                           # MaskTime.lua:31-40
+            _, dW, db = linear_backward(st['img_in'], P['img_embed.W'], dimgE)
+            G['img_embed.W'] += dW; G['img_embed.b'] += db
+        dx, _, _ = _stack_bwd(P, G, _layer_names('hist', p), st['hs'], dh_last_top=dh)
         lookup_backward(G['embed'], st['htok'], dx)
 
 

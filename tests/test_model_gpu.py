@@ -136,17 +136,19 @@ WIDE = {
 
 
 def fuse_masks(p, batch, rng):
-    enc = p['encoder']
-    if enc not in ('lf-ques', 'lf-ques-im-hist'):
+    from visdial_amd.dataloader import dropout_mask_shapes
+    shp = dropout_mask_shapes(p, batch)
+    if not shp:
         return None
-    N = batch['ques_fwd'].shape[0] * batch['ques_fwd'].shape[1]
-    D = p['rnnHiddenSize'] if enc == 'lf-ques' else 2 * p['rnnHiddenSize'] + p['imgFeatureSize']
-    return {'fuse': (rng.rand(N, D) > p['dropout']).astype(np.uint8)}
+    return {k: (rng.rand(*v) > (p['dropout'] if k == 'fuse' else 0.5)).astype(np.uint8) for k, v in shp.items()}
 
 
-@pytest.mark.parametrize("enc,dec", [('lf-ques', 'gen'), ('lf-ques-im-hist', 'gen'), ('hre-ques-im-hist', 'disc'),
-                                     ('hre-ques-im-hist', 'gen'), ('lf-ques-im-hist', 'disc'),
-                                     ('mn-att-ques-im-hist', 'gen')])
+ALL_ENC = ['lf-ques', 'lf-ques-im', 'lf-ques-hist', 'lf-ques-im-hist', 'lf-att-ques-im-hist', 'hre-ques-hist',
+           'hre-ques-im-hist', 'hrea-ques-im-hist', 'mn-ques-hist', 'mn-ques-im-hist', 'mn-att-ques-im-hist']
+
+
+@pytest.mark.parametrize("enc,dec", [(e, d) for e in ALL_ENC for d in ('disc', 'gen')
+                                     if (e, d) != ('mn-att-ques-im-hist', 'disc')])     # that pair: tests above
 @pytest.mark.parametrize("case", ['tiny', 'mid'])
 def test_widened_pairs_match_oracle(gpu, enc, dec, case):
     from visdial_amd.model import Model
@@ -157,8 +159,8 @@ def test_widened_pairs_match_oracle(gpu, enc, dec, case):
     dl = SyntheticDataloader(p, seed=21)
     batch = dl.getTrainBatch(p)
     model = Model(p)
-    masks = fuse_masks(p, batch, np.random.RandomState(8))
-    if masks is not None:
+    masks = fuse_masks(p, batch, np.random.RandomState(8)) if case == 'tiny' else None   # tiny: training mode with
+    if masks is not None:                                                                 # pinned dropout; mid: evaluate()
         model.set_dropout_masks(masks)
     else:
         model.wrapper.evaluate()

@@ -181,25 +181,74 @@ def torch_generic_forward(enc, dec, P, p, batch, drop):
             st.append((h, c))
             x = h
         return st
-    img = torch.from_numpy(batch['img_feat'].astype(np.float64)).repeat_interleave(R, 0) if 'img_feat' in batch else None
-    if enc == 'lf-ques':
+    img = None
+    if 'img_feat' in batch and batch['img_feat'].ndim == 2:
+        img = torch.from_numpy(batch['img_feat'].astype(np.float64)).repeat_interleave(R, 0)
+    d5 = (lambda x, k: x * torch.from_numpy(drop[k]) * 2.0) if drop else (lambda x, k: x)   # hard-coded Dropout(0.5)
+    qs = None
+    if enc.startswith('lf-ques'):
         qs = stack('ques', emb[qtok], qtok)
-        enc_out = torch.tanh(F.linear(dr(qs[-1][0][-1], 'fuse'), P['fuse.W'], P['fuse.b']))
-    elif enc == 'lf-ques-im-hist':
+        parts = [qs[-1][0][-1]]
+        if 'im' in enc:
+            parts.append(img)
+        if 'hist' in enc:
+            htok = tm(batch['hist'])
+            parts.append(stack('hist', emb[htok], htok)[-1][0][-1])
+        enc_out = torch.tanh(F.linear(dr(torch.cat(parts, 1), 'fuse'), P['fuse.W'], P['fuse.b']))
+    elif enc.startswith('hre'):
         htok = tm(batch['hist'])
-        qs = stack('ques', emb[qtok], qtok)
         hs = stack('hist', emb[htok], htok)
-        cat = torch.cat([qs[-1][0][-1], img, hs[-1][0][-1]], 1)
-        enc_out = torch.tanh(F.linear(dr(cat, 'fuse'), P['fuse.W'], P['fuse.b']))
-    elif enc == 'hre-ques-im-hist':
-        htok = tm(batch['hist'])
-        hs = stack('hist', emb[htok], htok)
-        imgE = F.linear(img, P['img_embed.W'], P['img_embed.b'])
-        xi = imgE[None].expand(qtok.shape[0], N, imgE.shape[1]) * (qtok != 0).to(f64)[:, :, None]
-        qs = stack('ques', torch.cat([emb[qtok], xi], 2), qtok)
-        j = torch.cat([qs[-1][0][-1], hs[-1][0][-1]], 1).view(B, R, 2 * H).transpose(0, 1)
-        dh, _ = torch_lstm2(j, P['dialog.W'], P['dialog.b'], None, H)
+        x = emb[qtok]
+        if 'im' in enc:
+            im = d5(img, 'img') if enc.startswith('hrea') else img
+            imgE = F.linear(im, P['img_embed.W'], P['img_embed.b'])
+            xi = imgE[None].expand(qtok.shape[0], N, imgE.shape[1]) * (qtok != 0).to(f64)[:, :, None]
+            x = torch.cat([x, xi], 2)
+        qs = stack('ques', x, qtok)
+        q, h = qs[-1][0][-1], hs[-1][0][-1]
+        if enc.startswith('hrea'):
+            sq = F.linear(q, P['att_q.W'], P['att_q.b']).view(B, R)
+            sh = F.linear(h, P['att_h.W'], P['att_h.b']).view(B, R)
+            A = sq[:, :, None] + sh[:, None, :]
+            A = A.masked_fill(torch.triu(torch.ones(R, R, dtype=torch.bool), 1)[None], float('-inf'))
+            att = torch.bmm(torch.softmax(A, -1), h.view(B, R, H)).reshape(N, H)
+            j = torch.cat([att, q], 1)
+        else:
+            j = torch.cat([q, h], 1)
+        dh, _ = torch_lstm2(j.view(B, R, 2 * H).transpose(0, 1), P['dialog.W'], P['dialog.b'], None, H)
         enc_out = dh.transpose(0, 1).reshape(N, H)
+    elif enc in ('mn-ques-hist', 'mn-ques-im-hist', 'mn-att-ques-im-hist', 'lf-att-ques-im-hist'):
+        htok = tm(batch['hist'])
+
+        def two(prefix, tok, key):
+            h1, _ = torch_lstm2(d5(emb[tok], key), P[prefix + '1.W'], P[prefix + '1.b'], tok, H)
+            h2, _ = torch_lstm2(h1, P[prefix + '2.W'], P[prefix + '2.b'], tok, H)
+            return h2[-1]
+        h3, q3 = two('hist', htok, 'h_emb'), two('ques', qtok, 'q_emb')
+        if enc == 'lf-att-ques-im-hist':
+            u = torch.tanh(F.linear(torch.cat([q3, h3], 1), P['qh.W'], P['qh.b']))
+        else:
+            query = q3
+            if enc == 'mn-ques-im-hist':
+                query = torch.tanh(F.linear(torch.cat([q3, img], 1), P['qi.W'], P['qi.b']))
+            sc = torch.bmm(query.view(B, R, H), h3.view(B, R, H).transpose(1, 2))
+            sc = sc.masked_fill(torch.triu(torch.ones(R, R, dtype=torch.bool), 1)[None], -9999999.0)
+            hatt = torch.bmm(torch.softmax(sc, -1), h3.view(B, R, H)).reshape(N, H)
+            hattTr = torch.tanh(F.linear(d5(hatt, 'hatt'), P['mn1.W'], P['mn1.b']))
+            u = torch.tanh(F.linear(hattTr + query, P['mn2.W'], P['mn2.b']))
+        if 'att' in enc:
+            S2 = p['imgSpatialSize'] ** 2
+            im = torch.from_numpy(batch['img_feat'].astype(np.float64)).reshape(B, S2, -1)
+            im = im[:, None].expand(B, R, S2, im.shape[-1]).reshape(N, S2, -1)
+            img_tr = d5(torch.tanh(F.linear(im, P['img_proj.W'], P['img_proj.b'])), 'img_tr')
+            ic = F.linear(img_tr, P['img_common.W'], P['img_common.b'])
+            qc = F.linear(u, P['ques_common.W'], P['ques_common.b'])
+            iqc = d5(torch.tanh(ic + qc[:, None, :]), 'iqc')
+            patt = torch.softmax(F.linear(iqc, P['att.W'], P['att.b']).squeeze(-1), 1)
+            u = torch.bmm(patt[:, None, :], img_tr).squeeze(1) + u
+            enc_out = torch.tanh(F.linear(d5(u, 'u'), P['out.W'], P['out.b']))
+        else:
+            enc_out = u
     else:
         raise ValueError(enc)
     if dec == 'disc':
@@ -212,7 +261,9 @@ def torch_generic_forward(enc, dec, P, p, batch, drop):
     ain, aout = tm(batch['answer_in']), tm(batch['answer_out'])
     x = emb[ain]
     for l in range(L):
-        h0, c0 = qs[l][0][-1], qs[l][1][-1]
+        h0 = c0 = None
+        if qs is not None:
+            h0, c0 = qs[l][0][-1], qs[l][1][-1]
         if l == L - 1:
             h0 = enc_out
         x, _ = torch_lstm2(x, P['dec%d.W' % (l + 1)], P['dec%d.b' % (l + 1)], ain, H, h0, c0)
@@ -224,19 +275,23 @@ def torch_generic_forward(enc, dec, P, p, batch, drop):
 
 
 def fuse_masks(p, batch, enc, rng):
-    if enc not in ('lf-ques', 'lf-ques-im-hist'):
+    from visdial_amd.dataloader import dropout_mask_shapes
+    shp = dropout_mask_shapes(p, batch)
+    if not shp:
         return None
-    N = batch['ques_fwd'].shape[0] * batch['ques_fwd'].shape[1]
-    D = p['rnnHiddenSize'] if enc == 'lf-ques' else 2 * p['rnnHiddenSize'] + p['imgFeatureSize']
-    return {'fuse': (rng.rand(N, D) > p['dropout']).astype(np.float64)}
+    return {k: (rng.rand(*s) > (p['dropout'] if k == 'fuse' else 0.5)).astype(np.float64) for k, s in shp.items()}
 
 
 @pytest.mark.parametrize("enc,dec", [('lf-ques', 'gen'), ('lf-ques-im-hist', 'gen'), ('hre-ques-im-hist', 'disc'),
-                                     ('hre-ques-im-hist', 'gen'), ('lf-ques', 'disc')])
+                                     ('hre-ques-im-hist', 'gen'), ('lf-ques', 'disc'), ('lf-ques-im', 'gen'),
+                                     ('lf-ques-hist', 'disc'), ('hre-ques-hist', 'gen'), ('hrea-ques-im-hist', 'disc'),
+                                     ('hrea-ques-im-hist', 'gen'), ('mn-ques-hist', 'disc'), ('mn-ques-im-hist', 'gen'),
+                                     ('mn-att-ques-im-hist', 'gen'), ('lf-att-ques-im-hist', 'disc'),
+                                     ('lf-att-ques-im-hist', 'gen')])
 @pytest.mark.parametrize("use_drop", [False, True])
 def test_oracle_widening_matches_torch_autograd(enc, dec, use_drop):
     from visdial_amd.opts import derive
-    p = derive(small_params(encoder=enc, decoder=dec, imgNorm=1, dropout=0.3))
+    p = derive(small_params(encoder=enc, decoder=dec, imgNorm=1, dropout=0.3, maxQuesCount=10 if enc.startswith('hrea') else 4))
     dl = SyntheticDataloader(p, seed=9)
     batch = dl.getTrainBatch(p)
     P = vo.init_params(enc, dec, p, seed=4)

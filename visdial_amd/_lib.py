@@ -63,6 +63,10 @@ PROTOTYPES = {
     "vd_axpby": [_p, _p, _p, _l, _f, _f, _p],
     "vd_mn_attention_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "vd_mn_attention_backward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "vd_hrea_attention_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "vd_hrea_attention_backward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "vd_rowdot_forward": [_p, _p, _p, _p, _i, _i, _p],
+    "vd_rowdot_backward": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
     "vd_img_common_forward": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "vd_img_att_forward": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "vd_img_att_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],

@@ -104,6 +104,124 @@ mn_att_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ Hm, con
 }
 
 // =====================================================================================
+// History attention of encoders/hrea-ques-im-hist.lua:83-131: additive scores
+//   A[i,j] = sq[i] + sh[j]  (nn.Linear(H,1) on question / history states, Replicate + CAddTable),
+//   MaskFuture (j > i -> 0), ReplaceZero(-inf) (every exact 0 -> -inf), SoftMax over j,
+//   att[i,:] = sum_j P[i,j] * h[j,:]   (CMulTable + Sum(3)).   One workgroup per dialog.
+// =====================================================================================
+__global__ void __launch_bounds__(256)
+hrea_att_fwd_kernel(const float* __restrict__ sq, const float* __restrict__ sh, const float* __restrict__ Hm,
+                    float* __restrict__ P, float* __restrict__ att, int R, int H) {
+  __shared__ float S[MN_MAX_R * MN_MAX_R];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* h = Hm + (long)b * R * H;
+  if (tid < R) {
+    const int i = tid;
+    float mx = -INFINITY;
+    for (int j = 0; j < R; ++j) {
+      float v = (j > i) ? 0.f : sq[b * R + i] + sh[b * R + j];
+      v = (v == 0.f) ? -INFINITY : v;
+      S[i * MN_MAX_R + j] = v;
+      mx = fmaxf(mx, v);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < R; ++j) {
+      const float e = expf(S[i * MN_MAX_R + j] - mx);
+      S[i * MN_MAX_R + j] = e;
+      sum += e;
+    }
+    const float inv = 1.f / sum;
+    for (int j = 0; j < R; ++j) {
+      const float pv = S[i * MN_MAX_R + j] * inv;
+      S[i * MN_MAX_R + j] = pv;
+      P[((long)b * R + i) * R + j] = pv;
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < R * H; idx += 256) {
+    const int i = idx / H, k = idx % H;
+    float a = 0.f;
+    for (int j = 0; j <= i; ++j) a += S[i * MN_MAX_R + j] * h[j * H + k];
+    att[(long)b * R * H + idx] = a;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+hrea_att_bwd_kernel(const float* __restrict__ Hm, const float* __restrict__ P, const float* __restrict__ datt,
+                    float* __restrict__ dsq, float* __restrict__ dsh, float* __restrict__ dHm, int R, int H) {
+  __shared__ float Ps[MN_MAX_R * MN_MAX_R];
+  __shared__ float dA[MN_MAX_R * MN_MAX_R];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* h = Hm + (long)b * R * H;
+  const float* da = datt + (long)b * R * H;
+  for (int p = wave; p < R * R; p += 4) {
+    const int i = p / R, j = p % R;
+    float s = 0.f;
+    for (int k = lane; k < H; k += 64) s += da[i * H + k] * h[j * H + k];
+    s = wave_sum(s);
+    if (lane == 0) {
+      dA[i * MN_MAX_R + j] = s;  // dP
+      Ps[i * MN_MAX_R + j] = P[((long)b * R + i) * R + j];
+    }
+  }
+  __syncthreads();
+  if (tid < R) {
+    const int i = tid;
+    float dot = 0.f;
+    for (int j = 0; j < R; ++j) dot += Ps[i * MN_MAX_R + j] * dA[i * MN_MAX_R + j];
+    float rs = 0.f;
+    for (int j = 0; j < R; ++j) {
+      const float v = Ps[i * MN_MAX_R + j] * (dA[i * MN_MAX_R + j] - dot);
+      dA[i * MN_MAX_R + j] = v;
+      rs += v;
+    }
+    dsq[b * R + i] = rs;
+  }
+  __syncthreads();
+  if (tid < R) {
+    const int j = tid;
+    float cs = 0.f;
+    for (int i = 0; i < R; ++i) cs += dA[i * MN_MAX_R + j];
+    dsh[b * R + j] = cs;
+  }
+  for (int idx = tid; idx < R * H; idx += 256) {
+    const int j = idx / H, k = idx % H;
+    float a = 0.f;
+    for (int i = j; i < R; ++i) a += Ps[i * MN_MAX_R + j] * da[i * H + k];
+    dHm[(long)b * R * H + idx] = a;
+  }
+}
+
+// nn.Linear(H, 1): out[n] = <x[n,:], w> + b, and its backward (dw, db accumulated; dx written)
+__global__ void __launch_bounds__(256)
+rowdot_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                  float* __restrict__ out, int N, int H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = lane; k < H; k += 64) s += x[(long)n * H + k] * w[k];
+  s = wave_sum(s);
+  if (lane == 0) out[n] = s + bias[0];
+}
+__global__ void __launch_bounds__(256)
+rowdot_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dout,
+                  float* __restrict__ dw, float* __restrict__ db, float* __restrict__ dx, int N, int H) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= H) return;
+  const float wk = w[k];
+  float a = 0.f, bsum = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float d = dout[n];
+    a += d * x[(long)n * H + k];
+    dx[(long)n * H + k] = d * wk;
+    bsum += d;
+  }
+  unsafeAtomicAdd(dw + k, a);
+  if (k == 0) unsafeAtomicAdd(db, bsum);
+}
+
+// =====================================================================================
 // Image attention
 // =====================================================================================
 // Row (n, s) of the per-round image tensor, read from the per-image map with the round's
@@ -341,6 +459,46 @@ int vd_mn_attention_backward(const float* Q, const float* Hm, const float* P, co
   if (B == 0) return VD_OK;
   hipLaunchKernelGGL(mn_att_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, Q, Hm, P, dhAtt, dQ, dHm,
                      R, H);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+int vd_hrea_attention_forward(const float* sq, const float* sh, const float* Hm, float* P, float* att, int B, int R,
+                              int H, void* stream) {
+  VD_CHECK_ARG(sq && sh && Hm && P && att && B >= 0 && R >= 1 && R <= MN_MAX_R && H > 0,
+               "vd_hrea_attention_forward: bad args (R=%d must be <= %d)", R, MN_MAX_R);
+  if (B == 0) return VD_OK;
+  hipLaunchKernelGGL(hrea_att_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, sq, sh, Hm, P, att, R, H);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+int vd_hrea_attention_backward(const float* Hm, const float* P, const float* datt, float* dsq, float* dsh,
+                               float* dHm, int B, int R, int H, void* stream) {
+  VD_CHECK_ARG(Hm && P && datt && dsq && dsh && dHm && B >= 0 && R >= 1 && R <= MN_MAX_R && H > 0,
+               "vd_hrea_attention_backward: bad args");
+  if (B == 0) return VD_OK;
+  hipLaunchKernelGGL(hrea_att_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, Hm, P, datt, dsq, dsh, dHm,
+                     R, H);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+int vd_rowdot_forward(const float* x, const float* w, const float* bias, float* out, int N, int H, void* stream) {
+  VD_CHECK_ARG(x && w && bias && out && N >= 0 && H > 0, "vd_rowdot_forward: bad args");
+  if (N == 0) return VD_OK;
+  hipLaunchKernelGGL(rowdot_fwd_kernel, dim3(vd_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, N,
+                     H);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+int vd_rowdot_backward(const float* x, const float* w, const float* dout, float* dw, float* db, float* dx, int N,
+                       int H, void* stream) {
+  VD_CHECK_ARG(x && w && dout && dw && db && dx && N >= 0 && H > 0, "vd_rowdot_backward: bad args");
+  if (N == 0) return VD_OK;
+  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(vd_cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, x, w, dout, dw,
+                     db, dx, N, H);
   VD_LAUNCH_CHECK();
   return VD_OK;
 }

@@ -106,3 +106,28 @@ class SyntheticDataloader(object):
         nb = min(B, n - start_id + 1)
         batch = self.getTrainBatch(params, batch_size=nb, full_length=False)
         return batch, start_id + nb
+
+
+def dropout_mask_shapes(params, batch):
+    """Shapes of the nn.Dropout keep-masks each encoder file instantiates (name -> shape), for hosts that
+    pin the noise (parity runs).  Names are the call sites: q_emb / h_emb (embedding dropout of the
+    nngraph encoders), hatt, img_tr, iqc, u (mn-att:24-25,64,74,92,106), fuse (lf-*), img (hrea:47)."""
+    enc = params['encoder']
+    B, R, Tq = batch['ques_fwd'].shape
+    N, H, E = B * R, params['rnnHiddenSize'], params['embedSize']
+    shp = {}
+    if enc.startswith('lf-ques'):
+        D = H * (2 if 'hist' in enc else 1) + (params['imgFeatureSize'] if 'im' in enc else 0)
+        if params.get('dropout', 0.5) > 0:
+            shp['fuse'] = (N, D)
+    elif enc.startswith('hrea'):
+        shp['img'] = (N, params['imgFeatureSize'])
+    elif enc.startswith('mn') or enc.startswith('lf-att'):
+        Th = batch['hist'].shape[2]
+        shp.update(q_emb=(Tq, N, E), h_emb=(Th, N, E))
+        if enc.startswith('mn'):
+            shp['hatt'] = (N, H)
+        if 'att' in enc:
+            S2, K = params['imgSpatialSize'] ** 2, params.get('commonEmbeddingSize', 512)
+            shp.update(img_tr=(N, S2, H), iqc=(N, S2, K), u=(N, H))
+    return shp

@@ -1,0 +1,210 @@
+"""Building blocks shared by the encoder plug-ins (each cites the reference lines it stands for).
+No arithmetic here: every method is an ordered list of C-ABI launches."""
+import numpy as np
+import torch
+
+from .. import ops
+from ..nn import (SeqLSTM, Linear, dropout_forward, dropout_backward, lstm_stack_forward, lstm_stack_backward,
+                  lstm2_bundle_forward, lstm2_bundle_backward)
+
+P5 = 0.5            # the nngraph encoders hard-code Dropout(0.5) (mn-att:24,25,64,74,92,106)
+S5 = 1.0 / (1.0 - P5)
+
+
+def round_index(N, R, device, cache):
+    """row n of a per-round tensor -> its image row n // R (model.lua:262-269 repeatTensor as a gather)"""
+    idx = cache.get(('rep', N))
+    if idx is None:
+        idx = torch.from_numpy((np.arange(N) // R).astype(np.int32)).to(device)
+        cache[('rep', N)] = idx
+    return idx
+
+
+class TextBranches(object):
+    """history + question branches of the nngraph encoders: shared embedding -> Dropout(0.5) ->
+    SeqLSTM(E,H):maskZero -> SeqLSTM(H,H):maskZero -> Select(1,-1)  (e.g. mn-att:21-45; two layers are
+    hard-coded in those files).  Both stacks advance together as one skewed wavefront."""
+
+    @staticmethod
+    def declare(params, spec):
+        E, H = params['embedSize'], params['rnnHiddenSize']
+        spec.lstm('hist1', E, H); spec.lstm('hist2', H, H)
+        spec.lstm('ques1', E, H); spec.lstm('ques2', H, H)
+
+    def __init__(self, params, fp, ws, drop):
+        E, H = params['embedSize'], params['rnnHiddenSize']
+        self.E, self.H, self.fp, self.ws, self.drop = E, H, fp, ws, drop
+        self.hist1, self.hist2 = SeqLSTM(fp, 'hist1', E, H, ws), SeqLSTM(fp, 'hist2', H, H, ws)
+        self.ques1, self.ques2 = SeqLSTM(fp, 'ques1', E, H, ws), SeqLSTM(fp, 'ques2', H, H, ws)
+
+    def _embed(self, name, tok):
+        T, N = tok.shape
+        m = self.drop.mask(name + '_emb', T * N * self.E, P5)
+        x = self.ws.get(name + '.x', (T * N, self.E))
+        ops.embed_gather(self.fp.w['embed'], tok, x, mask=m, scale=S5)
+        return x, m
+
+    def forward(self, ques, hist):
+        N = ques.shape[1]
+        hx, self.m_h = self._embed('h', hist)
+        qx, self.m_q = self._embed('q', ques)
+        hT, qT = hist.shape[0], ques.shape[0]
+        hh, qh = lstm2_bundle_forward([(self.hist1, self.hist2, hx, hT, N, hist),
+                                       (self.ques1, self.ques2, qx, qT, N, ques)])
+        return qh[qT - 1], hh[hT - 1]
+
+    def backward(self, ques, hist, dq3, dh3):
+        dhx, dqx = lstm2_bundle_backward([(self.hist1, self.hist2, dh3), (self.ques1, self.ques2, dq3)])
+        ops.embed_scatter_acc(self.fp.g['embed'], hist, dhx, mask=self.m_h, scale=S5)
+        ops.embed_scatter_acc(self.fp.g['embed'], ques, dqx, mask=self.m_q, scale=S5)
+
+
+class MemoryBlock(object):
+    """nn.MM(false,true) -> MaskSoftMax -> nn.MM -> Tanh(Linear(Dropout)) -> Tanh(Linear(hAttTr + query))
+    (mn-att:48-65; mn-ques-hist.lua:43-58; mn-ques-im-hist.lua:50-65)."""
+
+    @staticmethod
+    def declare(params, spec):
+        H = params['rnnHiddenSize']
+        spec.linear('mn1', H, H); spec.linear('mn2', H, H)
+
+    def __init__(self, params, fp, ws, drop):
+        self.H, self.R, self.ws, self.drop = params['rnnHiddenSize'], params['maxQuesCount'], ws, drop
+        self.mn1, self.mn2 = Linear(fp, 'mn1', self.H, self.H, ws), Linear(fp, 'mn2', self.H, self.H, ws)
+
+    def forward(self, query, h3, mask):
+        ws, H, R = self.ws, self.H, self.R
+        N = query.shape[0]
+        B = N // R
+        self.query, self.h3, self.N, self.B = query, h3, N, B
+        self.prob = ws.get('mn.prob', (N, R))
+        hatt = ws.get('mn.hatt', (N, H))
+        ops.mn_attention_forward(query, h3, mask, self.prob, hatt, B, R, H)
+        self.m_hatt = self.drop.mask('hatt', N * H, P5)
+        hatt_d = dropout_forward(ws, 'mn.hatt_d', hatt, self.m_hatt, S5)
+        hattTr = self.mn1.forward(hatt_d, N, tanh=True)
+        s2 = ops.axpby(hattTr, query, ws.get('mn.s2', (N, H)), 1.0, 1.0)         # CAddTable
+        return self.mn2.forward(s2, N, tanh=True)
+
+    def backward(self, dqh2):
+        """returns (d query, d h3)"""
+        ws, H, R, N, B = self.ws, self.H, self.R, self.N, self.B
+        ds2 = self.mn2.backward(dqh2)
+        dhatt_d = self.mn1.backward(ds2)
+        dhatt = dropout_backward(ws, 'mn.dhatt', dhatt_d, self.m_hatt, S5)
+        dq_att = ws.get('mn.dq', (N, H))
+        dh3 = ws.get('mn.dh', (N, H))
+        ops.mn_attention_backward(self.query, self.h3, self.prob, dhatt, dq_att, dh3, B, R, H)
+        dquery = ops.axpby(dq_att, ds2, ws.get('mn.dquery', (N, H)), 1.0, 1.0)
+        return dquery, dh3
+
+
+class SANBlock(object):
+    """1-hop stacked attention over the S x S image regions + output layer (mn-att:68-106;
+    lf-att-ques-im-hist.lua:45-86).  `pre` = tanh(Linear(img)) is computed once per IMAGE; the per-round
+    Dropout masks are applied by the GEMM loaders, the 10x repeat (model.lua:262-265) never materialises."""
+
+    @staticmethod
+    def declare(params, spec):
+        H, C, K = params['rnnHiddenSize'], params['imgFeatureSize'], params.get('commonEmbeddingSize', 512)
+        assert params.get('numAttentionLayers', 1) == 1, "only the default single attention hop is built"
+        spec.linear('img_proj', C, H)
+        spec.linear('img_common', H, K)
+        spec.linear('ques_common', H, K)
+        spec.linear('att', K, 1)
+        spec.linear('out', H, H)
+
+    def __init__(self, params, fp, ws, drop, streams):
+        self.fp, self.ws, self.drop, self.streams = fp, ws, drop, streams
+        self.H, self.C = params['rnnHiddenSize'], params['imgFeatureSize']
+        self.K = params.get('commonEmbeddingSize', 512)
+        self.S2, self.R = params['imgSpatialSize'] ** 2, params['maxQuesCount']
+        self.img_proj = Linear(fp, 'img_proj', self.C, self.H, ws)
+        self.ques_common = Linear(fp, 'ques_common', self.H, self.K, ws)
+        self.out = Linear(fp, 'out', self.H, self.H, ws)
+
+    def prefetch(self, img, N):
+        """per-image projection + this step's dropout masks: independent of the text branches, so it is
+        enqueued on its own stream before them"""
+        H, K, S2 = self.H, self.K, self.S2
+        B = N // self.R
+        with self.streams.fork('img'):
+            self.pre = self.img_proj.forward(img, B * S2, tanh=True)             # mn-att:74-78 (pre-dropout)
+            self.m1 = self.drop.mask('img_tr', N * S2 * H, P5)
+            self.m2 = self.drop.mask('iqc', N * S2 * K, P5)
+
+    def forward(self, u0):
+        fp, ws, H, K, S2, R = self.fp, self.ws, self.H, self.K, self.S2, self.R
+        N = u0.shape[0]
+        self.N, self.u0 = N, u0
+        self.streams.join('img')
+        sc = S5 if self.m1 is not None else 1.0
+        self.sc = sc
+        qc = self.ques_common.forward(u0, N)                                     # mn-att:88
+        self.iqc = ws.get('att.iqc', (N * S2, K))
+        ops.img_common_forward(self.pre, self.m1, fp.w['img_common.W'], fp.w['img_common.b'], qc, self.m2, self.iqc, N,
+                               R, S2, H, K, sc)                                  # mn-att:83-92
+        self.patt = ws.get('att.p', (N, S2))
+        u1 = ws.get('att.u1', (N, H))
+        ops.img_att_forward(self.iqc, fp.w['att.W'], fp.w['att.b'], self.pre, self.m1, u0, self.patt, u1, N, R, S2, H,
+                            K, sc)                                               # mn-att:93-102
+        self.m_u = self.drop.mask('u', N * H, P5)
+        u1_d = dropout_forward(ws, 'att.u1_d', u1, self.m_u, S5)
+        return self.out.forward(u1_d, N, tanh=True)                              # mn-att:106
+
+    def backward(self, grad_output):
+        """returns d u0"""
+        fp, ws, H, K, S2, R, N, sc = self.fp, self.ws, self.H, self.K, self.S2, self.R, self.N, self.sc
+        B = N // R
+        G = fp.g
+        du1d = self.out.backward(grad_output)
+        du1 = dropout_backward(ws, 'att.du1', du1d, self.m_u, S5)                # = d att, and the residual into u0
+        dqc = ws.get('att.dqc', (N, K))
+        ops.img_att_backward(self.iqc, fp.w['att.W'], self.pre, self.m1, self.m2, self.patt, du1, G['att.W'],
+                             G['att.b'], dqc, N, R, S2, H, K, sc)                # iqc now holds dz
+        dz = self.iqc
+        ops.colsum_acc(dz, G['img_common.b'], M=N * S2, N=K)
+        ops.img_common_wgrad(dz, self.pre, self.m1, G['img_common.W'], N, R, S2, H, K, sc)
+        dpre = ws.get('att.dpre', (B * S2, H))
+        dpre.zero_()
+        ops.img_tr_backward(dz, fp.w['img_common.W'], self.patt, du1, self.m1, dpre, N, R, S2, H, K, sc)
+        self.img_proj.backward(dpre, need_dx=False)                              # tanh' + dW, db of mn-att:77
+        du0 = self.ques_common.backward(dqc)
+        return ops.axpby(du0, du1, ws.get('att.du0', (N, H)), 1.0, 1.0)
+
+
+class CatLinear(object):
+    """Tanh(Linear(JoinTable(parts))) with optional Dropout(p) on the joined vector:
+    lf-*.lua fuse layer, mn-ques-im-hist.lua:47-48 (qi), lf-att-ques-im-hist.lua:43 (qh)."""
+
+    def __init__(self, fp, name, dims, H, ws):
+        self.dims, self.D, self.H, self.ws, self.name = list(dims), sum(dims), H, ws, name
+        self.lin = Linear(fp, name, self.D, H, ws)
+
+    def forward(self, parts, N, mask=None, scale=1.0):
+        ws, D = self.ws, self.D
+        cat = ws.get(self.name + '.cat', (N, D))
+        off = 0
+        for x, d in zip(parts, self.dims):
+            ops.copy_2d(cat, D, x, d, N, d, dst_off=off)
+            off += d
+        self.N, self.mask, self.scale = N, mask, scale
+        catd = dropout_forward(ws, self.name + '.in', cat, mask, scale)
+        return self.lin.forward(catd, N, tanh=True)
+
+    def backward(self, dy, need=None):
+        """returns the list of per-part gradients ([N x d_i] contiguous; None where not needed)"""
+        ws, D, N = self.ws, self.D, self.N
+        dcatd = self.lin.backward(dy)
+        dcat = dropout_backward(ws, self.name + '.din', dcatd, self.mask, self.scale)
+        outs, off = [], 0
+        need = need or [True] * len(self.dims)
+        for i, d in enumerate(self.dims):
+            if need[i]:
+                g = ws.get('%s.dpart%d' % (self.name, i), (N, d))
+                ops.copy_2d(g, d, dcat, D, N, d, src_off=off)
+                outs.append(g)
+            else:
+                outs.append(None)
+            off += d
+        return outs

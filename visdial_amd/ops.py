@@ -245,3 +245,23 @@ def lstm2_backward(stacks, H):
             setattr(a, k, _p(s[k], F32))
     import ctypes
     call("vd_lstm2_backward", ctypes.cast(arr, ctypes.c_void_p), len(stacks), H, _stream())
+
+
+def hrea_attention_forward(sq, sh, Hm, P, att, B, R, H):
+    call("vd_hrea_attention_forward", _p(sq, F32), _p(sh, F32), _p(Hm, F32), _p(P, F32), _p(att, F32), B, R, H, _stream())
+
+
+def hrea_attention_backward(Hm, P, datt, dsq, dsh, dHm, B, R, H):
+    call("vd_hrea_attention_backward", _p(Hm, F32), _p(P, F32), _p(datt, F32), _p(dsq, F32), _p(dsh, F32),
+         _p(dHm, F32), B, R, H, _stream())
+
+
+def rowdot_forward(x, w, bias, out, N, H):
+    call("vd_rowdot_forward", _p(x, F32), _p(w, F32), _p(bias, F32), _p(out, F32), N, H, _stream())
+    return out
+
+
+def rowdot_backward(x, w, dout, dw, db, dx, N, H):
+    call("vd_rowdot_backward", _p(x, F32), _p(w, F32), _p(dout, F32), _p(dw, F32), _p(db, F32), _p(dx, F32), N, H,
+         _stream())
+    return dx
