@@ -705,6 +705,54 @@ def gen_decoder_backward(P, G, p, st):
     return denc, None, None
 
 
+def compute_lhood(words, logp):
+    """utils.lua:86-102: sum over time of log p(word), pads (word == 0) contribute 0.  words [T,N], logp [T,N,V]."""
+    T, N = words.shape
+    keep = words != 0
+    idx = np.where(keep, words - 1, 0)
+    picked = logp[np.arange(T)[:, None], np.arange(N)[None, :], idx]
+    return (picked * keep).sum(0)
+
+
+def gen_retrieve_scores(P, p, batch, enc_out, enc_state):
+    """Model:retrieveBatch, gen branch (model.lua:392-420): for every candidate option run the decoder from
+    the encoder state (forwardConnect) and score it with its summed token log-likelihood.  -> [N, O]"""
+    L = p['numLayers']
+    oin, oout = batch['option_in'], batch['option_out']            # [B,R,O,T]
+    B, R, O, T = oin.shape
+    N = B * R
+    oin = oin.reshape(N, O, T).transpose(1, 2, 0)                   # model.lua:394-399: [O, T, N]
+    oout = oout.reshape(N, O, T).transpose(1, 2, 0)
+    qs = enc_state.get('qs') if isinstance(enc_state.get('qs'), list) else None
+    lhood = np.zeros((O, N), enc_out.dtype)
+    for o in range(O):
+        h0s, c0s = [None] * L, [None] * L
+        if qs is not None:
+            for i in range(L):
+                h0s[i], c0s[i] = qs[i]['h'][-1], qs[i]['c'][-1]
+            h0s[L - 1] = enc_out
+        else:
+            h0s[L - 1], c0s[L - 1] = enc_out, np.zeros_like(enc_out)
+        ds = _stack_fwd(P, _layer_names('dec', p), lookup(P['embed'], oin[o]), oin[o], h0s, c0s)
+        logits = ds[-1]['h'] @ P['vocab.W'].T + P['vocab.b']
+        m = logits.max(-1, keepdims=True)
+        logp = logits - (m + np.log(np.exp(logits - m).sum(-1, keepdims=True)))
+        logp = logp * (oin[o] != 0)[:, :, None]                     # MaskZero(LogSoftMax): pad steps give zero rows
+        lhood[o] = compute_lhood(oout[o], logp)
+    return lhood.T
+
+
+def retrieve(encoder, decoder, P, p, batch):
+    """evaluate()-mode scores of the 100 candidates of every round: disc -> dot products, gen -> likelihoods."""
+    P = dict(P)
+    P['embed'] = P['embed'].copy()
+    P['embed'][0] = 0
+    enc_out, st = encoder_forward(encoder, P, p, batch, None)
+    if decoder == 'disc':
+        return disc_decoder_forward(P, p, batch['options'], enc_out)[0]
+    return gen_retrieve_scores(P, p, batch, enc_out, st)
+
+
 def forward_backward(encoder, decoder, P, p, batch, drop=None, only_forward=False):
     """Model:forwardBackward (model.lua:249-342).  Returns dict(loss, scores, grads, enc_out)."""
     P = dict(P)

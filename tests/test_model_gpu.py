@@ -179,3 +179,25 @@ def test_widened_pairs_match_oracle(gpu, enc, dec, case):
     before = model.wrapperdW.clone()
     loss2 = model.forwardBackward(batch, onlyForward=True)
     assert abs(loss2 - loss) < 1e-5 * max(1.0, abs(loss)) and torch.equal(before, model.wrapperdW)
+
+
+@pytest.mark.parametrize("enc", ['lf-ques-im-hist', 'mn-att-ques-im-hist', 'hre-ques-im-hist'])
+def test_gen_retrieval_matches_oracle(gpu, enc):
+    """gen-decoder candidate ranking (model.lua:392-420, utils.computeLhood): likelihood scores + ranks"""
+    from visdial_amd.model import Model
+    kw = dict(imgNorm=1, dropout=0.5, numOptions=12, batchSize=2)
+    if 'att' in enc:
+        kw.update(imgFeatureSize=32, imgSpatialSize=3)
+    p = derive(small_params(encoder=enc, decoder='gen', **kw))
+    dl = SyntheticDataloader(p, seed=31, num_threads=4)
+    batch, _ = dl.getTestBatch(1, p, 'val')
+    model = Model(p)
+    model.wrapper.evaluate()
+    p['useGt'] = True
+    gt_ranks = model.retrieveBatch(batch)
+    P = {k: v.astype(np.float64) for k, v in model.get_parameters_dict().items()}
+    ref = vo.retrieve(enc, 'gen', P, p, batch)
+    dev = model.scores.cpu().numpy()
+    assert np.abs(dev - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    np.testing.assert_array_equal(gt_ranks, vo.compute_ranks(dev, batch['answer_ind'] - 1))
+    assert (gt_ranks != vo.compute_ranks(ref, batch['answer_ind'] - 1)).mean() <= 0.05

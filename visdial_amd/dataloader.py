@@ -100,12 +100,27 @@ class SyntheticDataloader(object):
         return batch
 
     def getTestBatch(self, start_id, params, dtype='val'):
-        """dataloader.lua:342-375: sequential batches; returns (batch, nextStartId)."""
+        """dataloader.lua:342-375: sequential batches; returns (batch, nextStartId).  For the gen decoder the
+        100 candidates arrive as option_in = <START>+tokens / option_out = tokens+<END> [B, R, O, To+1]
+        (processOptions, dataloader.lua:281-318; getIndexOption :437-462) plus answer_ind."""
         B = int(params['batchSize'])
         n = self.numThreads[dtype]
         nb = min(B, n - start_id + 1)
         batch = self.getTrainBatch(params, batch_size=nb, full_length=False)
+        if params['decoder'] == 'gen':
+            self.add_gen_options(batch, nb)
         return batch, start_id + nb
+
+    def add_gen_options(self, batch, B):
+        R, O, To = self.maxQuesCount, self.numOptions, self.maxAnsLen
+        N = B * R
+        ol = self.rng.randint(1, To + 1, size=N * O)
+        toks = [self._tokens(l) for l in ol]
+        T = int(ol.max()) + 1
+        batch['option_in'] = _left_align([np.concatenate([[self.startToken], t]) for t in toks], T).reshape(B, R, O, T)
+        batch['option_out'] = _left_align([np.concatenate([t, [self.endToken]]) for t in toks], T).reshape(B, R, O, T)
+        batch['answer_ind'] = self.rng.randint(1, O + 1, size=N).astype(np.int32)
+        return batch
 
 
 def dropout_mask_shapes(params, batch):

@@ -57,6 +57,54 @@ class Decoder(object):
         return float(loss_rows.cpu().numpy().astype(np.float64).sum())
 
 
+    def retrieve_lhood(self, model, option_in, option_out, encOut, seqLen):
+        """Model:retrieveBatch gen branch (model.lua:392-420) + utils.computeLhood (utils.lua:86-102).
+        The reference loops over the 100 options; here chunks of options are ONE decoder batch (rows =
+        round x option), seeded by the replicated encoder state, and the [rows x V] logits only ever exist
+        for one chunk.  option_in/out: [T x N*O] int32 time-major, row = n*O + o.  Returns lhood [N x O]."""
+        import torch
+        ws, H, V, Vp = self.ws, self.H, self.V, self.Vp
+        T, NO = option_in.shape
+        N = encOut.shape[0]
+        O = NO // N
+        enc = model.encoder
+        layers = getattr(enc, 'rnnLayers', None)
+        lhood = ws.get('ret.lhood', (N, O))
+        oc = max(1, min(O, int((1 << 30) // max(1, T * N * Vp))))           # options per chunk: <= 4 GiB of logits
+        tin = option_in.view(T, N, O)
+        tout = option_out.view(T, N, O)
+        for o0 in range(0, O, oc):
+            o1 = min(O, o0 + oc)
+            C = o1 - o0
+            rows = N * C
+            cin = tin[:, :, o0:o1].contiguous().view(T, rows)               # plumbing: strided int copies
+            cout = tout[:, :, o0:o1].contiguous().view(T, rows)
+            idx = ws.get('ret.idx', (rows,), torch.int32)
+            idx.copy_(torch.arange(rows, device=idx.device, dtype=torch.int32) // C)
+            # forwardConnect (gen.lua:30-42) with the encoder state replicated over the chunk's options
+            def rep(x, key):
+                return ops.embed_gather(x, idx, ws.get(key, (rows, H)))
+            if layers is not None:
+                for ii in range(len(layers)):
+                    self.rnnLayers[ii].userPrevOutput = rep(layers[ii].output[seqLen - 1], 'ret.h0_%d' % ii)
+                    self.rnnLayers[ii].userPrevCell = rep(layers[ii].cell[seqLen - 1], 'ret.c0_%d' % ii)
+                self.rnnLayers[len(layers) - 1].userPrevOutput = rep(encOut, 'ret.enc')
+            else:
+                self.rnnLayers[-1].userPrevOutput = rep(encOut, 'ret.enc')
+            x = ws.get('ret.x', (T * rows, self.E))
+            ops.embed_gather(self.emb, cin, x)
+            h = lstm_stack_forward(self.rnnLayers, x, T, rows, cin).view(T * rows, H)
+            logits = ws.get('ret.logits', (T * rows, Vp))
+            ops.gemm_nt(h, self.Wv, logits, bias=self.bv, M=T * rows, N=V, K=H, ldc=Vp)
+            nll = ws.get('ret.nll', (T, rows))
+            ops.logsoftmax_nll(logits, V, cin.view(-1), cout.view(-1), nll.view(-1), write_grad=False)
+            acc = ws.get('ret.acc', (rows,))
+            acc.zero_()
+            ops.colsum_acc(nll, acc, M=T, N=rows)                            # sum over time (utils.lua:98)
+            ops.copy_2d(lhood, O, acc, C, N, C, dst_off=o0)
+        return ops.axpby(lhood, None, lhood, -1.0, 0.0)                       # log-likelihood = -NLL
+
+
 def model(params, enc, fp, ws, drop):
     return Decoder(params, enc, fp, ws, drop)
 

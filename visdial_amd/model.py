@@ -115,15 +115,20 @@ class Model(object):
         if 'mn' in p['encoder']:
             inputs.append(self._causal_mask(B))
         dec_in = {}
+        if 'answer_ind' in batch:
+            dec_in['gt'] = self._dev(np.asarray(batch['answer_ind']).reshape(-1) - 1, np.int32)       # 0-based
         if p['decoder'] == 'disc':
             o = batch['options']
             dec_in['options'] = self._dev(o.reshape(-1, o.shape[2]).T, np.int32)     # [To x N*O]
-            if 'answer_ind' in batch:
-                dec_in['gt'] = self._dev(np.asarray(batch['answer_ind']).reshape(-1) - 1, np.int32)   # 0-based
         else:
             for k in ('answer_in', 'answer_out'):
-                a = batch[k]
-                dec_in[k] = self._dev(a.reshape(-1, a.shape[2]).T, np.int32)
+                if k in batch:
+                    a = batch[k]
+                    dec_in[k] = self._dev(a.reshape(-1, a.shape[2]).T, np.int32)
+            for k in ('option_in', 'option_out'):                                     # retrieval (model.lua:393-399)
+                if k in batch:
+                    a = batch[k]
+                    dec_in[k] = self._dev(a.reshape(-1, a.shape[3]).T, np.int32)       # [T x N*O], row = n*O + o
         return inputs, dec_in
 
     # ------------------------------------------------------------------ training
@@ -214,11 +219,15 @@ class Model(object):
         inputs, dec_in = self.prepare_inputs(batch)
         self.fp.w['embed'][0].zero_()
         encOut = self.encoder.forward(inputs)
-        if self.params['decoder'] != 'disc':
-            raise NotImplementedError("gen-decoder retrieval (computeLhood, model.lua:392-420) is not built yet")
-        scores = self.decoder.forward((dec_in['options'], encOut))
-        N, O, H = self.decoder.N, self.decoder.O, self.decoder.H
-        ops.score_ce(self.decoder.optH, encOut, scores, N, O, H)
+        if self.params['decoder'] == 'gen':
+            scores = self.decoder.retrieve_lhood(self, dec_in['option_in'], dec_in['option_out'], encOut,
+                                                 inputs[0].shape[0])
+            self.scores = scores
+        else:
+            scores = self.decoder.forward((dec_in['options'], encOut))
+            N, O, H = self.decoder.N, self.decoder.O, self.decoder.H
+            ops.score_ce(self.decoder.optH, encOut, scores, N, O, H)
+            self.scores = scores
         gt = dec_in.get('gt') if self.params.get('useGt') else None
         return utils.computeRanks(scores, gt, self.ws)
 
