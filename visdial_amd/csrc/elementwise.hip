@@ -184,32 +184,52 @@ __global__ void tok_fill_kernel(const int* __restrict__ tok, long n, int* __rest
 // token in registers (one float4 per thread per 1024 columns) and flushes with atomics when the
 // token changes, so a long run (the pad token) is split over many blocks.
 template <int CHUNK>
-__global__ void segment_rowsum_kernel(const float* __restrict__ X, long ldx, const int* __restrict__ tok,
-                                      const int* __restrict__ perm, long n, int ncol, float* __restrict__ out,
-                                      long ldo) {
+__global__ void __launch_bounds__(256)
+segment_rowsum_kernel(const float* __restrict__ X, long ldx, const int* __restrict__ tok,
+                      const int* __restrict__ perm, long n, int ncol, float* __restrict__ out, long ldo) {
+  __shared__ int srow[CHUNK], stok[CHUNK];
   const long p0 = (long)blockIdx.x * CHUNK;
   if (p0 >= n) return;
-  const long p1 = min(n, p0 + CHUNK);
+  const int cnt = (int)min((long)CHUNK, n - p0);
+  // stage the chunk's row ids / tokens once (removes two dependent loads from every row visit)
+  if (threadIdx.x < cnt) {
+    const int r = perm[p0 + threadIdx.x];
+    srow[threadIdx.x] = r;
+    stok[threadIdx.x] = tok[r];
+  }
+  __syncthreads();
   for (int c = threadIdx.x * 4; c < ncol; c += blockDim.x * 4) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int cur = tok[perm[p0]];
-    for (long p = p0; p < p1; ++p) {
-      const int r = perm[p];
-      const int t = tok[r];
-      if (t != cur) {
-        float* o = out + (long)cur * ldo + c;
-        unsafeAtomicAdd(o, acc.x);
-        unsafeAtomicAdd(o + 1, acc.y);
-        unsafeAtomicAdd(o + 2, acc.z);
-        unsafeAtomicAdd(o + 3, acc.w);
-        acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        cur = t;
+    int cur = stok[0];
+    int j = 0;
+    while (j < cnt) {
+      // rows are independent loads: keep 4 in flight
+      float4 v[4];
+      int t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int jj = min(j + u, cnt - 1);
+        t[u] = stok[jj];
+        v[u] = *reinterpret_cast<const float4*>(X + (long)srow[jj] * ldx + c);
       }
-      const float4 v = *reinterpret_cast<const float4*>(X + (long)r * ldx + c);
-      acc.x += v.x;
-      acc.y += v.y;
-      acc.z += v.z;
-      acc.w += v.w;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (j + u >= cnt) break;
+        if (t[u] != cur) {
+          float* o = out + (long)cur * ldo + c;
+          unsafeAtomicAdd(o, acc.x);
+          unsafeAtomicAdd(o + 1, acc.y);
+          unsafeAtomicAdd(o + 2, acc.z);
+          unsafeAtomicAdd(o + 3, acc.w);
+          acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          cur = t[u];
+        }
+        acc.x += v[u].x;
+        acc.y += v[u].y;
+        acc.z += v[u].z;
+        acc.w += v[u].w;
+      }
+      j += 4;
     }
     float* o = out + (long)cur * ldo + c;
     unsafeAtomicAdd(o, acc.x);

@@ -28,7 +28,7 @@ struct GemmCfg {
   static constexpr int THREADS = WM * WK * 64;
   static constexpr int STRIDE = BK + 4;  // floats
   static constexpr int BUF_FLOATS = (BM + BN) * STRIDE;
-  static constexpr int STAGE_BYTES = (DB ? 2 : 1) * BUF_FLOATS * 4;
+  static constexpr int STAGE_BYTES = (DB == 1 ? 2 : 1) * BUF_FLOATS * 4;
   static constexpr int RED_BYTES = (WK - 1) * WM * 16 * 64 * 4;  // one 32x32 tile per parked wave at a time
   static constexpr int LDS_BYTES = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
   static constexpr int NA = (BM * BK / 4) / THREADS;
@@ -106,8 +106,9 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   float4 ra[NA], rb[NB];
+  float4 ra2[NA], rb2[NB];  // second register stage (DB == 2 only; dead otherwise)
 
-  auto load_tile = [&](int k0) {
+  auto load_tile_into = [&](int k0, float4 (&ra)[NA], float4 (&rb)[NB]) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int f = tid + i * THREADS;
@@ -142,7 +143,9 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
     }
   };
 
-  auto store_tile = [&](int buf) {
+  auto load_tile = [&](int k0) { load_tile_into(k0, ra, rb); };
+
+  auto store_tile_from = [&](int buf, const float4 (&ra)[NA], const float4 (&rb)[NB]) {
     float* sa = smem + buf * Cfg::BUF_FLOATS;
     float* sb = sa + BM * STR;
 #pragma unroll
@@ -187,6 +190,8 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
     if (t >= nk) t -= nk;
     return ks + t * BK;
   };
+  auto store_tile = [&](int buf) { store_tile_from(buf, ra, rb); };
+
   const int frag_off = (lane & 31) * STR + wk * KW + (lane >> 5) * 4;
   auto mfma_tile = [&](int buf) {
     const float* sa = smem + buf * Cfg::BUF_FLOATS + (wm * 32) * STR + frag_off;
@@ -209,7 +214,26 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
     }
   };
 
-  if constexpr (Cfg::DB) {
+  if constexpr (Cfg::DB == 2) {
+    // one LDS buffer, TWO register stages: the loads of tiles k+1 and k+2 are in flight while tile k is
+    // multiplied, so a global-load round trip may span two MFMA bursts
+    if (nk > 0) load_tile_into(ktile(0), ra, rb);
+    if (nk > 1) load_tile_into(ktile(1), ra2, rb2);
+    for (int kt = 0; kt < nk; kt += 2) {
+      store_tile_from(0, ra, rb);
+      __syncthreads();
+      if (kt + 2 < nk) load_tile_into(ktile(kt + 2), ra, rb);
+      mfma_tile(0);
+      __syncthreads();
+      if (kt + 1 < nk) {
+        store_tile_from(0, ra2, rb2);
+        __syncthreads();
+        if (kt + 3 < nk) load_tile_into(ktile(kt + 3), ra2, rb2);
+        mfma_tile(0);
+        __syncthreads();
+      }
+    }
+  } else if constexpr (Cfg::DB == 1) {
     // two LDS buffers, one barrier per K tile
     if (nk > 0) {
       load_tile(ktile(0));

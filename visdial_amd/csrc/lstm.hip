@@ -116,9 +116,9 @@ using CfgF1 = GemmCfg<4, 1, 4, 32, 0, 3>;  // default
 using CfgF2 = GemmCfg<8, 1, 4, 32, 0, 4>;  // 256x128 tile, 512 threads, 2 WG/CU
 using CfgF3 = GemmCfg<4, 1, 4, 64, 0, 2>;  // BK = 64, 2 WG/CU
 using CfgF4 = GemmCfg<4, 1, 4, 16, 0, 3>;  // BK = 16
-using CfgF5 = GemmCfg<4, 1, 4, 16, 0, 4>;
-using CfgF6 = GemmCfg<4, 1, 4, 8, 0, 4>;
-using CfgF7 = GemmCfg<4, 1, 4, 8, 0, 3>;
+using CfgF5 = GemmCfg<4, 1, 4, 16, 2, 3>;  // two register stages
+using CfgF6 = GemmCfg<4, 1, 4, 8, 2, 3>;
+using CfgF7 = GemmCfg<4, 1, 4, 32, 2, 3>;
 using CfgF8 = GemmCfg<4, 1, 4, 16, 1, 3>;
 using CfgB0 = GemmCfg<4, 1, 4, 32, 1, 1>;
 using CfgB1 = GemmCfg<4, 1, 4, 32, 0, 3>;
@@ -127,9 +127,9 @@ using CfgB3 = GemmCfg<4, 1, 2, 32, 1, 3>;
 using CfgB4 = GemmCfg<4, 1, 2, 32, 0, 4>;  // 4 WG/CU
 using CfgB5 = GemmCfg<4, 1, 2, 64, 0, 3>;  // BK = 64
 using CfgB6 = GemmCfg<8, 1, 2, 32, 0, 4>;  // 256x64 tile
-using CfgB7 = GemmCfg<4, 1, 2, 16, 0, 4>;
+using CfgB7 = GemmCfg<4, 1, 2, 16, 2, 3>;  // two register stages
 using CfgB8 = GemmCfg<4, 1, 2, 16, 0, 3>;
-using CfgB10 = GemmCfg<4, 1, 4, 16, 0, 3>;
+using CfgB10 = GemmCfg<4, 1, 2, 32, 2, 3>;
 // latency shapes (N ~ 200 rows): 4-way intra-block split-K.  Single LDS buffer and <= 152 VGPRs so one
 // of these workgroups fits into the footprint a retiring throughput-shape workgroup frees (they run
 // concurrently on other streams).
@@ -184,7 +184,7 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
       case 6: return launch_gemm<CfgB6>(N, H, K, 1, a, b, e2, s);
       case 7: return launch_gemm<CfgB7>(N, H, K, 1, a, b, e2, s);
       case 8: return launch_gemm<CfgB8>(N, H, K, 1, a, b, e2, s);
-      case 10: return launch_gemm<CfgB10>(N, H, K, 1, a, b, e4, s);
+      case 10: return launch_gemm<CfgB10>(N, H, K, 1, a, b, e2, s);
       default: return launch_gemm<CfgB2>(N, H, K, 1, a, b, e2, s);
     }
   }
