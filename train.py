@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from visdial_amd import opts
-from visdial_amd.dataloader import SyntheticDataloader
+from visdial_amd.dataloader import Dataloader, SyntheticDataloader
 from visdial_amd.model import Model
 
 
@@ -30,10 +30,16 @@ def main():
         for k in ('numEpochs', 'maxIters', 'savePath', 'saveIter', 'numTrainThreads'):
             mp[k] = opt[k]
         opt = mp
-    dataloader = SyntheticDataloader(opt, seed=1234, num_threads=opt['numTrainThreads'])
+    have = lambda p: os.path.exists(p) or os.path.exists(p[:-3] + '.npz')
+    if os.path.exists(opt['inputJson']) and have(opt['inputQues']):
+        dataloader = Dataloader(seed=1234).initialize(opt, ['train'])            # train.lua:47-48 (real VisDial files)
+    else:
+        print('no dataset at %s: using synthetic VisDial-shaped batches' % opt['inputQues'])
+        dataloader = SyntheticDataloader(opt, seed=1234, num_threads=opt['numTrainThreads'])
     for k in ('vocabSize', 'maxQuesCount', 'maxQuesLen', 'maxAnsLen'):   # train.lua:55-59
         opt[k] = getattr(dataloader, k)
     opt['numTrainThreads'] = dataloader.numTrainThreads
+    opt['numOptions'] = getattr(dataloader, 'numOptions', 100)
     os.makedirs(opt['savePath'], exist_ok=True)
     opt['numIterPerEpoch'] = int(math.ceil(opt['numTrainThreads'] / float(opt['batchSize'])))
     print('\n%d iter per epoch.' % opt['numIterPerEpoch'])

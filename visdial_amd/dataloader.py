@@ -146,3 +146,252 @@ def dropout_mask_shapes(params, batch):
             S2, K = params['imgSpatialSize'] ** 2, params.get('commonEmbeddingSize', 512)
             shp.update(img_tr=(N, S2, H), iqc=(N, S2, K), u=(N, H))
     return shp
+
+
+# =====================================================================================================
+# Real-data loader: counterpart of the reference's dataloader.lua.
+# =====================================================================================================
+def rightAlign(sequences, lengths):
+    """utils.lua:6-45.  3-D case reproduces the reference's quirk: the inner loop BREAKS at the first
+    zero-length sequence of an image, leaving that image's remaining rounds all-zero."""
+    seq = np.asarray(sequences)
+    out = np.zeros_like(seq)
+    M = seq.shape[-1]
+    if seq.ndim == 3:
+        L = np.asarray(lengths).astype(np.int64)
+        alive = np.cumprod(L != 0, axis=1).astype(bool)              # False from the first zero length on
+        pos = np.arange(M)[None, None, :]
+        src = pos - (M - L[:, :, None])                              # source column for every target column
+        ok = (src >= 0) & alive[:, :, None]
+        out[ok] = np.take_along_axis(seq, np.clip(src, 0, M - 1), axis=2)[ok]
+    else:
+        L = np.asarray(lengths).astype(np.int64)
+        pos = np.arange(M)[None, :]
+        src = pos - (M - L[:, None])
+        ok = (src >= 0) & (L[:, None] > 0)
+        out[ok] = np.take_along_axis(seq, np.clip(src, 0, M - 1), axis=1)[ok]
+    return out
+
+
+def _open_arrays(path):
+    """HDF5 when h5py exists in this interpreter, else an .npz/.npy directory twin with the same dataset
+    names (scripts/h5_to_npz.py converts; no HDF5 library is available in the build image's python)."""
+    if path.endswith('.npz'):
+        return np.load(path)
+    try:
+        import h5py
+    except ImportError:
+        alt = path[:-3] + '.npz' if path.endswith('.h5') else path + '.npz'
+        import os
+        if os.path.exists(alt):
+            return np.load(alt)
+        raise RuntimeError("cannot read %s: h5py is not installed and no %s twin exists "
+                           "(convert with scripts/h5_to_npz.py)" % (path, alt))
+    return h5py.File(path, 'r')
+
+
+class Dataloader(object):
+    """Same public surface as the reference `dataloader` table: initialize(opt, subsets),
+    getTrainBatch(params[, batchSize]), getTestBatch(startId, params, dtype), getIndexData,
+    getIndexOption, and the size fields train.lua copies into the model params (train.lua:55-59).
+    Token matrices stay 1-based vocabulary ids with 0 = pad, exactly as prepro.py writes them."""
+
+    def __init__(self, seed=1234):
+        self.rng = np.random.RandomState(seed)
+
+    # -------------------------------------------------------------------------------- loading
+    def initialize(self, opt, subsets):
+        import json
+        info = json.load(open(opt['inputJson']))
+        ques = _open_arrays(opt['inputQues'])
+        img = _open_arrays(opt['inputImg']) if opt.get('useIm') else None
+        return self.from_arrays(info, ques, img, opt, subsets)
+
+    def from_arrays(self, info, ques, img, opt, subsets):
+        """dataloader.lua:10-140"""
+        for k, v in info.items():
+            setattr(self, k, v)
+        self.word2ind = dict(info['word2ind'])
+        count = len(self.word2ind)
+        self.word2ind['<START>'] = count + 1                       # :17-22
+        self.word2ind['<END>'] = count + 2
+        self.vocabSize = count + 2
+        self.ind2word = {i: w for w, i in self.word2ind.items()}
+        self.numThreads = {}
+        self.data = {}
+        self.useHistory, self.concatHistory = bool(opt.get('useHistory')), bool(opt.get('concatHistory'))
+        self.useIm = bool(opt.get('useIm'))
+        self.maxHistoryLen = int(opt.get('maxHistoryLen') or 60)
+        A = lambda name: np.asarray(ques[name])
+        for dtype in subsets:
+            d = {}
+            d['ques'], d['ques_len'] = A('ques_' + dtype).astype(np.int64), A('ques_length_' + dtype).astype(np.int64)
+            d['ans'], d['ans_len'] = A('ans_' + dtype).astype(np.int64), A('ans_length_' + dtype).astype(np.int64)
+            if dtype != 'test':
+                d['ans_ind'] = A('ans_index_' + dtype).astype(np.int64)
+            if self.useIm:
+                f = np.asarray(img['images_' + dtype], dtype=np.float32)
+                if int(opt.get('imgNorm', 1)) == 1:                 # :64-68 (L2 norm over dim 2)
+                    f = f / np.sqrt((f * f).sum(1, keepdims=True))
+                if 'att' in opt['encoder']:                        # :69-72 NCHW -> NHWC
+                    f = np.ascontiguousarray(f.transpose(0, 2, 3, 1))
+                d['img_fv'] = f
+                d['img_pos'] = A('img_pos_' + dtype).astype(np.int64) + 1     # :76-77 (1-indexed like Lua)
+            n = d['ques'].shape[0]
+            self.numThreads[dtype] = n
+            setattr(self, 'num%sThreads' % dtype.capitalize(), n)
+            d['opt'] = A('opt_' + dtype).astype(np.int64)
+            d['opt_len'] = A('opt_length_' + dtype).astype(np.int64)
+            d['opt_list'] = A('opt_list_' + dtype).astype(np.int64)
+            self.numOptions = d['opt'].shape[2]
+            d['num_rounds'] = A('num_rounds_' + dtype).astype(np.int64)
+            self.maxQuesCount, self.maxQuesLen = d['ques'].shape[1], d['ques'].shape[2]
+            self.maxAnsLen = d['ans'].shape[2]
+            if self.useHistory:
+                d['cap'], d['cap_len'] = A('cap_' + dtype).astype(np.int64), A('cap_length_' + dtype).astype(np.int64)
+            self.data[dtype] = d
+        for dtype in subsets:
+            self.prepareDataset(dtype)
+        return self
+
+    # -------------------------------------------------------------------------------- preprocessing
+    def prepareDataset(self, dtype):
+        """dataloader.lua:143-156"""
+        d = self.data[dtype]
+        d['ques_fwd'] = rightAlign(d['ques'], d['ques_len'])
+        if self.useHistory:
+            self.processHistory(dtype)
+        self.processOptions(dtype)
+        self.processAnswers(dtype)
+
+    def processAnswers(self, dtype):
+        """dataloader.lua:159-200: <START>+answer / answer+<END>; <END> is written even for empty answers"""
+        d = self.data[dtype]
+        ans, L = d['ans'], d['ans_len']
+        n, R, M = ans.shape
+        din = np.zeros((n, R, M + 1), np.int64)
+        dout = np.zeros((n, R, M + 1), np.int64)
+        din[:, :, 0] = self.word2ind['<START>']
+        keep = np.arange(M)[None, None, :] < L[:, :, None]           # the first `length` tokens
+        din[:, :, 1:][keep] = ans[keep]
+        dout[:, :, :M][keep] = ans[keep]
+        ii, rr = np.meshgrid(np.arange(n), np.arange(R), indexing='ij')
+        dout[ii, rr, L] = self.word2ind['<END>']
+        d['ans_len'] = L + 1
+        d['ans_in'], d['ans_out'] = din, dout
+
+    def processOptions(self, dtype):
+        """dataloader.lua:281-321: the same wrapping for the option list (used by the gen decoder only)"""
+        d = self.data[dtype]
+        ol, L = d['opt_list'], d['opt_len']
+        n, M0 = ol.shape
+        M = self.maxAnsLen
+        din = np.zeros((n, M + 1), np.int64)
+        dout = np.zeros((n, M + 1), np.int64)
+        din[:, 0] = self.word2ind['<START>']
+        keep = (np.arange(M)[None, :] < L[:, None])
+        src = ol[:, :M] if M0 >= M else np.pad(ol, ((0, 0), (0, M - M0)))
+        din[:, 1:][keep] = src[keep]
+        dout[:, :M][keep] = src[keep]
+        nz = L > 0                                                   # empty options get no <END> (:306-315)
+        dout[np.arange(n)[nz], L[nz]] = self.word2ind['<END>']
+        d['opt_len'] = L + 1
+        d['opt_in'], d['opt_out'] = din, dout
+
+    def processHistory(self, dtype):
+        """dataloader.lua:203-278: round 1 = caption (first maxQ+maxA tokens); round r = Q(r-1)+A(r-1), or the
+        running <END>-separated concatenation when concatHistory; then right-align."""
+        d = self.data[dtype]
+        cap, capL = d['cap'], d['cap_len']
+        q, qL, a, aL = d['ques'], d['ques_len'], d['ans'], d['ans_len']
+        n, R, MQ = q.shape
+        MA = a.shape[2]
+        W0 = MQ + MA
+        if self.concatHistory:
+            self.maxHistoryLen = min(R * W0, 300)
+            W = self.maxHistoryLen
+        else:
+            W = W0
+        hist = np.zeros((n, R, W), np.int64)
+        hl = np.zeros((n, R), np.int64)
+        END = self.word2ind['<END>']
+        for i in range(n):
+            lenH = 0
+            for r in range(R):
+                if r == 0:
+                    hist[i, 0, :W0] = cap[i, :W0]
+                    lenH = min(int(capL[i]), W0)
+                else:
+                    lq, la = int(qL[i, r - 1]), int(aL[i, r - 1])
+                    if self.concatHistory:
+                        hist[i, r, :lenH] = hist[i, r - 1, :lenH]
+                        hist[i, r, lenH] = END
+                        hist[i, r, lenH + 1:lenH + 1 + lq] = q[i, r - 1, :lq]
+                        hist[i, r, lenH + 1 + lq:lenH + 1 + lq + la] = a[i, r - 1, :la]
+                        lenH = lenH + lq + la + 1
+                    else:
+                        hist[i, r, :lq] = q[i, r - 1, :lq]
+                        hist[i, r, lq:lq + la] = a[i, r - 1, :la]
+                        lenH = lq + la
+                hl[i, r] = lenH
+        d['hist'] = rightAlign(hist, hl)
+        d['hist_len'] = hl
+
+    # -------------------------------------------------------------------------------- batches
+    def getTrainBatch(self, params, batchSize=None):
+        """dataloader.lua:324-339: `size` thread ids sampled WITH replacement"""
+        size = int(batchSize or params['batchSize'])
+        inds = self.rng.randint(1, int(params.get('numTrainThreads', self.numThreads['train'])) + 1, size=size)
+        out = self.getIndexData(inds, params, 'train')
+        if params['decoder'] == 'disc':
+            o = self.getIndexOption(inds, params, 'train')
+            out['options'] = o.reshape(o.shape[0] * o.shape[1], o.shape[2], -1)
+            out['answer_ind'] = out['answer_ind'].reshape(-1)
+        return out
+
+    def getTestBatch(self, startId, params, dtype):
+        """dataloader.lua:342-375"""
+        nxt = min(self.numThreads[dtype] + 1, startId + int(params['batchSize']))
+        inds = np.arange(startId, nxt)
+        out = self.getIndexData(inds, params, dtype)
+        o = self.getIndexOption(inds, params, dtype)
+        if params['decoder'] == 'disc':
+            out['options'] = o.reshape(o.shape[0] * o.shape[1], o.shape[2], -1)
+            if dtype != 'test':
+                out['answer_ind'] = out['answer_ind'].reshape(-1)
+        else:
+            out.update(o)
+        out['num_rounds'] = self.data[dtype]['num_rounds'][inds - 1]
+        return out, nxt
+
+    def getIndexData(self, inds, params, dtype):
+        """dataloader.lua:378-432 (inds are 1-based thread ids)"""
+        d = self.data[dtype]
+        ix = np.asarray(inds, np.int64) - 1
+        out = {}
+        mq = int(d['ques_len'][ix].max())
+        out['ques_fwd'] = np.ascontiguousarray(d['ques_fwd'][ix][:, :, d['ques_fwd'].shape[2] - mq:]).astype(np.int32)
+        if self.useHistory:
+            mh = min(int(d['hist_len'][ix].max()), self.maxHistoryLen)
+            out['hist'] = np.ascontiguousarray(d['hist'][ix][:, :, d['hist'].shape[2] - mh:]).astype(np.int32)
+        if self.useIm:
+            out['img_feat'] = d['img_fv'][d['img_pos'][ix] - 1]
+        ma = int(d['ans_len'][ix].max())
+        out['answer_in'] = np.ascontiguousarray(d['ans_in'][ix][:, :, :ma]).astype(np.int32)
+        out['answer_out'] = np.ascontiguousarray(d['ans_out'][ix][:, :, :ma]).astype(np.int32)
+        if dtype != 'test':
+            out['answer_ind'] = d['ans_ind'][ix].astype(np.int32)
+        return out
+
+    def getIndexOption(self, inds, params, dtype):
+        """dataloader.lua:435-477"""
+        d = self.data[dtype]
+        ix = np.asarray(inds, np.int64) - 1
+        oi = d['opt'][ix]                                             # [B, R, 100] 1-based rows of opt_list
+        flat = oi.reshape(-1) - 1
+        if params['decoder'] == 'gen':
+            ml = int(d['opt_len'][flat].max())
+            shp = oi.shape + (-1,)
+            return {'option_in': np.ascontiguousarray(d['opt_in'][flat].reshape(shp)[..., :ml]).astype(np.int32),
+                    'option_out': np.ascontiguousarray(d['opt_out'][flat].reshape(shp)[..., :ml]).astype(np.int32)}
+        return d['opt_list'][flat].reshape(oi.shape + (-1,)).astype(np.int32)
