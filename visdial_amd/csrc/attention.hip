@@ -267,7 +267,7 @@ struct EpiImgCommon {
   int S2;
   float scale;
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int col0, int lane, int M,
-                                             int N) const {
+                                             int N, float* /*scr*/ = nullptr) const {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = col0 + j * 32 + (lane & 31);
@@ -295,7 +295,7 @@ struct EpiImgTrBwd {
   int S2, R;
   float scale;
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int col0, int lane, int M,
-                                             int N) const {
+                                             int N, float* /*scr*/ = nullptr) const {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = col0 + j * 32 + (lane & 31);

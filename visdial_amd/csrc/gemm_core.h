@@ -30,7 +30,9 @@ struct GemmCfg {
   static constexpr int BUF_FLOATS = (BM + BN) * STRIDE;
   static constexpr int STAGE_BYTES = (DB == 1 ? 2 : 1) * BUF_FLOATS * 4;
   static constexpr int RED_BYTES = (WK - 1) * WM * 16 * 64 * 4;  // one 32x32 tile per parked wave at a time
-  static constexpr int LDS_BYTES = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
+  static constexpr int EPI_BYTES = WM * 32 * 32 * 4;  // per-wave 32x32 transposition scratch for row-vectorised epilogues
+  static constexpr int LDS_BYTES0 = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
+  static constexpr int LDS_BYTES = LDS_BYTES0 > EPI_BYTES ? LDS_BYTES0 : EPI_BYTES;
   static constexpr int NA = (BM * BK / 4) / THREADS;
   static constexpr int NB = (BN * BK / 4) / THREADS;
   static_assert(KW % 8 == 0, "KW must be a multiple of 8");
@@ -76,6 +78,21 @@ struct SrcKGate4 {
 
 __device__ __forceinline__ int mfma_row(int r, int lane) {
   return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+// Stage one 32x32 accumulator tile through the wave's private LDS scratch (1024 floats) and hand it back
+// row-vectorised: out[p] = tile[row = p*8 + (lane>>3)][col = (lane&7)*4 .. +3].  Lets an epilogue issue
+// 16-byte global accesses (8 lanes = one 128-byte row segment) instead of 4-byte ones.  Single wave:
+// LDS operations of a wave execute in order, no barrier needed.
+__device__ __forceinline__ void tile_to_rows(const f32x16& a, float* scr, int lane, float4 (&out)[4]) {
+  asm volatile("" ::: "memory");  // compiler-only fences: keep the scratch writes/reads in program order
+#pragma unroll
+  for (int r = 0; r < 16; ++r) scr[mfma_row(r, lane) * 32 + (lane & 31)] = a[r];
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    out[p] = *reinterpret_cast<const float4*>(scr + (p * 8 + (lane >> 3)) * 32 + (lane & 7) * 4);
+  asm volatile("" ::: "memory");
 }
 
 // XCD-aware bijective remap of the flat workgroup id (guide T1).
@@ -282,7 +299,7 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
     if (wk > 0) return;
   }
 
-  epi(acc, row_base + wm * 32, col_base, lane, M, N);
+  epi(acc, row_base + wm * 32, col_base, lane, M, N, smem + wm * 1024);
 }
 
 template <class Cfg, class ASrc, class BSrc, class Epi>
@@ -367,7 +384,7 @@ struct EpiStore {
   int act;
   int accumulate;
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[NT], int row0, int col0, int lane, int M,
-                                             int N) const {
+                                             int N, float* /*scr*/ = nullptr) const {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = col0 + j * 32 + (lane & 31);
@@ -393,7 +410,7 @@ struct EpiAtomic {
   float* C;
   long ldc;
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[NT], int row0, int col0, int lane, int M,
-                                             int N) const {
+                                             int N, float* /*scr*/ = nullptr) const {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = col0 + j * 32 + (lane & 31);

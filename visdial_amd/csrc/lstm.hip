@@ -27,33 +27,49 @@ struct EpiLstmFwd {
   float* h_out;           // [N x H]
   int H;
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int vcol0, int lane, int M,
-                                             int /*Nv*/) const {
-    const int j = (vcol0 >> 7) * 32 + (lane & 31);
+                                             int /*Nv*/, float* scr) const {
+    // The four accumulator tiles are i,f,o,g of hidden units [j0, j0+32).  Each is staged through the
+    // wave's LDS scratch so that a lane ends up with 4 consecutive hidden units of one row: every global
+    // access of the cell update is then a 16-byte one (8 lanes = one 128-byte segment of a row).
+    const int j = (vcol0 >> 7) * 32 + (lane & 7) * 4;
+    float4 ai[4], af[4], ao[4], ag[4];
+    tile_to_rows(acc[0], scr, lane, ai);
+    tile_to_rows(acc[1], scr, lane, af);
+    tile_to_rows(acc[2], scr, lane, ao);
+    tile_to_rows(acc[3], scr, lane, ag);
     if (j >= H) return;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row0 + mfma_row(r, lane);
+    for (int p = 0; p < 4; ++p) {
+      const int row = row0 + p * 8 + (lane >> 3);
       if (row >= M) continue;
-      const float* xr = xproj + (tok_gather ? (long)tok_gather[row] : (long)row) * xld;
-      float gi, gf, go, gg, c, h;
+      float4 gi, gf, go, gg, c, h;
       if (tok_mask && tok_mask[row] == 0) {
-        gi = gf = go = gg = c = h = 0.f;
+        gi = gf = go = gg = c = h = make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
-        gi = vd_sigmoid(acc[0][r] + xr[j]);
-        gf = vd_sigmoid(acc[1][r] + xr[H + j]);
-        go = vd_sigmoid(acc[2][r] + xr[2 * H + j]);
-        gg = vd_tanh(acc[3][r] + xr[3 * H + j]);
-        const float cp = c_prev ? c_prev[(long)row * H + j] : 0.f;
-        c = gf * cp + gi * gg;
-        h = go * vd_tanh(c);
+        const float* xr = xproj + (tok_gather ? (long)tok_gather[row] : (long)row) * xld + j;
+        const float4 xi = *reinterpret_cast<const float4*>(xr);
+        const float4 xf = *reinterpret_cast<const float4*>(xr + H);
+        const float4 xo = *reinterpret_cast<const float4*>(xr + 2 * H);
+        const float4 xg = *reinterpret_cast<const float4*>(xr + 3 * H);
+        float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c_prev) cp = *reinterpret_cast<const float4*>(c_prev + (long)row * H + j);
+#define VD_CELL(E)                                        \
+        gi.E = vd_sigmoid(ai[p].E + xi.E);                \
+        gf.E = vd_sigmoid(af[p].E + xf.E);                \
+        go.E = vd_sigmoid(ao[p].E + xo.E);                \
+        gg.E = vd_tanh(ag[p].E + xg.E);                   \
+        c.E = gf.E * cp.E + gi.E * gg.E;                  \
+        h.E = go.E * vd_tanh(c.E);
+        VD_CELL(x) VD_CELL(y) VD_CELL(z) VD_CELL(w)
+#undef VD_CELL
       }
-      float* gr = gates + (long)row * 4 * H;
-      gr[j] = gi;
-      gr[H + j] = gf;
-      gr[2 * H + j] = go;
-      gr[3 * H + j] = gg;
-      c_out[(long)row * H + j] = c;
-      h_out[(long)row * H + j] = h;
+      float* gr = gates + (long)row * 4 * H + j;
+      *reinterpret_cast<float4*>(gr) = gi;
+      *reinterpret_cast<float4*>(gr + H) = gf;
+      *reinterpret_cast<float4*>(gr + 2 * H) = go;
+      *reinterpret_cast<float4*>(gr + 3 * H) = gg;
+      *reinterpret_cast<float4*>(c_out + (long)row * H + j) = c;
+      *reinterpret_cast<float4*>(h_out + (long)row * H + j) = h;
     }
   }
 };
@@ -77,30 +93,55 @@ struct EpiLstmBwd {
   int dc_first;
   int H;
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[NT], int row0, int col0, int lane, int M,
-                                             int N) const {
+                                             int N, float* scr) const {
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
-      const int j = col0 + jt * 32 + (lane & 31);
+      float4 d4[4];
+      tile_to_rows(acc[jt], scr, lane, d4);  // row-vectorised: 4 consecutive hidden units per lane
+      const int j = col0 + jt * 32 + (lane & 7) * 4;
       if (j >= N) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + mfma_row(r, lane);
+      for (int p = 0; p < 4; ++p) {
+        const int row = row0 + p * 8 + (lane >> 3);
         if (row >= M) continue;
         const long o = (long)row * H + j;
-        float dh = acc[jt][r];
-        if (dh_a) dh += dh_a[o];
-        if (dh_b) dh += dh_b[o];
-        float* gr = gates + (long)row * 4 * H;
-        const float gi = gr[j], gf = gr[H + j], go = gr[2 * H + j], gg = gr[3 * H + j];
-        const float tc = vd_tanh(c_t[o]);
-        const float cp = c_prev ? c_prev[o] : 0.f;
-        float dcv = dc_first ? 0.f : dc[o];
-        dcv += dh * go * (1.f - tc * tc);
-        gr[j] = dcv * gg * gi * (1.f - gi);
-        gr[H + j] = dcv * cp * gf * (1.f - gf);
-        gr[2 * H + j] = dh * tc * go * (1.f - go);
-        gr[3 * H + j] = dcv * gi * (1.f - gg * gg);
-        dc[o] = dcv * gf;
+        float4 dh = d4[p];
+        if (dh_a) {
+          const float4 t = *reinterpret_cast<const float4*>(dh_a + o);
+          dh.x += t.x; dh.y += t.y; dh.z += t.z; dh.w += t.w;
+        }
+        if (dh_b) {
+          const float4 t = *reinterpret_cast<const float4*>(dh_b + o);
+          dh.x += t.x; dh.y += t.y; dh.z += t.z; dh.w += t.w;
+        }
+        float* gr = gates + (long)row * 4 * H + j;
+        const float4 gi = *reinterpret_cast<const float4*>(gr);
+        const float4 gf = *reinterpret_cast<const float4*>(gr + H);
+        const float4 go = *reinterpret_cast<const float4*>(gr + 2 * H);
+        const float4 gg = *reinterpret_cast<const float4*>(gr + 3 * H);
+        const float4 ct = *reinterpret_cast<const float4*>(c_t + o);
+        float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c_prev) cp = *reinterpret_cast<const float4*>(c_prev + o);
+        float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!dc_first) dcv = *reinterpret_cast<const float4*>(dc + o);
+        float4 ai, af, ao, ag, dn;
+#define VD_CELLB(E)                                                   \
+        {                                                             \
+          const float tc = vd_tanh(ct.E);                             \
+          const float d = dcv.E + dh.E * go.E * (1.f - tc * tc);      \
+          ai.E = d * gg.E * gi.E * (1.f - gi.E);                      \
+          af.E = d * cp.E * gf.E * (1.f - gf.E);                      \
+          ao.E = dh.E * tc * go.E * (1.f - go.E);                     \
+          ag.E = d * gi.E * (1.f - gg.E * gg.E);                      \
+          dn.E = d * gf.E;                                            \
+        }
+        VD_CELLB(x) VD_CELLB(y) VD_CELLB(z) VD_CELLB(w)
+#undef VD_CELLB
+        *reinterpret_cast<float4*>(gr) = ai;
+        *reinterpret_cast<float4*>(gr + H) = af;
+        *reinterpret_cast<float4*>(gr + 2 * H) = ao;
+        *reinterpret_cast<float4*>(gr + 3 * H) = ag;
+        *reinterpret_cast<float4*>(dc + o) = dn;
       }
     }
   }
@@ -224,8 +265,8 @@ struct EpiTickFwd {
   EpiLstmFwd f;
   EpiStore<4> s;
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int col0, int lane, int M,
-                                             int N) const {
-    if (kind == 0) f(acc, row0, col0, lane, M, N);
+                                             int N, float* scr) const {
+    if (kind == 0) f(acc, row0, col0, lane, M, N, scr);
     else s(acc, row0, col0, lane, M, N);
   }
 };
@@ -240,8 +281,8 @@ struct EpiTickBwd {
   EpiLstmBwd<1> f;
   EpiStore<1> s;
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[1], int row0, int col0, int lane, int M,
-                                             int N) const {
-    if (kind == 0) f(acc, row0, col0, lane, M, N);
+                                             int N, float* scr) const {
+    if (kind == 0) f(acc, row0, col0, lane, M, N, scr);
     else s(acc, row0, col0, lane, M, N);
   }
 };
