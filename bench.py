@@ -86,8 +86,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs a GPU"
     torch.cuda.set_device(local)
     group = None
-    if world > 1:
+    if 'RANK' in os.environ:      # launched by torch.distributed.run (any world size, incl. 1)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))   # nccl == RCCL on ROCm
         group = dist.group.WORLD
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world)
@@ -112,7 +113,7 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if group is not None:
         dist.barrier()
     torch.cuda.synchronize()
     ops.PROFILE = {}
@@ -120,13 +121,13 @@ def main():
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if group is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = ops.prof_summary()
     ops.PROFILE = None
-    if world > 1:
+    if group is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -181,7 +182,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if group is not None:
         dist.destroy_process_group()
 
 

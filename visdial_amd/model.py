@@ -81,6 +81,15 @@ class Model(object):
         self.adam_v = torch.zeros_like(self.wrapperW)
         self.runningLoss = 0.0
         self._mask_cache = {}
+        # flat-vector slice holding the encoder's own tensors (everything between the shared embedding and
+        # the decoder tensors): the first gradient bucket of the data-parallel all-reduce
+        names = [e[0] for e in spec.entries]
+        dec_first = None
+        tmp = ParamSpec()
+        self.decFile.declare(params, tmp)
+        dec_first = tmp.entries[0][0]
+        self._enc_slice = (self.fp.offsets[names[1]][0], self.fp.offsets[dec_first][0])
+        self._enc_bucket_work = None
 
     # ------------------------------------------------------------------ helpers
     def _dev(self, a, dtype):
@@ -149,9 +158,18 @@ class Model(object):
     def update(self):
         """[all-reduce] -> clamp(-5, 5) -> adam -> lr decay (model.lua:96-105)."""
         gscale = 1.0
-        if self.world > 1:
+        if self._dp_active():
             from .parallel import reduce_gradients
-            gscale, _ = reduce_gradients(self.wrapperdW, self.dist_group)   # RCCL sum over xGMI
+            if self._enc_bucket_work is not None:
+                # bucket 1 (encoder tensors) was launched when the encoder backward finished and has been
+                # running under the option-LSTM backward; only embedding + decoder slices remain exposed
+                lo, hi = self._enc_slice
+                for sl in (self.wrapperdW[:lo], self.wrapperdW[hi:]):
+                    gscale, _ = reduce_gradients(sl, self.dist_group)
+                self._enc_bucket_work.wait()
+                self._enc_bucket_work = None
+            else:
+                gscale, _ = reduce_gradients(self.wrapperdW, self.dist_group)   # RCCL sum over xGMI
         o = self.optims
         o['t'] += 1
         t = o['t']
@@ -160,6 +178,9 @@ class Model(object):
         if o['learningRate'] > self.params.get('minLRate', 5e-5):
             o['learningRate'] *= self.params.get('lrDecayRate', 0.9997592083)
         self.drop.next_step()
+
+    def _dp_active(self):
+        return self.dist_group is not None and (self.world > 1 or os.environ.get('VD_FORCE_ALLREDUCE') == '1')
 
     def forwardBackward(self, batch, onlyForward=False, encOutOnly=False, prepared=None):
         """model.lua:249-342.  Returns curLoss (python float)."""
@@ -206,6 +227,12 @@ class Model(object):
             self.decoder.backward(d_in, d_optH)                                   # model.lua:335 (main stream)
             with st.fork('enc', after=self._ce_done()):
                 self.encoder.backward(inputs, d_enc)                              # model.lua:337
+                if self._dp_active() and st.enabled:
+                    # gradient bucket 1: the encoder's own tensors are final here -> start their RCCL
+                    # all-reduce now, overlapped with the option-LSTM backward on the main stream
+                    from .parallel import reduce_gradients
+                    lo, hi = self._enc_slice
+                    _, self._enc_bucket_work = reduce_gradients(self.wrapperdW[lo:hi], self.dist_group, async_op=True)
             st.join('enc')
             self.decoder.backward_embed()
         curLoss = float(loss_rows.cpu().numpy().astype(np.float64).mean())

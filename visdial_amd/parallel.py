@@ -24,8 +24,6 @@ def reduce_gradients(flat_grad, group=None, async_op=False):
     if group is None and not dist.is_initialized():
         return 1.0, None
     world = dist.get_world_size(group)
-    if world == 1:
-        return 1.0, None
     work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     return 1.0 / world, work
 
