@@ -95,6 +95,9 @@ typedef struct {
   const int32_t* tok_mask;               /* [T x N] or NULL (maskZero) */
   const float *Wh1, *Wx2, *b2, *Wh2;
   float *gates1, *h1, *c1, *gates2, *h2, *c2;
+  const int32_t* nact;                   /* HOST int32[T] or NULL.  Rows sorted by sequence length: only rows
+                                            [0, nact[t]) are non-pad at step t and are computed; the caller
+                                            zero-fills the rest (vd_zero_inactive_rows / memset) */
 } vd_lstm2_fwd_t;
 typedef struct {
   int T, N;
@@ -106,9 +109,14 @@ typedef struct {
   const float* dh_last2;
   float* dh1_seq;
   float *dc1, *dc2;
+  const int32_t* nact;                   /* HOST int32[T] or NULL, as in vd_lstm2_fwd_t */
 } vd_lstm2_bwd_t;
 int vd_lstm2_forward(const vd_lstm2_fwd_t* stacks, int nstacks, int H, void* stream);
 int vd_lstm2_backward(const vd_lstm2_bwd_t* stacks, int nstacks, int H, void* stream);
+
+/* zero rows [nact[t], N) of every time slice of a [T x N x ld] buffer (nact_dev: DEVICE int32[T]) */
+int vd_zero_inactive_rows(float* buf, int64_t tstride, int64_t ld, int ncols, const int32_t* nact_dev, int T,
+                          int N, void* stream);
 
 /* ---- nn.LookupTableMaskZero / nn.Dropout / small glue ------------------------------------- */
 /* out[r,:] = emb[tok[r],:] * (mask ? mask*scale : 1)        mn-att:21,24-25; disc.lua:12 */

@@ -18,13 +18,15 @@ _u64 = C.c_uint64
 class Lstm2Fwd(C.Structure):
     _fields_ = [("T", C.c_int), ("N", C.c_int), ("tok_mask", C.c_void_p), ("Wh1", C.c_void_p), ("Wx2", C.c_void_p),
                 ("b2", C.c_void_p), ("Wh2", C.c_void_p), ("gates1", C.c_void_p), ("h1", C.c_void_p),
-                ("c1", C.c_void_p), ("gates2", C.c_void_p), ("h2", C.c_void_p), ("c2", C.c_void_p)]
+                ("c1", C.c_void_p), ("gates2", C.c_void_p), ("h2", C.c_void_p), ("c2", C.c_void_p),
+                ("nact", C.c_void_p)]
 
 
 class Lstm2Bwd(C.Structure):
     _fields_ = [("T", C.c_int), ("N", C.c_int), ("Wh1", C.c_void_p), ("Wx2", C.c_void_p), ("Wh2", C.c_void_p),
                 ("gates1", C.c_void_p), ("c1", C.c_void_p), ("gates2", C.c_void_p), ("c2", C.c_void_p),
-                ("dh_last2", C.c_void_p), ("dh1_seq", C.c_void_p), ("dc1", C.c_void_p), ("dc2", C.c_void_p)]
+                ("dh_last2", C.c_void_p), ("dh1_seq", C.c_void_p), ("dc1", C.c_void_p), ("dc2", C.c_void_p),
+                ("nact", C.c_void_p)]
 
 
 # name -> argtypes  (return type is int unless listed in _RESTYPE)
@@ -51,6 +53,7 @@ PROTOTYPES = {
     "vd_colsum_acc": [_p, _l, _i, _i, _p, _p],
     "vd_lstm_forward": [_p, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "vd_lstm_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "vd_zero_inactive_rows": [_p, _l, _l, _i, _p, _i, _i, _p],
     "vd_lstm2_forward": [_p, _i, _i, _p],
     "vd_lstm2_backward": [_p, _i, _i, _p],
     "vd_embed_gather": [_p, _p, _p, _p, _l, _i, _f, _p],

@@ -115,6 +115,20 @@ __global__ void mask_time_bwd_kernel(const float* __restrict__ dout, const int* 
   dfeat[idx] = s;
 }
 
+// zero rows [nact[t], N) of every time slice of a [T x N x ld] buffer (pad rows of length-sorted
+// right-aligned sequences: they are skipped by the recurrence kernels and must read as zeros)
+__global__ void zero_inactive_rows_kernel(float* __restrict__ buf, long tstride, long ld, int ncols,
+                                          const int* __restrict__ nact, int N) {
+  const int t = blockIdx.y;
+  const int first = nact[t];
+  const long total = (long)(N - first) * (ncols >> 2);
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / (ncols >> 2);
+    const int q = (int)(idx - r * (ncols >> 2));
+    *reinterpret_cast<float4*>(buf + t * tstride + (first + r) * ld + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 // ------------------------------------------------------------------ token counting sort
 // Wave-aggregated atomics: lanes holding the same token as the wave's first active lane are
 // counted with one atomic (the pad token dominates option batches: ~50% of all ids are 0).
@@ -334,6 +348,16 @@ int vd_mask_time_backward(const float* dout, const int32_t* tok, float* dfeat, i
   if ((long)N * D == 0) return VD_OK;
   hipLaunchKernelGGL(mask_time_bwd_kernel, grid1d((long)N * D, 256), dim3(256), 0, (hipStream_t)stream, dout,
                      tok, dfeat, T, N, D);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+int vd_zero_inactive_rows(float* buf, int64_t tstride, int64_t ld, int ncols, const int32_t* nact_dev, int T,
+                          int N, void* stream) {
+  VD_CHECK_ARG(buf && nact_dev && T >= 0 && N >= 0 && ncols % 4 == 0 && ld % 4 == 0, "vd_zero_inactive_rows: bad args");
+  if (T == 0 || N == 0) return VD_OK;
+  hipLaunchKernelGGL(zero_inactive_rows_kernel, dim3(64, T), dim3(256), 0, (hipStream_t)stream, buf, (long)tstride,
+                     (long)ld, ncols, nact_dev, N);
   VD_LAUNCH_CHECK();
   return VD_OK;
 }

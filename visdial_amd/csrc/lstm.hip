@@ -298,6 +298,7 @@ struct vd_lstm2_fwd_t {
   const int32_t* tok_mask;
   const float *Wh1, *Wx2, *b2, *Wh2;
   float *gates1, *h1, *c1, *gates2, *h2, *c2;
+  const int32_t* nact;  // HOST array [T] or NULL: rows [0, nact[t]) are the only non-pad rows at step t
 };
 struct vd_lstm2_bwd_t {
   int T, N;
@@ -309,6 +310,7 @@ struct vd_lstm2_bwd_t {
   const float* dh_last2;
   float* dh1_seq;
   float *dc1, *dc2;
+  const int32_t* nact;  // HOST array [T] or NULL (see vd_lstm2_fwd_t)
 };
 
 #define VD_MAX_STACKS 2
@@ -393,8 +395,10 @@ int vd_lstm2_forward(const vd_lstm2_fwd_t* st, int nstacks, int H, void* stream)
         float* gates = layer == 1 ? S.gates1 : S.gates2;
         float* h = layer == 1 ? S.h1 : S.h2;
         float* c = layer == 1 ? S.c1 : S.c2;
+        const int rows = S.nact ? S.nact[t] : S.N;
+        if (rows <= 0) continue;
         TickFwdProb& P = g.p[g.nprob++];
-        P.M = S.N; P.N = 4 * H; P.K = t ? H : 0;
+        P.M = rows; P.N = 4 * H; P.K = t ? H : 0;
         P.a = SrcRow{t ? h + (t - 1) * NH : h, H};
         P.b = SrcKSel{layer == 1 ? S.Wh1 : S.Wh2, 4L * H, H, 1};
         P.e.kind = 0;
@@ -406,9 +410,9 @@ int vd_lstm2_forward(const vd_lstm2_fwd_t* st, int nstacks, int H, void* stream)
         P.e.s = EpiStore<4>{nullptr, 0, nullptr, 0, 0};
       }
       const int t = tau - 1;  // layer-2 input projection of step t
-      if (t >= 0 && t < S.T) {
+      if (t >= 0 && t < S.T && (S.nact ? S.nact[t] : S.N) > 0) {
         TickFwdProb& P = g.p[g.nprob++];
-        P.M = S.N; P.N = 4 * H; P.K = H;
+        P.M = S.nact ? S.nact[t] : S.N; P.N = 4 * H; P.K = H;
         P.a = SrcRow{S.h1 + t * NH, H};
         P.b = SrcKSel{S.Wx2, 4L * H, H, 0};
         P.e.kind = 1;
@@ -444,8 +448,10 @@ int vd_lstm2_backward(const vd_lstm2_bwd_t* st, int nstacks, int H, void* stream
         float* gates = layer == 2 ? S.gates2 : S.gates1;
         const float* c = layer == 2 ? S.c2 : S.c1;
         const bool last = (t == S.T - 1);
+        const int rows = S.nact ? S.nact[t] : S.N;
+        if (rows <= 0) continue;
         TickBwdProb& P = g.p[g.nprob++];
-        P.M = S.N; P.N = H; P.K = last ? 0 : 4 * H;
+        P.M = rows; P.N = H; P.K = last ? 0 : 4 * H;
         P.a = SrcRow{last ? gates : gates + (long)(t + 1) * 4 * NH, 4L * H};
         P.b = SrcRow{layer == 2 ? S.Wh2 : S.Wh1, 4L * H};
         P.e.kind = 0;
@@ -460,9 +466,9 @@ int vd_lstm2_backward(const vd_lstm2_bwd_t* st, int nstacks, int H, void* stream
         P.e.s = EpiStore<1>{nullptr, 0, nullptr, 0, 0};
       }
       const int t = S.T - tau;  // dh1[t] = da2[t] * Wx2^T
-      if (t >= 0 && t < S.T) {
+      if (t >= 0 && t < S.T && (S.nact ? S.nact[t] : S.N) > 0) {
         TickBwdProb& P = g.p[g.nprob++];
-        P.M = S.N; P.N = H; P.K = 4 * H;
+        P.M = S.nact ? S.nact[t] : S.N; P.N = H; P.K = 4 * H;
         P.a = SrcRow{S.gates2 + (long)t * 4 * NH, 4L * H};
         P.b = SrcRow{S.Wx2, 4L * H};
         P.e.kind = 1;

@@ -44,17 +44,41 @@ class TextBranches(object):
         ops.embed_gather(self.fp.w['embed'], tok, x, mask=m, scale=S5)
         return x, m
 
+    def _stack_in(self, name, tok, l1, l2):
+        """(bundle entry, sort meta) for one branch.  With length-sort metadata on the token tensor
+        (Model.prepare_inputs) the stack runs on length-sorted rows and skips pad (t, row) pairs."""
+        T, N = tok.shape
+        x, m = self._embed(name, tok)
+        srt = getattr(tok, 'vd_sort', None)
+        if srt is None:
+            return (l1, l2, x, T, N, tok), None, m
+        xs = ops.embed_gather(x, srt.fwd_idx, self.ws.get(name + '.xs', (T * N, self.E)))   # permute rows per step
+        return (l1, l2, xs, T, N, srt.tok_sorted, srt.nact, srt.nact_dev), srt, m
+
     def forward(self, ques, hist):
-        N = ques.shape[1]
-        hx, self.m_h = self._embed('h', hist)
-        qx, self.m_q = self._embed('q', ques)
+        N, H = ques.shape[1], self.H
+        eh, self.s_h, self.m_h = self._stack_in('h', hist, self.hist1, self.hist2)
+        eq, self.s_q, self.m_q = self._stack_in('q', ques, self.ques1, self.ques2)
         hT, qT = hist.shape[0], ques.shape[0]
-        hh, qh = lstm2_bundle_forward([(self.hist1, self.hist2, hx, hT, N, hist),
-                                       (self.ques1, self.ques2, qx, qT, N, ques)])
-        return qh[qT - 1], hh[hT - 1]
+        hh, qh = lstm2_bundle_forward([eh, eq])
+        h3, q3 = hh[hT - 1], qh[qT - 1]
+        if self.s_h is not None:
+            h3 = ops.embed_gather(h3, self.s_h.inv, self.ws.get('h.last', (N, H)))          # back to batch order
+        if self.s_q is not None:
+            q3 = ops.embed_gather(q3, self.s_q.inv, self.ws.get('q.last', (N, H)))
+        return q3, h3
 
     def backward(self, ques, hist, dq3, dh3):
+        N, H, E = ques.shape[1], self.H, self.E
+        if self.s_h is not None:
+            dh3 = ops.embed_gather(dh3, self.s_h.perm, self.ws.get('h.dlast', (N, H)))
+        if self.s_q is not None:
+            dq3 = ops.embed_gather(dq3, self.s_q.perm, self.ws.get('q.dlast', (N, H)))
         dhx, dqx = lstm2_bundle_backward([(self.hist1, self.hist2, dh3), (self.ques1, self.ques2, dq3)])
+        if self.s_h is not None:
+            dhx = ops.embed_gather(dhx, self.s_h.inv_idx, self.ws.get('h.dxo', (hist.numel(), E)))
+        if self.s_q is not None:
+            dqx = ops.embed_gather(dqx, self.s_q.inv_idx, self.ws.get('q.dxo', (ques.numel(), E)))
         ops.embed_scatter_acc(self.fp.g['embed'], hist, dhx, mask=self.m_h, scale=S5)
         ops.embed_scatter_acc(self.fp.g['embed'], ques, dqx, mask=self.m_q, scale=S5)
 

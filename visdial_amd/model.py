@@ -13,7 +13,7 @@ import torch
 import os
 
 from . import decoders, encoders, ops, utils
-from .nn import DropoutState, StreamPool, Workspace
+from .nn import DropoutState, SeqSort, StreamPool, Workspace
 from .params import FlatParams, ParamSpec, init_host
 
 
@@ -112,15 +112,23 @@ class Model(object):
         inputs = []
         q = batch['ques_fwd']
         B = q.shape[0]
-        inputs.append(self._dev(q.reshape(-1, q.shape[2]).T, np.int32))             # [Tq x N]
+        sort_rows = os.environ.get('VD_SORT_ROWS', '1') != '0' and (p['encoder'].startswith('mn') or
+                                                                      p['encoder'].startswith('lf-att'))
+
+        def tokens(a):
+            th = np.ascontiguousarray(a.reshape(-1, a.shape[2]).T, dtype=np.int32)     # [T x N] time-major
+            t = self._dev(th, np.int32)
+            if sort_rows:
+                t.vd_sort = SeqSort(th, self.device)    # host-side length sort: the recurrences skip pad rows
+            return t
+        inputs.append(tokens(q))                                                     # [Tq x N]
         if p.get('useIm'):
             f = batch['img_feat']
             if 'att' in p['encoder']:
                 f = f.reshape(-1, f.shape[-1])                                        # [B*S2 x C]
             inputs.append(self._dev(f, np.float32))
         if p.get('useHistory'):
-            h = batch['hist']
-            inputs.append(self._dev(h.reshape(-1, h.shape[2]).T, np.int32))          # [Th x N]
+            inputs.append(tokens(batch['hist']))                                     # [Th x N]
         if 'mn' in p['encoder']:
             inputs.append(self._causal_mask(B))
         dec_in = {}

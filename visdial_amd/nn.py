@@ -211,13 +211,43 @@ class SeqLSTM(object):
         return dxs
 
 
+class SeqSort(object):
+    """Length-sorted view of a right-aligned [T x N] token matrix (host-side metadata computed where the
+    batch is still in host memory).  Rows are ordered by decreasing length, so at step t the non-pad rows
+    are the prefix [0, nact[t]) and the recurrence kernels skip every pad (t, row) pair.
+      tok_sorted  device int32 [T x N]     token matrix with permuted columns
+      fwd_idx     device int32 [T*N]       row of the ORIGINAL [T*N x .] tensor feeding sorted row i
+      inv_idx     device int32 [T*N]       row of the SORTED tensor feeding original row i
+      perm / inv  device int32 [N]         the same permutations for [N x .] tensors
+      nact        host   int32 [T], nact_dev its device copy"""
+
+    def __init__(self, tok_host, device):
+        import numpy as np
+        T, N = tok_host.shape
+        length = (tok_host != 0).sum(0)
+        perm = np.argsort(-length, kind='stable').astype(np.int32)
+        inv = np.empty(N, np.int32)
+        inv[perm] = np.arange(N, dtype=np.int32)
+        self.nact = np.ascontiguousarray((length[None, :] >= (T - np.arange(T))[:, None]).sum(1).astype(np.int32))
+        base = (np.arange(T, dtype=np.int32) * N)[:, None]
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.tok_sorted = dev(tok_host[:, perm].astype(np.int32))
+        self.fwd_idx = dev((base + perm[None, :]).reshape(-1))
+        self.inv_idx = dev((base + inv[None, :]).reshape(-1))
+        self.perm, self.inv, self.nact_dev = dev(perm), dev(inv), dev(self.nact)
+        self.T, self.N = T, N
+
+
 def lstm2_bundle_forward(bundle):
-    """bundle: list of (l1, l2, x, T, N, tok_mask) -- two-layer maskZero stacks advanced together as a
-    skewed wavefront (vd_lstm2_forward): one grouped launch per tick for ALL stacks.  Returns the top
-    layers' h tensors.  Fills the same saved-state fields SeqLSTM.forward does."""
+    """bundle: list of (l1, l2, x, T, N, tok_mask[, nact, nact_dev]) -- two-layer maskZero stacks advanced
+    together as a skewed wavefront (vd_lstm2_forward): one grouped launch per tick for ALL stacks.  With
+    nact (rows sorted by length) pad rows are skipped and zero-filled.  Returns the top layers' h tensors.
+    Fills the same saved-state fields SeqLSTM.forward does."""
     H = bundle[0][0].H
     descs = []
-    for l1, l2, x, T, N, tok in bundle:
+    for item in bundle:
+        l1, l2, x, T, N, tok = item[:6]
+        nact, nact_dev = (item[6], item[7]) if len(item) > 6 else (None, None)
         assert l1.H == H and l2.H == H and l2.D == H and len(l1.part_dims) == 1
         for l, xs in ((l1, [x]), (l2, None)):
             l.T, l.N, l.tok_mask, l.h0, l.c0 = T, N, tok, None, None
@@ -229,8 +259,15 @@ def lstm2_bundle_forward(bundle):
         l1.xs = [x]
         l2.xs = [l1.h.view(T * N, H)]
         ops.gemm_nn(x, l1.Wx, l1.gates.view(T * N, 4 * H), bias=l1.b, M=T * N, N=4 * H, K=l1.D)
+        l1.nact = l2.nact = nact
+        if nact is not None:
+            # skipped (t, row) pairs must read as zeros: previous state of rows that become active later,
+            # and da = 0 in the weight-gradient contractions
+            ops.zero_inactive_rows(l1.gates, nact_dev, T, N, 4 * H)
+            for b in (l1.h, l1.c, l2.h, l2.c, l2.gates):
+                b.zero_()
         descs.append(dict(T=T, N=N, tok_mask=tok, Wh1=l1.Wh, Wx2=l2.Wx, b2=l2.b, Wh2=l2.Wh, gates1=l1.gates, h1=l1.h,
-                          c1=l1.c, gates2=l2.gates, h2=l2.h, c2=l2.c))
+                          c1=l1.c, gates2=l2.gates, h2=l2.h, c2=l2.c, nact=nact))
     ops.lstm2_forward(descs, H)
     return [b[1].h for b in bundle]
 
@@ -245,7 +282,8 @@ def lstm2_bundle_backward(bundle):
         ws = l1.ws
         descs.append(dict(T=T, N=N, Wh1=l1.Wh, Wx2=l2.Wx, Wh2=l2.Wh, gates1=l1.gates, c1=l1.c, gates2=l2.gates,
                           c2=l2.c, dh_last2=dlast, dh1_seq=ws.get(l1.key + '.dhseq', (T, N, H)),
-                          dc1=ws.get(l1.key + '.dc', (N, H)), dc2=ws.get(l2.key + '.dc', (N, H))))
+                          dc1=ws.get(l1.key + '.dc', (N, H)), dc2=ws.get(l2.key + '.dc', (N, H)),
+                          nact=getattr(l1, 'nact', None)))
     ops.lstm2_backward(descs, H)
     out = []
     for l1, l2, _ in bundle:

@@ -233,6 +233,8 @@ def lstm2_forward(stacks, H):
         a.tok_mask = _p(s.get('tok_mask'), I32)
         for k in ('Wh1', 'Wx2', 'b2', 'Wh2', 'gates1', 'h1', 'c1', 'gates2', 'h2', 'c2'):
             setattr(a, k, _p(s[k], F32))
+        na = s.get('nact')            # host numpy int32[T] (kept alive by the caller's dict) or None
+        a.nact = na.ctypes.data if na is not None else None
     import ctypes
     call("vd_lstm2_forward", ctypes.cast(arr, ctypes.c_void_p), len(stacks), H, _stream())
 
@@ -243,6 +245,8 @@ def lstm2_backward(stacks, H):
         a.T, a.N = s['T'], s['N']
         for k in ('Wh1', 'Wx2', 'Wh2', 'gates1', 'c1', 'gates2', 'c2', 'dh_last2', 'dh1_seq', 'dc1', 'dc2'):
             setattr(a, k, _p(s[k], F32))
+        na = s.get('nact')
+        a.nact = na.ctypes.data if na is not None else None
     import ctypes
     call("vd_lstm2_backward", ctypes.cast(arr, ctypes.c_void_p), len(stacks), H, _stream())
 
@@ -265,3 +269,8 @@ def rowdot_backward(x, w, dout, dw, db, dx, N, H):
     call("vd_rowdot_backward", _p(x, F32), _p(w, F32), _p(dout, F32), _p(dw, F32), _p(db, F32), _p(dx, F32), N, H,
          _stream())
     return dx
+
+
+def zero_inactive_rows(buf, nact_dev, T, N, ncols):
+    """buf [T, N, ncols] contiguous"""
+    call("vd_zero_inactive_rows", _p(buf, F32), N * ncols, ncols, ncols, _p(nact_dev, I32), T, N, _stream())
