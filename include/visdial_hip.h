@@ -193,6 +193,8 @@ int vd_score_ce(const float* optH, const float* enc, const int32_t* gt, float* s
  * by d loss / d logits (softmax - onehot, zero rows at pads). */
 int vd_logsoftmax_nll(float* logits, int64_t ld, int64_t rows, int V, const int32_t* tok_in,
                       const int32_t* target, float* loss_rows, int write_grad, void* stream);
+/* in-place nn.LogSoftMax over `rows` rows of V logits (sampling / beam search, model.lua:432-613) */
+int vd_log_softmax_rows(float* x, int64_t ld, int64_t rows, int V, void* stream);
 /* utils.computeRanks (utils.lua:106-128): 1-based descending-sort position of every option */
 int vd_ranks(const float* scores, int32_t* ranks, int N, int O, void* stream);
 

@@ -742,6 +742,69 @@ def gen_retrieve_scores(P, p, batch, enc_out, enc_state):
     return lhood.T
 
 
+def generate_beam(encoder, P, p, batch, beam_size, beam_len, START, END):
+    """Model:generateAnswers, beam-search branch (model.lua:466-573), for ONE dialog: returns, per round,
+    (best token vector [beam_len], its score).  Candidate ties are broken by insertion order (stable sort)."""
+    P = dict(P)
+    P['embed'] = P['embed'].copy()
+    P['embed'][0] = 0
+    L = p['numLayers']
+    names = _layer_names('dec', p)
+    enc_out, st = encoder_forward(encoder, P, p, batch, None)
+    qs = st.get('qs') if isinstance(st.get('qs'), list) else None
+    R = batch['ques_fwd'].shape[1]
+    H = p['rnnHiddenSize']
+    out = []
+    for it in range(R):
+        hid = []
+        for lv in range(L):
+            if qs is not None:
+                h = enc_out[it] if lv == L - 1 else qs[lv]['h'][-1][it]
+                c = qs[lv]['c'][-1][it]
+            else:
+                h = enc_out[it] if lv == L - 1 else np.zeros(H)
+                c = np.zeros(H)
+            hid.append((np.tile(h, (beam_size, 1)), np.tile(c, (beam_size, 1))))
+        beams = np.zeros((beam_len, beam_size), np.int64)
+        beams[0] = START
+        scores = np.zeros(beam_size)
+        finish = []
+        for step in range(1, beam_len):
+            explore = 1 if step == 1 else beam_size
+            tok = beams[step - 1:step]
+            x = lookup(P['embed'], tok)
+            newh = []
+            for lv in range(L):
+                h, c, _ = lstm_forward(x, P[names[lv] + '.W'], P[names[lv] + '.b'], tok, hid[lv][0], hid[lv][1])
+                newh.append((h[0], c[0]))
+                x = h
+            logits = x[0] @ P['vocab.W'].T + P['vocab.b']
+            m = logits.max(-1, keepdims=True)
+            logp = logits - (m + np.log(np.exp(logits - m).sum(-1, keepdims=True)))
+            cands = []
+            for w in range(explore):
+                for cid in np.argsort(-logp[w], kind='stable')[:beam_size]:
+                    cb = beams[:, w].copy()
+                    cb[step] = cid + 1
+                    sc = scores[w] + logp[w, cid]
+                    if cid + 1 == END:
+                        finish.append((sc, cb))
+                    else:
+                        cands.append((sc, cb, w))
+            cands.sort(key=lambda a: -a[0])
+            for i, (sc, cb, w) in enumerate(cands[:beam_size]):
+                beams[:, i] = cb
+                scores[i] = sc
+                for lv in range(L):
+                    hid[lv][0][i] = newh[lv][0][w]
+                    hid[lv][1][i] = newh[lv][1][w]
+            # NOTE hid rows are overwritten in candidate order exactly like model.lua:556-566 (in-place, so a
+            # later candidate may copy from a slot an earlier one already replaced only via newh, which is a copy)
+        finish.sort(key=lambda a: -a[0])
+        out.append((finish[0][1], finish[0][0]) if finish else (beams[:, 0], scores[0]))
+    return out
+
+
 def retrieve(encoder, decoder, P, p, batch):
     """evaluate()-mode scores of the 100 candidates of every round: disc -> dot products, gen -> likelihoods."""
     P = dict(P)

@@ -201,3 +201,36 @@ def test_gen_retrieval_matches_oracle(gpu, enc):
     assert np.abs(dev - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
     np.testing.assert_array_equal(gt_ranks, vo.compute_ranks(dev, batch['answer_ind'] - 1))
     assert (gt_ranks != vo.compute_ranks(ref, batch['answer_ind'] - 1)).mean() <= 0.05
+
+
+@pytest.mark.parametrize("enc", ['lf-ques-im-hist', 'mn-ques-hist'])
+def test_beam_search_matches_oracle(gpu, enc):
+    """Model:generateAnswers (model.lua:432-613) on a tiny real-format dataset: beam-search token sequences
+    equal the fp64 oracle's; sampling mode returns well-formed sentences."""
+    from test_dataloader_cpu import raw_dataset
+    from visdial_amd.dataloader import Dataloader
+    from visdial_amd.model import Model
+    from visdial_amd.opts import default_params
+    rng = np.random.RandomState(2)
+    info, raw, img = raw_dataset(rng, n=3, R=3, MQ=5, MA=4, V=20, O=4, nopt=12, F=8)
+    raw = {k.replace('_train', '_val'): v for k, v in raw.items()}
+    img = {k.replace('_train', '_val'): v for k, v in img.items()}
+    info['unique_img_val'] = info.pop('unique_img_train')
+    p = derive(default_params(encoder=enc, decoder='gen', embedSize=12, rnnHiddenSize=32, imgFeatureSize=8, numLayers=2,
+                              batchSize=1, learningRate=1e-3, gpuid=0))
+    dl = Dataloader(seed=1).from_arrays(info, raw, img, p, ['val'])
+    for k in ('vocabSize', 'maxQuesCount', 'maxQuesLen', 'maxAnsLen'):
+        p[k] = getattr(dl, k)
+    model = Model(p)
+    out = model.generateAnswers(dl, 'val', dict(beamSize=3, beamLen=6, maxThreads=2))
+    assert len(out) == 2 and all(len(d['dialog']) == 3 for d in out)
+    P = {k: v.astype(np.float64) for k, v in model.get_parameters_dict().items()}
+    START, END = dl.word2ind['<START>'], dl.word2ind['<END>']
+    from visdial_amd import utils
+    for conv in (1, 2):
+        batch = dl.getIndexData(np.array([conv]), p, 'val')
+        ref = vo.generate_beam(enc, P, p, batch, 3, 6, START, END)
+        for it, (beam, score) in enumerate(ref):
+            assert out[conv - 1]['dialog'][it]['answer'] == utils.idToWords(beam, dl.ind2word), (conv, it)
+    smp = model.generateAnswers(dl, 'val', dict(sampleWords=1, temperature=0.7, beamLen=5, maxThreads=1))
+    assert all(a['answer'].startswith(' <START>') for a in smp[0]['dialog'])

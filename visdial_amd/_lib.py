@@ -46,6 +46,7 @@ PROTOTYPES = {
     "vd_copy_2d": [_p, _l, _p, _l, _l, _l, _p],
     "vd_mask_time_forward": [_p, _p, _p, _i, _i, _i, _p],
     "vd_mask_time_backward": [_p, _p, _p, _i, _i, _i, _p],
+    "vd_log_softmax_rows": [_p, _l, _l, _i, _p],
     "vd_logsoftmax_nll": [_p, _l, _l, _i, _p, _p, _p, _i, _p],
     "vd_gemm_nt": [_p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _i, _p],
     "vd_gemm_nn": [_p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _p],

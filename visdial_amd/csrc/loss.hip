@@ -117,7 +117,36 @@ logsoftmax_nll_kernel(float* __restrict__ logits, long ld, int V, const int* __r
   }
 }
 
+// in-place log-softmax of `rows` rows of V logits (decoders/gen.lua:24 at sampling / beam-search time)
+__global__ void __launch_bounds__(256)
+log_softmax_rows_kernel(float* __restrict__ x, long ld, int V) {
+  __shared__ float red[8];
+  float* row = x + (long)blockIdx.x * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float mx = -INFINITY;
+  for (int c = tid; c < V; c += 256) mx = fmaxf(mx, row[c]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int c = tid; c < V; c += 256) sum += expf(row[c] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float lse = mx + logf(red[4] + red[5] + red[6] + red[7]);
+  for (int c = tid; c < V; c += 256) row[c] -= lse;
+}
+
 extern "C" {
+
+int vd_log_softmax_rows(float* x, int64_t ld, int64_t rows, int V, void* stream) {
+  VD_CHECK_ARG(x && rows >= 0 && V >= 1 && ld >= V, "vd_log_softmax_rows: bad args");
+  if (rows == 0) return VD_OK;
+  hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, (long)ld, V);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
 
 int vd_logsoftmax_nll(float* logits, int64_t ld, int64_t rows, int V, const int32_t* tok_in,
                       const int32_t* target, float* loss_rows, int write_grad, void* stream) {

@@ -57,6 +57,23 @@ class Decoder(object):
         return float(loss_rows.cpu().numpy().astype(np.float64).sum())
 
 
+    def step_logprobs(self, tok, hidden):
+        """One decoder step for K hypotheses (the `self.decoder:forward(beams[{{step-1}}])` of model.lua:518):
+        tok device int32 [1 x K]; hidden = per-layer (h [K x H], c [K x H]).  Returns (log-probs [K x V] on the
+        host, new per-layer (h, c) device tensors)."""
+        ws, H, V, Vp = self.ws, self.H, self.V, self.Vp
+        K = tok.shape[1]
+        for l, (h0, c0) in zip(self.rnnLayers, hidden):
+            l.userPrevOutput, l.userPrevCell = h0, c0
+        x = ws.get('gen1.x', (K, self.E))
+        ops.embed_gather(self.emb, tok, x)
+        h = lstm_stack_forward(self.rnnLayers, x, 1, K, tok).view(K, H)
+        logits = ws.get('gen1.logits', (K, Vp))
+        ops.gemm_nt(h, self.Wv, logits, bias=self.bv, M=K, N=V, K=H, ldc=Vp)
+        ops.log_softmax_rows(logits, V)
+        new_hidden = [(l.output[0].clone(), l.cell[0].clone()) for l in self.rnnLayers]
+        return logits[:, :V].cpu().numpy(), new_hidden
+
     def retrieve_lhood(self, model, option_in, option_out, encOut, seqLen):
         """Model:retrieveBatch gen branch (model.lua:392-420) + utils.computeLhood (utils.lua:86-102).
         The reference loops over the 100 options; here chunks of options are ONE decoder batch (rows =

@@ -274,3 +274,8 @@ def rowdot_backward(x, w, dout, dw, db, dx, N, H):
 def zero_inactive_rows(buf, nact_dev, T, N, ncols):
     """buf [T, N, ncols] contiguous"""
     call("vd_zero_inactive_rows", _p(buf, F32), N * ncols, ncols, ncols, _p(nact_dev, I32), T, N, _stream())
+
+
+def log_softmax_rows(x, V):
+    call("vd_log_softmax_rows", _p(x, F32), x.stride(0), x.shape[0], V, _stream())
+    return x

@@ -56,3 +56,17 @@ def writeJSON(path, obj):
     """utils.lua:76-83"""
     with open(path, 'w') as f:
         json.dump(obj, f)
+
+
+def idToWords(vector, ind2word):
+    """utils.lua:48-63: ' w1 w2 ...' up to and including <END>; zeros are skipped."""
+    sentence = ''
+    nextWord = None
+    for w in list(vector):
+        w = int(w)
+        if w > 0:
+            nextWord = ind2word[w]
+            sentence = sentence + ' ' + nextWord
+        if nextWord == '<END>':
+            break
+    return sentence
