@@ -10,6 +10,7 @@ import torch
 from visdial_amd import opts, utils
 from visdial_amd.dataloader import SyntheticDataloader
 from visdial_amd.model import Model
+from visdial_amd.checkpoint import load_checkpoint, restore_weights
 
 
 def main():
@@ -23,12 +24,12 @@ def main():
     ap.add_argument('-saveRankPath', '--saveRankPath', default='logs/ranks.json')
     ap.add_argument('--numThreads', type=int, default=100)
     a = ap.parse_args()
-    saved = torch.load(a.loadPath, weights_only=False)
+    saved = load_checkpoint(a.loadPath)
     p = opts.derive(saved['modelParams'])
     p['gpuid'], p['batchSize'] = a.gpuid, a.batchSize
     dl = SyntheticDataloader(p, seed=4321, num_threads=a.numThreads)
     model = Model(p)
-    model.wrapperW.copy_(saved['modelW'].to(model.wrapperW.device))          # evaluate.lua:91
+    restore_weights(model, saved)          # evaluate.lua:91
     if a.useGt:
         metrics, records = model.retrieve(dl, a.split)
     else:

@@ -11,6 +11,7 @@ import torch
 from visdial_amd import opts, utils
 from visdial_amd.dataloader import Dataloader
 from visdial_amd.model import Model
+from visdial_amd.checkpoint import load_checkpoint, restore_weights
 
 
 def main():
@@ -27,13 +28,13 @@ def main():
     ap.add_argument('-maxThreads', '--maxThreads', type=int, default=50)
     ap.add_argument('-gpuid', '--gpuid', type=int, default=0)
     a = vars(ap.parse_args())
-    saved = torch.load(a['loadPath'], weights_only=False)
+    saved = load_checkpoint(a['loadPath'])
     p = opts.derive(saved['modelParams'])                      # generate.lua:57-70
     p['gpuid'] = a['gpuid']
     p.update(inputImg=a['inputImg'], inputQues=a['inputQues'], inputJson=a['inputJson'])
     dl = Dataloader(seed=1234).initialize(p, ['val'])
     model = Model(p)
-    model.wrapperW.copy_(saved['modelW'].to(model.wrapperW.device))
+    restore_weights(model, saved)
     answers = model.generateAnswers(dl, 'val', dict(beamSize=a['beamSize'], beamLen=a['beamLen'],
                                                     maxThreads=a['maxThreads'], sampleWords=a['sampleWords'],
                                                     temperature=a['temperature']))

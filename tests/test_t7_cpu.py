@@ -1,0 +1,70 @@
+"""Torch7 .t7 (de)serialisation round trips (visdial_amd/t7.py) for the checkpoint structure of
+train.lua:99-102: {modelW = tensor, optims = {learningRate, t, m, v}, modelParams = table}."""
+import struct
+
+import numpy as np
+
+from visdial_amd import t7
+from visdial_amd.params import ParamSpec
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    rng = np.random.RandomState(0)
+    ck = {'modelW': rng.randn(1000).astype(np.float32),
+          'optims': {'learningRate': 5e-4, 't': 12, 'm': rng.randn(1000).astype(np.float32), 'v': rng.rand(1000).astype(np.float32)},
+          'modelParams': {'encoder': 'lf-ques-im-hist', 'decoder': 'gen', 'rnnHiddenSize': 512, 'useIm': True,
+                          'dropout': 0.5, 'nested': {'a': [1, 2, 3]}, 'none': None}}
+    p = str(tmp_path / 'm.t7')
+    t7.save(p, ck, float_tensor_class='Cuda')
+    back = t7.load(p)
+    np.testing.assert_array_equal(back['modelW'], ck['modelW'])
+    np.testing.assert_array_equal(back['optims']['m'], ck['optims']['m'])
+    assert back['optims']['learningRate'] == 5e-4 and back['optims']['t'] == 12
+    mp = back['modelParams']
+    assert mp['encoder'] == 'lf-ques-im-hist' and mp['useIm'] is True and mp['nested']['a'] == [1, 2, 3] and mp['rnnHiddenSize'] == 512
+
+
+def test_layout_is_the_documented_one(tmp_path):
+    """byte-level check of a tiny object against the format description in the module docstring"""
+    p = str(tmp_path / 'x.t7')
+    t7.save(p, {'a': np.arange(6, dtype=np.float32).reshape(2, 3)})
+    b = open(p, 'rb').read()
+    i = lambda o: struct.unpack('<i', b[o:o + 4])[0]
+    assert i(0) == 3 and i(4) == 1 and i(8) == 1                      # table, ref 1, one pair
+    assert i(12) == 2 and i(16) == 1 and b[20:21] == b'a'             # key: string 'a'
+    assert i(21) == 4 and i(25) == 2                                  # value: torch object, ref 2
+    assert b[33:36] == b'V 1' and b[40:57] == b'torch.FloatTensor'
+    nd = i(57)
+    assert nd == 2 and struct.unpack('<qq', b[61:77]) == (2, 3) and struct.unpack('<qq', b[77:93]) == (3, 1)
+    np.testing.assert_array_equal(t7.load(p)['a'], np.arange(6, dtype=np.float32).reshape(2, 3))
+
+
+def test_non_contiguous_and_shared_storage(tmp_path):
+    """a hand-written file: two tensors viewing ONE storage with strides/offsets (what getParameters() saves)"""
+    p = str(tmp_path / 'v.t7')
+    s = np.arange(10, dtype=np.float64)
+    with open(p, 'wb') as f:
+        w = lambda fmt, *v: f.write(struct.pack('<' + fmt, *v))
+        def st(x):
+            w('i', len(x)); f.write(x.encode())
+        w('i', 3); w('i', 1); w('i', 2)
+        w('i', 1); w('d', 1.0)                                        # key 1
+        w('i', 4); w('i', 2); st('V 1'); st('torch.DoubleTensor'); w('i', 2); w('qq', 2, 2); w('qq', 1, 2); w('q', 3)
+        w('i', 4); w('i', 3); st('V 1'); st('torch.DoubleStorage'); w('q', 10); f.write(s.tobytes())
+        w('i', 1); w('d', 2.0)                                        # key 2
+        w('i', 4); w('i', 4); st('V 1'); st('torch.DoubleTensor'); w('i', 1); w('q', 4); w('q', 1); w('q', 1)
+        w('i', 4); w('i', 3)                                          # the SAME storage by reference
+    a, b = t7.load(p)
+    np.testing.assert_array_equal(a, [[2, 4], [3, 5]])                # offset 3 (1-based), strides (1, 2)
+    np.testing.assert_array_equal(b, [0, 1, 2, 3])
+
+
+def test_flat_vector_mapping():
+    spec = ParamSpec()
+    spec.embed('embed', 7, 3); spec.lstm('ques1', 3, 4); spec.linear('fuse', 4, 5)
+    named = {n: np.random.RandomState(1).randn(*s).astype(np.float32) for n, s, _ in spec.entries}
+    flat = t7.named_to_flat(named, spec.entries)
+    assert flat.size == 7 * 3 + 7 * 16 + 16 + 20 + 5
+    back = t7.flat_to_named(flat, spec.entries)
+    for n in named:
+        np.testing.assert_array_equal(back[n], named[n])

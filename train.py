@@ -16,6 +16,7 @@ import torch
 from visdial_amd import opts
 from visdial_amd.dataloader import Dataloader, SyntheticDataloader
 from visdial_amd.model import Model
+from visdial_amd.checkpoint import load_checkpoint, restore_weights
 
 
 def main():
@@ -24,7 +25,7 @@ def main():
     np.random.seed(1234)                                         # train.lua:12
     saved = None
     if opt['loadPath']:
-        saved = torch.load(opt['loadPath'], weights_only=False)   # train.lua:32-42
+        saved = load_checkpoint(opt['loadPath'])   # train.lua:32-42
         mp = saved['modelParams']
         mp['gpuid'], mp['batchSize'] = opt['gpuid'], opt['batchSize']
         for k in ('numEpochs', 'maxIters', 'savePath', 'saveIter', 'numTrainThreads'):
@@ -45,7 +46,7 @@ def main():
     print('\n%d iter per epoch.' % opt['numIterPerEpoch'])
     model = Model(opt)
     if saved is not None:                                        # train.lua:78-81
-        model.wrapperW.copy_(saved['modelW'].to(model.wrapperW.device))
+        restore_weights(model, saved)
         model.optims['learningRate'] = saved['optims']['learningRate']
     print('Training..')
     total = opt['numEpochs'] * opt['numIterPerEpoch']

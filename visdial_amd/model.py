@@ -420,6 +420,16 @@ class Model(object):
     def set_parameters_dict(self, d):
         self.fp.load_host(d)
 
+    def load_flat_parameters(self, modelW):
+        """`model.wrapperW:copy(savedModel.modelW)` (train.lua:79, evaluate.lua:91) for a flat vector in the
+        reference's getParameters() layout (no alignment padding) -- e.g. `modelW` of a .t7 checkpoint."""
+        from . import t7
+        self.set_parameters_dict(t7.flat_to_named(np.asarray(modelW), self.fp.spec.entries))
+
+    def flat_parameters(self):
+        from . import t7
+        return t7.named_to_flat(self.get_parameters_dict(), self.fp.spec.entries)
+
     def set_dropout_masks(self, masks):
         """Pin nn.Dropout noise (dict name -> uint8 numpy array) for parity runs; None = generator."""
         if masks is None:
