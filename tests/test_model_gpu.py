@@ -234,3 +234,36 @@ def test_beam_search_matches_oracle(gpu, enc):
             assert out[conv - 1]['dialog'][it]['answer'] == utils.idToWords(beam, dl.ind2word), (conv, it)
     smp = model.generateAnswers(dl, 'val', dict(sampleWords=1, temperature=0.7, beamLen=5, maxThreads=1))
     assert all(a['answer'].startswith(' <START>') for a in smp[0]['dialog'])
+
+
+def test_full_size_step_is_additive_over_dialogs(gpu):
+    """BASELINE.json configs[3] sizes (20 dialogs x 10 rounds x 100 options, 14x14x512, V=11322, H=512):
+    the oracle is too slow there, so the step is checked through a size-independent property -- dialogs are
+    independent, hence loss and every gradient of the 20-dialog batch equal the mean over its two 10-dialog
+    halves (the identity data parallelism relies on).  Exercises the throughput kernels at full shapes."""
+    from visdial_amd.model import Model
+    from visdial_amd.opts import default_params
+    p = default_params(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=512, imgSpatialSize=14,
+                       batchSize=20, vocabSize=11322, gpuid=0, maxHistoryLenPerRound=40)
+    dl = SyntheticDataloader(p, seed=77)
+    full = dl.getTrainBatch(p)
+    R, O = p['maxQuesCount'], p['numOptions']
+
+    def part(lo, hi):
+        return {'ques_fwd': full['ques_fwd'][lo:hi], 'hist': full['hist'][lo:hi], 'img_feat': full['img_feat'][lo:hi],
+                'options': full['options'][lo * R:hi * R], 'answer_ind': full['answer_ind'][lo * R:hi * R]}
+    model = Model(p)
+    model.wrapper.evaluate()                       # no dropout noise: the three runs must see the same function
+    out = []
+    for lo, hi in ((0, 20), (0, 10), (10, 20)):
+        model.wrapper.zeroGradParameters()
+        loss = model.forwardBackward(part(lo, hi))
+        out.append((loss, model.wrapperdW.clone()))
+    (lf, gf), (l1, g1), (l2, g2) = out
+    assert np.isfinite(lf) and abs(lf - 0.5 * (l1 + l2)) < 1e-5 * max(1.0, abs(lf))
+    gm = 0.5 * (g1 + g2)
+    err = float((gf - gm).norm() / gm.norm())
+    assert err < 1e-4, err
+    p['useGt'] = False
+    ranks = model.retrieveBatch(part(0, 20))
+    assert ranks.shape == (200, 100) and np.all(np.sort(ranks, 1) == np.arange(1, 101)[None, :])
