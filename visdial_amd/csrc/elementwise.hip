@@ -1,6 +1,8 @@
 // HBM-bound helper kernels: embedding gather / gradient scatter, dropout masks, small
 // pointwise glue, token counting-sort + segmented row sum (option-table gradient), and the
 // fused clamp + Adam update.  All are plain coalesced float4 / wave-per-row kernels.
+#include <stdlib.h>
+
 #include "common.h"
 
 // ------------------------------------------------------------------ dropout masks
@@ -410,6 +412,19 @@ int vd_segment_rowsum_acc(const float* X, int64_t ldx, const int32_t* tok, const
   VD_CHECK_ARG(X && tok && perm && out && n >= 0 && ncol > 0 && ncol % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0,
                "vd_segment_rowsum_acc: bad args");
   if (n == 0) return VD_OK;
+  static const int chunk_env = getenv("VD_SEG_CHUNK") ? atoi(getenv("VD_SEG_CHUNK")) : 256;
+  if (chunk_env == 128) {
+    hipLaunchKernelGGL(segment_rowsum_kernel<128>, grid1d(n, 128), dim3(256), 0, (hipStream_t)stream, X,
+                       (long)ldx, tok, perm, (long)n, ncol, out, (long)ldo);
+    VD_LAUNCH_CHECK();
+    return VD_OK;
+  }
+  if (chunk_env == 256) {
+    hipLaunchKernelGGL(segment_rowsum_kernel<256>, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, X,
+                       (long)ldx, tok, perm, (long)n, ncol, out, (long)ldo);
+    VD_LAUNCH_CHECK();
+    return VD_OK;
+  }
   constexpr int CHUNK = 32;
   hipLaunchKernelGGL(segment_rowsum_kernel<CHUNK>, grid1d(n, CHUNK), dim3(256), 0, (hipStream_t)stream, X,
                      (long)ldx, tok, perm, (long)n, ncol, out, (long)ldo);
