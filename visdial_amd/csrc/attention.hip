@@ -228,6 +228,7 @@ rowdot_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, cons
 // dropout mask applied on the fly.
 struct SrcImgDropRow {
   static constexpr bool KMAJOR = false;
+  static constexpr bool PLAIN = false;  // two streams (values + mask bytes): generic per-tile addressing
   const float* pre;      // [Bi*S2 x H]
   const uint8_t* mask;   // [N*S2 x H] or null
   int H, S2, R;
@@ -248,6 +249,7 @@ struct SrcImgDropRow {
 // same tensor as a k-major operand: "r" runs over H (contiguous), "k" over rows (n, s).
 struct SrcImgDropK {
   static constexpr bool KMAJOR = true;
+  static constexpr bool PLAIN = false;
   const float* pre;
   const uint8_t* mask;
   int H, S2, R;

@@ -48,16 +48,22 @@ struct GemmCfg {
 // ---------------------------------------------------------------------------
 struct SrcRow {
   static constexpr bool KMAJOR = false;
+  static constexpr bool PLAIN = true;  // element address is affine in k: hoisted out of the K loop
   const float* p;
   long ld;
+  __device__ __forceinline__ const float* ptr(int r, int k) const { return p + (long)r * ld + k; }
+  __device__ __forceinline__ long kstep() const { return 1; }
   __device__ __forceinline__ float4 ld4(int r, int k) const {
     return *reinterpret_cast<const float4*>(p + (long)r * ld + k);
   }
 };
 struct SrcK {
   static constexpr bool KMAJOR = true;
+  static constexpr bool PLAIN = true;
   const float* p;
   long ld;
+  __device__ __forceinline__ const float* ptr(int r, int k) const { return p + (long)k * ld + r; }
+  __device__ __forceinline__ long kstep() const { return ld; }
   __device__ __forceinline__ float4 ld4(int r, int k) const {
     return *reinterpret_cast<const float4*>(p + (long)k * ld + r);
   }
@@ -67,9 +73,15 @@ struct SrcK {
 // wave strip holds all four gates of 32 hidden units.
 struct SrcKGate4 {
   static constexpr bool KMAJOR = true;
+  static constexpr bool PLAIN = true;
   const float* p;
   long ld;
   int H;
+  __device__ __forceinline__ const float* ptr(int vc, int k) const {
+    const int jb = vc >> 7, g = (vc >> 5) & 3, jj = vc & 31;
+    return p + (long)k * ld + g * H + jb * 32 + jj;
+  }
+  __device__ __forceinline__ long kstep() const { return ld; }
   __device__ __forceinline__ float4 ld4(int vc, int k) const {
     const int jb = vc >> 7, g = (vc >> 5) & 3, jj = vc & 31;
     return *reinterpret_cast<const float4*>(p + (long)k * ld + g * H + jb * 32 + jj);
@@ -125,7 +137,52 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
   float4 ra[NA], rb[NB];
   float4 ra2[NA], rb2[NB];  // second register stage (DB == 2 only; dead otherwise)
 
+  // loop-invariant part of every staging load: this thread's source address at k = 0, its k offset
+  // inside a tile and whether its row exists.  Per K tile only `k0 * kstep` (wave-uniform) is added.
+  const float* pa[NA];
+  const float* pb[NB];
+  int ka[NA], kb[NB];
+  if constexpr (ASrc::PLAIN) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int f = tid + i * THREADS;
+      int gr;
+      if constexpr (!ASrc::KMAJOR) {
+        gr = row_base + f / (BK / 4);
+        ka[i] = (f % (BK / 4)) * 4;
+      } else {
+        const int g = f >> 3;
+        gr = row_base + (g % (BM / 4)) * 4;
+        ka[i] = (g / (BM / 4)) * 8 + (f & 7);
+      }
+      pa[i] = gr < M ? asrc.ptr(gr, ka[i]) : nullptr;
+    }
+  }
+  if constexpr (BSrc::PLAIN) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int f = tid + i * THREADS;
+      int gr;
+      if constexpr (!BSrc::KMAJOR) {
+        gr = col_base + f / (BK / 4);
+        kb[i] = (f % (BK / 4)) * 4;
+      } else {
+        const int g = f >> 3;
+        gr = col_base + (g % (BN / 4)) * 4;
+        kb[i] = (g / (BN / 4)) * 8 + (f & 7);
+      }
+      pb[i] = gr < N ? bsrc.ptr(gr, kb[i]) : nullptr;
+    }
+  }
+
   auto load_tile_into = [&](int k0, float4 (&ra)[NA], float4 (&rb)[NB]) {
+    if constexpr (ASrc::PLAIN) {
+      const long off = (long)k0 * asrc.kstep();
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        ra[i] = (pa[i] != nullptr && k0 + ka[i] < ke) ? *reinterpret_cast<const float4*>(pa[i] + off)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int f = tid + i * THREADS;
@@ -142,6 +199,14 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
       }
       ra[i] = v;
     }
+    }
+    if constexpr (BSrc::PLAIN) {
+      const long off = (long)k0 * bsrc.kstep();
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        rb[i] = (pb[i] != nullptr && k0 + kb[i] < ke) ? *reinterpret_cast<const float4*>(pb[i] + off)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int f = tid + i * THREADS;
@@ -157,6 +222,7 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
         if (gr < N && gk < ke) v = bsrc.ld4(gr, gk);
       }
       rb[i] = v;
+    }
     }
   };
 

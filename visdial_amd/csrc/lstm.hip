@@ -247,10 +247,20 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
 // ---------------------------------------------------------------------------
 struct SrcKSel {
   static constexpr bool KMAJOR = true;
+  static constexpr bool PLAIN = true;
   const float* p;
   long ld;
   int H;
   int gate4;
+  __device__ __forceinline__ const float* ptr(int vc, int k) const {
+    int col = vc;
+    if (gate4) {
+      const int jb = vc >> 7, g = (vc >> 5) & 3, jj = vc & 31;
+      col = g * H + jb * 32 + jj;
+    }
+    return p + (long)k * ld + col;
+  }
+  __device__ __forceinline__ long kstep() const { return ld; }
   __device__ __forceinline__ float4 ld4(int vc, int k) const {
     int col = vc;
     if (gate4) {
