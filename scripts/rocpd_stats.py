@@ -7,9 +7,9 @@ import sys
 
 def short(name):
     name = re.sub(r'\(.*$', '', name)
-    m = re.match(r'void gemm_f32_kernel<GemmCfg<(\d+), (\d+), (\d+), (\d+)>, (\w+), (\w+), (\w+)', name)
+    m = re.match(r'void (gemm_f32\w*)_kernel<GemmCfg<([\d, ]+)>, (.*)>$', name)
     if m:
-        return 'gemm_f32<%sx%sx%sx%s,%s,%s,%s>' % m.groups()
+        return ('%s<%s|%s>' % (m.group(1), m.group(2).replace(', ', 'x'), m.group(3)))[:90]
     return name.replace('void ', '')[:90]
 
 
