@@ -21,7 +21,9 @@
 
 #include "common.h"
 
-template <int WM_, int WK_, int NT_, int KW_, int DB_ = 1, int MINW_ = 1>
+// LDSMIN: request at least this much LDS per workgroup (occupancy shaping, see lstm.hip: throughput
+// shapes are held to 3 workgroups per CU so that a latency-shape workgroup of another stream always fits).
+template <int WM_, int WK_, int NT_, int KW_, int DB_ = 1, int MINW_ = 1, int LDSMIN_ = 0>
 struct GemmCfg {
   static constexpr int WM = WM_, WK = WK_, NT = NT_, KW = KW_, DB = DB_, MINW = MINW_;
   static constexpr int BM = WM * 32, BN = NT * 32, BK = WK * KW;
@@ -32,7 +34,8 @@ struct GemmCfg {
   static constexpr int RED_BYTES = (WK - 1) * WM * 16 * 64 * 4;  // one 32x32 tile per parked wave at a time
   static constexpr int EPI_BYTES = WM * 32 * 32 * 4;  // per-wave 32x32 transposition scratch for row-vectorised epilogues
   static constexpr int LDS_BYTES0 = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
-  static constexpr int LDS_BYTES = LDS_BYTES0 > EPI_BYTES ? LDS_BYTES0 : EPI_BYTES;
+  static constexpr int LDS_BYTES1 = LDS_BYTES0 > EPI_BYTES ? LDS_BYTES0 : EPI_BYTES;
+  static constexpr int LDS_BYTES = LDS_BYTES1 > LDSMIN_ ? LDS_BYTES1 : LDSMIN_;
   static constexpr int NA = (BM * BK / 4) / THREADS;
   static constexpr int NB = (BN * BK / 4) / THREADS;
   static_assert(KW % 8 == 0, "KW must be a multiple of 8");

@@ -161,6 +161,7 @@ using CfgF5 = GemmCfg<4, 1, 4, 16, 2, 3>;  // two register stages
 using CfgF6 = GemmCfg<4, 1, 4, 8, 2, 3>;
 using CfgF7 = GemmCfg<4, 1, 4, 32, 2, 3>;
 using CfgF8 = GemmCfg<4, 1, 4, 16, 1, 3>;
+using CfgF9 = GemmCfg<4, 1, 4, 16, 0, 4, 41984>;  // <=128 VGPR, LDS padded to 41 KB: exactly 3 WG/CU + room for one latency WG
 using CfgB0 = GemmCfg<4, 1, 4, 32, 1, 1>;
 using CfgB1 = GemmCfg<4, 1, 4, 32, 0, 3>;
 using CfgB2 = GemmCfg<4, 1, 2, 32, 0, 3>;  // default
@@ -171,6 +172,7 @@ using CfgB6 = GemmCfg<8, 1, 2, 32, 0, 4>;  // 256x64 tile
 using CfgB7 = GemmCfg<4, 1, 2, 16, 2, 3>;  // two register stages
 using CfgB8 = GemmCfg<4, 1, 2, 16, 0, 3>;
 using CfgB10 = GemmCfg<4, 1, 2, 32, 2, 3>;
+using CfgB11 = GemmCfg<4, 1, 2, 16, 0, 4, 41984>;
 // latency shapes (N ~ 200 rows): 4-way intra-block split-K.  Single LDS buffer and <= 152 VGPRs so one
 // of these workgroups fits into the footprint a retiring throughput-shape workgroup frees (they run
 // concurrently on other streams).
@@ -178,6 +180,8 @@ using CfgFwdSmallA = GemmCfg<1, 4, 4, 8, 0, 3>;   // 32 x (32 j x 4 gates), BK =
 using CfgFwdSmallB = GemmCfg<1, 4, 4, 16, 0, 3>;  // BK = 64, 43.5 KB LDS, half the dependent K iterations
 using CfgBwdSmallA = GemmCfg<1, 4, 1, 32, 0, 3>;  // 32 x 32 tile, BK = 128, 33.8 KB LDS
 using CfgBwdSmallB = GemmCfg<1, 4, 1, 64, 0, 3>;  // BK = 256, 66.6 KB LDS
+using CfgFwdSmallC = GemmCfg<1, 4, 4, 8, 0, 4>;   // as A, <=128 VGPR: fits beside 3 padded throughput workgroups
+using CfgBwdSmallC = GemmCfg<1, 4, 1, 32, 0, 4>;
 
 static int env_int(const char* name, int dflt) {
   const char* ev = getenv(name);
@@ -189,7 +193,7 @@ static int lstm_step_fwd(const float* h_prev, const float* Wh, int N, int H, int
   SrcRow a{h_prev, H};
   SrcKGate4 b{Wh, 4L * H, H};
   if (N >= 2048) {
-    static const int cfg = env_int("VD_LSTM_FWD_CFG", 4);
+    static const int cfg = env_int("VD_LSTM_FWD_CFG", 9);
     switch (cfg) {
       case 0: return launch_gemm<CfgF0>(N, 4 * H, K, 1, a, b, epi, s);
       case 2: return launch_gemm<CfgF2>(N, 4 * H, K, 1, a, b, epi, s);
@@ -199,11 +203,13 @@ static int lstm_step_fwd(const float* h_prev, const float* Wh, int N, int H, int
       case 6: return launch_gemm<CfgF6>(N, 4 * H, K, 1, a, b, epi, s);
       case 7: return launch_gemm<CfgF7>(N, 4 * H, K, 1, a, b, epi, s);
       case 8: return launch_gemm<CfgF8>(N, 4 * H, K, 1, a, b, epi, s);
+      case 9: return launch_gemm<CfgF9>(N, 4 * H, K, 1, a, b, epi, s);
       default: return launch_gemm<CfgF1>(N, 4 * H, K, 1, a, b, epi, s);
     }
   }
-  static const int scfg = env_int("VD_LSTM_FWD_SMALL", 0);
+  static const int scfg = env_int("VD_LSTM_FWD_SMALL", 2);
   if (scfg == 0) return launch_gemm<CfgFwdSmallA>(N, 4 * H, K, 1, a, b, epi, s);
+  if (scfg == 2) return launch_gemm<CfgFwdSmallC>(N, 4 * H, K, 1, a, b, epi, s);
   return launch_gemm<CfgFwdSmallB>(N, 4 * H, K, 1, a, b, epi, s);
 }
 
@@ -213,7 +219,7 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
   SrcRow a{da_next, 4L * H};
   SrcRow b{Wh, 4L * H};  // B[k][n] = Wh[n][k]
   if (N >= 2048) {
-    static const int cfg = env_int("VD_LSTM_BWD_CFG", 8);
+    static const int cfg = env_int("VD_LSTM_BWD_CFG", 11);
     EpiLstmBwd<4> e4{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
     EpiLstmBwd<2> e2{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
     switch (cfg) {
@@ -225,13 +231,15 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
       case 6: return launch_gemm<CfgB6>(N, H, K, 1, a, b, e2, s);
       case 7: return launch_gemm<CfgB7>(N, H, K, 1, a, b, e2, s);
       case 8: return launch_gemm<CfgB8>(N, H, K, 1, a, b, e2, s);
+      case 11: return launch_gemm<CfgB11>(N, H, K, 1, a, b, e2, s);
       case 10: return launch_gemm<CfgB10>(N, H, K, 1, a, b, e2, s);
       default: return launch_gemm<CfgB2>(N, H, K, 1, a, b, e2, s);
     }
   }
   EpiLstmBwd<1> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
-  static const int scfg = env_int("VD_LSTM_BWD_SMALL", 0);
+  static const int scfg = env_int("VD_LSTM_BWD_SMALL", 2);
   if (scfg == 0) return launch_gemm<CfgBwdSmallA>(N, H, K, 1, a, b, e, s);
+  if (scfg == 2) return launch_gemm<CfgBwdSmallC>(N, H, K, 1, a, b, e, s);
   return launch_gemm<CfgBwdSmallB>(N, H, K, 1, a, b, e, s);
 }
 
@@ -327,6 +335,67 @@ struct vd_lstm2_bwd_t {
 
 extern "C" {
 
+// ---------------------------------------------------------------------------
+// Row chains: fork/join of library-owned streams around a per-row-independent recurrence.
+// ---------------------------------------------------------------------------
+#define VD_MAX_CHAINS 4
+struct RowChains {
+  int n = 1;
+  int row0[VD_MAX_CHAINS + 1];
+  hipStream_t stream[VD_MAX_CHAINS];
+
+  struct Pool {
+    hipStream_t side[VD_MAX_CHAINS - 1];
+    hipEvent_t fork_ev, join_ev[VD_MAX_CHAINS - 1];
+    bool ready = false;
+  };
+  static Pool& pool() {
+    static thread_local Pool p;
+    return p;
+  }
+
+  int fork(int N, hipStream_t s, int want) {
+    n = (N >= 4096 && want > 1) ? (want > VD_MAX_CHAINS ? VD_MAX_CHAINS : want) : 1;
+    stream[0] = s;
+    row0[0] = 0;
+    if (n == 1) {
+      row0[1] = N;
+      return VD_OK;
+    }
+    Pool& p = pool();
+    if (!p.ready) {
+      int prio = 0;
+      hipStreamGetPriority(s, &prio);
+      for (int i = 0; i < VD_MAX_CHAINS - 1; ++i) {
+        VD_HIP(hipStreamCreateWithPriority(&p.side[i], hipStreamNonBlocking, prio));
+        VD_HIP(hipEventCreateWithFlags(&p.join_ev[i], hipEventDisableTiming));
+      }
+      VD_HIP(hipEventCreateWithFlags(&p.fork_ev, hipEventDisableTiming));
+      p.ready = true;
+    }
+    // chain boundaries on 128-row tile boundaries
+    const int tiles = (N + 127) / 128;
+    for (int i = 1; i < n; ++i) row0[i] = (int)((long)tiles * i / n) * 128;
+    row0[n] = N;
+    VD_HIP(hipEventRecord(p.fork_ev, s));
+    for (int i = 1; i < n; ++i) {
+      stream[i] = p.side[i - 1];
+      VD_HIP(hipStreamWaitEvent(stream[i], p.fork_ev, 0));
+    }
+    return VD_OK;
+  }
+
+  int join(hipStream_t s) {
+    if (n == 1) return VD_OK;
+    Pool& p = pool();
+    for (int i = 1; i < n; ++i) {
+      VD_HIP(hipEventRecord(p.join_ev[i - 1], stream[i]));
+      VD_HIP(hipStreamWaitEvent(s, p.join_ev[i - 1], 0));
+    }
+    return VD_OK;
+  }
+};
+
 // see include/visdial_hip.h
 int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const int32_t* tok_gather,
                     const int32_t* tok_mask, const float* Wh, const float* h0, const float* c0, float* gates,
@@ -337,23 +406,33 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
   VD_CHECK_ARG(x_ld % 4 == 0, "vd_lstm_forward: x_ld must be a multiple of 4");
   hipStream_t s = (hipStream_t)stream;
   const long NH = (long)N * H;
+  // The recurrence is independent per row: throughput shapes run as row chains on separate streams so the
+  // tail of one chain's step kernel is filled by the other chain's workgroups (no chip-wide drain per step).
+  RowChains rc_;
+  static const int nchains = env_int("VD_LSTM_CHAINS_FWD", 1);
+  int rc = rc_.fork(N, s, nchains);
+  if (rc) return rc;
   for (int t = 0; t < T; ++t) {
-    const float* hp = t ? h + (t - 1) * NH : h0;
-    const float* cp = t ? c + (t - 1) * NH : c0;
-    EpiLstmFwd e;
-    e.xproj = xproj + (long)t * x_tstride;
-    e.xld = x_ld;
-    e.tok_gather = tok_gather ? tok_gather + (long)t * N : nullptr;
-    e.tok_mask = tok_mask ? tok_mask + (long)t * N : nullptr;
-    e.c_prev = cp;
-    e.gates = gates + (long)t * 4 * NH;
-    e.c_out = c + t * NH;
-    e.h_out = h + t * NH;
-    e.H = H;
-    int rc = lstm_step_fwd(hp, Wh, N, H, hp ? H : 0, e, s);
-    if (rc) return rc;
+    for (int ch = 0; ch < rc_.n; ++ch) {
+      const long r0 = rc_.row0[ch];
+      const int nr = rc_.row0[ch + 1] - rc_.row0[ch];
+      const float* hp = t ? h + (t - 1) * NH + r0 * H : (h0 ? h0 + r0 * H : nullptr);
+      const float* cp = t ? c + (t - 1) * NH + r0 * H : (c0 ? c0 + r0 * H : nullptr);
+      EpiLstmFwd e;
+      e.xproj = xproj + (long)t * x_tstride + (tok_gather ? 0 : r0 * x_ld);
+      e.xld = x_ld;
+      e.tok_gather = tok_gather ? tok_gather + (long)t * N + r0 : nullptr;
+      e.tok_mask = tok_mask ? tok_mask + (long)t * N + r0 : nullptr;
+      e.c_prev = cp;
+      e.gates = gates + (long)t * 4 * NH + r0 * 4 * H;
+      e.c_out = c + t * NH + r0 * H;
+      e.h_out = h + t * NH + r0 * H;
+      e.H = H;
+      rc = lstm_step_fwd(hp, Wh, nr, H, hp ? H : 0, e, rc_.stream[ch]);
+      if (rc) return rc;
+    }
   }
-  return VD_OK;
+  return rc_.join(s);
 }
 
 int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float* c0, const float* dh_seq,
@@ -364,20 +443,32 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
   hipStream_t s = (hipStream_t)stream;
   const long NH = (long)N * H;
   if (dc_last) VD_HIP(hipMemcpyAsync(dc_work, dc_last, NH * sizeof(float), hipMemcpyDeviceToDevice, s));
+  RowChains rc_;
+  static const int nchains = env_int("VD_LSTM_CHAINS_BWD", 1);
+  int rc = rc_.fork(N, s, nchains);
+  if (rc) return rc;
   for (int t = T - 1; t >= 0; --t) {
     const bool last = (t == T - 1);
-    const float* da_next = last ? nullptr : gates + (long)(t + 1) * 4 * NH;
-    int rc = lstm_step_bwd(da_next, Wh, N, H, last ? 0 : 4 * H, dh_seq ? dh_seq + t * NH : nullptr,
-                           last ? dh_last : nullptr, gates + (long)t * 4 * NH, c + t * NH,
-                           t ? c + (t - 1) * NH : c0, dc_work, (last && !dc_last) ? 1 : 0, s);
-    if (rc) return rc;
+    for (int ch = 0; ch < rc_.n; ++ch) {
+      const long r0 = rc_.row0[ch];
+      const int nr = rc_.row0[ch + 1] - rc_.row0[ch];
+      const float* da_next = last ? nullptr : gates + (long)(t + 1) * 4 * NH + r0 * 4 * H;
+      const float* c0r = c0 ? c0 + r0 * H : nullptr;
+      rc = lstm_step_bwd(da_next, Wh, nr, H, last ? 0 : 4 * H, dh_seq ? dh_seq + t * NH + r0 * H : nullptr,
+                         (last && dh_last) ? dh_last + r0 * H : nullptr, gates + (long)t * 4 * NH + r0 * 4 * H,
+                         c + t * NH + r0 * H, t ? c + (t - 1) * NH + r0 * H : c0r, dc_work + r0 * H,
+                         (last && !dc_last) ? 1 : 0, rc_.stream[ch]);
+      if (rc) return rc;
+    }
   }
+  rc = rc_.join(s);
+  if (rc) return rc;
   if (dh0) {
     // gradient w.r.t. the initial hidden state: da_0 * Wh^T (dc_work already holds dL/dc0)
     SrcRow a{gates, 4L * H};
     SrcRow b{Wh, 4L * H};
     EpiStore<4> e{dh0, H, nullptr, VD_ACT_NONE, 0};
-    int rc = launch_gemm<CfgB1>(N, H, 4 * H, 1, a, b, e, s);
+    rc = launch_gemm<CfgB1>(N, H, 4 * H, 1, a, b, e, s);
     if (rc) return rc;
   }
   return VD_OK;
@@ -431,7 +522,10 @@ int vd_lstm2_forward(const vd_lstm2_fwd_t* st, int nstacks, int H, void* stream)
       }
     }
     if (g.nprob == 0) continue;
-    if (int rc = launch_grouped<CfgFwdSmallA>(g, (hipStream_t)stream)) return rc;
+    static const int scfg = env_int("VD_LSTM_FWD_SMALL", 2);
+    if (int rc = scfg == 2 ? launch_grouped<CfgFwdSmallC>(g, (hipStream_t)stream)
+                           : launch_grouped<CfgFwdSmallA>(g, (hipStream_t)stream))
+      return rc;
   }
   return VD_OK;
 }
@@ -487,7 +581,10 @@ int vd_lstm2_backward(const vd_lstm2_bwd_t* st, int nstacks, int H, void* stream
       }
     }
     if (g.nprob == 0) continue;
-    if (int rc = launch_grouped<CfgBwdSmallA>(g, (hipStream_t)stream)) return rc;
+    static const int scfg = env_int("VD_LSTM_BWD_SMALL", 2);
+    if (int rc = scfg == 2 ? launch_grouped<CfgBwdSmallC>(g, (hipStream_t)stream)
+                           : launch_grouped<CfgBwdSmallA>(g, (hipStream_t)stream))
+      return rc;
   }
   return VD_OK;
 }
