@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvisdial_hip.so")
+LIB_PATH = os.environ.get("VD_LIB_PATH") or os.path.join(_HERE, "libvisdial_hip.so")   # override: A/B builds
 
 _p = C.c_void_p
 _i = C.c_int

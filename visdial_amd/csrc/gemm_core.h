@@ -21,6 +21,24 @@
 
 #include "common.h"
 
+// Diagnostic build only (-DVD_TIMING, `make timing`): wave 0 of every workgroup stamps the shader clock
+// (s_memtime) at the phase boundaries of gemm_block and the 100 MHz chip-wide clock (s_memrealtime) at
+// its start and end; scripts/block_timing.py reads the table back.  Never compiled into the product.
+#ifdef VD_TIMING
+#define VD_TSLOTS 8
+#define VD_TBLOCKS 8192
+static __device__ unsigned long long vd_tbuf[VD_TBLOCKS * VD_TSLOTS];
+#define VD_TSTAMP(i, clk)                                                                \
+  do {                                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x < VD_TBLOCKS) vd_tbuf[blockIdx.x * VD_TSLOTS + (i)] = (clk); \
+  } while (0)
+#define VD_T(i) VD_TSTAMP(i, __builtin_amdgcn_s_memtime())
+#define VD_TREAL(i) VD_TSTAMP(i, __builtin_amdgcn_s_memrealtime())
+#else
+#define VD_T(i) do {} while (0)
+#define VD_TREAL(i) do {} while (0)
+#endif
+
 // LDSMIN: request at least this much LDS per workgroup (occupancy shaping, see lstm.hip: throughput
 // shapes are held to 3 workgroups per CU so that a latency-shape workgroup of another stream always fits).
 template <int WM_, int WK_, int NT_, int KW_, int DB_ = 1, int MINW_ = 1, int LDSMIN_ = 0>
@@ -131,6 +149,8 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
   const int wm = wave % WM, wk = wave / WM;
   const int nk = ke > ks ? (ke - ks + BK - 1) / BK : 0;
 
+  VD_T(0);
+  VD_TREAL(6);
   f32x16 acc[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
@@ -340,10 +360,12 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
     for (int kt = 0; kt < nk; ++kt) {
       store_tile(0);
       __syncthreads();
+      if (kt == 0) VD_T(1);
       if (kt + 1 < nk) load_tile(ktile(kt + 1));
       mfma_tile(0);
       __syncthreads();
     }
+    VD_T(2);
   }
 
   if constexpr (Cfg::WK > 1) {
@@ -369,6 +391,8 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
   }
 
   epi(acc, row_base + wm * 32, col_base, lane, M, N, smem + wm * 1024);
+  VD_T(4);
+  VD_TREAL(7);
 }
 
 template <class Cfg, class ASrc, class BSrc, class Epi>

@@ -37,6 +37,7 @@ struct EpiLstmFwd {
     tile_to_rows(acc[1], scr, lane, af);
     tile_to_rows(acc[2], scr, lane, ao);
     tile_to_rows(acc[3], scr, lane, ag);
+    VD_T(3);
     if (j >= H) return;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -590,3 +591,12 @@ int vd_lstm2_backward(const vd_lstm2_bwd_t* st, int nstacks, int H, void* stream
 }
 
 }  // extern "C"
+
+#ifdef VD_TIMING
+// diagnostic build only: copy the per-workgroup phase stamps of the last launches to the host
+extern "C" int vd_debug_timing(unsigned long long* out, int n) {
+  VD_HIP(hipDeviceSynchronize());
+  VD_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(vd_tbuf), (size_t)n * sizeof(unsigned long long)));
+  return VD_OK;
+}
+#endif
