@@ -175,7 +175,8 @@ int vd_img_att_forward(const float* iqc, const float* wa, const float* ba, const
                        int Kc, float scale, void* stream);
 int vd_img_att_backward(float* iqc_dz, const float* wa, const float* pre, const uint8_t* mask1,
                         const uint8_t* mask2, const float* p, const float* datt, float* dwa, float* dba,
-                        float* dqc, int N, int R, int S2, int H, int Kc, float scale, void* stream);
+                        float* dqc, float* work /* [N x S2] scratch */, int N, int R, int S2, int H, int Kc,
+                        float scale, void* stream);
 int vd_img_tr_backward(const float* dz, const float* Wc, const float* p, const float* datt,
                        const uint8_t* mask1, float* dpre, int N, int R, int S2, int H, int Kc, float scale,
                        void* stream);

@@ -80,6 +80,23 @@ def main():
     ms = timeit(lambda: ops.img_common_forward(pre, m1, Wc, bc, qc, m2, iqc, Nn, R, S2, H, Kc, 2.0))
     print("img_common fwd [39200x512x512]: %.3f ms  %.1f TFLOP/s" % (ms, 2.0 * Nn * S2 * H * Kc / ms / 1e9))
 
+    wa, ba, u0 = rnd(Kc) * 0.05, rnd(1), rnd(Nn, H)
+    patt, u1 = torch.empty(Nn, S2, device=dev), torch.empty(Nn, H, device=dev)
+    ms = timeit(lambda: ops.img_att_forward(iqc, wa, ba, pre, m1, u0, patt, u1, Nn, R, S2, H, Kc, 2.0), iters=10)
+    print("img_att fwd [200x196x512]: %.1f us" % (ms * 1e3))
+    datt, dwa, dba = rnd(Nn, H), torch.zeros(Kc, device=dev), torch.zeros(1, device=dev)
+    dqc, wk = torch.empty(Nn, Kc, device=dev), torch.empty(Nn, S2, device=dev)
+    ms = timeit(lambda: ops.img_att_backward(iqc, wa, pre, m1, m2, patt, datt, dwa, dba, dqc, wk, Nn, R, S2, H, Kc, 2.0), iters=10)
+    print("img_att bwd [200x196x512]: %.1f us" % (ms * 1e3))
+    Qm, Hmm = rnd(Nn, H), rnd(Nn, H)
+    mk = torch.triu(torch.ones(R, R, device=dev, dtype=torch.uint8), 1).repeat(B, 1, 1).contiguous()
+    Pm, hatt = torch.empty(B, R, R, device=dev), torch.empty(Nn, H, device=dev)
+    ms = timeit(lambda: ops.mn_attention_forward(Qm, Hmm, mk, Pm, hatt, B, R, H), iters=20)
+    print("mn_att fwd [20x10x10x512]: %.1f us" % (ms * 1e3))
+    dQ, dHm = torch.empty(Nn, H, device=dev), torch.empty(Nn, H, device=dev)
+    ms = timeit(lambda: ops.mn_attention_backward(Qm, Hmm, Pm, datt, dQ, dHm, B, R, H), iters=20)
+    print("mn_att bwd [20x10x10x512]: %.1f us" % (ms * 1e3))
+
     # plain GEMMs
     A = rnd(8000, E)
     Wx = rnd(E, 4 * H)

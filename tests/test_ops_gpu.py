@@ -257,7 +257,8 @@ def test_image_attention(ops, use_drop):
     dwa = torch.zeros(Kc, device="cuda")
     dba = torch.zeros(1, device="cuda")
     dqc = torch.empty(N, Kc, device="cuda")
-    ops.img_att_backward(iqc, dev(wa), pre_d, m1_d, m2_d, p, dev(datt), dwa, dba, dqc, N, R, S2, H, Kc, sc)
+    work = torch.empty(N, S2, device="cuda")
+    ops.img_att_backward(iqc, dev(wa), pre_d, m1_d, m2_d, p, dev(datt), dwa, dba, dqc, work, N, R, S2, H, Kc, sc)
     assert relerr(iqc, dz_ref.reshape(N * S2, Kc)) < 1e-5
     assert relerr(dwa, dwa_ref) < 1e-5 and relerr(dqc, dqc_ref) < 1e-5
     assert abs(float(dba.item()) - dscore.sum()) < 1e-4

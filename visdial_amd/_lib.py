@@ -73,7 +73,7 @@ PROTOTYPES = {
     "vd_rowdot_backward": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
     "vd_img_common_forward": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "vd_img_att_forward": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
-    "vd_img_att_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "vd_img_att_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "vd_img_tr_backward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "vd_img_common_wgrad": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "vd_score_ce": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],

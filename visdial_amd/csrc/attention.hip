@@ -17,14 +17,24 @@
 // =====================================================================================
 #define MN_MAX_R 16
 
-__global__ void __launch_bounds__(256)
+// One 16-wave workgroup per dialog.  The R question states and R facts of the dialog (2 x 20 KB) are
+// staged in LDS with one coalesced pass, so the R*R dot products and the R*H weighted sums never touch
+// global memory again: the kernel is a handful of dependent global round trips instead of ~60.
+#define MN_THREADS 1024
+__global__ void __launch_bounds__(MN_THREADS)
 mn_att_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Hm, const uint8_t* __restrict__ mask,
                   float* __restrict__ P, float* __restrict__ hAtt, int R, int H) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // q [R*H] | h [R*H]
   __shared__ float S[MN_MAX_R * MN_MAX_R];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* q = Q + (long)b * R * H;
-  const float* h = Hm + (long)b * R * H;
-  for (int p = wave; p < R * R; p += 4) {
+  float* q = lds;
+  float* h = lds + R * H;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = MN_THREADS / 64;
+  for (int i = tid * 4; i < R * H; i += MN_THREADS * 4) {
+    *reinterpret_cast<float4*>(q + i) = *reinterpret_cast<const float4*>(Q + (long)b * R * H + i);
+    *reinterpret_cast<float4*>(h + i) = *reinterpret_cast<const float4*>(Hm + (long)b * R * H + i);
+  }
+  __syncthreads();
+  for (int p = wave; p < R * R; p += nw) {
     const int i = p / R, j = p % R;
     float s = 0.f;
     for (int k = lane; k < H; k += 64) s += q[i * H + k] * h[j * H + k];
@@ -55,7 +65,7 @@ mn_att_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Hm, con
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < R * H; idx += 256) {
+  for (int idx = tid; idx < R * H; idx += MN_THREADS) {
     const int i = idx / H, k = idx % H;
     float a = 0.f;
     for (int j = 0; j < R; ++j) a += S[i * MN_MAX_R + j] * h[j * H + k];
@@ -63,17 +73,24 @@ mn_att_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Hm, con
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(MN_THREADS)
 mn_att_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ Hm, const float* __restrict__ P,
                   const float* __restrict__ dhAtt, float* __restrict__ dQ, float* __restrict__ dHm, int R,
                   int H) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // q | h | dhAtt, [R*H] each
   __shared__ float Ps[MN_MAX_R * MN_MAX_R];
   __shared__ float dS[MN_MAX_R * MN_MAX_R];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* q = Q + (long)b * R * H;
-  const float* h = Hm + (long)b * R * H;
-  const float* da = dhAtt + (long)b * R * H;
-  for (int p = wave; p < R * R; p += 4) {
+  float* q = lds;
+  float* h = lds + R * H;
+  float* da = lds + 2 * R * H;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = MN_THREADS / 64;
+  for (int i = tid * 4; i < R * H; i += MN_THREADS * 4) {
+    *reinterpret_cast<float4*>(q + i) = *reinterpret_cast<const float4*>(Q + (long)b * R * H + i);
+    *reinterpret_cast<float4*>(h + i) = *reinterpret_cast<const float4*>(Hm + (long)b * R * H + i);
+    *reinterpret_cast<float4*>(da + i) = *reinterpret_cast<const float4*>(dhAtt + (long)b * R * H + i);
+  }
+  __syncthreads();
+  for (int p = wave; p < R * R; p += nw) {
     const int i = p / R, j = p % R;
     float s = 0.f;
     for (int k = lane; k < H; k += 64) s += da[i * H + k] * h[j * H + k];
@@ -91,7 +108,7 @@ mn_att_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ Hm, con
     for (int j = 0; j < R; ++j) dS[i * MN_MAX_R + j] = Ps[i * MN_MAX_R + j] * (dS[i * MN_MAX_R + j] - dot);
   }
   __syncthreads();
-  for (int idx = tid; idx < R * H; idx += 256) {
+  for (int idx = tid; idx < R * H; idx += MN_THREADS) {
     const int i = idx / H, k = idx % H;  // i doubles as the fact index j for dHm
     float aq = 0.f, ah = 0.f;
     for (int j = 0; j < R; ++j) {
@@ -315,18 +332,36 @@ struct EpiImgTrBwd {
   }
 };
 
-// score + softmax over the S2 regions + weighted sum, one workgroup per QA round n:
-//   score[s] = <iqc[n,s,:], wa> + ba ; p = softmax(score) ; u1[n,:] = u0[n,:] + sum_s p[s]*img_tr[n,s,:]
-__global__ void __launch_bounds__(256)
-img_att_fwd_kernel(const float* __restrict__ iqc, const float* __restrict__ wa, const float* __restrict__ ba,
-                   const float* __restrict__ pre, const uint8_t* __restrict__ mask1,
-                   const float* __restrict__ u0, float* __restrict__ p_out, float* __restrict__ u1, int S2,
-                   int R, int H, int Kc, float scale) {
+// ---------------------------------------------------------------------------
+// SAN attention head.  Forward = two kernels:
+//   img_att_score_kernel  (one 16-wave workgroup per QA round n):
+//       score[s] = <iqc[n,s,:], wa> + ba ; p[n,:] = softmax_s(score)
+//   img_att_wsum_kernel   (grid N x H/128): u1[n,h] = u0[n,h] + sum_s p[n,s]*img_tr[n,s,h]
+// The first version ran everything as ONE 256-thread workgroup per round (200 workgroups, each thread
+// walking the 196 regions serially): 160 us alone, ~0.6 ms under the option LSTM.  Both kernels now keep
+// >= 8 independent 16-byte loads per lane in flight and spread a round over several workgroups.
+// ---------------------------------------------------------------------------
+#define IMG_ATT_WAVES 16
+__device__ __forceinline__ float block_reduce(float v, float* red, int wave, int lane, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();  // red may still be read from a previous reduction
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+#pragma unroll
+  for (int w = 1; w < IMG_ATT_WAVES; ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+  return r;
+}
+
+__global__ void __launch_bounds__(IMG_ATT_WAVES * 64)
+img_att_score_kernel(const float* __restrict__ iqc, const float* __restrict__ wa, const float* __restrict__ ba,
+                     float* __restrict__ p_out, int S2, int Kc) {
   extern __shared__ float sc[];  // [S2]
-  __shared__ float red[8];
+  __shared__ float red[IMG_ATT_WAVES];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* iq = iqc + (long)n * S2 * Kc;
-  for (int s = wave; s < S2; s += 4) {
+  const float b0 = ba[0];
+  for (int s = wave; s < S2; s += IMG_ATT_WAVES) {
     float a = 0.f;
     for (int k = lane * 4; k < Kc; k += 256) {
       const float4 v = *reinterpret_cast<const float4*>(iq + (long)s * Kc + k);
@@ -334,108 +369,165 @@ img_att_fwd_kernel(const float* __restrict__ iqc, const float* __restrict__ wa, 
       a += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
     }
     a = wave_sum(a);
-    if (lane == 0) sc[s] = a + ba[0];
+    if (lane == 0) sc[s] = a + b0;
   }
   __syncthreads();
   float mx = -INFINITY;
-  for (int s = tid; s < S2; s += 256) mx = fmaxf(mx, sc[s]);
-  mx = wave_max(mx);
-  if (lane == 0) red[wave] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  for (int s = tid; s < S2; s += IMG_ATT_WAVES * 64) mx = fmaxf(mx, sc[s]);
+  mx = block_reduce(mx, red, wave, lane, true);
   float sum = 0.f;
-  for (int s = tid; s < S2; s += 256) {
+  for (int s = tid; s < S2; s += IMG_ATT_WAVES * 64) {
     const float e = expf(sc[s] - mx);
     sc[s] = e;
     sum += e;
   }
-  sum = wave_sum(sum);
-  if (lane == 0) red[4 + wave] = sum;
+  sum = block_reduce(sum, red, wave, lane, false);
+  const float inv = 1.f / sum;
+  for (int s = tid; s < S2; s += IMG_ATT_WAVES * 64) p_out[(long)n * S2 + s] = sc[s] * inv;
+}
+
+// 256 threads = 8 region groups x 32 lanes; lane l owns 4 consecutive channels of a 128-channel tile.
+__global__ void __launch_bounds__(256)
+img_att_wsum_kernel(const float* __restrict__ pre, const uint8_t* __restrict__ mask1,
+                    const float* __restrict__ p, const float* __restrict__ u0, float* __restrict__ u1, int S2,
+                    int R, int H, float scale) {
+  extern __shared__ float sh[];  // p [S2] | partial sums [8][128]
+  float* ps = sh;
+  float* part = sh + ((S2 + 3) & ~3);
+  const int n = blockIdx.x, tid = threadIdx.x, g = tid >> 5, l = tid & 31;
+  const int h = blockIdx.y * 128 + l * 4;
+  for (int s = tid; s < S2; s += 256) ps[s] = p[(long)n * S2 + s];
   __syncthreads();
-  const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
-  for (int s = tid; s < S2; s += 256) {
-    const float pv = sc[s] * inv;
-    sc[s] = pv;
-    p_out[(long)n * S2 + s] = pv;
-  }
-  __syncthreads();
-  const float* pr = pre + (long)(n / R) * S2 * H;
-  const uint8_t* m1 = mask1 ? mask1 + (long)n * S2 * H : nullptr;
-  for (int h = tid; h < H; h += 256) {
-    float a = 0.f;
-    for (int s = 0; s < S2; ++s) {
-      float v = pr[(long)s * H + h];
-      if (m1) v = m1[(long)s * H + h] ? v * scale : 0.f;
-      a += sc[s] * v;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (h < H) {
+    const float* pr = pre + (long)(n / R) * S2 * H + h;
+    const uint8_t* m1 = mask1 ? mask1 + (long)n * S2 * H + h : nullptr;
+#pragma unroll 4
+    for (int s = g; s < S2; s += 8) {
+      float4 v = *reinterpret_cast<const float4*>(pr + (long)s * H);
+      if (m1) {
+        const uint32_t m = *reinterpret_cast<const uint32_t*>(m1 + (long)s * H);
+        v.x = (m & 0xffu) ? v.x * scale : 0.f;
+        v.y = (m & 0xff00u) ? v.y * scale : 0.f;
+        v.z = (m & 0xff0000u) ? v.z * scale : 0.f;
+        v.w = (m & 0xff000000u) ? v.w * scale : 0.f;
+      }
+      const float w = ps[s];
+      acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
     }
-    u1[(long)n * H + h] = u0[(long)n * H + h] + a;
+  }
+  *reinterpret_cast<float4*>(part + g * 128 + l * 4) = acc;
+  __syncthreads();
+  if (g == 0 && h < H) {
+    float4 t = *reinterpret_cast<const float4*>(u0 + (long)n * H + h);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(part + q * 128 + l * 4);
+      t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+    }
+    *reinterpret_cast<float4*>(u1 + (long)n * H + h) = t;
   }
 }
 
-// backward of the kernel above + of the tanh/dropout epilogue.  Per QA round n:
-//   dp[s] = <datt[n,:], img_tr[n,s,:]> ; dscore = p*(dp - <p,dp>)
+// ---------------------------------------------------------------------------
+// Backward of the attention head + of the tanh/dropout epilogue of img_common.  Per QA round n:
+//   dp[s] = <datt[n,:], img_tr[n,s,:]> ; dscore = p*(dp - <p,dp>)            (img_att_dscore_kernel)
 //   dwa += sum_s dscore[s]*iqc[n,s,:] ; dba += sum_s dscore[s]
 //   dz[n,s,k] = dscore[s]*wa[k]*scale2*mask2*(1 - tanh^2)   (written over iqc in place)
-//   dqc[n,k] = sum_s dz[n,s,k]
-__global__ void __launch_bounds__(256)
-img_att_bwd_kernel(float* __restrict__ iqc, const float* __restrict__ wa, const float* __restrict__ pre,
-                   const uint8_t* __restrict__ mask1, const uint8_t* __restrict__ mask2,
-                   const float* __restrict__ p, const float* __restrict__ datt, float* __restrict__ dwa,
-                   float* __restrict__ dba, float* __restrict__ dqc, int S2, int R, int H, int Kc, float scale) {
-  extern __shared__ float sh[];  // dscore [S2]
-  __shared__ float red[4];
+//   dqc[n,k] = sum_s dz[n,s,k]                                               (img_att_dz_kernel)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(IMG_ATT_WAVES * 64)
+img_att_dscore_kernel(const float* __restrict__ pre, const uint8_t* __restrict__ mask1,
+                      const float* __restrict__ p, const float* __restrict__ datt, float* __restrict__ dscore,
+                      float* __restrict__ dba, int S2, int R, int H, float scale) {
+  extern __shared__ float sc[];  // dp [S2]
+  __shared__ float red[IMG_ATT_WAVES];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* pr = pre + (long)(n / R) * S2 * H;
   const uint8_t* m1 = mask1 ? mask1 + (long)n * S2 * H : nullptr;
   const float* da = datt + (long)n * H;
-  for (int s = wave; s < S2; s += 4) {
+  for (int s = wave; s < S2; s += IMG_ATT_WAVES) {
     float a = 0.f;
-    for (int h = lane; h < H; h += 64) {
-      float v = pr[(long)s * H + h];
-      if (m1) v = m1[(long)s * H + h] ? v * scale : 0.f;
-      a += da[h] * v;
+    for (int h = lane * 4; h < H; h += 256) {
+      float4 v = *reinterpret_cast<const float4*>(pr + (long)s * H + h);
+      if (m1) {
+        const uint32_t m = *reinterpret_cast<const uint32_t*>(m1 + (long)s * H + h);
+        v.x = (m & 0xffu) ? v.x * scale : 0.f;
+        v.y = (m & 0xff00u) ? v.y * scale : 0.f;
+        v.z = (m & 0xff0000u) ? v.z * scale : 0.f;
+        v.w = (m & 0xff000000u) ? v.w * scale : 0.f;
+      }
+      const float4 d = *reinterpret_cast<const float4*>(da + h);
+      a += d.x * v.x + d.y * v.y + d.z * v.z + d.w * v.w;
     }
     a = wave_sum(a);
-    if (lane == 0) sh[s] = a;
+    if (lane == 0) sc[s] = a;
   }
   __syncthreads();
   float dot = 0.f;
-  for (int s = tid; s < S2; s += 256) dot += p[(long)n * S2 + s] * sh[s];
-  dot = wave_sum(dot);
-  if (lane == 0) red[wave] = dot;
-  __syncthreads();
-  dot = red[0] + red[1] + red[2] + red[3];
+  for (int s = tid; s < S2; s += IMG_ATT_WAVES * 64) dot += p[(long)n * S2 + s] * sc[s];
+  dot = block_reduce(dot, red, wave, lane, false);
   float dsum = 0.f;
-  for (int s = tid; s < S2; s += 256) {
-    const float ds = p[(long)n * S2 + s] * (sh[s] - dot);
-    sh[s] = ds;
+  for (int s = tid; s < S2; s += IMG_ATT_WAVES * 64) {
+    const float ds = p[(long)n * S2 + s] * (sc[s] - dot);
+    dscore[(long)n * S2 + s] = ds;
     dsum += ds;
   }
-  dsum = wave_sum(dsum);
-  if (lane == 0) unsafeAtomicAdd(dba, dsum);
+  dsum = block_reduce(dsum, red, wave, lane, false);
+  if (tid == 0) unsafeAtomicAdd(dba, dsum);
+}
+
+__global__ void __launch_bounds__(256)
+img_att_dz_kernel(float* __restrict__ iqc, const float* __restrict__ wa, const uint8_t* __restrict__ mask2,
+                  const float* __restrict__ dscore, float* __restrict__ dwa, float* __restrict__ dqc, int S2,
+                  int Kc, float scale) {
+  extern __shared__ float sh[];  // dscore [S2] | partial sums [2][8][128]
+  float* dsv = sh;
+  float* part = sh + ((S2 + 3) & ~3);
+  const int n = blockIdx.x, tid = threadIdx.x, g = tid >> 5, l = tid & 31;
+  const int k = blockIdx.y * 128 + l * 4;
+  for (int s = tid; s < S2; s += 256) dsv[s] = dscore[(long)n * S2 + s];
   __syncthreads();
-  float* iq = iqc + (long)n * S2 * Kc;
-  const uint8_t* m2 = mask2 ? mask2 + (long)n * S2 * Kc : nullptr;
-  const float inv_scale = m2 ? 1.f / scale : 1.f;
-  const float sc2 = m2 ? scale : 1.f;
-  for (int k = tid; k < Kc; k += 256) {
-    const float w = wa[k];
-    float aw = 0.f, aq = 0.f;
-    for (int s = 0; s < S2; ++s) {
-      const long o = (long)s * Kc + k;
-      const float y = iq[o];
-      const float ds = sh[s];
-      aw += ds * y;
-      float dz = 0.f;
-      if (!m2 || m2[o]) {
-        const float t = y * inv_scale;
-        dz = ds * w * sc2 * (1.f - t * t);
-      }
-      iq[o] = dz;
-      aq += dz;
+  float4 aw = make_float4(0.f, 0.f, 0.f, 0.f), aq = aw;
+  if (k < Kc) {
+    float* iq = iqc + (long)n * S2 * Kc + k;
+    const uint8_t* m2 = mask2 ? mask2 + (long)n * S2 * Kc + k : nullptr;
+    const float inv_scale = m2 ? 1.f / scale : 1.f;
+    const float sc2 = m2 ? scale : 1.f;
+    float4 w = *reinterpret_cast<const float4*>(wa + k);
+    w.x *= sc2; w.y *= sc2; w.z *= sc2; w.w *= sc2;
+#pragma unroll 4
+    for (int s = g; s < S2; s += 8) {
+      const float4 y = *reinterpret_cast<const float4*>(iq + (long)s * Kc);
+      const uint32_t m = m2 ? *reinterpret_cast<const uint32_t*>(m2 + (long)s * Kc) : 0xffffffffu;
+      const float ds = dsv[s];
+      aw.x += ds * y.x; aw.y += ds * y.y; aw.z += ds * y.z; aw.w += ds * y.w;
+      float4 dz;
+      { const float t = y.x * inv_scale; dz.x = (m & 0xffu) ? ds * w.x * (1.f - t * t) : 0.f; }
+      { const float t = y.y * inv_scale; dz.y = (m & 0xff00u) ? ds * w.y * (1.f - t * t) : 0.f; }
+      { const float t = y.z * inv_scale; dz.z = (m & 0xff0000u) ? ds * w.z * (1.f - t * t) : 0.f; }
+      { const float t = y.w * inv_scale; dz.w = (m & 0xff000000u) ? ds * w.w * (1.f - t * t) : 0.f; }
+      *reinterpret_cast<float4*>(iq + (long)s * Kc) = dz;
+      aq.x += dz.x; aq.y += dz.y; aq.z += dz.z; aq.w += dz.w;
     }
-    unsafeAtomicAdd(dwa + k, aw);
-    dqc[(long)n * Kc + k] = aq;
+  }
+  *reinterpret_cast<float4*>(part + g * 128 + l * 4) = aw;
+  *reinterpret_cast<float4*>(part + 1024 + g * 128 + l * 4) = aq;
+  __syncthreads();
+  if (g == 0 && k < Kc) {
+    float4 tw = make_float4(0.f, 0.f, 0.f, 0.f), tq = tw;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(part + q * 128 + l * 4);
+      const float4 b = *reinterpret_cast<const float4*>(part + 1024 + q * 128 + l * 4);
+      tw.x += a.x; tw.y += a.y; tw.z += a.z; tw.w += a.w;
+      tq.x += b.x; tq.y += b.y; tq.z += b.z; tq.w += b.w;
+    }
+    *reinterpret_cast<float4*>(dqc + (long)n * Kc + k) = tq;
+    unsafeAtomicAdd(dwa + k, tw.x);
+    unsafeAtomicAdd(dwa + k + 1, tw.y);
+    unsafeAtomicAdd(dwa + k + 2, tw.z);
+    unsafeAtomicAdd(dwa + k + 3, tw.w);
   }
 }
 
@@ -446,21 +538,26 @@ extern "C" {
 
 int vd_mn_attention_forward(const float* Q, const float* Hm, const uint8_t* mask, float* P, float* hAtt, int B,
                             int R, int H, void* stream) {
-  VD_CHECK_ARG(Q && Hm && mask && P && hAtt && B >= 0 && R >= 1 && R <= MN_MAX_R && H > 0,
-               "vd_mn_attention_forward: bad args (R=%d must be <= %d)", R, MN_MAX_R);
+  VD_CHECK_ARG(Q && Hm && mask && P && hAtt && B >= 0 && R >= 1 && R <= MN_MAX_R && H > 0 && H % 4 == 0,
+               "vd_mn_attention_forward: bad args (R=%d must be <= %d, H %% 4 == 0)", R, MN_MAX_R);
   if (B == 0) return VD_OK;
-  hipLaunchKernelGGL(mn_att_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, Q, Hm, mask, P, hAtt, R, H);
+  const size_t lds = (size_t)2 * R * H * sizeof(float);
+  VD_CHECK_ARG(lds <= 64 * 1024, "vd_mn_attention_forward: R*H = %d does not fit the LDS staging", R * H);
+  hipLaunchKernelGGL(mn_att_fwd_kernel, dim3(B), dim3(MN_THREADS), lds, (hipStream_t)stream, Q, Hm, mask, P, hAtt,
+                     R, H);
   VD_LAUNCH_CHECK();
   return VD_OK;
 }
 
 int vd_mn_attention_backward(const float* Q, const float* Hm, const float* P, const float* dhAtt, float* dQ,
                              float* dHm, int B, int R, int H, void* stream) {
-  VD_CHECK_ARG(Q && Hm && P && dhAtt && dQ && dHm && B >= 0 && R >= 1 && R <= MN_MAX_R && H > 0,
+  VD_CHECK_ARG(Q && Hm && P && dhAtt && dQ && dHm && B >= 0 && R >= 1 && R <= MN_MAX_R && H > 0 && H % 4 == 0,
                "vd_mn_attention_backward: bad args");
   if (B == 0) return VD_OK;
-  hipLaunchKernelGGL(mn_att_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, Q, Hm, P, dhAtt, dQ, dHm,
-                     R, H);
+  const size_t lds = (size_t)3 * R * H * sizeof(float);
+  VD_CHECK_ARG(lds <= 64 * 1024, "vd_mn_attention_backward: R*H = %d does not fit the LDS staging", R * H);
+  hipLaunchKernelGGL(mn_att_bwd_kernel, dim3(B), dim3(MN_THREADS), lds, (hipStream_t)stream, Q, Hm, P, dhAtt, dQ,
+                     dHm, R, H);
   VD_LAUNCH_CHECK();
   return VD_OK;
 }
@@ -520,22 +617,35 @@ int vd_img_common_forward(const float* pre, const uint8_t* mask1, const float* W
 int vd_img_att_forward(const float* iqc, const float* wa, const float* ba, const float* pre,
                        const uint8_t* mask1, const float* u0, float* p, float* u1, int N, int R, int S2, int H,
                        int Kc, float scale, void* stream) {
-  VD_CHECK_ARG(iqc && wa && ba && pre && u0 && p && u1 && N >= 0 && Kc % 4 == 0, "vd_img_att_forward: bad args");
+  VD_CHECK_ARG(iqc && wa && ba && pre && u0 && p && u1 && N >= 0 && Kc % 4 == 0 && H % 4 == 0,
+               "vd_img_att_forward: bad args");
   if (N == 0) return VD_OK;
-  hipLaunchKernelGGL(img_att_fwd_kernel, dim3(N), dim3(256), S2 * sizeof(float), (hipStream_t)stream, iqc, wa,
-                     ba, pre, mask1, u0, p, u1, S2, R, H, Kc, scale);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(img_att_score_kernel, dim3(N), dim3(IMG_ATT_WAVES * 64), S2 * sizeof(float), s, iqc, wa, ba,
+                     p, S2, Kc);
+  VD_LAUNCH_CHECK();
+  const size_t lds = (((S2 + 3) & ~3) + 8 * 128) * sizeof(float);
+  hipLaunchKernelGGL(img_att_wsum_kernel, dim3(N, vd_cdiv(H, 128)), dim3(256), lds, s, pre, mask1, p, u0, u1, S2,
+                     R, H, scale);
   VD_LAUNCH_CHECK();
   return VD_OK;
 }
 
-// iqc is overwritten by dz.  dwa/dba are accumulated, dqc is written.
+// iqc is overwritten by dz.  dwa/dba are accumulated, dqc is written.  work: [N x S2] floats (dscore).
 int vd_img_att_backward(float* iqc_dz, const float* wa, const float* pre, const uint8_t* mask1,
                         const uint8_t* mask2, const float* p, const float* datt, float* dwa, float* dba,
-                        float* dqc, int N, int R, int S2, int H, int Kc, float scale, void* stream) {
-  VD_CHECK_ARG(iqc_dz && wa && pre && p && datt && dwa && dba && dqc && N >= 0, "vd_img_att_backward: bad args");
+                        float* dqc, float* work, int N, int R, int S2, int H, int Kc, float scale, void* stream) {
+  VD_CHECK_ARG(iqc_dz && wa && pre && p && datt && dwa && dba && dqc && work && N >= 0 && Kc % 4 == 0 &&
+                   H % 4 == 0,
+               "vd_img_att_backward: bad args");
   if (N == 0) return VD_OK;
-  hipLaunchKernelGGL(img_att_bwd_kernel, dim3(N), dim3(256), S2 * sizeof(float), (hipStream_t)stream, iqc_dz,
-                     wa, pre, mask1, mask2, p, datt, dwa, dba, dqc, S2, R, H, Kc, scale);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(img_att_dscore_kernel, dim3(N), dim3(IMG_ATT_WAVES * 64), S2 * sizeof(float), s, pre, mask1,
+                     p, datt, work, dba, S2, R, H, scale);
+  VD_LAUNCH_CHECK();
+  const size_t lds = (((S2 + 3) & ~3) + 2 * 8 * 128) * sizeof(float);
+  hipLaunchKernelGGL(img_att_dz_kernel, dim3(N, vd_cdiv(Kc, 128)), dim3(256), lds, s, iqc_dz, wa, mask2, work,
+                     dwa, dqc, S2, Kc, scale);
   VD_LAUNCH_CHECK();
   return VD_OK;
 }

@@ -185,7 +185,7 @@ class SANBlock(object):
         du1 = dropout_backward(ws, 'att.du1', du1d, self.m_u, S5)                # = d att, and the residual into u0
         dqc = ws.get('att.dqc', (N, K))
         ops.img_att_backward(self.iqc, fp.w['att.W'], self.pre, self.m1, self.m2, self.patt, du1, G['att.W'],
-                             G['att.b'], dqc, N, R, S2, H, K, sc)                # iqc now holds dz
+                             G['att.b'], dqc, ws.get('att.dscore', (N, S2)), N, R, S2, H, K, sc)   # iqc now holds dz
         dz = self.iqc
         ops.colsum_acc(dz, G['img_common.b'], M=N * S2, N=K)
         ops.img_common_wgrad(dz, self.pre, self.m1, G['img_common.W'], N, R, S2, H, K, sc)

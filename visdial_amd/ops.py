@@ -171,9 +171,12 @@ def img_att_forward(iqc, wa, ba, pre, mask1, u0, p, u1, N, R, S2, H, Kc, scale):
          _p(p, F32), _p(u1, F32), N, R, S2, H, Kc, float(scale), _stream())
 
 
-def img_att_backward(iqc_dz, wa, pre, mask1, mask2, p, datt, dwa, dba, dqc, N, R, S2, H, Kc, scale):
+def img_att_backward(iqc_dz, wa, pre, mask1, mask2, p, datt, dwa, dba, dqc, work, N, R, S2, H, Kc, scale):
+    """work: [N x S2] fp32 scratch (softmax-backward scores)."""
+    assert work.numel() >= N * S2
     call("vd_img_att_backward", _p(iqc_dz, F32), _p(wa, F32), _p(pre, F32), _p(mask1, U8), _p(mask2, U8), _p(p, F32),
-         _p(datt, F32), _p(dwa, F32), _p(dba, F32), _p(dqc, F32), N, R, S2, H, Kc, float(scale), _stream())
+         _p(datt, F32), _p(dwa, F32), _p(dba, F32), _p(dqc, F32), _p(work, F32), N, R, S2, H, Kc, float(scale),
+         _stream())
 
 
 def img_tr_backward(dz, Wc, p, datt, mask1, dpre, N, R, S2, H, Kc, scale):
