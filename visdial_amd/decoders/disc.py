@@ -10,6 +10,7 @@ gradients are one wave-reduction kernel.
 import torch
 
 from .. import ops
+from ..nn import StreamPool
 
 
 def declare(params, spec):
@@ -24,6 +25,7 @@ class Decoder(object):
         W, dW = fp.w['opt.W'], fp.g['opt.W']
         self.Wx, self.Wh, self.b = W[:self.E], W[self.E:], fp.w['opt.b']
         self.dWx, self.dWh, self.db = dW[:self.E], dW[self.E:], fp.g['opt.b']
+        self.streams = StreamPool(ws.device, enabled=False)     # Model attaches its own pool
 
     def forward(self, inputs):
         """inputs = {options [To x N*O] int32 time-major, encOut [N x H]} -> scores [N x O]"""
@@ -52,6 +54,16 @@ class Decoder(object):
         otok, enc_out = inputs
         ws, H, V, To, NO = self.ws, self.H, self.V, self.To, self.NO
         dc = ws.get('opt.dc', (NO, H))
+        # the token counting sort and the zero-fill of the table gradient depend on the inputs only:
+        # they run on a side stream underneath the backward recurrence
+        tokf = otok.view(-1)
+        offset = ws.get('opt.sort_off', (V + 2,), torch.int32)
+        work = ws.get('opt.sort_work', (2 * (V + 1),), torch.int32)
+        perm = ws.get('opt.sort_perm', (To * NO,), torch.int32)
+        dtab = ws.get('opt.dtable', (V + 1, 4 * H))
+        with self.streams.fork('tab'):
+            ops.token_sort(tokf, V + 1, offset, work, perm)
+            dtab.zero_()
         t0 = ops.prof_begin('opt_lstm_bwd_step')
         ops.lstm_backward(self.Wh, self.gates, self.c, dc, To, NO, H, dh_last=d_optH)
         ops.prof_end('opt_lstm_bwd_step', t0, To)
@@ -60,14 +72,8 @@ class Decoder(object):
             t0 = ops.prof_begin('opt_lstm_dWh')
             ops.gemm_tn_acc(self.h.view(To * NO, H), da[NO:], self.dWh, M=H, N=4 * H, K=(To - 1) * NO)
             ops.prof_end('opt_lstm_dWh', t0, 1)
-        # gradient of the gathered table: counting-sort the tokens, segmented row sums
-        tokf = otok.view(-1)
-        offset = ws.get('opt.sort_off', (V + 2,), torch.int32)
-        work = ws.get('opt.sort_work', (2 * (V + 1),), torch.int32)
-        perm = ws.get('opt.sort_perm', (To * NO,), torch.int32)
-        ops.token_sort(tokf, V + 1, offset, work, perm)
-        dtab = ws.get('opt.dtable', (V + 1, 4 * H))
-        dtab.zero_()
+        # gradient of the gathered table: segmented row sums over the token-sorted rows
+        self.streams.join('tab')
         ops.segment_rowsum_acc(da, tokf, perm, dtab)
         ops.colsum_acc(dtab, self.db, M=V + 1, N=4 * H)
         ops.gemm_tn_acc(self.emb, dtab, self.dWx, M=self.E, N=4 * H, K=V + 1)

@@ -68,6 +68,7 @@ class Model(object):
         self.streams = StreamPool(self.device, enabled=os.environ.get('VD_STREAMS', '1') != '0')
         self.encoder = self.encFile.model(params, self.fp, self.ws, self.drop, self.streams)
         self.decoder = self.decFile.model(params, self.encoder, self.fp, self.ws, self.drop)
+        self.decoder.streams = self.streams
         # decoder hooks (model.lua:28-29)
         self.forwardConnect = self.decFile.forwardConnect
         self.backwardConnect = self.decFile.backwardConnect
