@@ -25,7 +25,7 @@ def timeit(fn, iters=5, warm=2):
 def main():
     only_big = len(sys.argv) > 1 and sys.argv[1] == "big"
     dev = "cuda"
-    T, N, H, E, V = 20, 20000, 512, 300, 11322
+    T, N, H, E, V = 20, int(os.environ.get("MB_N", 20000)), 512, 300, 11322
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
     Wh = rnd(H, 4 * H) * 0.04
@@ -39,12 +39,12 @@ def main():
 
     ms = timeit(lambda: ops.lstm_forward(table, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok))
     fl = 2.0 * N * H * 4 * H * (T - 1)
-    print("option LSTM fwd  T=20 N=20000: %.2f ms  %.1f TFLOP/s (recurrent GEMM only)" % (ms, fl / ms / 1e9))
+    print("option LSTM fwd  T=20 N=%d: %.2f ms  %.1f TFLOP/s (recurrent GEMM only)" % (N, ms, fl / ms / 1e9))
 
     def bwd():
         ops.lstm_backward(Wh, gates, c, dcw, T, N, H, dh_last=dh_last)
     ms = timeit(bwd, iters=3, warm=1)
-    print("option LSTM bwd  T=20 N=20000: %.2f ms  %.1f TFLOP/s" % (ms, fl / ms / 1e9))
+    print("option LSTM bwd  T=20 N=%d: %.2f ms  %.1f TFLOP/s" % (N, ms, fl / ms / 1e9))
 
     dWh = torch.zeros(H, 4 * H, device=dev)
     hh = h.view(T * N, H)

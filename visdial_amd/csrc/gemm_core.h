@@ -17,6 +17,7 @@
 // * workgroup id -> tile mapping is XCD-aware (block b runs on XCD b % 8; every XCD
 //   gets a contiguous range of tiles so its private L2 sees a compact working set).
 #pragma once
+#include <stdint.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -412,6 +413,198 @@ gemm_f32_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, int r
   const int ke = min(K, ks + kchunk);
   gemm_block<Cfg>(M, N, ks, ke, tile_m * Cfg::BM, tile_n * Cfg::BN, rotate ? tile_m * 5 + tile_n * 3 + split : -1,
                   asrc, bsrc, epi, smem);
+}
+
+// ---------------------------------------------------------------------------
+// LDS-DMA pipeline for the throughput recurrences (both operands k-contiguous: A[M x K] rows, B given as
+// its transpose Bt[N x K] rows; K % 16 == 0).  Differences from gemm_block:
+//   * operand tiles go global -> LDS directly (global_load_lds_dwordx4): no staging VGPRs, no ds_write;
+//   * two LDS buffers of [rows][16 floats] with the 16-byte chunk index XOR-swizzled by (row >> 2) & 3 on
+//     the SOURCE side (the DMA writes lane-linear), which keeps every ds_read_b128 fragment read
+//     conflict-free without padding;
+//   * ONE barrier per K tile, in the middle of the 32-MFMA burst: by then this wave has read its last
+//     fragment of tile k (so buffer k&1 may be refilled with tile k+2) and its share of tile k+1 has landed
+//     (so tile k+1's first fragments can be fetched under the second half of the burst).
+// The waits are explicit (hipcc does not count inline-asm memory operations).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(unsigned voff, const float* sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+
+template <class Cfg, class Epi>
+__device__ __forceinline__ void gemm_block_glds(int M, int N, int K, int row_base, int col_base, int rot_seed,
+                                                const float* A, long lda, const float* Bt, long ldb,
+                                                const Epi& epi, float* smem) {
+  constexpr int WM = Cfg::WM, NT = Cfg::NT;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN;
+  constexpr int NIA = (BM / 16) / WM, NIB = (BN / 16) / WM;  // DMA instructions per wave per tile
+  constexpr int ABUF = BM * 16, BBUF = BN * 16;               // floats per buffer
+  // Buffer counts: tile kt+NB is requested in the middle of iteration kt, NB-1 iterations before its
+  // first fragment read.  A (activations, HBM/L2 latency) gets 3 buffers, Bt (weights, L2-resident) 3 if
+  // they fit the LDS request, else 2.
+  constexpr int NBA = (3 * ABUF + 2 * BBUF) * 4 <= Cfg::LDS_BYTES ? 3 : 2;
+  constexpr int NBB = (NBA == 3 && (3 * ABUF + 3 * BBUF) * 4 <= Cfg::LDS_BYTES) ? 3 : 2;
+  static_assert(Cfg::WK == 1 && Cfg::KW == 16, "LDS-DMA pipeline: BK = 16, no intra-block split-K");
+  static_assert((BM / 16) % WM == 0 && (BN / 16) % WM == 0, "16-row DMA groups must split evenly over the waves");
+  static_assert((NBA * ABUF + NBB * BBUF) * 4 <= Cfg::LDS_BYTES, "DMA buffers must fit the LDS request");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = K / 16;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // per-thread source offsets (bytes, k = 0) of this wave's DMA instructions; chunk index swizzled
+  unsigned voffa[NIA], voffb[NIB];
+#pragma unroll
+  for (int i = 0; i < NIA; ++i) {
+    const int r = (i * WM + wm) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((r >> 2) & 3);
+    voffa[i] = (unsigned)(((long)min(row_base + r, M - 1) * lda + c * 4) * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NIB; ++i) {
+    const int r = (i * WM + wm) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((r >> 2) & 3);
+    voffb[i] = (unsigned)(((long)min(col_base + r, N - 1) * ldb + c * 4) * 4);
+  }
+  float* const sA = smem;
+  float* const sB = smem + NBA * ABUF;
+  const unsigned ldsA = (unsigned)(uintptr_t)sA, ldsB = (unsigned)(uintptr_t)sB;  // LDS byte addresses
+  const int rot = (rot_seed >= 0 && nk > 1) ? rot_seed % nk : 0;
+  auto koff = [&](int kt) {
+    int t = kt + rot;
+    if (t >= nk) t -= nk;
+    return t * 16;
+  };
+  auto issue_a = [&](int kt, int buf) {
+    const float* ak = A + koff(kt);
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) glds16(voffa[i], ak, ldsA + buf * (ABUF * 4) + (i * WM + wm) * 1024);
+  };
+  auto issue_b = [&](int kt, int buf) {
+    const float* bk = Bt + koff(kt);
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) glds16(voffb[i], bk, ldsB + buf * (BBUF * 4) + (i * WM + wm) * 1024);
+  };
+
+  const int sw = ((lane & 31) >> 2) & 3, hi = lane >> 5;
+  const int rowoff = (lane & 31) * 16;
+  const int ch0 = ((0 + hi) ^ sw) * 4, ch1 = ((2 + hi) ^ sw) * 4;
+  auto read_frags = [&](int bufa, int bufb, int chunk_off, float4& a4, float4 (&b4)[NT]) {
+    const float* sa = sA + bufa * ABUF + (wm * 32) * 16 + rowoff + chunk_off;
+    const float* sb = sB + bufb * BBUF + rowoff + chunk_off;
+    a4 = *reinterpret_cast<const float4*>(sa);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b4[j] = *reinterpret_cast<const float4*>(sb + j * 32 * 16);
+  };
+  auto mfma16 = [&](const float4& a4, const float4 (&b4)[NT]) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[j].x, acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[j].y, acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[j].z, acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[j].w, acc[j], 0, 0, 0);
+  };
+  // s_waitcnt needs an immediate.  n = DMA instructions of this wave allowed to stay in flight.
+  auto wait_vm = [&](int n) {
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
+  static_assert(NIA * (NBA - 1) + NIB * (NBB - 1) <= 6 || true, "wait_vm immediates");
+
+  if (nk > 0) {
+    float4 a0, b0[NT], a1, b1[NT];
+    // request order inside every group is Bt first, then A: the operand with fewer buffers is always the
+    // older request, so "tile kt+1 of both operands has landed" == "at most the younger A requests are left"
+    issue_b(0, 0);
+    issue_a(0, 0);
+#pragma unroll
+    for (int b = 1; b < NBA; ++b) {
+      if (b < NBB && b < nk) issue_b(b, b);
+      if (b < nk) issue_a(b, b);
+    }
+    wait_vm(NIA * (min(nk, NBA) - 1) + NIB * (min(nk, NBB) - 1));
+    asm volatile("s_barrier" ::: "memory");
+    read_frags(0, 0, ch0, a0, b0);
+    int ca = 0, cb = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int na = (ca + 1 == NBA) ? 0 : ca + 1, nb = (cb + 1 == NBB) ? 0 : cb + 1;
+      read_frags(ca, cb, ch1, a1, b1);
+      mfma16(a0, b0);
+      // tile kt fully consumed by this wave, its share of tile kt+1 landed -> meet the other waves.
+      // (sched_barrier: MFMAs carry no side effects, the scheduler would otherwise sink the burst below
+      // the barrier and expose the fragment-read latency in front of it)
+      __builtin_amdgcn_sched_barrier(0);
+      wait_vm(NIA * max(0, min(kt + NBA - 1, nk - 1) - (kt + 1)) + NIB * max(0, min(kt + NBB - 1, nk - 1) - (kt + 1)));
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + NBB < nk) issue_b(kt + NBB, cb);
+      if (kt + NBA < nk) issue_a(kt + NBA, ca);
+      if (kt + 1 < nk) read_frags(na, nb, ch0, a0, b0);
+      mfma16(a1, b1);
+      ca = na;
+      cb = nb;
+    }
+  }
+  epi(acc, row_base + wm * 32, col_base, lane, M, N, smem + wm * 1024);
+}
+
+template <class Cfg, class Epi>
+__global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW)
+gemm_f32_glds_kernel(int M, int N, int K, int tiles_m, int tiles_n, int rotate, const float* A, long lda,
+                     const float* Bt, long ldb, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = wg % tiles_n;
+  const int tile_m = wg / tiles_n;
+  gemm_block_glds<Cfg>(M, N, K, tile_m * Cfg::BM, tile_n * Cfg::BN, rotate ? tile_m * 5 + tile_n * 3 : -1, A, lda, Bt,
+                       ldb, epi, smem);
+}
+
+// C[M x N] = epi(A[M x K] * Bt[N x K]^T), K % 16 == 0, row byte offsets below 4 GB.
+template <class Cfg, class Epi>
+static int launch_gemm_glds(int M, int N, int K, const float* A, long lda, const float* Bt, long ldb, const Epi& e,
+                            hipStream_t stream) {
+  if (M <= 0 || N <= 0) return VD_OK;
+  VD_CHECK_ARG(K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (long)M * lda * 4 < (1L << 32) &&
+                   (long)N * ldb * 4 < (1L << 32),
+               "launch_gemm_glds: unsupported shape M=%d N=%d K=%d", M, N, K);
+  const int tiles_m = vd_cdiv(M, Cfg::BM), tiles_n = vd_cdiv(N, Cfg::BN);
+  auto kern = gemm_f32_glds_kernel<Cfg, Epi>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               Cfg::LDS_BYTES));
+    attr_set = true;
+  }
+  static int rotate = -1;
+  if (rotate < 0) {
+    const char* ev = getenv("VD_GEMM_ROTATE");
+    rotate = ev ? atoi(ev) : 1;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, M, N, K, tiles_m,
+                     tiles_n, rotate, A, lda, Bt, ldb, e);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -189,12 +189,62 @@ static int env_int(const char* name, int dflt) {
   return ev ? atoi(ev) : dflt;
 }
 
+// WhT[vc][k] = Wh[k][g*H + jb*32 + jj], vc = jb*128 + g*32 + jj: the recurrent weights as k-contiguous rows
+// in the gate-interleaved column order of the forward step, so that both operands of the LDS-DMA pipeline
+// are plain row-major.  4 MB, rebuilt once per forward pass (the weights change every update).
+__global__ void __launch_bounds__(256) wh_gate_transpose_kernel(const float* __restrict__ Wh,
+                                                                float* __restrict__ WhT, int H) {
+  __shared__ float tile[32][33];
+  const int vt = blockIdx.x, kt = blockIdx.y;
+  const int jb = vt >> 2, g = vt & 3;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long src_col = (long)g * H + jb * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = kt * 32 + ty + i * 8;
+    tile[ty + i * 8][tx] = Wh[(long)k * 4 * H + src_col + tx];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int vc = vt * 32 + ty + i * 8;
+    WhT[(long)vc * H + kt * 32 + tx] = tile[tx][ty + i * 8];
+  }
+}
+
+// library-owned scratch for WhT (one per host thread / device context; grows on demand)
+static int wht_scratch(int H, float** out) {
+  static thread_local float* buf = nullptr;
+  static thread_local size_t cap = 0;
+  const size_t need = (size_t)4 * H * H * sizeof(float);
+  if (cap < need) {
+    if (buf) VD_HIP(hipFree(buf));
+    buf = nullptr;
+    cap = 0;
+    VD_HIP(hipMalloc((void**)&buf, need));
+    cap = need;
+  }
+  *out = buf;
+  return VD_OK;
+}
+
+// LDS-DMA pipeline eligibility: throughput shape, K % 16 == 0, 32-bit row byte offsets
+static bool use_glds_fwd(int N, int H) {
+  static const int cfg = env_int("VD_LSTM_FWD_CFG", 20);
+  return cfg == 20 && N >= 2048 && H % 32 == 0 && (long)N * H * 4 < (1L << 32);
+}
+static bool use_glds_bwd(int N, int H) {
+  static const int cfg = env_int("VD_LSTM_BWD_CFG", 20);
+  return cfg == 20 && N >= 2048 && H % 32 == 0 && (long)N * 4 * H * 4 < (1L << 32);
+}
+
 static int lstm_step_fwd(const float* h_prev, const float* Wh, int N, int H, int K, const EpiLstmFwd& epi,
                          hipStream_t s) {
   SrcRow a{h_prev, H};
   SrcKGate4 b{Wh, 4L * H, H};
   if (N >= 2048) {
-    static const int cfg = env_int("VD_LSTM_FWD_CFG", 9);
+    static const int cfg0 = env_int("VD_LSTM_FWD_CFG", 20);
+    const int cfg = cfg0 == 20 ? 9 : cfg0;   // 20 = LDS-DMA pipeline, handled by the drivers
     switch (cfg) {
       case 0: return launch_gemm<CfgF0>(N, 4 * H, K, 1, a, b, epi, s);
       case 2: return launch_gemm<CfgF2>(N, 4 * H, K, 1, a, b, epi, s);
@@ -220,7 +270,13 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
   SrcRow a{da_next, 4L * H};
   SrcRow b{Wh, 4L * H};  // B[k][n] = Wh[n][k]
   if (N >= 2048) {
-    static const int cfg = env_int("VD_LSTM_BWD_CFG", 11);
+    static const int cfg0 = env_int("VD_LSTM_BWD_CFG", 20);
+    const int cfg = cfg0 == 20 ? 11 : cfg0;
+    if (use_glds_bwd(N, H) && K > 0) {
+      // LDS-DMA pipeline: A = da_{t+1} rows, Bt = Wh rows (both contiguous in k = the 4H gate columns)
+      EpiLstmBwd<2> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
+      return launch_gemm_glds<CfgB11>(N, H, K, da_next, 4L * H, Wh, 4L * H, e, s);
+    }
     EpiLstmBwd<4> e4{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
     EpiLstmBwd<2> e2{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
     switch (cfg) {
@@ -366,7 +422,7 @@ struct RowChains {
     Pool& p = pool();
     if (!p.ready) {
       int prio = 0;
-      hipStreamGetPriority(s, &prio);
+      (void)hipStreamGetPriority(s, &prio);
       for (int i = 0; i < VD_MAX_CHAINS - 1; ++i) {
         VD_HIP(hipStreamCreateWithPriority(&p.side[i], hipStreamNonBlocking, prio));
         VD_HIP(hipEventCreateWithFlags(&p.join_ev[i], hipEventDisableTiming));
@@ -409,6 +465,13 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
   const long NH = (long)N * H;
   // The recurrence is independent per row: throughput shapes run as row chains on separate streams so the
   // tail of one chain's step kernel is filled by the other chain's workgroups (no chip-wide drain per step).
+  float* WhT = nullptr;
+  const bool glds = use_glds_fwd(N, H) && T > 1;
+  if (glds) {
+    if (int rc0 = wht_scratch(H, &WhT)) return rc0;
+    hipLaunchKernelGGL(wh_gate_transpose_kernel, dim3(4 * H / 32, H / 32), dim3(256), 0, s, Wh, WhT, H);
+    VD_LAUNCH_CHECK();
+  }
   RowChains rc_;
   static const int nchains = env_int("VD_LSTM_CHAINS_FWD", 1);
   int rc = rc_.fork(N, s, nchains);
@@ -429,7 +492,10 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
       e.c_out = c + t * NH + r0 * H;
       e.h_out = h + t * NH + r0 * H;
       e.H = H;
-      rc = lstm_step_fwd(hp, Wh, nr, H, hp ? H : 0, e, rc_.stream[ch]);
+      if (glds && hp)
+        rc = launch_gemm_glds<CfgF9>(nr, 4 * H, H, hp, (long)H, WhT, (long)H, e, rc_.stream[ch]);
+      else
+        rc = lstm_step_fwd(hp, Wh, nr, H, hp ? H : 0, e, rc_.stream[ch]);
       if (rc) return rc;
     }
   }
