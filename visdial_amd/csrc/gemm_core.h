@@ -436,25 +436,28 @@ __device__ __forceinline__ void glds16(unsigned voff, const float* sbase, unsign
       : "memory");
 }
 
-template <class Cfg, class Epi>
-__device__ __forceinline__ void gemm_block_glds(int M, int N, int K, int row_base, int col_base, int rot_seed,
-                                                const float* A, long lda, const float* Bt, long ldb,
+// KMAJ == false: A[M x K] rows, Bt[N x K] rows (k contiguous), tiles [row][16 k] with swizzled chunks.
+// KMAJ == true : A[K x M] rows, B[K x N] rows (k = row index: weight gradients X^T * dY), tiles [16 k][128]
+//                dense; fragments are ds_read_b32 (32 consecutive floats per half-wave, conflict-free).
+template <class Cfg, bool KMAJ, class Epi>
+__device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, int row_base, int col_base,
+                                                int rot_seed, const float* A, long lda, const float* B, long ldb,
                                                 const Epi& epi, float* smem) {
   constexpr int WM = Cfg::WM, NT = Cfg::NT;
   constexpr int BM = Cfg::BM, BN = Cfg::BN;
   constexpr int NIA = (BM / 16) / WM, NIB = (BN / 16) / WM;  // DMA instructions per wave per tile
   constexpr int ABUF = BM * 16, BBUF = BN * 16;               // floats per buffer
   // Buffer counts: tile kt+NB is requested in the middle of iteration kt, NB-1 iterations before its
-  // first fragment read.  A (activations, HBM/L2 latency) gets 3 buffers, Bt (weights, L2-resident) 3 if
-  // they fit the LDS request, else 2.
+  // first fragment read.  A gets 3 buffers, B 3 if they fit the LDS request, else 2.
   constexpr int NBA = (3 * ABUF + 2 * BBUF) * 4 <= Cfg::LDS_BYTES ? 3 : 2;
   constexpr int NBB = (NBA == 3 && (3 * ABUF + 3 * BBUF) * 4 <= Cfg::LDS_BYTES) ? 3 : 2;
   static_assert(Cfg::WK == 1 && Cfg::KW == 16, "LDS-DMA pipeline: BK = 16, no intra-block split-K");
   static_assert((BM / 16) % WM == 0 && (BN / 16) % WM == 0, "16-row DMA groups must split evenly over the waves");
   static_assert((NBA * ABUF + NBB * BBUF) * 4 <= Cfg::LDS_BYTES, "DMA buffers must fit the LDS request");
+  static_assert(!KMAJ || (BM == 128 && BN == 128), "k-major tiles: one DMA instruction = two 128-float k rows");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nk = K / 16;
+  const int nk = ke > ks ? (ke - ks) / 16 : 0;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -462,19 +465,29 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int K, int row_bas
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // per-thread source offsets (bytes, k = 0) of this wave's DMA instructions; chunk index swizzled
+  // per-thread source offsets (bytes, first K tile) of this wave's DMA instructions
   unsigned voffa[NIA], voffb[NIB];
 #pragma unroll
   for (int i = 0; i < NIA; ++i) {
-    const int r = (i * WM + wm) * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((r >> 2) & 3);
-    voffa[i] = (unsigned)(((long)min(row_base + r, M - 1) * lda + c * 4) * 4);
+    if constexpr (KMAJ) {
+      const int krow = (i * WM + wm) * 2 + (lane >> 5);
+      voffa[i] = (unsigned)(((long)krow * lda + row_base + (lane & 31) * 4) * 4);
+    } else {
+      const int r = (i * WM + wm) * 16 + (lane >> 2);
+      const int c = (lane & 3) ^ ((r >> 2) & 3);  // chunk index swizzled on the source side
+      voffa[i] = (unsigned)(((long)min(row_base + r, M - 1) * lda + c * 4) * 4);
+    }
   }
 #pragma unroll
   for (int i = 0; i < NIB; ++i) {
-    const int r = (i * WM + wm) * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((r >> 2) & 3);
-    voffb[i] = (unsigned)(((long)min(col_base + r, N - 1) * ldb + c * 4) * 4);
+    if constexpr (KMAJ) {
+      const int krow = (i * WM + wm) * 2 + (lane >> 5);
+      voffb[i] = (unsigned)(((long)krow * ldb + col_base + (lane & 31) * 4) * 4);
+    } else {
+      const int r = (i * WM + wm) * 16 + (lane >> 2);
+      const int c = (lane & 3) ^ ((r >> 2) & 3);
+      voffb[i] = (unsigned)(((long)min(col_base + r, N - 1) * ldb + c * 4) * 4);
+    }
   }
   float* const sA = smem;
   float* const sB = smem + NBA * ABUF;
@@ -483,38 +496,52 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int K, int row_bas
   auto koff = [&](int kt) {
     int t = kt + rot;
     if (t >= nk) t -= nk;
-    return t * 16;
+    return ks + t * 16;
   };
   auto issue_a = [&](int kt, int buf) {
-    const float* ak = A + koff(kt);
+    const float* ak = A + (KMAJ ? (long)koff(kt) * lda : (long)koff(kt));
 #pragma unroll
     for (int i = 0; i < NIA; ++i) glds16(voffa[i], ak, ldsA + buf * (ABUF * 4) + (i * WM + wm) * 1024);
   };
   auto issue_b = [&](int kt, int buf) {
-    const float* bk = Bt + koff(kt);
+    const float* bk = B + (KMAJ ? (long)koff(kt) * ldb : (long)koff(kt));
 #pragma unroll
     for (int i = 0; i < NIB; ++i) glds16(voffb[i], bk, ldsB + buf * (BBUF * 4) + (i * WM + wm) * 1024);
   };
 
-  const int sw = ((lane & 31) >> 2) & 3, hi = lane >> 5;
-  const int rowoff = (lane & 31) * 16;
-  const int ch0 = ((0 + hi) ^ sw) * 4, ch1 = ((2 + hi) ^ sw) * 4;
-  auto read_frags = [&](int bufa, int bufb, int chunk_off, float4& a4, float4 (&b4)[NT]) {
-    const float* sa = sA + bufa * ABUF + (wm * 32) * 16 + rowoff + chunk_off;
-    const float* sb = sB + bufb * BBUF + rowoff + chunk_off;
-    a4 = *reinterpret_cast<const float4*>(sa);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) b4[j] = *reinterpret_cast<const float4*>(sb + j * 32 * 16);
+  // fragments of half a tile (8 k values = 4 MFMA k-steps): af[s] / bf[j][s] feed k-step s
+  struct Frag {
+    float a[4];
+    float b[NT][4];
   };
-  auto mfma16 = [&](const float4& a4, const float4 (&b4)[NT]) {
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int sw = (l31 >> 2) & 3;
+  auto read_frags = [&](int bufa, int bufb, int half, Frag& f) {
+    if constexpr (KMAJ) {
+      const float* sa = sA + bufa * ABUF + (half * 8 + hi) * BM + wm * 32 + l31;
+      const float* sb = sB + bufb * BBUF + (half * 8 + hi) * BN + l31;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[j].x, acc[j], 0, 0, 0);
+      for (int s4 = 0; s4 < 4; ++s4) {
+        f.a[s4] = sa[s4 * 2 * BM];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[j].y, acc[j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) f.b[j][s4] = sb[s4 * 2 * BN + j * 32];
+      }
+    } else {
+      const int ch = ((half * 2 + hi) ^ sw) * 4;
+      const float4 a4 = *reinterpret_cast<const float4*>(sA + bufa * ABUF + (wm * 32 + l31) * 16 + ch);
+      f.a[0] = a4.x; f.a[1] = a4.y; f.a[2] = a4.z; f.a[3] = a4.w;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[j].z, acc[j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) {
+        const float4 b4 = *reinterpret_cast<const float4*>(sB + bufb * BBUF + (j * 32 + l31) * 16 + ch);
+        f.b[j][0] = b4.x; f.b[j][1] = b4.y; f.b[j][2] = b4.z; f.b[j][3] = b4.w;
+      }
+    }
+  };
+  auto mfma16 = [&](const Frag& f) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[j].w, acc[j], 0, 0, 0);
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s4], f.b[j][s4], acc[j], 0, 0, 0);
   };
   // s_waitcnt needs an immediate.  n = DMA instructions of this wave allowed to stay in flight.
   auto wait_vm = [&](int n) {
@@ -526,14 +553,15 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int K, int row_bas
       case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
       case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
       case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
   };
-  static_assert(NIA * (NBA - 1) + NIB * (NBB - 1) <= 6 || true, "wait_vm immediates");
 
   if (nk > 0) {
-    float4 a0, b0[NT], a1, b1[NT];
-    // request order inside every group is Bt first, then A: the operand with fewer buffers is always the
+    Frag f0, f1;
+    // request order inside every group is B first, then A: the operand with fewer buffers is always the
     // older request, so "tile kt+1 of both operands has landed" == "at most the younger A requests are left"
     issue_b(0, 0);
     issue_a(0, 0);
@@ -544,12 +572,12 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int K, int row_bas
     }
     wait_vm(NIA * (min(nk, NBA) - 1) + NIB * (min(nk, NBB) - 1));
     asm volatile("s_barrier" ::: "memory");
-    read_frags(0, 0, ch0, a0, b0);
+    read_frags(0, 0, 0, f0);
     int ca = 0, cb = 0;
     for (int kt = 0; kt < nk; ++kt) {
       const int na = (ca + 1 == NBA) ? 0 : ca + 1, nb = (cb + 1 == NBB) ? 0 : cb + 1;
-      read_frags(ca, cb, ch1, a1, b1);
-      mfma16(a0, b0);
+      read_frags(ca, cb, 1, f1);
+      mfma16(f0);
       // tile kt fully consumed by this wave, its share of tile kt+1 landed -> meet the other waves.
       // (sched_barrier: MFMAs carry no side effects, the scheduler would otherwise sink the burst below
       // the barrier and expose the fragment-read latency in front of it)
@@ -559,8 +587,8 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int K, int row_bas
       __builtin_amdgcn_sched_barrier(0);
       if (kt + NBB < nk) issue_b(kt + NBB, cb);
       if (kt + NBA < nk) issue_a(kt + NBA, ca);
-      if (kt + 1 < nk) read_frags(na, nb, ch0, a0, b0);
-      mfma16(a1, b1);
+      if (kt + 1 < nk) read_frags(na, nb, 0, f0);
+      mfma16(f1);
       ca = na;
       cb = nb;
     }
@@ -568,28 +596,38 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int K, int row_bas
   epi(acc, row_base + wm * 32, col_base, lane, M, N, smem + wm * 1024);
 }
 
-template <class Cfg, class Epi>
+template <class Cfg, bool KMAJ, class Epi>
 __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW)
-gemm_f32_glds_kernel(int M, int N, int K, int tiles_m, int tiles_n, int rotate, const float* A, long lda,
-                     const float* Bt, long ldb, Epi epi) {
+gemm_f32_glds_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, int rotate, const float* A, long lda,
+                     const float* B, long ldb, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = wg % tiles_n;
-  const int tile_m = wg / tiles_n;
-  gemm_block_glds<Cfg>(M, N, K, tile_m * Cfg::BM, tile_n * Cfg::BN, rotate ? tile_m * 5 + tile_n * 3 : -1, A, lda, Bt,
-                       ldb, epi, smem);
+  const int tile_m = (wg / tiles_n) % tiles_m;
+  const int split = wg / (tiles_n * tiles_m);
+  const int ks = split * kchunk, ke = min(K, ks + kchunk);
+  gemm_block_glds<Cfg, KMAJ>(M, N, ks, ke, tile_m * Cfg::BM, tile_n * Cfg::BN,
+                             rotate ? tile_m * 5 + tile_n * 3 + split : -1, A, lda, B, ldb, epi, smem);
 }
 
-// C[M x N] = epi(A[M x K] * Bt[N x K]^T), K % 16 == 0, row byte offsets below 4 GB.
-template <class Cfg, class Epi>
-static int launch_gemm_glds(int M, int N, int K, const float* A, long lda, const float* Bt, long ldb, const Epi& e,
-                            hipStream_t stream) {
+// KMAJ == false: C[M x N] = epi(A[M x K] * Bt[N x K]^T), K % 16 == 0, row byte offsets below 4 GB.
+// KMAJ == true : C[M x N] (+)= epi over `splits` K ranges of A[K x M]^T * B[K x N]; M, N % 128 == 0, K % 16 == 0.
+template <class Cfg, bool KMAJ, class Epi>
+static int launch_gemm_glds(int M, int N, int K, int splits, const float* A, long lda, const float* B, long ldb,
+                            const Epi& e, hipStream_t stream) {
   if (M <= 0 || N <= 0) return VD_OK;
-  VD_CHECK_ARG(K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (long)M * lda * 4 < (1L << 32) &&
-                   (long)N * ldb * 4 < (1L << 32),
+  VD_CHECK_ARG(K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && splits >= 1,
                "launch_gemm_glds: unsupported shape M=%d N=%d K=%d", M, N, K);
+  if (KMAJ)
+    VD_CHECK_ARG(M % Cfg::BM == 0 && N % Cfg::BN == 0, "launch_gemm_glds: k-major tiles need M, N %% 128 == 0");
+  else
+    VD_CHECK_ARG((long)M * lda * 4 < (1L << 32) && (long)N * ldb * 4 < (1L << 32) && splits == 1,
+                 "launch_gemm_glds: row offsets beyond 32 bits");
   const int tiles_m = vd_cdiv(M, Cfg::BM), tiles_n = vd_cdiv(N, Cfg::BN);
-  auto kern = gemm_f32_glds_kernel<Cfg, Epi>;
+  int kchunk = vd_cdiv(vd_cdiv(K, splits), 16) * 16;
+  if (kchunk < 16) kchunk = 16;
+  splits = vd_cdiv(K, kchunk);
+  auto kern = gemm_f32_glds_kernel<Cfg, KMAJ, Epi>;
   static bool attr_set = false;
   if (!attr_set) {
     VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -601,8 +639,8 @@ static int launch_gemm_glds(int M, int N, int K, const float* A, long lda, const
     const char* ev = getenv("VD_GEMM_ROTATE");
     rotate = ev ? atoi(ev) : 1;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, M, N, K, tiles_m,
-                     tiles_n, rotate, A, lda, Bt, ldb, e);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, M, N, K,
+                     kchunk, tiles_m, tiles_n, rotate, A, lda, B, ldb, e);
   VD_LAUNCH_CHECK();
   return VD_OK;
 }

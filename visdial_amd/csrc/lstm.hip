@@ -275,7 +275,7 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
     if (use_glds_bwd(N, H) && K > 0) {
       // LDS-DMA pipeline: A = da_{t+1} rows, Bt = Wh rows (both contiguous in k = the 4H gate columns)
       EpiLstmBwd<2> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
-      return launch_gemm_glds<CfgB11>(N, H, K, da_next, 4L * H, Wh, 4L * H, e, s);
+      return launch_gemm_glds<CfgB11, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e, s);
     }
     EpiLstmBwd<4> e4{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
     EpiLstmBwd<2> e2{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
@@ -493,7 +493,7 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
       e.h_out = h + t * NH + r0 * H;
       e.H = H;
       if (glds && hp)
-        rc = launch_gemm_glds<CfgF9>(nr, 4 * H, H, hp, (long)H, WhT, (long)H, e, rc_.stream[ch]);
+        rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e, rc_.stream[ch]);
       else
         rc = lstm_step_fwd(hp, Wh, nr, H, hp ? H : 0, e, rc_.stream[ch]);
       if (rc) return rc;
