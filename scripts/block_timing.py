@@ -39,11 +39,11 @@ def main():
     print("T=%d steps: %.3f ms (%.1f us / step)" % (T, e0.elapsed_time(e1), e0.elapsed_time(e1) / T * 1e3))
     lib = _lib.load()
     nb = ((N + 127) // 128) * 16
-    buf = np.zeros(nb * 8, dtype=np.uint64)
+    buf = np.zeros(nb * 12, dtype=np.uint64)
     lib.vd_debug_timing.argtypes = [C.c_void_p, C.c_int]
     rc = lib.vd_debug_timing(buf.ctypes.data, buf.size)
     assert rc == 0
-    t = buf.reshape(nb, 8).astype(np.int64)
+    t = buf.reshape(nb, 12).astype(np.int64)
     ok = (t[:, 0] > 0) & (t[:, 4] > t[:, 0])
     print('workgroups with complete stamps: %d of %d' % (ok.sum(), nb))
     t = t[ok]
@@ -64,6 +64,15 @@ def main():
         span / 100.0, (r1 - r0).mean() / 100.0, (r1 - r0).sum() / span))
     res = [int(((r0 <= s0 + f * span) & (r1 > s0 + f * span)).sum()) for f in np.linspace(0.025, 0.975, 20)]
     print("resident workgroups at 20 points across the launch:", res)
+    if t[:, 8].min() > 0:
+        l0, l1 = t[:, 8], t[:, 9]
+        pts = np.linspace(0.02, 0.98, 49)
+        inloop = [int(((l0 <= s0 + f * span) & (l1 > s0 + f * span)).sum()) for f in pts]
+        alive = [int(((r0 <= s0 + f * span) & (r1 > s0 + f * span)).sum()) for f in pts]
+        print("workgroups inside their K loop / alive at 49 points across the launch:")
+        print(" ".join("%d/%d" % (a, b) for a, b in zip(inloop, alive)))
+        print("time-averaged: %.0f in K loop, %.0f alive (768 slots); K-loop share of lifetime %.1f %%" % (
+            (l1 - l0).sum() / span, (r1 - r0).sum() / span, 100.0 * (l1 - l0).sum() / (r1 - r0).sum()))
     print("shader clock during the launch ~ %.2f GHz" % (tot.mean() / ((r1 - r0).mean() * 10.0)))
 
 

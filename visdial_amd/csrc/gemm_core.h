@@ -26,7 +26,7 @@
 // (s_memtime) at the phase boundaries of gemm_block and the 100 MHz chip-wide clock (s_memrealtime) at
 // its start and end; scripts/block_timing.py reads the table back.  Never compiled into the product.
 #ifdef VD_TIMING
-#define VD_TSLOTS 8
+#define VD_TSLOTS 12
 #define VD_TBLOCKS 8192
 static __device__ unsigned long long vd_tbuf[VD_TBLOCKS * VD_TSLOTS];
 #define VD_TSTAMP(i, clk)                                                                \
@@ -458,6 +458,8 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
   const int tid = threadIdx.x, lane = tid & 63;
   const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nk = ke > ks ? (ke - ks) / 16 : 0;
+  VD_T(0);
+  VD_TREAL(6);
 
   f32x16 acc[NT];
 #pragma unroll
@@ -572,6 +574,8 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
     }
     wait_vm(NIA * (min(nk, NBA) - 1) + NIB * (min(nk, NBB) - 1));
     asm volatile("s_barrier" ::: "memory");
+    VD_T(1);
+    VD_TREAL(8);
     read_frags(0, 0, 0, f0);
     int ca = 0, cb = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -582,7 +586,17 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
       // (sched_barrier: MFMAs carry no side effects, the scheduler would otherwise sink the burst below
       // the barrier and expose the fragment-read latency in front of it)
       __builtin_amdgcn_sched_barrier(0);
-      wait_vm(NIA * max(0, min(kt + NBA - 1, nk - 1) - (kt + 1)) + NIB * max(0, min(kt + NBB - 1, nk - 1) - (kt + 1)));
+      if (kt + NBA <= nk) {  // steady state: constant allowance, one immediate
+        constexpr int STEADY = NIA * (NBA - 2) + NIB * (NBB - 2);
+        if constexpr (STEADY == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (STEADY == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if constexpr (STEADY == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if constexpr (STEADY == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if constexpr (STEADY == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else static_assert(STEADY <= 4, "steady-state vmcnt immediate");
+      } else {
+        wait_vm(NIA * max(0, min(kt + NBA - 1, nk - 1) - (kt + 1)) + NIB * max(0, min(kt + NBB - 1, nk - 1) - (kt + 1)));
+      }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       if (kt + NBB < nk) issue_b(kt + NBB, cb);
@@ -592,8 +606,12 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
       ca = na;
       cb = nb;
     }
+    VD_T(2);
+    VD_TREAL(9);
   }
   epi(acc, row_base + wm * 32, col_base, lane, M, N, smem + wm * 1024);
+  VD_T(4);
+  VD_TREAL(7);
 }
 
 template <class Cfg, bool KMAJ, class Epi>
