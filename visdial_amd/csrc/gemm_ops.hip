@@ -90,7 +90,8 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
   SrcK a{A, lda}, b{B, ldb};
   EpiAtomic<4> e{C, ldc};
   const long tiles = (long)vd_cdiv(M, CfgBig::BM) * vd_cdiv(N, CfgBig::BN);
-  long splits = vd_cdiv(1024, tiles);
+  static const int target = getenv("VD_TN_BLOCKS") ? atoi(getenv("VD_TN_BLOCKS")) : 1024;
+  long splits = vd_cdiv(target, tiles);
   const long max_splits = vd_cdiv(K, 4 * CfgBig::BK);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
