@@ -79,6 +79,102 @@ def test_mnatt_disc_step_matches_oracle(gpu, case, train_mode):
         assert np.abs(after[k].reshape(-1) - w2).max() < 1e-6, k
 
 
+def _make_ragged(batch, p, rng):
+    """Hand-made corner cases on top of a synthetic batch: empty and full-length questions / history rounds /
+    options, a whole dialog of empty questions, all-identical tokens (scatter collisions), duplicated options."""
+    q, h, o = batch['ques_fwd'], batch['hist'], batch['options']
+    B, R, Tq = q.shape
+    Th, To = h.shape[2], o.shape[2]
+    V = p['vocabSize']
+    q[0, 0, :] = 0                                        # zero-length question (all pad)
+    q[0, 1, :] = rng.randint(1, V + 1, size=Tq)           # maximum-length question
+    q[B - 1, :, :] = 0                                    # a dialog whose questions are all empty
+    q[1 % B, R - 1, :] = 0
+    q[1 % B, R - 1, Tq - 1] = 7                           # one-token question (right-aligned)
+    h[0, 0, :] = rng.randint(1, V + 1, size=Th)           # maximum-length history round
+    h[0, R - 1, :] = 0                                    # empty history round
+    h[B - 1, 0, :] = 0
+    h[B - 1, 0, Th - 1] = 3
+    N = B * R
+    o[0, 0, :] = 0                                        # zero-length option (all pad)
+    o[0, 1, :] = rng.randint(1, V + 1, size=To)           # maximum-length option
+    o[1 % N, :, :] = 0
+    o[1 % N, :, 0] = 5                                    # every option of a round identical (ties) ...
+    o[1 % N, 0, 0] = 9                                    # ... except the ground truth
+    batch['answer_ind'][1 % N] = 1
+    o[N - 1, 2, :] = o[N - 1, 3, :]                       # duplicated option inside a round
+    o[2 % N, :, :] = np.where(o[2 % N] > 0, 11, 0)        # one token id everywhere (embedding-gradient collisions)
+    return batch
+
+
+@pytest.mark.parametrize("train_mode", [False, True])
+def test_ragged_empty_and_max_length_inputs(gpu, train_mode):
+    """Edge cases of the batch contract: pad-only rows, full-length rows, ties, collisions."""
+    from visdial_amd.model import Model
+    p = derive(small_params(**CASES['odd']))
+    dl = SyntheticDataloader(p, seed=23)
+    rng = np.random.RandomState(3)
+    batch = _make_ragged(dl.getTrainBatch(p), p, rng)
+    model = Model(p)
+    masks = None
+    if train_mode:
+        masks = make_masks(p, batch, np.random.RandomState(6))
+        model.set_dropout_masks(masks)
+    else:
+        model.wrapper.evaluate()
+    P0 = {k: v.astype(np.float64) for k, v in model.get_parameters_dict().items()}
+    model.wrapper.zeroGradParameters()
+    loss = model.forwardBackward(batch)
+    drop = {k: v.astype(np.float64) for k, v in masks.items()} if masks else None
+    ref = vo.forward_backward(p['encoder'], p['decoder'], P0, p, batch, drop)
+    assert np.isfinite(loss) and abs(loss - ref['loss']) < 1e-4
+    g = model.get_gradients_dict()
+    bad = [(rel(g[k], ref['grads'][k]), k) for k in ref['grads']
+           if rel(g[k], ref['grads'][k]) >= 1e-4 and np.abs(g[k] - ref['grads'][k]).max() >= 1e-6]
+    assert not bad, bad
+    assert all(np.isfinite(v).all() for v in g.values())
+    assert rel(model.decoder.output.cpu().numpy(), ref['scores']) < 1e-4
+
+
+@pytest.mark.parametrize("enc", ['lf-ques-im-hist', 'hre-ques-im-hist'])
+def test_ragged_inputs_gen_decoder(gpu, enc):
+    """Same corner cases for the generative decoder: empty questions / history, an empty answer (only
+    <START> -> <END>), a maximum-length answer."""
+    from visdial_amd.model import Model
+    p = derive(small_params(encoder=enc, decoder='gen', **CASES['odd']))
+    dl = SyntheticDataloader(p, seed=29)
+    batch = dl.getTrainBatch(p)
+    rng = np.random.RandomState(8)
+    q, h = batch['ques_fwd'], batch['hist']
+    B, R, Tq = q.shape
+    q[0, 0, :] = 0
+    q[B - 1, :, :] = 0
+    q[0, 1, :] = rng.randint(1, p['vocabSize'] - 2, size=Tq)
+    h[0, R - 1, :] = 0
+    h[1 % B, 0, :] = rng.randint(1, p['vocabSize'] - 2, size=h.shape[2])
+    ai, ao = batch['answer_in'], batch['answer_out']
+    Ta = ai.shape[2]
+    start, end = ai[0, 0, 0], dl.endToken
+    ai[0, 0, :] = 0
+    ao[0, 0, :] = 0
+    ai[0, 0, 0] = start                                   # empty answer: <START> -> <END>
+    ao[0, 0, 0] = end
+    full = rng.randint(1, p['vocabSize'] - 2, size=Ta - 1)
+    ai[0, 1, :] = np.concatenate([[start], full])         # maximum-length answer
+    ao[0, 1, :] = np.concatenate([full, [end]])
+    model = Model(p)
+    model.wrapper.evaluate()
+    P0 = {k: v.astype(np.float64) for k, v in model.get_parameters_dict().items()}
+    model.wrapper.zeroGradParameters()
+    loss = model.forwardBackward(batch)
+    ref = vo.forward_backward(p['encoder'], p['decoder'], P0, p, batch, None)
+    assert np.isfinite(loss) and abs(loss - ref['loss']) < 1e-4 * max(1.0, abs(ref['loss']))
+    g = model.get_gradients_dict()
+    bad = [(rel(g[k], ref['grads'][k]), k) for k in ref['grads']
+           if rel(g[k], ref['grads'][k]) >= 1e-4 and np.abs(g[k] - ref['grads'][k]).max() >= 1e-6]
+    assert not bad, bad
+
+
 def test_ranks_and_metrics_match_oracle(gpu):
     from visdial_amd.model import Model
     from visdial_amd import utils
