@@ -69,7 +69,10 @@ int vd_colsum_acc(const float* X, int64_t ld, int M, int N, float* out, void* st
  * (tok_gather != NULL, [T x N]): row = xproj + tok_gather[t,n]*x_ld (xproj = Emb*Wx+b, [V+1 x 4H]).
  * tok_mask ([T x N] or NULL) implements :maskZero(): rows with token 0 get h = c = gates = 0.
  * h0/c0 ([N x H] or both NULL = zeros) are userPrevOutput/userPrevCell (gen.lua:32-38).
- * Outputs: gates [T x N x 4H] post-activation (i,f,o,g), h and c [T x N x H]. */
+ * Outputs: gates [T x N x 4H] post-activation (i,f,o,g), h and c [T x N x H].
+ * Throughput shapes (N >= 2048) run on the LDS-DMA pipeline and use a library-owned 4H x H scratch
+ * (gate-interleaved transpose of Wh, rebuilt per call): such calls must not overlap on different
+ * streams of the same host thread. */
 int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const int32_t* tok_gather,
                     const int32_t* tok_mask, const float* Wh, const float* h0, const float* c0, float* gates,
                     float* h, float* c, int T, int N, int H, void* stream);
