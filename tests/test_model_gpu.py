@@ -38,12 +38,15 @@ CASES = {
     'mid': dict(vocabSize=300, embedSize=300, rnnHiddenSize=512, imgFeatureSize=512, imgSpatialSize=14,
                  commonEmbeddingSize=512, maxQuesCount=10, batchSize=2, numOptions=100, maxQuesLen=20, maxAnsLen=20,
                  maxHistoryLenPerRound=40),
+    # BASELINE.json configs[4] shape (ResNet-200 7x7x2048 features), other dims reduced for the oracle
+    'resnet': dict(vocabSize=120, embedSize=48, rnnHiddenSize=128, imgFeatureSize=2048, imgSpatialSize=7,
+                   commonEmbeddingSize=128, maxQuesCount=4, batchSize=2, numOptions=20, maxQuesLen=8, maxAnsLen=6),
     'odd': dict(vocabSize=97, embedSize=36, rnnHiddenSize=96, imgFeatureSize=40, imgSpatialSize=5,
                 commonEmbeddingSize=64, maxQuesCount=3, batchSize=5, numOptions=11, maxQuesLen=9, maxAnsLen=4),
 }
 
 
-@pytest.mark.parametrize("case", ['tiny', 'odd', 'mid'])
+@pytest.mark.parametrize("case", ['tiny', 'odd', 'mid', 'resnet'])
 @pytest.mark.parametrize("train_mode", [False, True])
 def test_mnatt_disc_step_matches_oracle(gpu, case, train_mode):
     from visdial_amd.model import Model
