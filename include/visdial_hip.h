@@ -48,6 +48,11 @@ int vd_stream_synchronize(void* stream);
 int vd_copy_2d(float* dst, int64_t dst_ld, const float* src, int64_t src_ld, int64_t rows, int64_t cols,
                void* stream);
 
+/* `flags` of the contraction / recurrence entry points: VD_FLAG_BF16 rounds the GEMM operands to bf16 (RNE) and
+ * multiplies them on the bf16 MFMA with fp32 accumulation -- the opt-in "bf16 LSTM step" of BASELINE.json
+ * configs[4].  0 = exact fp32 (the reference's arithmetic, the headline configuration). */
+#define VD_FLAG_BF16 1
+
 /* ---- dense contractions (nn.Linear / hoisted SeqLSTM input projection / weight grads) -- */
 /* C[MxN] (+)= act(A[MxK] * W[NxK]^T + bias)   -- nn.Linear:updateOutput (+nn.Tanh),
  * e.g. encoders/mn-att-ques-im-hist.lua:64-65,77,88,106; also dX = dA * Wh^T style products. */
@@ -58,7 +63,7 @@ int vd_gemm_nn(const float* A, int64_t lda, const float* B, int64_t ldb, const f
                int64_t ldc, int M, int N, int K, int accumulate, void* stream);
 /* C[MxN] += A[KxM]^T * B[KxN]                  -- accGradParameters of nn.Linear / nn.SeqLSTM */
 int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
-                   int N, int K, void* stream);
+                   int N, int K, int flags, void* stream);
 /* out[N] += column sums of X[MxN]              -- gradBias */
 int vd_colsum_acc(const float* X, int64_t ld, int M, int N, float* out, void* stream);
 
@@ -75,7 +80,7 @@ int vd_colsum_acc(const float* X, int64_t ld, int M, int N, float* out, void* st
  * streams of the same host thread. */
 int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const int32_t* tok_gather,
                     const int32_t* tok_mask, const float* Wh, const float* h0, const float* c0, float* gates,
-                    float* h, float* c, int T, int N, int H, void* stream);
+                    float* h, float* c, int T, int N, int H, int flags, void* stream);
 /* Backward through time.  gates is overwritten IN PLACE by da (gradient w.r.t. the pre-activation
  * gates, = gradient of xproj).  dh_seq [T x N x H] or NULL: gradient arriving at every h_t;
  * dh_last [N x H] or NULL: extra gradient at h_{T-1} (nn.Select(1,-1)); dc_last or NULL:
@@ -83,7 +88,7 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
  * dh0 [N x H] or NULL receives dL/dh0 (userGradPrevOutput, gen.lua:50-58). */
 int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float* c0, const float* dh_seq,
                      const float* dh_last, const float* dc_last, float* dc_work, float* dh0, int T, int N,
-                     int H, void* stream);
+                     int H, int flags, void* stream);
 
 /* Two stacked nn.SeqLSTM layers (the pattern of every encoder branch: mn-att:27-45, lf-ques.lua:17-24)
  * advanced as a skewed wavefront, up to 2 independent stacks per call (history + question branches):

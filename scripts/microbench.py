@@ -53,6 +53,13 @@ def main():
     ms = timeit(lambda: ops.gemm_tn_acc(hh, gg[N:], dWh, M=H, N=4 * H, K=K), iters=3, warm=1)
     print("dWh tn_acc K=%d: %.2f ms  %.1f TFLOP/s" % (K, ms, 2.0 * H * 4 * H * K / ms / 1e9))
 
+    if os.environ.get("MB_BF16"):
+        ms = timeit(lambda: ops.lstm_forward(table, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok, flags=1))
+        print("option LSTM fwd  bf16 operands: %.2f ms  (%.1f TFLOP/s-equivalent)" % (ms, fl / ms / 1e9))
+        ms = timeit(lambda: ops.lstm_backward(Wh, gates, c, dcw, T, N, H, dh_last=dh_last, flags=1), iters=3, warm=1)
+        print("option LSTM bwd  bf16 operands: %.2f ms  (%.1f TFLOP/s-equivalent)" % (ms, fl / ms / 1e9))
+        ms = timeit(lambda: ops.gemm_tn_acc(hh, gg[N:], dWh, M=H, N=4 * H, K=K, flags=1), iters=3, warm=1)
+        print("dWh tn_acc bf16 operands: %.2f ms  (%.1f TFLOP/s-equivalent)" % (ms, 2.0 * H * 4 * H * K / ms / 1e9))
     if only_big:
         return
     # encoder-sized recurrent steps (latency-bound)

@@ -9,6 +9,7 @@
 #define VD_ERR_ARG -1
 #define VD_ERR_HIP -2
 #define VD_ERR_STATE -3
+#define VD_FLAG_BF16 1  // see include/visdial_hip.h
 
 // thread-local message returned by vd_last_error()
 void vd_set_error(const char* fmt, ...);

@@ -42,14 +42,19 @@ static __device__ unsigned long long vd_tbuf[VD_TBLOCKS * VD_TSLOTS];
 
 // LDSMIN: request at least this much LDS per workgroup (occupancy shaping, see lstm.hip: throughput
 // shapes are held to 3 workgroups per CU so that a latency-shape workgroup of another stream always fits).
-template <int WM_, int WK_, int NT_, int KW_, int DB_ = 1, int MINW_ = 1, int LDSMIN_ = 0>
+// BF16: operands are rounded to bf16 (RNE) while they are staged into LDS and multiplied on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the opt-in reduced-precision recurrence of BASELINE.json
+// configs[4]; never used by the fp32 headline path.
+template <int WM_, int WK_, int NT_, int KW_, int DB_ = 1, int MINW_ = 1, int LDSMIN_ = 0, int BF16_ = 0>
 struct GemmCfg {
   static constexpr int WM = WM_, WK = WK_, NT = NT_, KW = KW_, DB = DB_, MINW = MINW_;
   static constexpr int BM = WM * 32, BN = NT * 32, BK = WK * KW;
   static constexpr int THREADS = WM * WK * 64;
-  static constexpr int STRIDE = BK + 4;  // floats
+  static constexpr int BF16 = BF16_;
+  static constexpr int ELEM_BYTES = BF16 ? 2 : 4;
+  static constexpr int STRIDE = BF16 ? BK + 8 : BK + 4;  // LDS row stride in elements (fp32 or bf16)
   static constexpr int BUF_FLOATS = (BM + BN) * STRIDE;
-  static constexpr int STAGE_BYTES = (DB == 1 ? 2 : 1) * BUF_FLOATS * 4;
+  static constexpr int STAGE_BYTES = (DB == 1 ? 2 : 1) * BUF_FLOATS * ELEM_BYTES;  // BUF_FLOATS counts elements
   static constexpr int RED_BYTES = (WK - 1) * WM * 16 * 64 * 4;  // one 32x32 tile per parked wave at a time
   static constexpr int EPI_BYTES = WM * 32 * 32 * 4;  // per-wave 32x32 transposition scratch for row-vectorised epilogues
   static constexpr int LDS_BYTES0 = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
@@ -58,6 +63,7 @@ struct GemmCfg {
   static constexpr int NA = (BM * BK / 4) / THREADS;
   static constexpr int NB = (BN * BK / 4) / THREADS;
   static_assert(KW % 8 == 0, "KW must be a multiple of 8");
+  static_assert(!BF16 || (KW % 16 == 0 && DB == 0), "bf16 tiles: 16 k per MFMA, single-buffer pipeline only");
   static_assert((BM * BK / 4) % THREADS == 0 && NA >= 1, "A tile must split evenly");
   static_assert((BN * BK / 4) % THREADS == 0 && NB >= 1, "B tile must split evenly");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -252,23 +258,37 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
 
   auto load_tile = [&](int k0) { load_tile_into(k0, ra, rb); };
 
+  using elem_t = std::conditional_t<Cfg::BF16 != 0, __bf16, float>;
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  elem_t* const smem_e = reinterpret_cast<elem_t*>(smem);
+  auto put_row4 = [&](elem_t* d, const float4& v) {  // 4 consecutive k of one row
+    if constexpr (Cfg::BF16) {
+      bf16x4_t t = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      *reinterpret_cast<bf16x4_t*>(d) = t;
+    } else {
+      *reinterpret_cast<float4*>(d) = v;
+    }
+  };
+  auto put_col4 = [&](elem_t* d, const float4& v) {  // one k of 4 consecutive rows (transposing store)
+    d[0] = (elem_t)v.x;
+    d[STR] = (elem_t)v.y;
+    d[2 * STR] = (elem_t)v.z;
+    d[3 * STR] = (elem_t)v.w;
+  };
   auto store_tile_from = [&](int buf, const float4 (&ra)[NA], const float4 (&rb)[NB]) {
-    float* sa = smem + buf * Cfg::BUF_FLOATS;
-    float* sb = sa + BM * STR;
+    elem_t* sa = smem_e + buf * Cfg::BUF_FLOATS;
+    elem_t* sb = sa + BM * STR;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int f = tid + i * THREADS;
       if constexpr (!ASrc::KMAJOR) {
         const int r = f / (BK / 4), kq = f % (BK / 4);
-        *reinterpret_cast<float4*>(sa + r * STR + kq * 4) = ra[i];
+        put_row4(sa + r * STR + kq * 4, ra[i]);
       } else {
         const int klo = f & 7, g = f >> 3;
         const int r4 = g % (BM / 4), kk = (g / (BM / 4)) * 8 + klo;
-        float* d = sa + (r4 * 4) * STR + kk;
-        d[0] = ra[i].x;
-        d[STR] = ra[i].y;
-        d[2 * STR] = ra[i].z;
-        d[3 * STR] = ra[i].w;
+        put_col4(sa + (r4 * 4) * STR + kk, ra[i]);
       }
     }
 #pragma unroll
@@ -276,15 +296,11 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
       const int f = tid + i * THREADS;
       if constexpr (!BSrc::KMAJOR) {
         const int r = f / (BK / 4), kq = f % (BK / 4);
-        *reinterpret_cast<float4*>(sb + r * STR + kq * 4) = rb[i];
+        put_row4(sb + r * STR + kq * 4, rb[i]);
       } else {
         const int klo = f & 7, g = f >> 3;
         const int r4 = g % (BN / 4), kk = (g / (BN / 4)) * 8 + klo;
-        float* d = sb + (r4 * 4) * STR + kk;
-        d[0] = rb[i].x;
-        d[STR] = rb[i].y;
-        d[2 * STR] = rb[i].z;
-        d[3 * STR] = rb[i].w;
+        put_col4(sb + (r4 * 4) * STR + kk, rb[i]);
       }
     }
   };
@@ -299,25 +315,37 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
   };
   auto store_tile = [&](int buf) { store_tile_from(buf, ra, rb); };
 
-  const int frag_off = (lane & 31) * STR + wk * KW + (lane >> 5) * 4;
+  const int frag_off = (lane & 31) * STR + wk * KW + (lane >> 5) * (Cfg::BF16 ? 8 : 4);
   auto mfma_tile = [&](int buf) {
-    const float* sa = smem + buf * Cfg::BUF_FLOATS + (wm * 32) * STR + frag_off;
-    const float* sb = smem + buf * Cfg::BUF_FLOATS + BM * STR + frag_off;
+    const elem_t* sa = smem_e + buf * Cfg::BUF_FLOATS + (wm * 32) * STR + frag_off;
+    const elem_t* sb = smem_e + buf * Cfg::BUF_FLOATS + BM * STR + frag_off;
+    if constexpr (Cfg::BF16) {
+      // 32x32x16: a lane feeds 8 consecutive k (lanes 0-31: k..k+7, lanes 32-63: k+8..k+15) = one ds_read_b128
 #pragma unroll
-    for (int kc = 0; kc < KW / 8; ++kc) {
-      const float4 a4 = *reinterpret_cast<const float4*>(sa + kc * 8);
-      float4 b4[NT];
+      for (int kc = 0; kc < KW / 16; ++kc) {
+        const bf16x8_t a8 = *reinterpret_cast<const bf16x8_t*>(sa + kc * 16);
+        bf16x8_t b8[NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        b4[j] = *reinterpret_cast<const float4*>(sb + j * 32 * STR + kc * 8);
+        for (int j = 0; j < NT; ++j) b8[j] = *reinterpret_cast<const bf16x8_t*>(sb + j * 32 * STR + kc * 16);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[j].x, acc[j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8[j], acc[j], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[j].y, acc[j], 0, 0, 0);
+      for (int kc = 0; kc < KW / 8; ++kc) {
+        const float4 a4 = *reinterpret_cast<const float4*>(sa + kc * 8);
+        float4 b4[NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[j].z, acc[j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) b4[j] = *reinterpret_cast<const float4*>(sb + j * 32 * STR + kc * 8);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[j].w, acc[j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[j].x, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[j].y, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[j].z, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[j].w, acc[j], 0, 0, 0);
+      }
     }
   };
 

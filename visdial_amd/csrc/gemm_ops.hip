@@ -79,7 +79,7 @@ int vd_gemm_nn(const float* A, int64_t lda, const float* B, int64_t ldb, const f
 
 // C[M x N] += A[K x M]^T * B[K x N]   (weight gradients; split-K with float atomics)
 int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
-                   int N, int K, void* stream) {
+                   int N, int K, int flags, void* stream) {
   // M (resp. N) need not be a multiple of 4 when the rows of A (resp. B) are padded to one.
   VD_CHECK_ARG(A && B && C && M >= 0 && N >= 0 && K >= 0 && (M % 4 == 0 || lda >= (M + 3) / 4 * 4) &&
                    (N % 4 == 0 || ldb >= (N + 3) / 4 * 4),
@@ -95,6 +95,8 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
   const long max_splits = vd_cdiv(K, 4 * CfgBig::BK);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
+  if (flags & VD_FLAG_BF16)   // opt-in reduced precision: bf16 operands, fp32 accumulation
+    return launch_gemm<GemmCfg<4, 1, 4, 32, 0, 3, 0, 1>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
   // (VD_TN_CFG=20: the LDS-DMA pipeline with k-major tiles; measured 119 vs 127 TFLOP/s for the register-staged
   //  default on the option dWh shape, so it stays opt-in)
   static const int cfg = getenv("VD_TN_CFG") ? atoi(getenv("VD_TN_CFG")) : 5;

@@ -177,6 +177,8 @@ using CfgB11 = GemmCfg<4, 1, 2, 16, 0, 4, 41984>;
 // latency shapes (N ~ 200 rows): 4-way intra-block split-K.  Single LDS buffer and <= 152 VGPRs so one
 // of these workgroups fits into the footprint a retiring throughput-shape workgroup frees (they run
 // concurrently on other streams).
+using CfgFbf16 = GemmCfg<4, 1, 4, 32, 0, 3, 0, 1>;  // bf16 operands (opt-in), BK = 32 = two 32x32x16 MFMAs per tile
+using CfgBbf16 = GemmCfg<4, 1, 2, 32, 0, 3, 0, 1>;
 using CfgFwdSmallA = GemmCfg<1, 4, 4, 8, 0, 3>;   // 32 x (32 j x 4 gates), BK = 32, 23 KB LDS
 using CfgFwdSmallB = GemmCfg<1, 4, 4, 16, 0, 3>;  // BK = 64, 43.5 KB LDS, half the dependent K iterations
 using CfgBwdSmallA = GemmCfg<1, 4, 1, 32, 0, 3>;  // 32 x 32 tile, BK = 128, 33.8 KB LDS
@@ -266,9 +268,13 @@ static int lstm_step_fwd(const float* h_prev, const float* Wh, int N, int H, int
 
 static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, int K, const float* dh_a,
                          const float* dh_b, float* gates, const float* c_t, const float* c_prev, float* dc,
-                         int dc_first, hipStream_t s) {
+                         int dc_first, hipStream_t s, int flags = 0) {
   SrcRow a{da_next, 4L * H};
   SrcRow b{Wh, 4L * H};  // B[k][n] = Wh[n][k]
+  if ((flags & VD_FLAG_BF16) && N >= 2048 && K > 0) {
+    EpiLstmBwd<2> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
+    return launch_gemm<CfgBbf16>(N, H, K, 1, a, b, e, s);
+  }
   if (N >= 2048) {
     static const int cfg0 = env_int("VD_LSTM_BWD_CFG", 20);
     const int cfg = cfg0 == 20 ? 11 : cfg0;
@@ -456,7 +462,7 @@ struct RowChains {
 // see include/visdial_hip.h
 int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const int32_t* tok_gather,
                     const int32_t* tok_mask, const float* Wh, const float* h0, const float* c0, float* gates,
-                    float* h, float* c, int T, int N, int H, void* stream) {
+                    float* h, float* c, int T, int N, int H, int flags, void* stream) {
   VD_CHECK_ARG(T >= 0 && N >= 0 && H > 0 && H % 32 == 0, "vd_lstm_forward: bad dims T=%d N=%d H=%d", T, N, H);
   VD_CHECK_ARG(xproj && Wh && gates && h && c, "vd_lstm_forward: null pointer");
   VD_CHECK_ARG((h0 == nullptr) == (c0 == nullptr), "vd_lstm_forward: h0 and c0 must both be set or both null");
@@ -466,7 +472,8 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
   // The recurrence is independent per row: throughput shapes run as row chains on separate streams so the
   // tail of one chain's step kernel is filled by the other chain's workgroups (no chip-wide drain per step).
   float* WhT = nullptr;
-  const bool glds = use_glds_fwd(N, H) && T > 1;
+  const bool bf16 = (flags & VD_FLAG_BF16) && N >= 2048 && H % 32 == 0;
+  const bool glds = (use_glds_fwd(N, H) || bf16) && T > 1;   // both paths multiply by the transposed copy
   if (glds) {
     if (int rc0 = wht_scratch(H, &WhT)) return rc0;
     hipLaunchKernelGGL(wh_gate_transpose_kernel, dim3(4 * H / 32, H / 32), dim3(256), 0, s, Wh, WhT, H);
@@ -492,7 +499,9 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
       e.c_out = c + t * NH + r0 * H;
       e.h_out = h + t * NH + r0 * H;
       e.H = H;
-      if (glds && hp)
+      if (bf16 && hp)
+        rc = launch_gemm<CfgFbf16>(nr, 4 * H, H, 1, SrcRow{hp, H}, SrcRow{WhT, H}, e, rc_.stream[ch]);
+      else if (glds && hp)
         rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e, rc_.stream[ch]);
       else
         rc = lstm_step_fwd(hp, Wh, nr, H, hp ? H : 0, e, rc_.stream[ch]);
@@ -504,7 +513,7 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
 
 int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float* c0, const float* dh_seq,
                      const float* dh_last, const float* dc_last, float* dc_work, float* dh0, int T, int N,
-                     int H, void* stream) {
+                     int H, int flags, void* stream) {
   VD_CHECK_ARG(T >= 1 && N >= 0 && H > 0 && H % 32 == 0, "vd_lstm_backward: bad dims T=%d N=%d H=%d", T, N, H);
   VD_CHECK_ARG(Wh && gates && c && dc_work, "vd_lstm_backward: null pointer");
   hipStream_t s = (hipStream_t)stream;
@@ -524,7 +533,7 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
       rc = lstm_step_bwd(da_next, Wh, nr, H, last ? 0 : 4 * H, dh_seq ? dh_seq + t * NH + r0 * H : nullptr,
                          (last && dh_last) ? dh_last + r0 * H : nullptr, gates + (long)t * 4 * NH + r0 * 4 * H,
                          c + t * NH + r0 * H, t ? c + (t - 1) * NH + r0 * H : c0r, dc_work + r0 * H,
-                         (last && !dc_last) ? 1 : 0, rc_.stream[ch]);
+                         (last && !dc_last) ? 1 : 0, rc_.stream[ch], flags);
       if (rc) return rc;
     }
   }

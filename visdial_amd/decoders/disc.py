@@ -26,6 +26,8 @@ class Decoder(object):
         self.Wx, self.Wh, self.b = W[:self.E], W[self.E:], fp.w['opt.b']
         self.dWx, self.dWh, self.db = dW[:self.E], dW[self.E:], fp.g['opt.b']
         self.streams = StreamPool(ws.device, enabled=False)     # Model attaches its own pool
+        # opt-in reduced precision of the option recurrence (BASELINE.json configs[4]); default = exact fp32
+        self.flags = ops.FLAG_BF16 if params.get('lstmPrecision', 'fp32') == 'bf16' else 0
 
     def forward(self, inputs):
         """inputs = {options [To x N*O] int32 time-major, encOut [N x H]} -> scores [N x O]"""
@@ -41,7 +43,8 @@ class Decoder(object):
         self.h = ws.get('opt.h', (To, NO, H))
         self.c = ws.get('opt.c', (To, NO, H))
         t0 = ops.prof_begin('opt_lstm_fwd_step')
-        ops.lstm_forward(self.table, self.Wh, self.gates, self.h, self.c, To, NO, H, 0, 4 * H, tok_gather=otok)
+        ops.lstm_forward(self.table, self.Wh, self.gates, self.h, self.c, To, NO, H, 0, 4 * H, tok_gather=otok,
+                         flags=self.flags)
         ops.prof_end('opt_lstm_fwd_step', t0, To)
         self.optH = self.h[To - 1]
         self.output = ws.get('opt.scores', (N, O))
@@ -65,12 +68,13 @@ class Decoder(object):
             ops.token_sort(tokf, V + 1, offset, work, perm)
             dtab.zero_()
         t0 = ops.prof_begin('opt_lstm_bwd_step')
-        ops.lstm_backward(self.Wh, self.gates, self.c, dc, To, NO, H, dh_last=d_optH)
+        ops.lstm_backward(self.Wh, self.gates, self.c, dc, To, NO, H, dh_last=d_optH, flags=self.flags)
         ops.prof_end('opt_lstm_bwd_step', t0, To)
         da = self.gates.view(To * NO, 4 * H)
         if To > 1:
             t0 = ops.prof_begin('opt_lstm_dWh')
-            ops.gemm_tn_acc(self.h.view(To * NO, H), da[NO:], self.dWh, M=H, N=4 * H, K=(To - 1) * NO)
+            ops.gemm_tn_acc(self.h.view(To * NO, H), da[NO:], self.dWh, M=H, N=4 * H, K=(To - 1) * NO,
+                            flags=self.flags)
             ops.prof_end('opt_lstm_dWh', t0, 1)
         # gradient of the gathered table: segmented row sums over the token-sorted rows
         self.streams.join('tab')

@@ -78,13 +78,16 @@ def gemm_nn(A, B, C_out, bias=None, accumulate=False, M=None, N=None, K=None, ld
     return C_out
 
 
-def gemm_tn_acc(A, B, C_acc, M=None, N=None, K=None, lda=None, ldb=None, ldc=None):
+FLAG_BF16 = 1      # VD_FLAG_BF16: bf16 operands / fp32 accumulation (opt-in, BASELINE configs[4])
+
+
+def gemm_tn_acc(A, B, C_acc, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, flags=0):
     """C[MxN] += A[KxM].T @ B[KxN]"""
     K = A.shape[0] if K is None else K
     M = A.shape[1] if M is None else M
     N = B.shape[1] if N is None else N
     call("vd_gemm_tn_acc", _p(A, F32), lda or A.stride(0), _p(B, F32), ldb or B.stride(0), _p(C_acc, F32),
-         ldc or C_acc.stride(0), M, N, K, _stream())
+         ldc or C_acc.stride(0), M, N, K, int(flags), _stream())
     return C_acc
 
 
@@ -96,14 +99,16 @@ def colsum_acc(X, out, M=None, N=None, ld=None):
 
 
 # ---------------------------------------------------------------- LSTM
-def lstm_forward(xproj, Wh, gates, h, c, T, N, H, x_tstride, x_ld, tok_gather=None, tok_mask=None, h0=None, c0=None):
+def lstm_forward(xproj, Wh, gates, h, c, T, N, H, x_tstride, x_ld, tok_gather=None, tok_mask=None, h0=None, c0=None,
+                 flags=0):
     call("vd_lstm_forward", _p(xproj, F32), x_tstride, x_ld, _p(tok_gather, I32), _p(tok_mask, I32), _p(Wh, F32),
-         _p(h0, F32), _p(c0, F32), _p(gates, F32), _p(h, F32), _p(c, F32), T, N, H, _stream())
+         _p(h0, F32), _p(c0, F32), _p(gates, F32), _p(h, F32), _p(c, F32), T, N, H, int(flags), _stream())
 
 
-def lstm_backward(Wh, gates, c, dc_work, T, N, H, c0=None, dh_seq=None, dh_last=None, dc_last=None, dh0=None):
+def lstm_backward(Wh, gates, c, dc_work, T, N, H, c0=None, dh_seq=None, dh_last=None, dc_last=None, dh0=None,
+                  flags=0):
     call("vd_lstm_backward", _p(Wh, F32), _p(gates, F32), _p(c, F32), _p(c0, F32), _p(dh_seq, F32), _p(dh_last, F32),
-         _p(dc_last, F32), _p(dc_work, F32), _p(dh0, F32), T, N, H, _stream())
+         _p(dc_last, F32), _p(dc_work, F32), _p(dh0, F32), T, N, H, int(flags), _stream())
 
 
 # ---------------------------------------------------------------- embedding / dropout / glue

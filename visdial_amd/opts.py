@@ -33,6 +33,8 @@ OPTIONS = [
     ('minLRate', 5e-5, 'Minimum learning rate'),
     ('gpuid', 0, 'GPU id to use'),
     ('backend', 'cudnn', 'accepted for CLI compatibility; ignored'),
+    # not a reference flag: the bf16 LSTM step of BASELINE.json configs[4] (option recurrence only; default exact fp32)
+    ('lstmPrecision', 'fp32', "arithmetic of the option-LSTM recurrence GEMMs: 'fp32' | 'bf16' (fp32 accumulation)"),
 ]
 
 
