@@ -85,10 +85,12 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
  * gates, = gradient of xproj).  dh_seq [T x N x H] or NULL: gradient arriving at every h_t;
  * dh_last [N x H] or NULL: extra gradient at h_{T-1} (nn.Select(1,-1)); dc_last or NULL:
  * userNextGradCell (gen.lua:49).  dc_work [N x H] scratch, on return = dL/dc0 (userGradPrevCell);
- * dh0 [N x H] or NULL receives dL/dh0 (userGradPrevOutput, gen.lua:50-58). */
+ * dh0 [N x H] or NULL receives dL/dh0 (userGradPrevOutput, gen.lua:50-58).
+ * h_seq [T x N x H] + dWh_acc [H x 4H] (both or neither): also accumulate the recurrent weight gradient
+ * dWh += sum_{t>=1} h_{t-1}^T da_t (accGradParameters). */
 int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float* c0, const float* dh_seq,
-                     const float* dh_last, const float* dc_last, float* dc_work, float* dh0, int T, int N,
-                     int H, int flags, void* stream);
+                     const float* dh_last, const float* dc_last, float* dc_work, float* dh0, const float* h_seq,
+                     float* dWh_acc, int T, int N, int H, int flags, void* stream);
 
 /* Two stacked nn.SeqLSTM layers (the pattern of every encoder branch: mn-att:27-45, lf-ques.lua:17-24)
  * advanced as a skewed wavefront, up to 2 independent stacks per call (history + question branches):

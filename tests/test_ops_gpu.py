@@ -115,17 +115,21 @@ def test_lstm_forward_backward(ops, T, N, H, masked, table):
 
     dh_seq = f32(rng, T, N, H)
     dh_last = f32(rng, N, H)
-    _, _, _, dh0_ref, dc0_ref, da_ref = vo.lstm_backward(
+    _, dW_ref, _, dh0_ref, dc0_ref, da_ref = vo.lstm_backward(
         x.astype(np.float64), W.astype(np.float64), g_ref, h_ref, c_ref, dh_seq=dh_seq.astype(np.float64),
         dh_last=dh_last.astype(np.float64), return_da=True)
     # feed the device its own forward state (already checked above)
     dc_work = torch.empty(N, H, device="cuda")
     dh0 = torch.empty(N, H, device="cuda")
-    ops.lstm_backward(Wh, gates, c, dc_work, T, N, H, dh_seq=dev(dh_seq), dh_last=dev(dh_last), dh0=dh0)
+    dWh0 = f32(rng, H, 4 * H)
+    dWh = dev(dWh0)            # accumulated INTO (accGradParameters): recurrence + trailing weight gradient
+    ops.lstm_backward(Wh, gates, c, dc_work, T, N, H, dh_seq=dev(dh_seq), dh_last=dev(dh_last), dh0=dh0,
+                      h_seq=h, dWh=dWh)
     torch.cuda.synchronize()
     assert relerr(gates, da_ref) < 2e-5
     assert relerr(dc_work, dc0_ref) < 2e-5
     assert relerr(dh0, dh0_ref) < 2e-5
+    assert relerr(dWh, dWh0 + dW_ref[D:]) < 2e-5
 
 
 def test_embed_gather_scatter(ops):

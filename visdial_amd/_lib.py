@@ -53,7 +53,7 @@ PROTOTYPES = {
     "vd_gemm_tn_acc": [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p],
     "vd_colsum_acc": [_p, _l, _i, _i, _p, _p],
     "vd_lstm_forward": [_p, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "vd_lstm_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "vd_lstm_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "vd_zero_inactive_rows": [_p, _l, _l, _i, _p, _i, _i, _p],
     "vd_lstm2_forward": [_p, _i, _i, _p],
     "vd_lstm2_backward": [_p, _i, _i, _p],

@@ -13,6 +13,10 @@
 // and the whole cell update (+ mask) runs in the epilogue on the accumulator registers.
 #include "gemm_core.h"
 
+// defined in gemm_ops.hip (declared in include/visdial_hip.h)
+extern "C" int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
+                              int N, int K, int flags, void* stream);
+
 // ---------------------------------------------------------------------------
 // forward epilogue: acc[g] = (h_prev*Wh)[row, g*H + j]
 // ---------------------------------------------------------------------------
@@ -511,14 +515,48 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
   return rc_.join(s);
 }
 
+// Library-owned side stream + event ring for work that trails the backward recurrence step by step.
+#define VD_TRAIL_EVENTS 64
+struct TrailStream {
+  hipStream_t side = nullptr;
+  hipEvent_t ev[VD_TRAIL_EVENTS];
+  hipEvent_t done;
+  bool ready = false;
+  int init(hipStream_t s) {
+    if (ready) return VD_OK;
+    int prio = 0;
+    (void)hipStreamGetPriority(s, &prio);
+    VD_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio));
+    for (int i = 0; i < VD_TRAIL_EVENTS; ++i) VD_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    VD_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    ready = true;
+    return VD_OK;
+  }
+};
+static TrailStream& trail_stream() {
+  static thread_local TrailStream t;
+  return t;
+}
+
 int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float* c0, const float* dh_seq,
-                     const float* dh_last, const float* dc_last, float* dc_work, float* dh0, int T, int N,
-                     int H, int flags, void* stream) {
+                     const float* dh_last, const float* dc_last, float* dc_work, float* dh0, const float* h_seq,
+                     float* dWh_acc, int T, int N, int H, int flags, void* stream) {
   VD_CHECK_ARG(T >= 1 && N >= 0 && H > 0 && H % 32 == 0, "vd_lstm_backward: bad dims T=%d N=%d H=%d", T, N, H);
   VD_CHECK_ARG(Wh && gates && c && dc_work, "vd_lstm_backward: null pointer");
+  VD_CHECK_ARG((h_seq == nullptr) == (dWh_acc == nullptr), "vd_lstm_backward: h_seq and dWh_acc go together");
   hipStream_t s = (hipStream_t)stream;
   const long NH = (long)N * H;
   if (dc_last) VD_HIP(hipMemcpyAsync(dc_work, dc_last, NH * sizeof(float), hipMemcpyDeviceToDevice, s));
+  // Recurrent weight gradient dWh += sum_{t>=1} h_{t-1}^T da_t.  Default: one contraction over all (T-1)*N
+  // rows after the recurrence.  VD_LSTM_WGRAD_OVERLAP=1 issues it as one chunk per step on a side stream as
+  // soon as step t has produced da_t, so the chunks fill the tails / epilogue phases of the step kernels:
+  // 13.9 -> 12.6 ms for both together on the option LSTM alone, but -1.8 % on the whole training step (the
+  // encoder streams lose the idle phases they live on), hence opt-in.
+  static const int overlap = env_int("VD_LSTM_WGRAD_OVERLAP", 0);
+  const bool trail = dWh_acc && N >= 2048 && T > 1 && T <= VD_TRAIL_EVENTS && overlap;
+  TrailStream& ts = trail_stream();
+  if (trail)
+    if (int rc0 = ts.init(s)) return rc0;
   RowChains rc_;
   static const int nchains = env_int("VD_LSTM_CHAINS_BWD", 1);
   int rc = rc_.fork(N, s, nchains);
@@ -536,9 +574,25 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
                          (last && !dc_last) ? 1 : 0, rc_.stream[ch], flags);
       if (rc) return rc;
     }
+    if (trail && t >= 1 && rc_.n == 1) {
+      VD_HIP(hipEventRecord(ts.ev[t], s));
+      VD_HIP(hipStreamWaitEvent(ts.side, ts.ev[t], 0));
+      rc = vd_gemm_tn_acc(h_seq + (long)(t - 1) * NH, H, gates + (long)t * 4 * NH, 4L * H, dWh_acc, 4L * H, H, 4 * H, N,
+                          flags, ts.side);
+      if (rc) return rc;
+    }
   }
   rc = rc_.join(s);
   if (rc) return rc;
+  if (dWh_acc && T > 1) {
+    if (trail && rc_.n == 1) {
+      VD_HIP(hipEventRecord(ts.done, ts.side));
+      VD_HIP(hipStreamWaitEvent(s, ts.done, 0));
+    } else {   // one contraction over all (T-1)*N rows
+      rc = vd_gemm_tn_acc(h_seq, H, gates + 4 * NH, 4L * H, dWh_acc, 4L * H, H, 4 * H, (T - 1) * N, flags, s);
+      if (rc) return rc;
+    }
+  }
   if (dh0) {
     // gradient w.r.t. the initial hidden state: da_0 * Wh^T (dc_work already holds dL/dc0)
     SrcRow a{gates, 4L * H};

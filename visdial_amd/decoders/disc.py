@@ -7,6 +7,8 @@ clones ARE one batch of N*100 option sequences: the option LSTM runs as a single
 (exact: no dropout on option embeddings, disc.lua:12-14), and scoring + cross-entropy + their
 gradients are one wave-reduction kernel.
 """
+import os
+
 import torch
 
 from .. import ops
@@ -68,10 +70,12 @@ class Decoder(object):
             ops.token_sort(tokf, V + 1, offset, work, perm)
             dtab.zero_()
         t0 = ops.prof_begin('opt_lstm_bwd_step')
-        ops.lstm_backward(self.Wh, self.gates, self.c, dc, To, NO, H, dh_last=d_optH, flags=self.flags)
+        fused = os.environ.get('VD_LSTM_WGRAD_OVERLAP', '0') == '1'   # dWh chunks trail the steps (opt-in)
+        ops.lstm_backward(self.Wh, self.gates, self.c, dc, To, NO, H, dh_last=d_optH, flags=self.flags,
+                          h_seq=self.h if fused else None, dWh=self.dWh if fused else None)
         ops.prof_end('opt_lstm_bwd_step', t0, To)
         da = self.gates.view(To * NO, 4 * H)
-        if To > 1:
+        if To > 1 and not fused:
             t0 = ops.prof_begin('opt_lstm_dWh')
             ops.gemm_tn_acc(self.h.view(To * NO, H), da[NO:], self.dWh, M=H, N=4 * H, K=(To - 1) * NO,
                             flags=self.flags)

@@ -106,9 +106,11 @@ def lstm_forward(xproj, Wh, gates, h, c, T, N, H, x_tstride, x_ld, tok_gather=No
 
 
 def lstm_backward(Wh, gates, c, dc_work, T, N, H, c0=None, dh_seq=None, dh_last=None, dc_last=None, dh0=None,
-                  flags=0):
+                  flags=0, h_seq=None, dWh=None):
+    """h_seq + dWh: also accumulate dWh += sum_t h_{t-1}^T da_t (overlapped with the recurrence)."""
     call("vd_lstm_backward", _p(Wh, F32), _p(gates, F32), _p(c, F32), _p(c0, F32), _p(dh_seq, F32), _p(dh_last, F32),
-         _p(dc_last, F32), _p(dc_work, F32), _p(dh0, F32), T, N, H, int(flags), _stream())
+         _p(dc_last, F32), _p(dc_work, F32), _p(dh0, F32), _p(h_seq, F32), _p(dWh, F32), T, N, H, int(flags),
+         _stream())
 
 
 # ---------------------------------------------------------------- embedding / dropout / glue
