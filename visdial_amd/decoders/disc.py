@@ -83,14 +83,18 @@ class Decoder(object):
         # gradient of the gathered table: segmented row sums over the token-sorted rows
         self.streams.join('tab')
         ops.segment_rowsum_acc(da, tokf, perm, dtab)
-        ops.colsum_acc(dtab, self.db, M=V + 1, N=4 * H)
-        ops.gemm_tn_acc(self.emb, dtab, self.dWx, M=self.E, N=4 * H, K=V + 1)
+        # three small independent consumers of dtab: bias + input-weight gradients go to the side stream and
+        # run beside the embedding-gradient product of backward_embed()
+        with self.streams.fork('tab'):
+            ops.colsum_acc(dtab, self.db, M=V + 1, N=4 * H)
+            ops.gemm_tn_acc(self.emb, dtab, self.dWx, M=self.E, N=4 * H, K=V + 1)
         self.dtab = dtab
 
     def backward_embed(self):
         """dEmb += dTable * Wx^T.  Non-atomic read-modify-write of the SHARED embedding gradient: must be
         ordered after every other writer of that buffer (the encoder's atomic scatters)."""
         ops.gemm_nt(self.dtab, self.Wx, self.demb, accumulate=True, M=self.V + 1, N=self.E, K=4 * self.H)
+        self.streams.join('tab')
 
 
 def model(params, enc, fp, ws, drop):
