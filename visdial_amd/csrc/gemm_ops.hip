@@ -54,6 +54,10 @@ int vd_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const f
     return launch_gemm<CfgSmall>(M, N, K, 1, a, b, e, s);
   }
   EpiStore<4> e{C, ldc, bias, act, accumulate};
+  // both operands are k-contiguous rows: throughput shapes take the LDS-DMA pipeline (gemm_core.h)
+  static const int nt_glds = getenv("VD_NT_GLDS") ? atoi(getenv("VD_NT_GLDS")) : 1;
+  if (nt_glds && M >= 1024 && K >= 64 && K % 16 == 0 && (long)M * lda * 4 < (1L << 32) && (long)N * ldw * 4 < (1L << 32))
+    return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 41984>, false>(M, N, K, 1, A, lda, W, ldw, e, s);
   return launch_gemm<CfgBig>(M, N, K, 1, a, b, e, s);
 }
 
