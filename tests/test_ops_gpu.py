@@ -33,7 +33,9 @@ def f32(rng, *shape):
 
 
 # asymmetric operands everywhere (guide: symmetric inputs hide transposes)
+# (M >= 1024 with K % 16 == 0 runs on the LDS-DMA pipeline: 4 / 5 / 128 K tiles, partial row and column tiles)
 @pytest.mark.parametrize("M,N,K", [(200, 512, 512), (3920, 512, 512), (260, 300, 300), (33, 40, 4), (1, 512, 2048),
+                                   (1500, 300, 64), (1025, 44, 80), (11323, 300, 2048),
                                    (5000, 2048, 300)])
 @pytest.mark.parametrize("act", [0, 1])
 def test_gemm_nt(ops, M, N, K, act):
@@ -79,8 +81,11 @@ def test_colsum(ops):
     assert relerr(out, out0 + X.astype(np.float64).sum(0)) < 1e-5
 
 
+# N >= 2048 rows take the LDS-DMA pipeline: H = 32 / 64 / 96 give 2, 4 and 6 K tiles in the forward step (fewer
+# than, equal to and more than the 3 LDS buffers), ragged last row tile, masked and gathered input rows
 @pytest.mark.parametrize("T,N,H,masked,table", [(5, 200, 64, True, False), (4, 2500, 64, False, True),
-                                                (3, 2100, 512, True, False), (6, 37, 32, True, False)])
+                                                (3, 2100, 512, True, False), (6, 37, 32, True, False),
+                                                (3, 2049, 32, False, True), (3, 2177, 96, True, True)])
 def test_lstm_forward_backward(ops, T, N, H, masked, table):
     rng = np.random.RandomState(T * 1000 + N + H)
     D = 20
