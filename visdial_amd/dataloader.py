@@ -174,20 +174,25 @@ def rightAlign(sequences, lengths):
 
 
 def _open_arrays(path):
-    """HDF5 when h5py exists in this interpreter, else an .npz/.npy directory twin with the same dataset
-    names (scripts/h5_to_npz.py converts; no HDF5 library is available in the build image's python)."""
+    """The reference's HDF5 inputs (dataloader.lua:36-140 reads them with torch-hdf5).  Order of preference:
+    an explicit .npz; h5py if this interpreter has it; visdial_amd.h5lite (ctypes over the libhdf5 C library);
+    an .npz twin with the same dataset names (scripts/h5_to_npz.py) when no HDF5 library exists at all."""
     if path.endswith('.npz'):
         return np.load(path)
     try:
         import h5py
+        return h5py.File(path, 'r')
     except ImportError:
-        alt = path[:-3] + '.npz' if path.endswith('.h5') else path + '.npz'
-        import os
-        if os.path.exists(alt):
-            return np.load(alt)
-        raise RuntimeError("cannot read %s: h5py is not installed and no %s twin exists "
-                           "(convert with scripts/h5_to_npz.py)" % (path, alt))
-    return h5py.File(path, 'r')
+        pass
+    import os
+    from . import h5lite
+    if os.path.exists(path) and h5lite.available():
+        return h5lite.File(path)
+    alt = path[:-3] + '.npz' if path.endswith('.h5') else path + '.npz'
+    if os.path.exists(alt):
+        return np.load(alt)
+    raise RuntimeError("cannot read %s: no h5py, no libhdf5 (set VD_HDF5_LIB) and no %s twin "
+                       "(convert with scripts/h5_to_npz.py)" % (path, alt))
 
 
 class Dataloader(object):
