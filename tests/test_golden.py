@@ -12,7 +12,7 @@ from conftest import ROOT, small_params
 from oracle import visdial_oracle as vo
 from visdial_amd.opts import derive
 
-FILES = sorted(glob.glob(os.path.join(ROOT, 'tests', 'golden', '*.npz')))
+FILES = sorted(glob.glob(os.path.join(ROOT, 'tests', 'golden', '*__*.npz')))   # <encoder>__<decoder>.npz
 KW = {'lf-ques': dict(dropout=0.5, imgNorm=1, batchSize=2), 'lf-ques-im-hist': dict(dropout=0.5, imgNorm=1, batchSize=2),
       'hre-ques-im-hist': dict(imgNorm=1, batchSize=2), 'mn-att-ques-im-hist': dict(batchSize=2)}
 
