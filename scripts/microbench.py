@@ -37,21 +37,54 @@ def main():
     dcw = torch.empty(N, H, device=dev)
     dh_last = rnd(N, H)
 
-    ms = timeit(lambda: ops.lstm_forward(table, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok))
     fl = 2.0 * N * H * 4 * H * (T - 1)
-    print("option LSTM fwd  T=20 N=%d: %.2f ms  %.1f TFLOP/s (recurrent GEMM only)" % (N, ms, fl / ms / 1e9))
-
-    def bwd():
-        ops.lstm_backward(Wh, gates, c, dcw, T, N, H, dh_last=dh_last)
-    ms = timeit(bwd, iters=3, warm=1)
-    print("option LSTM bwd  T=20 N=%d: %.2f ms  %.1f TFLOP/s" % (N, ms, fl / ms / 1e9))
-
     dWh = torch.zeros(H, 4 * H, device=dev)
     hh = h.view(T * N, H)
     gg = gates.view(T * N, 4 * H)
     K = (T - 1) * N
-    ms = timeit(lambda: ops.gemm_tn_acc(hh, gg[N:], dWh, M=H, N=4 * H, K=K), iters=3, warm=1)
-    print("dWh tn_acc K=%d: %.2f ms  %.1f TFLOP/s" % (K, ms, 2.0 * H * 4 * H * K / ms / 1e9))
+
+    def bwd():
+        ops.lstm_backward(Wh, gates, c, dcw, T, N, H, dh_last=dh_last)
+
+    def fwd():
+        ops.lstm_forward(table, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok)
+
+    # A/B sweep of the recurrence launch structure (one process, knobs through vd_tune_set)
+    variants = [("per-step launches", dict(VD_LSTM_PERSIST_FWD=0, VD_LSTM_PERSIST_BWD=0)),
+                ("persistent", dict()),
+                ("persistent, no K rotation", dict(VD_GEMM_ROTATE=0)),
+                ("persistent, stagger 20us", dict(VD_LSTM_STAGGER_US=20)),
+                ("persistent, stagger 40us", dict(VD_LSTM_STAGGER_US=40)),
+                ("persistent, stagger 80us", dict(VD_LSTM_STAGGER_US=80)),
+                ("persistent, 2 WG/CU grid", dict(VD_LSTM_SEQ_WGS_PER_CU=2)),
+                ("persistent, 4 WG/CU grid", dict(VD_LSTM_SEQ_WGS_PER_CU=4))]
+    if os.environ.get("MB_SWEEP", "1") == "0":
+        variants = variants[1:2]
+    for name, knobs in variants:
+        ops.tune_clear()
+        for k, v in knobs.items():
+            ops.tune_set(k, v)
+        ms = timeit(fwd, iters=5, warm=2)
+        ms2 = timeit(bwd, iters=3, warm=1)
+        bad = ops.lstm_seq_status()
+        print("option LSTM T=20 N=%d [%-28s] fwd %.2f ms %.1f TF | bwd %.2f ms %.1f TF%s" % (
+            N, name, ms, fl / ms / 1e9, ms2, fl / ms2 / 1e9, "  TIMEOUT FLAG SET" if bad else ""))
+    ops.tune_clear()
+    fwd()
+    bwd()
+    for name, knobs in [("1024 blocks (round 1)", dict()), ("768 blocks", dict(VD_TN_BLOCKS=768)),
+                        ("512 blocks", dict(VD_TN_BLOCKS=512)), ("1536 blocks", dict(VD_TN_BLOCKS=1536)),
+                        ("768 blocks, no rotation", dict(VD_TN_BLOCKS=768, VD_GEMM_ROTATE=0)),
+                        ("1024 blocks, no rotation", dict(VD_GEMM_ROTATE=0)),
+                        ("768 blocks, double-buffered cfg", dict(VD_TN_BLOCKS=768, VD_TN_CFG=0)),
+                        ("512 blocks, double-buffered cfg", dict(VD_TN_BLOCKS=512, VD_TN_CFG=0)),
+                        ("768 blocks, k-major LDS-DMA", dict(VD_TN_BLOCKS=768, VD_TN_CFG=20))]:
+        ops.tune_clear()
+        for k, v in knobs.items():
+            ops.tune_set(k, v)
+        ms = timeit(lambda: ops.gemm_tn_acc(hh, gg[N:], dWh, M=H, N=4 * H, K=K), iters=3, warm=1)
+        print("dWh tn_acc K=%d [%-32s]: %.2f ms  %.1f TFLOP/s" % (K, name, ms, 2.0 * H * 4 * H * K / ms / 1e9))
+    ops.tune_clear()
 
     if os.environ.get("MB_BF16"):
         ms = timeit(lambda: ops.lstm_forward(table, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok, flags=1))

@@ -1,0 +1,41 @@
+"""The HIP `Model`'s data-parallel branch on real hardware: bucketed gradient all-reduce through a
+process group, checked against the single-process step on the concatenated batch.
+  * world 1 over RCCL (backend nccl) with VD_FORCE_ALLREDUCE=1 -- the collectives really run;
+  * world 2, both ranks on the one GPU of the test box: RCCL refuses duplicate devices, so the group is gloo and
+    the gradient is staged through host memory (parallel.reduce_gradients) -- exercises sharding + both buckets."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(nproc, backend, extra_env):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, VD_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'tests', 'dp_gpu_worker.py')]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert 'DP_GPU_OK' in out.stdout, out.stdout[-2000:]
+    return out.stdout
+
+
+def test_world1_rccl_forced_allreduce():
+    out = _run(1, 'nccl', dict(VD_FORCE_ALLREDUCE='1', NCCL_DEBUG='VERSION'))
+    assert 'async_encoder_bucket=True' in out
+
+
+def test_world2_shared_gpu_gloo():
+    out = _run(2, 'gloo', {})
+    assert 'world=2' in out

@@ -83,10 +83,26 @@ def test_colsum(ops):
 
 # N >= 2048 rows take the LDS-DMA pipeline: H = 32 / 64 / 96 give 2, 4 and 6 K tiles in the forward step (fewer
 # than, equal to and more than the 3 LDS buffers), ragged last row tile, masked and gathered input rows
+# (N >= 2048 and T > 1: the whole recurrence is ONE persistent launch, tile queues + arrival counters; `persist` = 0
+#  re-runs the same shapes as one launch per step.)  (6, 2300, 512, table): the headline's H = 512 table-gather mode.
+@pytest.mark.parametrize("persist", [1, 0])
 @pytest.mark.parametrize("T,N,H,masked,table", [(5, 200, 64, True, False), (4, 2500, 64, False, True),
                                                 (3, 2100, 512, True, False), (6, 37, 32, True, False),
-                                                (3, 2049, 32, False, True), (3, 2177, 96, True, True)])
-def test_lstm_forward_backward(ops, T, N, H, masked, table):
+                                                (3, 2049, 32, False, True), (3, 2177, 96, True, True),
+                                                (6, 2300, 512, False, True)])
+def test_lstm_forward_backward(ops, T, N, H, masked, table, persist):
+    if persist == 0 and N < 2048:
+        pytest.skip("latency shapes never take the persistent path")
+    ops.tune_set("VD_LSTM_PERSIST_FWD", persist)
+    ops.tune_set("VD_LSTM_PERSIST_BWD", persist)
+    try:
+        _lstm_forward_backward(ops, T, N, H, masked, table)
+        assert not ops.lstm_seq_status()
+    finally:
+        ops.tune_clear()
+
+
+def _lstm_forward_backward(ops, T, N, H, masked, table):
     rng = np.random.RandomState(T * 1000 + N + H)
     D = 20
     V = 30
@@ -135,6 +151,49 @@ def test_lstm_forward_backward(ops, T, N, H, masked, table):
     assert relerr(dc_work, dc0_ref) < 2e-5
     assert relerr(dh0, dh0_ref) < 2e-5
     assert relerr(dWh, dWh0 + dW_ref[D:]) < 2e-5
+
+
+@pytest.mark.parametrize("stagger", [0, 30])
+def test_lstm_persistent_equals_per_step_launches(ops, stagger):
+    """The persistent recurrence executes exactly the per-step kernels' tile code, so its outputs must be
+    BIT-IDENTICAL to the one-launch-per-step path -- under load that makes the dependency waits real: 20 000 rows x
+    12 steps of short tiles (H = 64: K loop of 4 tiles), a competing stream hammering HBM, consumer L1s warm.
+    Every word of h / c / gates (forward) and da / dc (backward) is compared."""
+    T, N, H, V = 12, 20000, 64, 50
+    rng = np.random.RandomState(7)
+    Wh = dev(f32(rng, H, 4 * H) / np.sqrt(H))
+    tab = dev(f32(rng, V + 1, 4 * H) * 0.5)
+    tok = dev(rng.randint(0, V + 1, size=(T, N)).astype(np.int32))
+    dh_last = dev(f32(rng, N, H))
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, device="cuda")
+    out = {}
+    for persist in (0, 1):
+        ops.tune_set("VD_LSTM_PERSIST_FWD", persist)
+        ops.tune_set("VD_LSTM_PERSIST_BWD", persist)
+        ops.tune_set("VD_LSTM_STAGGER_US", stagger if persist else 0)
+        gates = torch.empty(T, N, 4 * H, device="cuda")
+        h = torch.empty(T, N, H, device="cuda")
+        c = torch.empty(T, N, H, device="cuda")
+        dc = torch.empty(N, H, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):           # uneven background load on the memory system
+            for _ in range(40):
+                junk.mul_(1.0001)
+        ops.lstm_forward(tab, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok)
+        assert not ops.lstm_seq_status()
+        fwd = (gates.clone(), h.clone(), c.clone())
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                junk.mul_(1.0001)
+        ops.lstm_backward(Wh, gates, c, dc, T, N, H, dh_last=dh_last)
+        assert not ops.lstm_seq_status()
+        torch.cuda.synchronize()
+        out[persist] = fwd + (gates.clone(), dc.clone())
+    ops.tune_clear()
+    for a, b, name in zip(out[0], out[1], ("gates", "h", "c", "da", "dc")):
+        assert torch.equal(a, b), "%s differs between per-step and persistent launches (%d words)" % (
+            name, int((a != b).sum()))
 
 
 def test_embed_gather_scatter(ops):

@@ -19,24 +19,44 @@ from visdial_amd.model import Model
 from visdial_amd.checkpoint import load_checkpoint, restore_weights
 
 
+def _plain(d):
+    """options as python primitives only (checkpoints are read back with torch.load(weights_only=True))"""
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, (bool, str)) or v is None:
+            out[k] = v
+        elif isinstance(v, (int, np.integer)):
+            out[k] = int(v)
+        elif isinstance(v, (float, np.floating)):
+            out[k] = float(v)
+    return out
+
+
 def main():
     opt = opts.parse()
     print(opt)
     np.random.seed(1234)                                         # train.lua:12
     saved = None
+    mp = opt                                                     # `modelParams = opt` (train.lua:26)
     if opt['loadPath']:
-        saved = load_checkpoint(opt['loadPath'])   # train.lua:32-42
+        saved = load_checkpoint(opt['loadPath'])                 # train.lua:32-41
         mp = saved['modelParams']
+        for k in ('imgNorm', 'encoder', 'decoder'):              # the only three options taken from the checkpoint
+            opt[k] = mp[k]
         mp['gpuid'], mp['batchSize'] = opt['gpuid'], opt['batchSize']
-        for k in ('numEpochs', 'maxIters', 'savePath', 'saveIter', 'numTrainThreads'):
-            mp[k] = opt[k]
-        opt = mp
+        for k in ('numEpochs', 'maxIters', 'savePath', 'saveIter'):   # run control stays with the command line
+            mp[k] = opt.get(k)
+    # the dataloader is built from the CURRENT command line (train.lua:47-48), never from paths stored in a checkpoint
     have = lambda p: os.path.exists(p) or os.path.exists(p[:-3] + '.npz')
     if os.path.exists(opt['inputJson']) and have(opt['inputQues']):
-        dataloader = Dataloader(seed=1234).initialize(opt, ['train'])            # train.lua:47-48 (real VisDial files)
+        dataloader = Dataloader(seed=1234).initialize(opt, ['train'])            # real VisDial files
+    elif opt['loadPath'] and not opt.get('synthetic'):
+        raise SystemExit('-loadPath given but no dataset at %s / %s: refusing to resume on synthetic data '
+                         '(pass -synthetic 1 to force)' % (opt['inputJson'], opt['inputQues']))
     else:
         print('no dataset at %s: using synthetic VisDial-shaped batches' % opt['inputQues'])
         dataloader = SyntheticDataloader(opt, seed=1234, num_threads=opt['numTrainThreads'])
+    opt = mp
     for k in ('vocabSize', 'maxQuesCount', 'maxQuesLen', 'maxAnsLen'):   # train.lua:55-59
         opt[k] = getattr(dataloader, k)
     opt['numTrainThreads'] = dataloader.numTrainThreads
@@ -57,7 +77,7 @@ def main():
         model.trainIteration(dataloader)
         if it % (opt['saveIter'] * opt['numIterPerEpoch']) == 0:      # train.lua:95-102
             ep = it // opt['numIterPerEpoch']
-            torch.save({'modelW': model.wrapperW.cpu(), 'optims': dict(model.optims), 'modelParams': opt},
+            torch.save({'modelW': model.wrapperW.cpu(), 'optims': dict(model.optims), 'modelParams': _plain(opt)},
                        os.path.join(opt['savePath'], 'model_epoch_%d.pt' % ep))
         if it % 100 == 0:                                            # train.lua:108-115
             torch.cuda.synchronize()
@@ -66,7 +86,7 @@ def main():
                 time.ctime(), it / float(opt['numIterPerEpoch']), it, model.runningLoss,
                 model.optims['learningRate'], rounds / (time.time() - t0)))
             t0 = time.time()
-    torch.save({'modelW': model.wrapperW.float().cpu(), 'modelParams': opt, 'optims': dict(model.optims)},
+    torch.save({'modelW': model.wrapperW.float().cpu(), 'modelParams': _plain(opt), 'optims': dict(model.optims)},
                os.path.join(opt['savePath'], 'model_final.pt'))     # train.lua:120-121
 
 

@@ -12,7 +12,7 @@ def load_checkpoint(path):
         ck = t7.load(path)
         ck['_flat_reference_layout'] = True
         return ck
-    return torch.load(path, weights_only=False)
+    return torch.load(path, weights_only=True)      # plain tensors and primitives only
 
 
 def restore_weights(model, saved):

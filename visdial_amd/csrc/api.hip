@@ -1,6 +1,12 @@
 // Library-level entry points: error string, device memory helpers for hosts that have no
 // tensor library of their own (the LuaJIT-FFI host), device queries.
 #include <stdarg.h>
+#include <stdlib.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
 
 #include "common.h"
 
@@ -13,9 +19,83 @@ void vd_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- runtime tuning knobs ---------------------------------------------------------------------------------
+static std::mutex g_tune_mu;
+static std::map<std::string, int>& tune_table() {
+  static std::map<std::string, int> t;
+  return t;
+}
+
+int vd_tune_get(const char* key, int dflt) {
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto& t = tune_table();
+    auto it = t.find(key);
+    if (it != t.end()) return it->second;
+  }
+  const char* ev = getenv(key);
+  return ev ? atoi(ev) : dflt;
+}
+
+// ---- per-(device, stream) scratch -----------------------------------------------------------------------
+static std::mutex g_scr_mu;
+static std::map<std::pair<int, hipStream_t>, VdStreamScratch>& scratch_table() {
+  static std::map<std::pair<int, hipStream_t>, VdStreamScratch> t;
+  return t;
+}
+
+int vd_stream_scratch(hipStream_t stream, size_t wht_bytes, size_t sync_bytes, VdStreamScratch* out) {
+  int dev = 0;
+  VD_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_scr_mu);
+  VdStreamScratch& s = scratch_table()[std::make_pair(dev, stream)];
+  // Growing frees the old buffer: hipFree synchronises the device, so earlier stream-ordered users are done.
+  if (s.wht_bytes < wht_bytes) {
+    if (s.wht) VD_HIP(hipFree(s.wht));
+    s.wht = nullptr;
+    s.wht_bytes = 0;
+    VD_HIP(hipMalloc((void**)&s.wht, wht_bytes));
+    s.wht_bytes = wht_bytes;
+  }
+  if (s.sync_bytes < sync_bytes) {
+    if (s.sync) VD_HIP(hipFree(s.sync));
+    s.sync = nullptr;
+    s.sync_bytes = 0;
+    VD_HIP(hipMalloc((void**)&s.sync, sync_bytes));
+    s.sync_bytes = sync_bytes;
+  }
+  *out = s;
+  return VD_OK;
+}
+
+int vd_num_cus() {
+  static thread_local int cached_dev = -1, cached = 256;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return cached;
+  if (dev != cached_dev) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cached = n;
+    cached_dev = dev;
+  }
+  return cached;
+}
+
 extern "C" {
 
 const char* vd_last_error(void) { return g_err; }
+
+int vd_tune_set(const char* key, int value) {
+  VD_CHECK_ARG(key && key[0], "vd_tune_set: empty key");
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  tune_table()[key] = value;
+  return VD_OK;
+}
+
+int vd_tune_clear(void) {
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  tune_table().clear();
+  return VD_OK;
+}
 
 int vd_abi_version(void) { return 1; }
 

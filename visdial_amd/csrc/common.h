@@ -36,6 +36,22 @@ void vd_set_error(const char* fmt, ...);
 
 static inline int vd_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Runtime tuning knobs (api.hip): value set by vd_tune_set(key, v), else the environment variable `key`,
+// else `dflt`.  Read at launch time, so one process can A/B several settings (scripts/microbench.py).
+int vd_tune_get(const char* key, int dflt);
+
+// Library-owned per-(device, stream) scratch (api.hip): work buffers whose lifetime is one stream-ordered call
+// (the gate-interleaved Wh^T copy and the tile queues / arrival counters of the persistent recurrence kernels).
+// Calls on different streams get different buffers, so they may overlap freely.
+struct VdStreamScratch {
+  float* wht = nullptr;      // [4H x H]
+  size_t wht_bytes = 0;
+  unsigned* sync = nullptr;  // persistent-kernel queue heads + arrival counters
+  size_t sync_bytes = 0;
+};
+int vd_stream_scratch(hipStream_t stream, size_t wht_bytes, size_t sync_bytes, VdStreamScratch* out);
+int vd_num_cus();  // compute units of the current device (cached)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -470,7 +470,7 @@ __device__ __forceinline__ void glds16(unsigned voff, const float* sbase, unsign
 template <class Cfg, bool KMAJ, class Epi>
 __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, int row_base, int col_base,
                                                 int rot_seed, const float* A, long lda, const float* B, long ldb,
-                                                const Epi& epi, float* smem) {
+                                                const Epi& epi, float* smem, int tid_in = -1) {
   constexpr int WM = Cfg::WM, NT = Cfg::NT;
   constexpr int BM = Cfg::BM, BN = Cfg::BN;
   constexpr int NIA = (BM / 16) / WM, NIB = (BN / 16) / WM;  // DMA instructions per wave per tile
@@ -483,7 +483,9 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
   static_assert((BM / 16) % WM == 0 && (BN / 16) % WM == 0, "16-row DMA groups must split evenly over the waves");
   static_assert((NBA * ABUF + NBB * BBUF) * 4 <= Cfg::LDS_BYTES, "DMA buffers must fit the LDS request");
   static_assert(!KMAJ || (BM == 128 && BN == 128), "k-major tiles: one DMA instruction = two 128-float k rows");
-  const int tid = threadIdx.x, lane = tid & 63;
+  // tid_in: callers that loop over tiles pass a laundered thread id so per-lane address terms are re-derived
+  // per tile instead of being hoisted out of the tile loop (they would stay live across the epilogue)
+  const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63;
   const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nk = ke > ks ? (ke - ks) / 16 : 0;
   VD_T(0);
@@ -680,11 +682,7 @@ static int launch_gemm_glds(int M, int N, int K, int splits, const float* A, lon
                                Cfg::LDS_BYTES));
     attr_set = true;
   }
-  static int rotate = -1;
-  if (rotate < 0) {
-    const char* ev = getenv("VD_GEMM_ROTATE");
-    rotate = ev ? atoi(ev) : 1;
-  }
+  const int rotate = vd_tune_get("VD_GEMM_ROTATE", 1);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, M, N, K,
                      kchunk, tiles_m, tiles_n, rotate, A, lda, B, ldb, e);
   VD_LAUNCH_CHECK();
@@ -812,11 +810,7 @@ static int launch_gemm(int M, int N, int K, int splits, ASrc a, BSrc b, Epi e, h
     attr_set = true;
   }
   const int grid = tiles_m * tiles_n * splits;
-  static int rotate = -1;
-  if (rotate < 0) {
-    const char* ev = getenv("VD_GEMM_ROTATE");
-    rotate = ev ? atoi(ev) : 1;
-  }
+  const int rotate = vd_tune_get("VD_GEMM_ROTATE", 1);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, M, N, K, kchunk, tiles_m,
                      tiles_n, rotate, a, b, e);
   VD_LAUNCH_CHECK();

@@ -94,7 +94,7 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
   SrcK a{A, lda}, b{B, ldb};
   EpiAtomic<4> e{C, ldc};
   const long tiles = (long)vd_cdiv(M, CfgBig::BM) * vd_cdiv(N, CfgBig::BN);
-  static const int target = getenv("VD_TN_BLOCKS") ? atoi(getenv("VD_TN_BLOCKS")) : 1024;
+  const int target = vd_tune_get("VD_TN_BLOCKS", 1024);
   long splits = vd_cdiv(target, tiles);
   const long max_splits = vd_cdiv(K, 4 * CfgBig::BK);
   if (splits > max_splits) splits = max_splits;
@@ -103,7 +103,7 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
     return launch_gemm<GemmCfg<4, 1, 4, 32, 0, 3, 0, 1>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
   // (VD_TN_CFG=20: the LDS-DMA pipeline with k-major tiles; measured 119 vs 127 TFLOP/s for the register-staged
   //  default on the option dWh shape, so it stays opt-in)
-  static const int cfg = getenv("VD_TN_CFG") ? atoi(getenv("VD_TN_CFG")) : 5;
+  const int cfg = vd_tune_get("VD_TN_CFG", 5);
   if (cfg == 20 && M % 128 == 0 && N % 128 == 0 && K % 16 == 0 && K >= 1024)
     return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 41984>, true>(M, N, K, (int)splits, A, lda, B, ldb, e,
                                                                       (hipStream_t)stream);

@@ -91,7 +91,11 @@ logsoftmax_nll_kernel(float* __restrict__ logits, long ld, int V, const int* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* row = logits + r * ld;
   if (write_grad && tid < ld - V) row[V + tid] = 0.f;  // keep the alignment pad columns finite (K-padding rule)
-  if (tok_in[r] == 0) {
+  // masked rows: a pad decoder input (MaskZero, gen.lua:23-24) or a pad TARGET -- utils.computeLhood masks on
+  // words == 0 (utils.lua:86-102): an empty candidate has option_in = <START>,0.. and option_out = 0.. (processOptions
+  // writes no <END> for length 0), so its first row has a non-pad input and target 0; it must contribute 0, not
+  // read column -1
+  if (tok_in[r] == 0 || target[r] <= 0) {
     if (tid == 0) loss_rows[r] = 0.f;
     if (write_grad)
       for (int c = tid; c < V; c += 256) row[c] = 0.f;

@@ -218,22 +218,6 @@ __global__ void __launch_bounds__(256) wh_gate_transpose_kernel(const float* __r
   }
 }
 
-// library-owned scratch for WhT (one per host thread / device context; grows on demand)
-static int wht_scratch(int H, float** out) {
-  static thread_local float* buf = nullptr;
-  static thread_local size_t cap = 0;
-  const size_t need = (size_t)4 * H * H * sizeof(float);
-  if (cap < need) {
-    if (buf) VD_HIP(hipFree(buf));
-    buf = nullptr;
-    cap = 0;
-    VD_HIP(hipMalloc((void**)&buf, need));
-    cap = need;
-  }
-  *out = buf;
-  return VD_OK;
-}
-
 // LDS-DMA pipeline eligibility: throughput shape, K % 16 == 0, 32-bit row byte offsets
 static bool use_glds_fwd(int N, int H) {
   static const int cfg = env_int("VD_LSTM_FWD_CFG", 20);
@@ -242,6 +226,251 @@ static bool use_glds_fwd(int N, int H) {
 static bool use_glds_bwd(int N, int H) {
   static const int cfg = env_int("VD_LSTM_BWD_CFG", 20);
   return cfg == 20 && N >= 2048 && H % 32 == 0 && (long)N * 4 * H * 4 < (1L << 32);
+}
+
+// ---------------------------------------------------------------------------
+// Persistent sequence kernels: the WHOLE T-step recurrence of a throughput shape in one launch.
+//
+// The per-step launches above start 768 workgroups at the same instant with identical lifetimes: they reach
+// their epilogues together (matrix pipe idle while the gate/cell traffic drains), every step ends in a
+// partially filled last round (2512 tiles on 768 slots), and the pattern repeats 20 times per direction.
+// Here the tiles of ALL steps form one work list.  Resident workgroups pull (step, row tile, column tile)
+// items from it and the only ordering is the real data dependency: tile (r, *, s) needs the 128 rows r of
+// step s-1 complete, i.e. all column tiles of (r, s-1) -- one arrival counter per (row tile, step).  Items are
+// listed step-major, so the rows a tile depends on were issued ~3 rounds earlier and the wait is almost
+// never taken; workgroups drift out of phase, epilogues of some overlap K loops of others, and there is one
+// tail per direction instead of one per step.
+//
+// Work lists: 8 queues (one per XCD, selected at run time from HW_REG_XCC_ID) that own contiguous ranges of
+// ROW tiles, so a row tile's h / da panels stay in one XCD's L2; a workgroup whose queue is exhausted takes
+// from the next queue.  Placement is a speed choice only: every cross-workgroup hand-off uses the
+// agent-scope release (producer, after its stores) / relaxed poll + agent-scope acquire (consumer) protocol,
+// which is correct for any workgroup->CU/XCD placement and any dispatch order.  Deadlock freedom needs no
+// co-residency: a workgroup only ever waits for items that were dequeued (hence are being executed by a
+// resident workgroup) earlier in the same queue, and dependencies point to strictly earlier steps.
+// Every spin is bounded (VD_SEQ_TIMEOUT_TICKS of the 100 MHz clock); a timeout sets a sticky error word that
+// the host can read back with vd_lstm_seq_status().
+// ---------------------------------------------------------------------------
+#define VD_SEQ_QUEUES 8
+#define VD_SEQ_HEAD_STRIDE 32                                   // uints: one 128-byte line per queue head
+#define VD_SEQ_ERR_WORD (VD_SEQ_QUEUES * VD_SEQ_HEAD_STRIDE)    // sticky timeout flag
+#define VD_SEQ_CU_WORDS (VD_SEQ_ERR_WORD + 32)                  // 8 x 256 per-CU arrival tickets (start stagger)
+#define VD_SEQ_CNT0 (VD_SEQ_CU_WORDS + VD_SEQ_QUEUES * 256)     // arrival counters [T x tiles_m]
+#define VD_SEQ_TIMEOUT_TICKS 200000000ull                       // 2 s of s_memrealtime
+
+static size_t seq_sync_bytes(int T, int tiles_m) { return ((size_t)VD_SEQ_CNT0 + (size_t)T * tiles_m) * sizeof(unsigned); }
+
+struct SeqSched {
+  unsigned* sync;
+  int T, tiles_m, tiles_n;
+  int stagger_ticks;  // >0: the k-th workgroup to arrive on a CU sleeps k * stagger_ticks (100 MHz ticks) once
+};
+
+__device__ __forceinline__ unsigned vd_xcc_id() {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+  return x & 7u;
+}
+__device__ __forceinline__ unsigned vd_cu_key() {  // CU / SH / SE id bits of HW_ID: identifies the CU inside its XCC
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 8, 8)" : "=s"(x));
+  return x & 255u;
+}
+
+// Thread 0 only.  Pull the next item (processing step s, row tile r, column tile j) and wait until the rows it
+// depends on are complete.  Returns false when every queue is exhausted.
+__device__ __forceinline__ bool seq_next(const SeqSched& sc, int& q, int& tried, int& s, int& r, int& j) {
+  unsigned* const sync = sc.sync;
+  for (;;) {
+    const int rt0 = (int)((long)q * sc.tiles_m / VD_SEQ_QUEUES), rt1 = (int)((long)(q + 1) * sc.tiles_m / VD_SEQ_QUEUES);
+    const int per_step = (rt1 - rt0) * sc.tiles_n;
+    if (per_step > 0) {
+      const unsigned idx = __hip_atomic_fetch_add(sync + q * VD_SEQ_HEAD_STRIDE, 1u, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+      if (idx < (unsigned)per_step * (unsigned)sc.T) {
+        s = (int)(idx / (unsigned)per_step);
+        const int rem = (int)(idx - (unsigned)s * (unsigned)per_step);
+        r = rt0 + rem / sc.tiles_n;
+        j = rem % sc.tiles_n;
+        break;
+      }
+    }
+    q = (q + 1) & (VD_SEQ_QUEUES - 1);
+    if (++tried >= VD_SEQ_QUEUES) return false;
+  }
+  if (s > 0) {
+    unsigned* const cnt = sync + VD_SEQ_CNT0 + (long)(s - 1) * sc.tiles_m + r;
+    unsigned* const err = sync + VD_SEQ_ERR_WORD;
+    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)sc.tiles_n) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        __builtin_amdgcn_s_sleep(4);
+        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)sc.tiles_n) break;
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > VD_SEQ_TIMEOUT_TICKS) {
+          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's stale L1 lines; plain loads follow the barrier
+  }
+  return true;
+}
+
+// All threads.  Publish a finished tile: every wave drains its stores, then one lane releases at agent scope
+// and bumps the (row tile, step) arrival counter.
+__device__ __forceinline__ void seq_publish(const SeqSched& sc, int s, int r) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler may drop the wait behind buffer_wbl2 (guide, G16 pitfall 12)
+    __hip_atomic_fetch_add(sc.sync + VD_SEQ_CNT0 + (long)s * sc.tiles_m + r, 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// One-time start stagger: the k-th workgroup of this launch to arrive on a CU waits k * stagger_ticks, so the
+// co-resident workgroups of a CU begin out of phase instead of drifting apart over the first steps.
+__device__ __forceinline__ void seq_stagger(const SeqSched& sc, unsigned xcc) {
+  if (sc.stagger_ticks <= 0) return;
+  if (threadIdx.x == 0) {
+    const unsigned k = __hip_atomic_fetch_add(sc.sync + VD_SEQ_CU_WORDS + xcc * 256 + vd_cu_key(), 1u, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long wait = (unsigned long long)(k % 3u) * (unsigned)sc.stagger_ticks;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+  }
+  __syncthreads();
+}
+
+struct LstmSeqFwdArgs {
+  const float* xproj;   // dense: [T x N x 4H] (x_tstride per step); table mode: [V+1 x 4H]
+  long x_tstride, xld;
+  const int* tok_gather;  // [T x N] or null
+  const int* tok_mask;    // [T x N] or null
+  const float* WhT;       // [4H x H] gate-interleaved transpose of Wh
+  const float *h0, *c0;   // [N x H] or null
+  float *gates, *h, *c;   // [T x N x 4H], [T x N x H] x 2
+  int N, H, rotate;
+  SeqSched sc;
+};
+
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) lstm_seq_fwd_kernel(LstmSeqFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* const slot = reinterpret_cast<int*>(smem) + Cfg::LDS_BYTES / 4 - 4;  // beyond the DMA buffers / epilogue scratch
+  const unsigned xcc = vd_xcc_id();
+  seq_stagger(a.sc, xcc);
+  if (threadIdx.x == 0) slot[3] = (int)xcc;  // queue cursor: q | tried << 8 (thread 0's state lives in LDS, not in VGPRs)
+  const long NH = (long)a.N * a.H;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      int s = -1, r = 0, j = 0;
+      int q = slot[3] & 255, tried = slot[3] >> 8;
+      if (!seq_next(a.sc, q, tried, s, r, j)) s = -1;
+      slot[0] = s;
+      slot[1] = r;
+      slot[2] = j;
+      slot[3] = q | (tried << 8);
+    }
+    __syncthreads();
+    const int t = __builtin_amdgcn_readfirstlane(slot[0]);
+    const int r = __builtin_amdgcn_readfirstlane(slot[1]);
+    const int j = __builtin_amdgcn_readfirstlane(slot[2]);
+    if (t < 0) break;
+    const float* hp = t ? a.h + (t - 1) * NH : a.h0;
+    EpiLstmFwd e;
+    e.xproj = a.xproj + (long)t * a.x_tstride;
+    e.xld = a.xld;
+    e.tok_gather = a.tok_gather ? a.tok_gather + (long)t * a.N : nullptr;
+    e.tok_mask = a.tok_mask ? a.tok_mask + (long)t * a.N : nullptr;
+    e.c_prev = t ? a.c + (t - 1) * NH : a.c0;
+    e.gates = a.gates + (long)t * 4 * NH;
+    e.c_out = a.c + t * NH;
+    e.h_out = a.h + t * NH;
+    e.H = a.H;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // per-lane address terms are rebuilt per tile, not kept live across tiles
+    gemm_block_glds<Cfg, false>(a.N, 4 * a.H, 0, hp ? a.H : 0, r * Cfg::BM, j * Cfg::BN, a.rotate ? r * 5 + j * 3 : -1, hp,
+                                (long)a.H, a.WhT, (long)a.H, e, smem, tid);
+    seq_publish(a.sc, t, r);
+  }
+}
+
+struct LstmSeqBwdArgs {
+  const float* Wh;        // [H x 4H]
+  float* gates;           // [T x N x 4H] in: gates, out: da
+  const float *c, *c0;    // [T x N x H], [N x H] or null
+  const float* dh_seq;    // [T x N x H] or null
+  const float* dh_last;   // [N x H] or null
+  float* dc;              // [N x H] work (holds dc_last on entry when dc_has_last)
+  int dc_has_last;
+  int T, N, H, rotate;
+  SeqSched sc;
+};
+
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* const slot = reinterpret_cast<int*>(smem) + Cfg::LDS_BYTES / 4 - 4;
+  const unsigned xcc = vd_xcc_id();
+  seq_stagger(a.sc, xcc);
+  if (threadIdx.x == 0) slot[3] = (int)xcc;  // queue cursor: q | tried << 8 (thread 0's state lives in LDS, not in VGPRs)
+  const long NH = (long)a.N * a.H;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      int s = -1, r = 0, j = 0;
+      int q = slot[3] & 255, tried = slot[3] >> 8;
+      if (!seq_next(a.sc, q, tried, s, r, j)) s = -1;
+      slot[0] = s;
+      slot[1] = r;
+      slot[2] = j;
+      slot[3] = q | (tried << 8);
+    }
+    __syncthreads();
+    const int s = __builtin_amdgcn_readfirstlane(slot[0]);
+    const int r = __builtin_amdgcn_readfirstlane(slot[1]);
+    const int j = __builtin_amdgcn_readfirstlane(slot[2]);
+    if (s < 0) break;
+    const int t = a.T - 1 - s;
+    const bool last = (s == 0);
+    const float* da_next = last ? nullptr : a.gates + (long)(t + 1) * 4 * NH;
+    EpiLstmBwd<Cfg::NT> e;
+    e.dh_a = a.dh_seq ? a.dh_seq + t * NH : nullptr;
+    e.dh_b = (last && a.dh_last) ? a.dh_last : nullptr;
+    e.gates = a.gates + (long)t * 4 * NH;
+    e.c_t = a.c + t * NH;
+    e.c_prev = t ? a.c + (t - 1) * NH : a.c0;
+    e.dc = a.dc;
+    e.dc_first = (last && !a.dc_has_last) ? 1 : 0;
+    e.H = a.H;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    gemm_block_glds<Cfg, false>(a.N, a.H, 0, last ? 0 : 4 * a.H, r * Cfg::BM, j * Cfg::BN, a.rotate ? r * 5 + j * 3 : -1,
+                                da_next, 4L * a.H, a.Wh, 4L * a.H, e, smem, tid);
+    seq_publish(a.sc, s, r);
+  }
+}
+
+// persistent path eligibility (on top of the LDS-DMA eligibility): more than one step, one row chain
+static bool use_persistent(const char* knob) { return vd_tune_get(knob, 1) != 0; }
+
+template <class Kern, class Args>
+static int launch_seq(Kern kern, const Args& a, int lds_bytes, int threads, int total_tiles, hipStream_t s) {
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    attr_set = true;
+  }
+  // resident capacity: 3 workgroups per CU (41 KB LDS request each); a larger grid would only queue
+  int grid = vd_tune_get("VD_LSTM_SEQ_WGS_PER_CU", 3) * vd_num_cus();
+  if (grid > total_tiles) grid = total_tiles;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, s, a);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
 }
 
 static int lstm_step_fwd(const float* h_prev, const float* Wh, int N, int H, int K, const EpiLstmFwd& epi,
@@ -478,13 +707,29 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
   float* WhT = nullptr;
   const bool bf16 = (flags & VD_FLAG_BF16) && N >= 2048 && H % 32 == 0;
   const bool glds = (use_glds_fwd(N, H) || bf16) && T > 1;   // both paths multiply by the transposed copy
+  static const int nchains = env_int("VD_LSTM_CHAINS_FWD", 1);
+  const bool persist = glds && !bf16 && nchains <= 1 && use_persistent("VD_LSTM_PERSIST_FWD");
+  VdStreamScratch scr;
   if (glds) {
-    if (int rc0 = wht_scratch(H, &WhT)) return rc0;
+    const int tiles_m = vd_cdiv(N, CfgF9::BM);
+    if (int rc0 = vd_stream_scratch(s, (size_t)4 * H * H * sizeof(float), seq_sync_bytes(T, tiles_m), &scr)) return rc0;
+    WhT = scr.wht;
     hipLaunchKernelGGL(wh_gate_transpose_kernel, dim3(4 * H / 32, H / 32), dim3(256), 0, s, Wh, WhT, H);
     VD_LAUNCH_CHECK();
   }
+  if (persist) {
+    // one launch for all T steps (see "Persistent sequence kernels" above)
+    const int tiles_m = vd_cdiv(N, CfgF9::BM), tiles_n = vd_cdiv(4 * H, CfgF9::BN);
+    VD_HIP(hipMemsetAsync(scr.sync, 0, seq_sync_bytes(T, tiles_m), s));
+    LstmSeqFwdArgs a;
+    a.xproj = xproj; a.x_tstride = x_tstride; a.xld = x_ld;
+    a.tok_gather = tok_gather; a.tok_mask = tok_mask;
+    a.WhT = WhT; a.h0 = h0; a.c0 = c0; a.gates = gates; a.h = h; a.c = c;
+    a.N = N; a.H = H; a.rotate = vd_tune_get("VD_GEMM_ROTATE", 1);
+    a.sc = SeqSched{scr.sync, T, tiles_m, tiles_n, vd_tune_get("VD_LSTM_STAGGER_US", 0) * 100};
+    return launch_seq(lstm_seq_fwd_kernel<CfgF9>, a, CfgF9::LDS_BYTES, CfgF9::THREADS, T * tiles_m * tiles_n, s);
+  }
   RowChains rc_;
-  static const int nchains = env_int("VD_LSTM_CHAINS_FWD", 1);
   int rc = rc_.fork(N, s, nchains);
   if (rc) return rc;
   for (int t = 0; t < T; ++t) {
@@ -557,11 +802,26 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
   TrailStream& ts = trail_stream();
   if (trail)
     if (int rc0 = ts.init(s)) return rc0;
-  RowChains rc_;
   static const int nchains = env_int("VD_LSTM_CHAINS_BWD", 1);
-  int rc = rc_.fork(N, s, nchains);
+  const bool persist = use_glds_bwd(N, H) && !(flags & VD_FLAG_BF16) && T > 1 && nchains <= 1 && !trail &&
+                       use_persistent("VD_LSTM_PERSIST_BWD");
+  if (persist) {
+    const int tiles_m = vd_cdiv(N, CfgB11::BM), tiles_n = vd_cdiv(H, CfgB11::BN);
+    VdStreamScratch scr;
+    if (int rc0 = vd_stream_scratch(s, 0, seq_sync_bytes(T, tiles_m), &scr)) return rc0;
+    VD_HIP(hipMemsetAsync(scr.sync, 0, seq_sync_bytes(T, tiles_m), s));
+    LstmSeqBwdArgs a;
+    a.Wh = Wh; a.gates = gates; a.c = c; a.c0 = c0; a.dh_seq = dh_seq; a.dh_last = dh_last; a.dc = dc_work;
+    a.dc_has_last = dc_last ? 1 : 0;
+    a.T = T; a.N = N; a.H = H; a.rotate = vd_tune_get("VD_GEMM_ROTATE", 1);
+    a.sc = SeqSched{scr.sync, T, tiles_m, tiles_n, vd_tune_get("VD_LSTM_STAGGER_US", 0) * 100};
+    if (int rc0 = launch_seq(lstm_seq_bwd_kernel<CfgB11>, a, CfgB11::LDS_BYTES, CfgB11::THREADS, T * tiles_m * tiles_n, s))
+      return rc0;
+  }
+  RowChains rc_;
+  int rc = rc_.fork(N, s, persist ? 1 : nchains);
   if (rc) return rc;
-  for (int t = T - 1; t >= 0; --t) {
+  for (int t = T - 1; t >= 0 && !persist; --t) {
     const bool last = (t == T - 1);
     for (int ch = 0; ch < rc_.n; ++ch) {
       const long r0 = rc_.row0[ch];
@@ -601,6 +861,21 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
     rc = launch_gemm<CfgB1>(N, H, 4 * H, 1, a, b, e, s);
     if (rc) return rc;
   }
+  return VD_OK;
+}
+
+// see include/visdial_hip.h
+int vd_lstm_seq_status(void* stream, int* timed_out) {
+  VD_CHECK_ARG(timed_out, "vd_lstm_seq_status: null");
+  *timed_out = 0;
+  hipStream_t s = (hipStream_t)stream;
+  VdStreamScratch scr;
+  if (int rc = vd_stream_scratch(s, 0, 0, &scr)) return rc;
+  VD_HIP(hipStreamSynchronize(s));
+  if (!scr.sync || scr.sync_bytes < (VD_SEQ_ERR_WORD + 1) * sizeof(unsigned)) return VD_OK;  // no persistent launch yet
+  unsigned v = 0;
+  VD_HIP(hipMemcpy(&v, scr.sync + VD_SEQ_ERR_WORD, sizeof(v), hipMemcpyDeviceToHost));
+  *timed_out = (int)v;
   return VD_OK;
 }
 

@@ -29,12 +29,29 @@ def _left_align(rows, T):
     return out
 
 
+def _aligned_random(rng, lens, T, lo, hi, right):
+    """[len(lens) x T] int32 token matrix, row i holding lens[i] ids from [lo, hi) right- or left-aligned, 0 elsewhere
+    (vectorised equivalent of _right_align / _left_align over per-row random draws)"""
+    lens = np.asarray(lens)
+    tok = rng.randint(lo, hi, size=(len(lens), T)).astype(np.int32)
+    pos = np.arange(T)[None, :]
+    keep = (pos >= T - lens[:, None]) if right else (pos < lens[:, None])
+    tok *= keep
+    return tok
+
+
 class SyntheticDataloader(object):
     """Stand-in for `dataloader` (dataloader.lua): same attributes the model reads
-    (vocabSize, maxQuesCount, maxQuesLen, maxAnsLen, numThreads) and getTrainBatch/getTestBatch."""
+    (vocabSize, maxQuesCount, maxQuesLen, maxAnsLen, numThreads) and getTrainBatch/getTestBatch.
+    fast=True draws every token matrix in one vectorised call (same layout contract and distributions, a
+    different random stream): a fresh full-size batch costs a few ms of host time instead of ~0.2 s, which is
+    what lets bench.py draw a new batch every step like the reference's trainIteration does (model.lua:71)."""
 
-    def __init__(self, opt, seed=1234, num_threads=None):
+    def __init__(self, opt, seed=1234, num_threads=None, fast=False):
         self.opt = opt
+        self.fast = bool(fast)
+        self.gen = np.random.default_rng(seed) if fast else None
+        self._img_pool = None
         self.vocabSize = int(opt.get('vocabSize', 11322))   # incl. <START>, <END> (dataloader.lua:17-22)
         self.maxQuesCount = int(opt.get('maxQuesCount', 10))
         self.maxQuesLen = int(opt.get('maxQuesLen', 20))
@@ -63,7 +80,10 @@ class SyntheticDataloader(object):
         if full_length:
             qlen[rng.randint(N)] = self.maxQuesLen
         Tq = int(qlen.max())
-        batch['ques_fwd'] = _right_align([self._tokens(l) for l in qlen], Tq).reshape(B, R, Tq)
+        if self.fast:
+            batch['ques_fwd'] = _aligned_random(rng, qlen, Tq, 1, V - 1, True).reshape(B, R, Tq)
+        else:
+            batch['ques_fwd'] = _right_align([self._tokens(l) for l in qlen], Tq).reshape(B, R, Tq)
         enc = params['encoder']
         if 'hist' in enc:
             if enc.startswith('lf'):   # concatenated history (opts.lua:59, dataloader.lua:217-221,243-255)
@@ -75,11 +95,21 @@ class SyntheticDataloader(object):
                 if full_length:
                     hl[rng.randint(N)] = self.maxHistLen
             Th = int(hl.max())
-            batch['hist'] = _right_align([self._tokens(l) for l in hl], Th).reshape(B, R, Th)
+            if self.fast:
+                batch['hist'] = _aligned_random(rng, hl, Th, 1, V - 1, True).reshape(B, R, Th)
+            else:
+                batch['hist'] = _right_align([self._tokens(l) for l in hl], Th).reshape(B, R, Th)
         if 'im' in enc:
             if 'att' in enc:
                 S, C = int(params['imgSpatialSize']), int(params['imgFeatureSize'])
-                batch['img_feat'] = np.abs(rng.randn(B, S, S, C)).astype(np.float32)
+                if self.fast:
+                    # like the reference (dataloader.lua:378-390: `img_fv:index(1, inds)`): B rows of a resident
+                    # image-feature tensor picked by random thread ids, not freshly drawn noise
+                    if self._img_pool is None or self._img_pool.shape[1:] != (S, S, C):
+                        self._img_pool = np.abs(self.gen.standard_normal((max(64, 2 * B), S, S, C), dtype=np.float32))
+                    batch['img_feat'] = self._img_pool[self.gen.integers(0, len(self._img_pool), size=B)]
+                else:
+                    batch['img_feat'] = np.abs(rng.randn(B, S, S, C)).astype(np.float32)
             else:
                 f = rng.randn(B, int(params['imgFeatureSize'])).astype(np.float32)
                 if int(params.get('imgNorm', 1)) == 1:
@@ -88,7 +118,10 @@ class SyntheticDataloader(object):
         if params['decoder'] == 'disc':
             O, To = self.numOptions, self.maxAnsLen
             ol = rng.randint(1, To + 1, size=N * O)
-            opts = _left_align([self._tokens(l) for l in ol], To).reshape(N, O, To)
+            if self.fast:
+                opts = _aligned_random(rng, ol, To, 1, V - 1, False).reshape(N, O, To)
+            else:
+                opts = _left_align([self._tokens(l) for l in ol], To).reshape(N, O, To)
             batch['options'] = opts
             batch['answer_ind'] = rng.randint(1, O + 1, size=N).astype(np.int32)
         else:

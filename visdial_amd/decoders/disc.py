@@ -44,10 +44,10 @@ class Decoder(object):
         self.gates = ws.get('opt.gates', (To, NO, 4 * H))
         self.h = ws.get('opt.h', (To, NO, H))
         self.c = ws.get('opt.c', (To, NO, H))
-        t0 = ops.prof_begin('opt_lstm_fwd_step')
+        t0 = ops.prof_begin('opt_lstm_fwd')
         ops.lstm_forward(self.table, self.Wh, self.gates, self.h, self.c, To, NO, H, 0, 4 * H, tok_gather=otok,
                          flags=self.flags)
-        ops.prof_end('opt_lstm_fwd_step', t0, To)
+        ops.prof_end('opt_lstm_fwd', t0, 1)      # one persistent launch for all To steps
         self.optH = self.h[To - 1]
         self.output = ws.get('opt.scores', (N, O))
         return self.output          # filled by the criterion call (scores + loss are one kernel)
@@ -68,12 +68,12 @@ class Decoder(object):
         dtab = ws.get('opt.dtable', (V + 1, 4 * H))
         with self.streams.fork('tab'):
             ops.token_sort(tokf, V + 1, offset, work, perm)
-            dtab.zero_()
-        t0 = ops.prof_begin('opt_lstm_bwd_step')
+            ops.zero(dtab)
+        t0 = ops.prof_begin('opt_lstm_bwd')
         fused = os.environ.get('VD_LSTM_WGRAD_OVERLAP', '0') == '1'   # dWh chunks trail the steps (opt-in)
         ops.lstm_backward(self.Wh, self.gates, self.c, dc, To, NO, H, dh_last=d_optH, flags=self.flags,
                           h_seq=self.h if fused else None, dWh=self.dWh if fused else None)
-        ops.prof_end('opt_lstm_bwd_step', t0, To)
+        ops.prof_end('opt_lstm_bwd', t0, 1)
         da = self.gates.view(To * NO, 4 * H)
         if To > 1 and not fused:
             t0 = ops.prof_begin('opt_lstm_dWh')

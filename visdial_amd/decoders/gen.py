@@ -116,7 +116,7 @@ class Decoder(object):
             nll = ws.get('ret.nll', (T, rows))
             ops.logsoftmax_nll(logits, V, cin.view(-1), cout.view(-1), nll.view(-1), write_grad=False)
             acc = ws.get('ret.acc', (rows,))
-            acc.zero_()
+            ops.zero(acc)
             ops.colsum_acc(nll, acc, M=T, N=rows)                            # sum over time (utils.lua:98)
             ops.copy_2d(lhood, O, acc, C, N, C, dst_off=o0)
         return ops.axpby(lhood, None, lhood, -1.0, 0.0)                       # log-likelihood = -NLL

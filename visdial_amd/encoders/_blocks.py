@@ -190,7 +190,7 @@ class SANBlock(object):
         ops.colsum_acc(dz, G['img_common.b'], M=N * S2, N=K)
         ops.img_common_wgrad(dz, self.pre, self.m1, G['img_common.W'], N, R, S2, H, K, sc)
         dpre = ws.get('att.dpre', (B * S2, H))
-        dpre.zero_()
+        ops.zero(dpre)
         ops.img_tr_backward(dz, fp.w['img_common.W'], self.patt, du1, self.m1, dpre, N, R, S2, H, K, sc)
         self.img_proj.backward(dpre, need_dx=False)                              # tanh' + dW, db of mn-att:77
         du0 = self.ques_common.backward(dqc)

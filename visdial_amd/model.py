@@ -31,7 +31,7 @@ class Wrapper(object):
         self._m.drop.training = False
 
     def zeroGradParameters(self):
-        self._m.fp.dW.zero_()
+        ops.zero(self._m.fp.dW)
 
     def getParameters(self):
         return self._m.fp.W, self._m.fp.dW
@@ -91,6 +91,11 @@ class Model(object):
         dec_first = tmp.entries[0][0]
         self._enc_slice = (self.fp.offsets[names[1]][0], self.fp.offsets[dec_first][0])
         self._enc_bucket_work = None
+        # input pipeline: the next batch is fetched and uploaded on its own stream while the device still executes
+        # the current step (Model.trainIteration); the loss leaves the device through a pinned buffer
+        self._copy_stream = torch.cuda.Stream(device=self.device)
+        self._next = None
+        self._loss_host = None
 
     # ------------------------------------------------------------------ helpers
     def _dev(self, a, dtype):
@@ -150,18 +155,37 @@ class Model(object):
         return inputs, dec_in
 
     # ------------------------------------------------------------------ training
-    def trainIteration(self, dataloader):
-        """model.lua:66-106"""
-        self.wrapper.zeroGradParameters()
+    def _fetch(self, dataloader):
+        """getTrainBatch (model.lua:71) + the input re-layout / upload of model.lua:255-294, on the copy stream."""
         batch = dataloader.getTrainBatch(self.params)
-        curLoss = self.forwardBackward(batch)
+        with torch.cuda.stream(self._copy_stream):
+            prepared = self.prepare_inputs(batch)
+            ready = torch.cuda.Event()
+            ready.record()
+        return batch, prepared, ready
+
+    def trainIteration(self, dataloader):
+        """model.lua:66-106.  Same order of effects as the reference (zero grads, batch, forward/backward, loss
+        EMA, clamp, adam, lr decay); the host side is software-pipelined: the whole step is enqueued first, then
+        the NEXT batch is fetched and uploaded on the copy stream while the device executes, and only then does
+        the host wait for this step's loss."""
+        self.wrapper.zeroGradParameters()
+        if self._next is None or self._next[3] is not dataloader:
+            self._next = self._fetch(dataloader) + (dataloader,)
+        batch, prepared, ready, _ = self._next
+        self._next = None
+        torch.cuda.current_stream().wait_event(ready)
+        pending = self.forwardBackward(batch, prepared=prepared, deferLoss=True)
+        self.update()
+        if os.environ.get('VD_PREFETCH', '1') != '0':
+            self._next = self._fetch(dataloader) + (dataloader,)
+        curLoss = pending()
         if self.params['decoder'] == 'gen':
             numTokens = float((batch['answer_out'] > 0).sum())
             cur = curLoss / numTokens
         else:
             cur = curLoss
         self.runningLoss = 0.95 * self.runningLoss + 0.05 * cur if self.runningLoss > 0 else cur
-        self.update()
         return curLoss
 
     def update(self):
@@ -191,18 +215,21 @@ class Model(object):
     def _dp_active(self):
         return self.dist_group is not None and (self.world > 1 or os.environ.get('VD_FORCE_ALLREDUCE') == '1')
 
-    def forwardBackward(self, batch, onlyForward=False, encOutOnly=False, prepared=None):
-        """model.lua:249-342.  Returns curLoss (python float)."""
+    def forwardBackward(self, batch, onlyForward=False, encOutOnly=False, prepared=None, deferLoss=False):
+        """model.lua:249-342.  Returns curLoss (python float); with deferLoss a callable that waits for the
+        device and returns it (everything is enqueued when forwardBackward returns)."""
         inputs, dec_in = prepared if prepared is not None else self.prepare_inputs(batch)
         # LookupTableMaskZero zeroes the pad row on every forward
-        self.fp.w['embed'][0].zero_()
+        ops.zero(self.fp.w['embed'][0])
         if self.params['decoder'] == 'disc' and not encOutOnly:
-            return self._forwardBackward_disc(inputs, dec_in, onlyForward)
+            pending = self._forwardBackward_disc(inputs, dec_in, onlyForward)
+            return pending if deferLoss else pending()
         encOut = self.encoder.forward(inputs)
         self.forwardConnect(self.encoder, self.decoder, encOut, inputs[0].shape[0])
         if encOutOnly:
             return encOut
-        return self.decoder.forward_backward_gen(self, inputs, dec_in, encOut, onlyForward)
+        loss = self.decoder.forward_backward_gen(self, inputs, dec_in, encOut, onlyForward)
+        return (lambda: loss) if deferLoss else loss
 
     def _forwardBackward_disc(self, inputs, dec_in, onlyForward):
         """disc branch of model.lua:326-338.  The encoder (latency-bound chains) runs on a side stream
@@ -244,8 +271,18 @@ class Model(object):
                     _, self._enc_bucket_work = reduce_gradients(self.wrapperdW[lo:hi], self.dist_group, async_op=True)
             st.join('enc')
             self.decoder.backward_embed()
-        curLoss = float(loss_rows.cpu().numpy().astype(np.float64).mean())
-        return curLoss
+        # the per-round losses leave through a pinned buffer; the host waits only when the value is asked for
+        if self._loss_host is None or self._loss_host.numel() < N:
+            self._loss_host = torch.empty(N, dtype=torch.float32).pin_memory()
+        host = self._loss_host[:N]
+        host.copy_(loss_rows, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+
+        def pending():
+            done.synchronize()
+            return float(host.numpy().astype(np.float64).mean())
+        return pending
 
     def _ce_done(self):
         return self._ce_event
@@ -253,7 +290,7 @@ class Model(object):
     # ------------------------------------------------------------------ retrieval (model.lua:142-246,344-430)
     def retrieveBatch(self, batch):
         inputs, dec_in = self.prepare_inputs(batch)
-        self.fp.w['embed'][0].zero_()
+        ops.zero(self.fp.w['embed'][0])
         encOut = self.encoder.forward(inputs)
         if self.params['decoder'] == 'gen':
             scores = self.decoder.retrieve_lhood(self, dec_in['option_in'], dec_in['option_out'], encOut,
@@ -326,7 +363,7 @@ class Model(object):
             R = batch['ques_fwd'].shape[1]
             Tq = batch['ques_fwd'].shape[2]
             inputs, _ = self.prepare_inputs(batch)
-            self.fp.w['embed'][0].zero_()
+            ops.zero(self.fp.w['embed'][0])
             encOut = self.encoder.forward(inputs)                                   # forwardBackward(batch, true, true)
             encLayers = getattr(self.encoder, 'rnnLayers', None)
             threadAnswers = []
@@ -421,15 +458,18 @@ class Model(object):
     def set_parameters_dict(self, d):
         self.fp.load_host(d)
 
-    def load_flat_parameters(self, modelW):
+    def load_flat_parameters(self, modelW, allow_unverified=False):
         """`model.wrapperW:copy(savedModel.modelW)` (train.lua:79, evaluate.lua:91) for a flat vector in the
-        reference's getParameters() layout (no alignment padding) -- e.g. `modelW` of a .t7 checkpoint."""
+        reference's getParameters() layout (no alignment padding, Torch7 module order) -- e.g. `modelW` of a .t7
+        checkpoint.  Raises for the nngraph encoders, whose order is not derivable (t7.VERIFIED_ORDER)."""
         from . import t7
-        self.set_parameters_dict(t7.flat_to_named(np.asarray(modelW), self.fp.spec.entries))
+        self.set_parameters_dict(t7.flat_to_named(np.asarray(modelW), self.fp.spec.entries, self.params['encoder'],
+                                                  allow_unverified))
 
     def flat_parameters(self):
+        """the parameters as the reference's flat `modelW` (Torch7 module order for this encoder)"""
         from . import t7
-        return t7.named_to_flat(self.get_parameters_dict(), self.fp.spec.entries)
+        return t7.named_to_flat(self.get_parameters_dict(), self.fp.spec.entries, self.params['encoder'])
 
     def set_dropout_masks(self, masks):
         """Pin nn.Dropout noise (dict name -> uint8 numpy array) for parity runs; None = generator."""

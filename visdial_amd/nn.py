@@ -94,6 +94,7 @@ class DropoutState(object):
         self.step = 0
         self.training = True
         self.external = None
+        self._sites = {}
 
     def mask(self, name, numel, p):
         if not self.training or p <= 0.0:
@@ -103,7 +104,12 @@ class DropoutState(object):
             assert m.numel() == numel and m.dtype == U8, name
             return m
         m = self.ws.get('dropmask.' + name, (numel,), U8)
-        ops.dropout_mask(m, (self.seed * 1000003 + self.step) * 64 + (zlib.crc32(name.encode()) & 63), p)
+        # one independent counter stream per (seed, step, call site): the full 32-bit crc of the site name goes into
+        # the 64-bit generator seed (6 bits of it once made 'h_emb' and 'hatt' share a stream)
+        site = zlib.crc32(name.encode()) & 0xffffffff
+        clash = self._sites.setdefault(site, name)
+        assert clash == name, "dropout sites %r and %r hash to the same stream" % (clash, name)
+        ops.dropout_mask(m, (((self.seed * 1000003 + self.step) & 0xffffffff) << 32) | site, p)
         return m
 
     def next_step(self):
@@ -151,10 +157,10 @@ class SeqLSTM(object):
         self.userPrevOutput = self.userPrevCell = None          # consumed once (rnn semantics)
         if h0 is not None and c0 is None:
             c0 = self.ws.get(k + '.c0zero', (N, H))
-            c0.zero_()
+            ops.zero(c0)
         if c0 is not None and h0 is None:
             h0 = self.ws.get(k + '.h0zero', (N, H))
-            h0.zero_()
+            ops.zero(h0)
         self.T, self.N, self.xs, self.tok_mask, self.h0, self.c0 = T, N, xs, tok_mask, h0, c0
         self.gates = self.ws.get(k + '.gates', (T, N, 4 * H))
         self.h = self.ws.get(k + '.h', (T, N, H))
@@ -265,7 +271,7 @@ def lstm2_bundle_forward(bundle):
             # and da = 0 in the weight-gradient contractions
             ops.zero_inactive_rows(l1.gates, nact_dev, T, N, 4 * H)
             for b in (l1.h, l1.c, l2.h, l2.c, l2.gates):
-                b.zero_()
+                ops.zero(b)
         descs.append(dict(T=T, N=N, tok_mask=tok, Wh1=l1.Wh, Wx2=l2.Wx, b2=l2.b, Wh2=l2.Wh, gates1=l1.gates, h1=l1.h,
                           c1=l1.c, gates2=l2.gates, h2=l2.h, c2=l2.c, nact=nact))
     ops.lstm2_forward(descs, H)

@@ -18,12 +18,24 @@ def shard_dialogs(num_dialogs, rank, world):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+class _DoneWork(object):
+    def wait(self):
+        return True
+
+
 def reduce_gradients(flat_grad, group=None, async_op=False):
     """Sum the flat gradient over the group.  Returns (gscale, work): multiply by gscale (= 1/world)
-    inside the fused clamp+Adam kernel.  Works for HIP tensors (RCCL) and CPU tensors (gloo tests)."""
+    inside the fused clamp+Adam kernel.  HIP tensors go over RCCL (backend "nccl"); CPU tensors over gloo.
+    A HIP tensor on a gloo group (the 2-ranks-on-one-GPU test, where RCCL refuses duplicate devices) is staged
+    through host memory -- a test vehicle only, never the production path."""
     if group is None and not dist.is_initialized():
         return 1.0, None
     world = dist.get_world_size(group)
+    if flat_grad.is_cuda and dist.get_backend(group) == 'gloo':
+        host = flat_grad.detach().cpu()             # synchronises the current stream
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat_grad.copy_(host)
+        return 1.0 / world, (_DoneWork() if async_op else None)
     work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     return 1.0 / world, work
 

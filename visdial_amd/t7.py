@@ -170,14 +170,41 @@ def save(path, obj, float_tensor_class=None):
 
 # ---------------------------------------------------------------------------------------------------------
 # flat parameter vector <-> named tensors
-def flat_to_named(modelW, spec_entries):
+# Torch7's getParameters() flattens parameter storages in depth-first module order.  For the
+# encoders built from nn.Sequential / nn.ConcatTable that order can be read off the reference file:
+#   lf-*    : wordBranch(embed, ques LSTMs) | [image: no parameters] | histBranch(hist LSTMs) | fuse Linear
+#             (encoders/lf-ques-im-hist.lua:12-58) -- equals this repo's declaration order;
+#   hre-*   : concat = wordBranch(embed), imageBranch(Linear F->imgEmbed), histBranch(hist LSTMs)
+#             (encoders/hre-ques-im-hist.lua:56-60), then the question LSTMs (:72-80), [hrea: the two Linear(H,1),
+#             hrea-ques-im-hist.lua:88-95], then the dialog LSTM (:92) -- the image Linear comes BEFORE the history
+#             LSTMs, unlike this repo's declaration order (hist, img_embed, ques, ...).
+# The nngraph encoders (mn-*, lf-att-*) are flattened in nngraph's internal node order, which cannot be derived
+# without nngraph: UNVERIFIED, refused unless the caller insists.
+VERIFIED_ORDER = ('lf-ques', 'lf-ques-im', 'lf-ques-hist', 'lf-ques-im-hist', 'hre-ques-hist', 'hre-ques-im-hist',
+                  'hrea-ques-im-hist')
+
+
+def reference_order(encoder, spec_entries):
+    """spec entries re-ordered to the reference's getParameters() order for `encoder`"""
+    entries = list(spec_entries)
+    if encoder is not None and encoder.startswith('hre'):
+        img = [e for e in entries if e[0].startswith('img_embed.')]
+        rest = [e for e in entries if not e[0].startswith('img_embed.')]
+        at = 1 if rest and rest[0][0] == 'embed' else 0
+        entries = rest[:at] + img + rest[at:]
+    return entries
+
+
+def flat_to_named(modelW, spec_entries, encoder=None, allow_unverified=False):
     """Split a reference-style flat vector (getParameters(): tensors back to back, NO alignment padding) into
-    this repo's named tensors.  Order assumption: embed | encoder tensors in plug-in declaration order | decoder
-    tensors, weight before bias -- the depth-first module order Torch7 uses for nn.Sequential encoders (lf-*,
-    hre-*).  For the nngraph encoders (mn-*, lf-att) Torch7's order follows nngraph's internal node order, which
-    cannot be derived without nngraph: treat those as unverified."""
+    this repo's named tensors, using the reference's parameter order for `encoder` (reference_order).  encoder=None
+    keeps this repo's own declaration order (checkpoints written by this repo's named_to_flat with encoder=None)."""
+    if encoder is not None and encoder not in VERIFIED_ORDER and not allow_unverified:
+        raise ValueError("the getParameters() order of the nngraph encoder '%s' cannot be derived without nngraph "
+                         "(SURVEY.md App. A7): refusing to load a reference flat vector (it would load silently "
+                         "scrambled); pass allow_unverified=True to assume declaration order" % encoder)
     out, o = {}, 0
-    for name, shape, _ in spec_entries:
+    for name, shape, _ in reference_order(encoder, spec_entries):
         n = int(np.prod(shape))
         out[name] = np.asarray(modelW[o:o + n], np.float32).reshape(shape)
         o += n
@@ -186,5 +213,6 @@ def flat_to_named(modelW, spec_entries):
     return out
 
 
-def named_to_flat(named, spec_entries):
-    return np.concatenate([np.asarray(named[n], np.float32).reshape(-1) for n, _, _ in spec_entries])
+def named_to_flat(named, spec_entries, encoder=None):
+    return np.concatenate([np.asarray(named[n], np.float32).reshape(-1)
+                           for n, _, _ in reference_order(encoder, spec_entries)])
