@@ -277,16 +277,30 @@ __device__ __forceinline__ unsigned vd_cu_key() {  // CU / SH / SE id bits of HW
   return x & 255u;
 }
 
-// Thread 0 only.  Pull the next item (processing step s, row tile r, column tile j) and wait until the rows it
-// depends on are complete.  Returns false when every queue is exhausted.
-__device__ __forceinline__ bool seq_next(const SeqSched& sc, int& q, int& tried, int& s, int& r, int& j) {
+// Wave-level helpers.  All control flow of the scheduler is WAVE-UNIFORM (scalar branch conditions): a divergent
+// `if (threadIdx.x == 0) { loops ... }` region next to s_barrier lets the compiler's CFG structurizer rotate the
+// tile loop so that lanes 1..63 of wave 0 run ahead through the barrier while lane 0 is parked (observed: an endless
+// loop re-reading a stale work item).  The only per-lane regions left are single instructions under `lane == 0`.
+__device__ __forceinline__ unsigned wave_fetch_add(unsigned* p, unsigned v, int lane) {
+  unsigned r = 0;
+  if (lane == 0) r = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+}
+__device__ __forceinline__ unsigned wave_load(unsigned* p, int lane) {
+  unsigned r = 0;
+  if (lane == 0) r = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+}
+
+// Executed by ONE wave (all lanes, uniformly).  Pull the next item (processing step s, row tile r, column tile j)
+// and wait until the rows it depends on are complete.  Returns false when every queue is exhausted.
+__device__ __forceinline__ bool seq_next(const SeqSched& sc, int lane, int& q, int& tried, int& s, int& r, int& j) {
   unsigned* const sync = sc.sync;
   for (;;) {
     const int rt0 = (int)((long)q * sc.tiles_m / VD_SEQ_QUEUES), rt1 = (int)((long)(q + 1) * sc.tiles_m / VD_SEQ_QUEUES);
     const int per_step = (rt1 - rt0) * sc.tiles_n;
     if (per_step > 0) {
-      const unsigned idx = __hip_atomic_fetch_add(sync + q * VD_SEQ_HEAD_STRIDE, 1u, __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned idx = wave_fetch_add(sync + q * VD_SEQ_HEAD_STRIDE, 1u, lane);
       if (idx < (unsigned)per_step * (unsigned)sc.T) {
         s = (int)(idx / (unsigned)per_step);
         const int rem = (int)(idx - (unsigned)s * (unsigned)per_step);
@@ -301,14 +315,14 @@ __device__ __forceinline__ bool seq_next(const SeqSched& sc, int& q, int& tried,
   if (s > 0) {
     unsigned* const cnt = sync + VD_SEQ_CNT0 + (long)(s - 1) * sc.tiles_m + r;
     unsigned* const err = sync + VD_SEQ_ERR_WORD;
-    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)sc.tiles_n) {
+    if (wave_load(cnt, lane) < (unsigned)sc.tiles_n) {
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       for (;;) {
         __builtin_amdgcn_s_sleep(4);
-        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)sc.tiles_n) break;
-        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if (wave_load(cnt, lane) >= (unsigned)sc.tiles_n) break;
+        if (wave_load(err, lane) != 0u) break;
         if (__builtin_amdgcn_s_memrealtime() - t0 > VD_SEQ_TIMEOUT_TICKS) {
-          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
       }
@@ -318,32 +332,56 @@ __device__ __forceinline__ bool seq_next(const SeqSched& sc, int& q, int& tried,
   return true;
 }
 
-// All threads.  Publish a finished tile: every wave drains its stores, then one lane releases at agent scope
+// All threads.  Publish a finished tile: every wave drains its stores, then one wave releases at agent scope
 // and bumps the (row tile, step) arrival counter.
-__device__ __forceinline__ void seq_publish(const SeqSched& sc, int s, int r) {
+__device__ __forceinline__ void seq_publish(const SeqSched& sc, int s, int r, int wave, int lane) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (wave == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler may drop the wait behind buffer_wbl2 (guide, G16 pitfall 12)
-    __hip_atomic_fetch_add(sc.sync + VD_SEQ_CNT0 + (long)s * sc.tiles_m + r, 1u, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0)
+      __hip_atomic_fetch_add(sc.sync + VD_SEQ_CNT0 + (long)s * sc.tiles_m + r, 1u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 // One-time start stagger: the k-th workgroup of this launch to arrive on a CU waits k * stagger_ticks, so the
 // co-resident workgroups of a CU begin out of phase instead of drifting apart over the first steps.
-__device__ __forceinline__ void seq_stagger(const SeqSched& sc, unsigned xcc) {
+__device__ __forceinline__ void seq_stagger(const SeqSched& sc, unsigned xcc, int wave, int lane) {
   if (sc.stagger_ticks <= 0) return;
-  if (threadIdx.x == 0) {
-    const unsigned k = __hip_atomic_fetch_add(sc.sync + VD_SEQ_CU_WORDS + xcc * 256 + vd_cu_key(), 1u, __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
+  if (wave == 0) {
+    const unsigned k = wave_fetch_add(sc.sync + VD_SEQ_CU_WORDS + xcc * 256 + vd_cu_key(), 1u, lane);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long wait = (unsigned long long)(k % 3u) * (unsigned)sc.stagger_ticks;
     while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
   }
   __syncthreads();
 }
+
+// Scheduler state of a workgroup (wave 0 owns it, in SGPRs) + the LDS mailbox the other waves read the item from.
+#define VD_SEQ_LOOP_HEAD(ARGS)                                                                          \
+  int* const slot = reinterpret_cast<int*>(smem) + Cfg::LDS_BYTES / 4 - 4; /* beyond DMA buffers / scratch */ \
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);                               \
+  const int lane0 = (int)threadIdx.x & 63;                                                              \
+  const unsigned xcc = vd_xcc_id();                                                                     \
+  int q = (int)xcc, tried = 0;                                                                          \
+  seq_stagger((ARGS).sc, xcc, wave, lane0);
+
+#define VD_SEQ_NEXT_ITEM(ARGS, S, R, J)                                                                 \
+  if (wave == 0) {                                                                                      \
+    int s_ = -1, r_ = 0, j_ = 0;                                                                        \
+    if (!seq_next((ARGS).sc, lane0, q, tried, s_, r_, j_)) s_ = -1;                                     \
+    if (lane0 == 0) {                                                                                   \
+      slot[0] = s_;                                                                                     \
+      slot[1] = r_;                                                                                     \
+      slot[2] = j_;                                                                                     \
+    }                                                                                                   \
+  }                                                                                                     \
+  __syncthreads();                                                                                      \
+  const int S = __builtin_amdgcn_readfirstlane(slot[0]);                                                \
+  const int R = __builtin_amdgcn_readfirstlane(slot[1]);                                                \
+  const int J = __builtin_amdgcn_readfirstlane(slot[2]);
 
 struct LstmSeqFwdArgs {
   const float* xproj;   // dense: [T x N x 4H] (x_tstride per step); table mode: [V+1 x 4H]
@@ -360,25 +398,10 @@ struct LstmSeqFwdArgs {
 template <class Cfg>
 __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) lstm_seq_fwd_kernel(LstmSeqFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  int* const slot = reinterpret_cast<int*>(smem) + Cfg::LDS_BYTES / 4 - 4;  // beyond the DMA buffers / epilogue scratch
-  const unsigned xcc = vd_xcc_id();
-  seq_stagger(a.sc, xcc);
-  if (threadIdx.x == 0) slot[3] = (int)xcc;  // queue cursor: q | tried << 8 (thread 0's state lives in LDS, not in VGPRs)
+  VD_SEQ_LOOP_HEAD(a)
   const long NH = (long)a.N * a.H;
   for (;;) {
-    if (threadIdx.x == 0) {
-      int s = -1, r = 0, j = 0;
-      int q = slot[3] & 255, tried = slot[3] >> 8;
-      if (!seq_next(a.sc, q, tried, s, r, j)) s = -1;
-      slot[0] = s;
-      slot[1] = r;
-      slot[2] = j;
-      slot[3] = q | (tried << 8);
-    }
-    __syncthreads();
-    const int t = __builtin_amdgcn_readfirstlane(slot[0]);
-    const int r = __builtin_amdgcn_readfirstlane(slot[1]);
-    const int j = __builtin_amdgcn_readfirstlane(slot[2]);
+    VD_SEQ_NEXT_ITEM(a, t, r, j)
     if (t < 0) break;
     const float* hp = t ? a.h + (t - 1) * NH : a.h0;
     EpiLstmFwd e;
@@ -395,7 +418,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) lstm_seq_fwd_kernel(L
     asm volatile("" : "+v"(tid));  // per-lane address terms are rebuilt per tile, not kept live across tiles
     gemm_block_glds<Cfg, false>(a.N, 4 * a.H, 0, hp ? a.H : 0, r * Cfg::BM, j * Cfg::BN, a.rotate ? r * 5 + j * 3 : -1, hp,
                                 (long)a.H, a.WhT, (long)a.H, e, smem, tid);
-    seq_publish(a.sc, t, r);
+    seq_publish(a.sc, t, r, wave, lane0);
   }
 }
 
@@ -414,25 +437,10 @@ struct LstmSeqBwdArgs {
 template <class Cfg>
 __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  int* const slot = reinterpret_cast<int*>(smem) + Cfg::LDS_BYTES / 4 - 4;
-  const unsigned xcc = vd_xcc_id();
-  seq_stagger(a.sc, xcc);
-  if (threadIdx.x == 0) slot[3] = (int)xcc;  // queue cursor: q | tried << 8 (thread 0's state lives in LDS, not in VGPRs)
+  VD_SEQ_LOOP_HEAD(a)
   const long NH = (long)a.N * a.H;
   for (;;) {
-    if (threadIdx.x == 0) {
-      int s = -1, r = 0, j = 0;
-      int q = slot[3] & 255, tried = slot[3] >> 8;
-      if (!seq_next(a.sc, q, tried, s, r, j)) s = -1;
-      slot[0] = s;
-      slot[1] = r;
-      slot[2] = j;
-      slot[3] = q | (tried << 8);
-    }
-    __syncthreads();
-    const int s = __builtin_amdgcn_readfirstlane(slot[0]);
-    const int r = __builtin_amdgcn_readfirstlane(slot[1]);
-    const int j = __builtin_amdgcn_readfirstlane(slot[2]);
+    VD_SEQ_NEXT_ITEM(a, s, r, j)
     if (s < 0) break;
     const int t = a.T - 1 - s;
     const bool last = (s == 0);
@@ -450,7 +458,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) lstm_seq_bwd_kernel(L
     asm volatile("" : "+v"(tid));
     gemm_block_glds<Cfg, false>(a.N, a.H, 0, last ? 0 : 4 * a.H, r * Cfg::BM, j * Cfg::BN, a.rotate ? r * 5 + j * 3 : -1,
                                 da_next, 4L * a.H, a.Wh, 4L * a.H, e, smem, tid);
-    seq_publish(a.sc, s, r);
+    seq_publish(a.sc, s, r, wave, lane0);
   }
 }
 
