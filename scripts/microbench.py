@@ -78,7 +78,12 @@ def main():
                         ("1024 blocks, no rotation", dict(VD_GEMM_ROTATE=0)),
                         ("768 blocks, double-buffered cfg", dict(VD_TN_BLOCKS=768, VD_TN_CFG=0)),
                         ("512 blocks, double-buffered cfg", dict(VD_TN_BLOCKS=512, VD_TN_CFG=0)),
-                        ("768 blocks, k-major LDS-DMA", dict(VD_TN_BLOCKS=768, VD_TN_CFG=20))]:
+                        ("768 blocks, k-major LDS-DMA", dict(VD_TN_BLOCKS=768, VD_TN_CFG=20)),
+                        ("512 blocks, k-major LDS-DMA", dict(VD_TN_BLOCKS=512, VD_TN_CFG=20)),
+                        ("1024 blocks, k-major LDS-DMA", dict(VD_TN_BLOCKS=1024, VD_TN_CFG=20)),
+                        ("1536 blocks, k-major LDS-DMA", dict(VD_TN_BLOCKS=1536, VD_TN_CFG=20)),
+                        ("768 blocks, k-major, no rot", dict(VD_TN_BLOCKS=768, VD_TN_CFG=20, VD_GEMM_ROTATE=0)),
+                        ("2304 blocks, k-major", dict(VD_TN_BLOCKS=2304, VD_TN_CFG=20))]:
         ops.tune_clear()
         for k, v in knobs.items():
             ops.tune_set(k, v)

@@ -161,7 +161,7 @@ def test_lstm_persistent_equals_per_step_launches(ops, stagger):
     Every word of h / c / gates (forward) and da / dc (backward) is compared."""
     T, N, H, V = 12, 20000, 64, 50
     rng = np.random.RandomState(7)
-    Wh = dev(f32(rng, H, 4 * H) / np.sqrt(H))
+    Wh = dev((f32(rng, H, 4 * H) / np.sqrt(H)).astype(np.float32))
     tab = dev(f32(rng, V + 1, 4 * H) * 0.5)
     tok = dev(rng.randint(0, V + 1, size=(T, N)).astype(np.int32))
     dh_last = dev(f32(rng, N, H))
