@@ -50,16 +50,14 @@ def main():
         ops.lstm_forward(table, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok)
 
     # A/B sweep of the recurrence launch structure (one process, knobs through vd_tune_set)
-    variants = [("per-step launches", dict(VD_LSTM_PERSIST_FWD=0, VD_LSTM_PERSIST_BWD=0)),
-                ("persistent", dict()),
-                ("persistent, no K rotation", dict(VD_GEMM_ROTATE=0)),
-                ("persistent, stagger 20us", dict(VD_LSTM_STAGGER_US=20)),
-                ("persistent, stagger 40us", dict(VD_LSTM_STAGGER_US=40)),
-                ("persistent, stagger 80us", dict(VD_LSTM_STAGGER_US=80)),
-                ("persistent, 2 WG/CU grid", dict(VD_LSTM_SEQ_WGS_PER_CU=2)),
-                ("persistent, 4 WG/CU grid", dict(VD_LSTM_SEQ_WGS_PER_CU=4))]
+    variants = [("per-step, bwd epilogue batch 1 (<=128 VGPR)", dict(VD_LSTM_BWD_BATCH2=0)),
+                ("per-step launches", dict()),
+                ("persistent", dict(VD_LSTM_PERSIST_FWD=1, VD_LSTM_PERSIST_BWD=1)),
+                ("persistent, bwd batch 1", dict(VD_LSTM_PERSIST_FWD=1, VD_LSTM_PERSIST_BWD=1, VD_LSTM_BWD_BATCH2=0)),
+                ("persistent, stagger 40us", dict(VD_LSTM_PERSIST_FWD=1, VD_LSTM_PERSIST_BWD=1, VD_LSTM_STAGGER_US=40)),
+                ("persistent, 2 WG/CU grid", dict(VD_LSTM_PERSIST_FWD=1, VD_LSTM_PERSIST_BWD=1, VD_LSTM_SEQ_WGS_PER_CU=2))]
     if os.environ.get("MB_SWEEP", "1") == "0":
-        variants = variants[1:2]
+        variants = variants[:2]
     for name, knobs in variants:
         ops.tune_clear()
         for k, v in knobs.items():
@@ -67,7 +65,7 @@ def main():
         ms = timeit(fwd, iters=5, warm=2)
         ms2 = timeit(bwd, iters=3, warm=1)
         bad = ops.lstm_seq_status()
-        print("option LSTM T=20 N=%d [%-28s] fwd %.2f ms %.1f TF | bwd %.2f ms %.1f TF%s" % (
+        print("option LSTM T=20 N=%d [%-44s] fwd %.2f ms %.1f TF | bwd %.2f ms %.1f TF%s" % (
             N, name, ms, fl / ms / 1e9, ms2, fl / ms2 / 1e9, "  TIMEOUT FLAG SET" if bad else ""))
     ops.tune_clear()
     fwd()

@@ -30,51 +30,90 @@ struct EpiLstmFwd {
   float* c_out;           // [N x H]
   float* h_out;           // [N x H]
   int H;
+  // The four accumulator tiles are i,f,o,g of hidden units [j0, j0+32).  Each is staged through the wave's LDS
+  // scratch so that a lane ends up with 4 consecutive hidden units of one row: every global access of the cell
+  // update is a 16-byte one (8 lanes = one 128-byte segment of a row).
+  //
+  // Memory-level parallelism is scheduled by hand: a lane serves 4 rows (p = 0..3) and every row needs a dependent
+  // chain token id -> projection row -> math -> stores.  Left to the compiler this became 4 x (id load, wait, 5 row
+  // loads, wait, math, stores): 8 serialised round trips, about as long as the whole K loop of the tile (the
+  // workgroup's matrix pipe share sits idle meanwhile).  Here the 4 token / mask ids are fetched in ONE batch whose
+  // latency hides under the LDS transposes, and the row loads of p+1 are issued as soon as the loaded values of p
+  // have been folded into the pre-activations (one buffer of 20 VGPRs, reused), so they fly under the
+  // transcendental math and the stores of p.
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int vcol0, int lane, int M,
                                              int /*Nv*/, float* scr) const {
-    // The four accumulator tiles are i,f,o,g of hidden units [j0, j0+32).  Each is staged through the
-    // wave's LDS scratch so that a lane ends up with 4 consecutive hidden units of one row: every global
-    // access of the cell update is then a 16-byte one (8 lanes = one 128-byte segment of a row).
-    const int j = (vcol0 >> 7) * 32 + (lane & 7) * 4;
-    float4 ai[4], af[4], ao[4], ag[4];
-    tile_to_rows(acc[0], scr, lane, ai);
-    tile_to_rows(acc[1], scr, lane, af);
-    tile_to_rows(acc[2], scr, lane, ao);
-    tile_to_rows(acc[3], scr, lane, ag);
-    VD_T(3);
-    if (j >= H) return;
+    const int j = (vcol0 >> 7) * 32 + (lane & 7) * 4;  // < H: H % 32 == 0 and vcol0 < 4H
+    const int rl = lane >> 3;
+    int rowc[4], tk[4], keep[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int row = row0 + p * 8 + (lane >> 3);
-      if (row >= M) continue;
+      const int row = row0 + p * 8 + rl;
+      rowc[p] = row < M ? row : M - 1;  // rows past the end load from a valid address and are not stored
+      tk[p] = rowc[p];
+      keep[p] = 1;
+    }
+    // (one uniform branch per id array with its 4 loads back to back: a per-row `ptr ? ptr[row] : row` select made
+    //  the compiler wait for each load before the next)
+    if (tok_gather) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) tk[p] = tok_gather[rowc[p]];
+    }
+    if (tok_mask) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) keep[p] = tok_mask[rowc[p]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float4 a[4][4];  // [gate][p]
+    tile_to_rows(acc[0], scr, lane, a[0]);
+    tile_to_rows(acc[1], scr, lane, a[1]);
+    tile_to_rows(acc[2], scr, lane, a[2]);
+    tile_to_rows(acc[3], scr, lane, a[3]);
+    VD_T(3);
+    float4 x[4], cp;
+    auto issue = [&](int p) {
+      const float* xr = xproj + (long)tk[p] * xld + j;
+      x[0] = *reinterpret_cast<const float4*>(xr);
+      x[1] = *reinterpret_cast<const float4*>(xr + H);
+      x[2] = *reinterpret_cast<const float4*>(xr + 2 * H);
+      x[3] = *reinterpret_cast<const float4*>(xr + 3 * H);
+      cp = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c_prev) cp = *reinterpret_cast<const float4*>(c_prev + (long)rowc[p] * H + j);
+    };
+    issue(0);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      // fold the loaded values into the pre-activations; x / cp are dead afterwards
+      float4 pi = a[0][p], pf = a[1][p], po = a[2][p], pg = a[3][p];
+      pi.x += x[0].x; pi.y += x[0].y; pi.z += x[0].z; pi.w += x[0].w;
+      pf.x += x[1].x; pf.y += x[1].y; pf.z += x[1].z; pf.w += x[1].w;
+      po.x += x[2].x; po.y += x[2].y; po.z += x[2].z; po.w += x[2].w;
+      pg.x += x[3].x; pg.y += x[3].y; pg.z += x[3].z; pg.w += x[3].w;
+      const float4 cq = cp;
+      __builtin_amdgcn_sched_barrier(0);
+      if (p + 1 < 4) issue(p + 1);  // in flight under the math and stores below
+      __builtin_amdgcn_sched_barrier(0);
+      const float km = keep[p] != 0 ? 1.f : 0.f;  // maskZero(): h = c = gates = 0 for pad rows
       float4 gi, gf, go, gg, c, h;
-      if (tok_mask && tok_mask[row] == 0) {
-        gi = gf = go = gg = c = h = make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {
-        const float* xr = xproj + (tok_gather ? (long)tok_gather[row] : (long)row) * xld + j;
-        const float4 xi = *reinterpret_cast<const float4*>(xr);
-        const float4 xf = *reinterpret_cast<const float4*>(xr + H);
-        const float4 xo = *reinterpret_cast<const float4*>(xr + 2 * H);
-        const float4 xg = *reinterpret_cast<const float4*>(xr + 3 * H);
-        float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c_prev) cp = *reinterpret_cast<const float4*>(c_prev + (long)row * H + j);
-#define VD_CELL(E)                                        \
-        gi.E = vd_sigmoid(ai[p].E + xi.E);                \
-        gf.E = vd_sigmoid(af[p].E + xf.E);                \
-        go.E = vd_sigmoid(ao[p].E + xo.E);                \
-        gg.E = vd_tanh(ag[p].E + xg.E);                   \
-        c.E = gf.E * cp.E + gi.E * gg.E;                  \
-        h.E = go.E * vd_tanh(c.E);
-        VD_CELL(x) VD_CELL(y) VD_CELL(z) VD_CELL(w)
+#define VD_CELL(E)                                  \
+      gi.E = km * vd_sigmoid(pi.E);                 \
+      gf.E = km * vd_sigmoid(pf.E);                 \
+      go.E = km * vd_sigmoid(po.E);                 \
+      gg.E = km * vd_tanh(pg.E);                    \
+      c.E = gf.E * cq.E + gi.E * gg.E;              \
+      h.E = go.E * vd_tanh(c.E);
+      VD_CELL(x) VD_CELL(y) VD_CELL(z) VD_CELL(w)
 #undef VD_CELL
+      const int row = row0 + p * 8 + rl;
+      if (row < M) {
+        float* gr = gates + (long)row * 4 * H + j;
+        *reinterpret_cast<float4*>(gr) = gi;
+        *reinterpret_cast<float4*>(gr + H) = gf;
+        *reinterpret_cast<float4*>(gr + 2 * H) = go;
+        *reinterpret_cast<float4*>(gr + 3 * H) = gg;
+        *reinterpret_cast<float4*>(c_out + (long)row * H + j) = c;
+        *reinterpret_cast<float4*>(h_out + (long)row * H + j) = h;
       }
-      float* gr = gates + (long)row * 4 * H + j;
-      *reinterpret_cast<float4*>(gr) = gi;
-      *reinterpret_cast<float4*>(gr + H) = gf;
-      *reinterpret_cast<float4*>(gr + 2 * H) = go;
-      *reinterpret_cast<float4*>(gr + 3 * H) = gg;
-      *reinterpret_cast<float4*>(c_out + (long)row * H + j) = c;
-      *reinterpret_cast<float4*>(h_out + (long)row * H + j) = h;
     }
   }
 };
@@ -87,7 +126,8 @@ struct EpiLstmFwd {
 //   dc_next <- dc*f
 // da_t overwrites the saved gates of step t in place.
 // ---------------------------------------------------------------------------
-template <int NT>
+// BATCH = slots whose loads are issued together before any is consumed (1 or 2; see the comment inside).
+template <int NT, int BATCH = (NT == 1 ? 2 : 1)>
 struct EpiLstmBwd {
   const float* dh_a;  // nullable [N x H]
   const float* dh_b;  // nullable [N x H]
@@ -97,56 +137,84 @@ struct EpiLstmBwd {
   float* dc;            // [N x H] in: dc_next (ignored when dc_first), out: dc for step t-1
   int dc_first;
   int H;
+  // A lane serves NT x 4 (column tile, row) slots of 4 consecutive hidden units.  Each slot reads 7-9 float4 (saved
+  // gates, c_t, c_{t-1}, dc, incoming dh) before ~30 flops of math, so the epilogue is pure memory latency.  Left to
+  // the compiler the slots ran back to back, each behind its own s_waitcnt vmcnt(0) (plus one more round trip per
+  // optional dh operand): 8-24 serialised round trips per tile.  Here every operand of a slot (optional ones included)
+  // is requested in one batch, and with BATCH = 2 the loads of TWO slots are issued before any of them is consumed
+  // (half the round trips).  BATCH = 2 needs ~140 VGPRs next to the second accumulator tile of the 128x64
+  // throughput shape (it spills at the 128-register cap), so that shape has two builds: <=128 VGPRs with BATCH = 1
+  // (a latency-shape workgroup of another stream still fits beside three of these on a SIMD) and <=168 VGPRs with
+  // BATCH = 2; the single-tile latency shapes (NT = 1) fit BATCH = 2 inside 128.
+  struct Slot {
+    float4 g[4], ct, cp, dcv, dhx;
+  };
+  __device__ __forceinline__ void load_slot(Slot& L, int rc, int jc) const {
+    const long o = (long)rc * H + jc;
+    const float* gr = gates + (long)rc * 4 * H + jc;
+    L.g[0] = *reinterpret_cast<const float4*>(gr);
+    L.g[1] = *reinterpret_cast<const float4*>(gr + H);
+    L.g[2] = *reinterpret_cast<const float4*>(gr + 2 * H);
+    L.g[3] = *reinterpret_cast<const float4*>(gr + 3 * H);
+    L.ct = *reinterpret_cast<const float4*>(c_t + o);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    L.cp = c_prev ? *reinterpret_cast<const float4*>(c_prev + o) : z;
+    L.dcv = dc_first ? z : *reinterpret_cast<const float4*>(dc + o);
+    const float* dh1 = dh_a ? dh_a : dh_b;   // the common case has at most one incoming-gradient operand
+    L.dhx = dh1 ? *reinterpret_cast<const float4*>(dh1 + o) : z;
+  }
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[NT], int row0, int col0, int lane, int M,
                                              int N, float* scr) const {
+    const int rl = lane >> 3, cl = (lane & 7) * 4;
+    const bool two_dh = dh_a && dh_b;
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
       float4 d4[4];
       tile_to_rows(acc[jt], scr, lane, d4);  // row-vectorised: 4 consecutive hidden units per lane
-      const int j = col0 + jt * 32 + (lane & 7) * 4;
-      if (j >= N) continue;
+      const int j = col0 + jt * 32 + cl;
+      const int jc = j < N ? j : N - 4;      // N = H here; columns past the end load a valid address, never stored
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int row = row0 + p * 8 + (lane >> 3);
-        if (row >= M) continue;
-        const long o = (long)row * H + j;
-        float4 dh = d4[p];
-        if (dh_a) {
-          const float4 t = *reinterpret_cast<const float4*>(dh_a + o);
-          dh.x += t.x; dh.y += t.y; dh.z += t.z; dh.w += t.w;
+      for (int pp = 0; pp < 4; pp += BATCH) {
+        Slot L[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) {
+          const int row = row0 + (pp + q) * 8 + rl;
+          load_slot(L[q], row < M ? row : M - 1, jc);
         }
-        if (dh_b) {
-          const float4 t = *reinterpret_cast<const float4*>(dh_b + o);
-          dh.x += t.x; dh.y += t.y; dh.z += t.z; dh.w += t.w;
-        }
-        float* gr = gates + (long)row * 4 * H + j;
-        const float4 gi = *reinterpret_cast<const float4*>(gr);
-        const float4 gf = *reinterpret_cast<const float4*>(gr + H);
-        const float4 go = *reinterpret_cast<const float4*>(gr + 2 * H);
-        const float4 gg = *reinterpret_cast<const float4*>(gr + 3 * H);
-        const float4 ct = *reinterpret_cast<const float4*>(c_t + o);
-        float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c_prev) cp = *reinterpret_cast<const float4*>(c_prev + o);
-        float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!dc_first) dcv = *reinterpret_cast<const float4*>(dc + o);
-        float4 ai, af, ao, ag, dn;
-#define VD_CELLB(E)                                                   \
-        {                                                             \
-          const float tc = vd_tanh(ct.E);                             \
-          const float d = dcv.E + dh.E * go.E * (1.f - tc * tc);      \
-          ai.E = d * gg.E * gi.E * (1.f - gi.E);                      \
-          af.E = d * cp.E * gf.E * (1.f - gf.E);                      \
-          ao.E = dh.E * tc * go.E * (1.f - go.E);                     \
-          ag.E = d * gi.E * (1.f - gg.E * gg.E);                      \
-          dn.E = d * gf.E;                                            \
-        }
-        VD_CELLB(x) VD_CELLB(y) VD_CELLB(z) VD_CELLB(w)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) {
+          const Slot& C = L[q];
+          float4 dh = d4[pp + q];
+          dh.x += C.dhx.x; dh.y += C.dhx.y; dh.z += C.dhx.z; dh.w += C.dhx.w;
+          const int row = row0 + (pp + q) * 8 + rl;
+          const long o = (long)(row < M ? row : M - 1) * H + jc;
+          if (two_dh) {
+            const float4 t = *reinterpret_cast<const float4*>(dh_b + o);
+            dh.x += t.x; dh.y += t.y; dh.z += t.z; dh.w += t.w;
+          }
+          float4 ai, af, ao, ag, dn;
+#define VD_CELLB(E)                                                       \
+          {                                                               \
+            const float tc = vd_tanh(C.ct.E);                             \
+            const float d = C.dcv.E + dh.E * C.g[2].E * (1.f - tc * tc);  \
+            ai.E = d * C.g[3].E * C.g[0].E * (1.f - C.g[0].E);            \
+            af.E = d * C.cp.E * C.g[1].E * (1.f - C.g[1].E);              \
+            ao.E = dh.E * tc * C.g[2].E * (1.f - C.g[2].E);               \
+            ag.E = d * C.g[0].E * (1.f - C.g[3].E * C.g[3].E);            \
+            dn.E = d * C.g[1].E;                                          \
+          }
+          VD_CELLB(x) VD_CELLB(y) VD_CELLB(z) VD_CELLB(w)
 #undef VD_CELLB
-        *reinterpret_cast<float4*>(gr) = ai;
-        *reinterpret_cast<float4*>(gr + H) = af;
-        *reinterpret_cast<float4*>(gr + 2 * H) = ao;
-        *reinterpret_cast<float4*>(gr + 3 * H) = ag;
-        *reinterpret_cast<float4*>(dc + o) = dn;
+          if (row < M && j < N) {
+            float* gr = gates + (long)row * 4 * H + j;
+            *reinterpret_cast<float4*>(gr) = ai;
+            *reinterpret_cast<float4*>(gr + H) = af;
+            *reinterpret_cast<float4*>(gr + 2 * H) = ao;
+            *reinterpret_cast<float4*>(gr + 3 * H) = ag;
+            *reinterpret_cast<float4*>(dc + o) = dn;
+          }
+        }
       }
     }
   }
@@ -178,6 +246,7 @@ using CfgB7 = GemmCfg<4, 1, 2, 16, 2, 3>;  // two register stages
 using CfgB8 = GemmCfg<4, 1, 2, 16, 0, 3>;
 using CfgB10 = GemmCfg<4, 1, 2, 32, 2, 3>;
 using CfgB11 = GemmCfg<4, 1, 2, 16, 0, 4, 41984>;
+using CfgB12 = GemmCfg<4, 1, 2, 16, 0, 3, 41984>;  // <=168 VGPR build of B11 for the two-slot epilogue (EpiLstmBwd<2, 2>)
 // latency shapes (N ~ 200 rows): 4-way intra-block split-K.  Single LDS buffer and <= 152 VGPRs so one
 // of these workgroups fits into the footprint a retiring throughput-shape workgroup frees (they run
 // concurrently on other streams).
@@ -445,7 +514,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) lstm_seq_bwd_kernel(L
     const int t = a.T - 1 - s;
     const bool last = (s == 0);
     const float* da_next = last ? nullptr : a.gates + (long)(t + 1) * 4 * NH;
-    EpiLstmBwd<Cfg::NT> e;
+    EpiLstmBwd<Cfg::NT, (Cfg::MINW <= 3 ? 2 : 1)> e;
     e.dh_a = a.dh_seq ? a.dh_seq + t * NH : nullptr;
     e.dh_b = (last && a.dh_last) ? a.dh_last : nullptr;
     e.gates = a.gates + (long)t * 4 * NH;
@@ -463,7 +532,11 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) lstm_seq_bwd_kernel(L
 }
 
 // persistent path eligibility (on top of the LDS-DMA eligibility): more than one step, one row chain
-static bool use_persistent(const char* knob) { return vd_tune_get(knob, 1) != 0; }
+// Opt-in (default off).  Measured on MI355X (profiles/r02_persistent_vs_per_step.txt): alone the persistent launches
+// run at the per-step kernels' speed (fwd 7.36 vs 7.02 ms, bwd 6.90 vs 6.90 ms), and inside the training step they
+// LOSE 1.9 ms (29.5 vs 27.6 ms/step): a 7 ms launch that owns every workgroup slot leaves the encoder's ~170 small
+// launches only the one spare wave slot per SIMD, so they pile up behind it and surface on the critical path.
+static bool use_persistent(const char* knob) { return vd_tune_get(knob, 0) != 0; }
 
 template <class Kern, class Args>
 static int launch_seq(Kern kern, const Args& a, int lds_bytes, int threads, int total_tiles, hipStream_t s) {
@@ -501,7 +574,9 @@ static int lstm_step_fwd(const float* h_prev, const float* Wh, int N, int H, int
       default: return launch_gemm<CfgF1>(N, 4 * H, K, 1, a, b, epi, s);
     }
   }
-  static const int scfg = env_int("VD_LSTM_FWD_SMALL", 2);
+  // (the <=128-VGPR build C spills 20 registers with the hand-scheduled epilogue; this un-bundled path is not on the
+  //  headline step, so it takes the 140-VGPR build A)
+  static const int scfg = env_int("VD_LSTM_FWD_SMALL", 0);
   if (scfg == 0) return launch_gemm<CfgFwdSmallA>(N, 4 * H, K, 1, a, b, epi, s);
   if (scfg == 2) return launch_gemm<CfgFwdSmallC>(N, 4 * H, K, 1, a, b, epi, s);
   return launch_gemm<CfgFwdSmallB>(N, 4 * H, K, 1, a, b, epi, s);
@@ -521,6 +596,10 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
     const int cfg = cfg0 == 20 ? 11 : cfg0;
     if (use_glds_bwd(N, H) && K > 0) {
       // LDS-DMA pipeline: A = da_{t+1} rows, Bt = Wh rows (both contiguous in k = the 4H gate columns)
+      if (vd_tune_get("VD_LSTM_BWD_BATCH2", 1)) {
+        EpiLstmBwd<2, 2> e2b{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
+        return launch_gemm_glds<CfgB12, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e2b, s);
+      }
       EpiLstmBwd<2> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
       return launch_gemm_glds<CfgB11, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e, s);
     }
@@ -823,8 +902,10 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
     a.dc_has_last = dc_last ? 1 : 0;
     a.T = T; a.N = N; a.H = H; a.rotate = vd_tune_get("VD_GEMM_ROTATE", 1);
     a.sc = SeqSched{scr.sync, T, tiles_m, tiles_n, vd_tune_get("VD_LSTM_STAGGER_US", 0) * 100};
-    if (int rc0 = launch_seq(lstm_seq_bwd_kernel<CfgB11>, a, CfgB11::LDS_BYTES, CfgB11::THREADS, T * tiles_m * tiles_n, s))
-      return rc0;
+    const int rc0 = vd_tune_get("VD_LSTM_BWD_BATCH2", 1)
+                        ? launch_seq(lstm_seq_bwd_kernel<CfgB12>, a, CfgB12::LDS_BYTES, CfgB12::THREADS, T * tiles_m * tiles_n, s)
+                        : launch_seq(lstm_seq_bwd_kernel<CfgB11>, a, CfgB11::LDS_BYTES, CfgB11::THREADS, T * tiles_m * tiles_n, s);
+    if (rc0) return rc0;
   }
   RowChains rc_;
   int rc = rc_.fork(N, s, persist ? 1 : nchains);
