@@ -52,12 +52,15 @@ def main():
     # A/B sweep of the recurrence launch structure (one process, knobs through vd_tune_set)
     variants = [("per-step, bwd epilogue batch 1 (<=128 VGPR)", dict(VD_LSTM_BWD_BATCH2=0)),
                 ("per-step launches", dict()),
+                ("per-step, fwd epilogue compiler-scheduled (r1)", dict(VD_LSTM_FWD_EPI_SEQ=1)),
+                ("per-step launches (repeat)", dict()),
+                ("per-step, bwd batch 2 (<=168 VGPR)", dict(VD_LSTM_BWD_BATCH2=1)),
                 ("persistent", dict(VD_LSTM_PERSIST_FWD=1, VD_LSTM_PERSIST_BWD=1)),
                 ("persistent, bwd batch 1", dict(VD_LSTM_PERSIST_FWD=1, VD_LSTM_PERSIST_BWD=1, VD_LSTM_BWD_BATCH2=0)),
                 ("persistent, stagger 40us", dict(VD_LSTM_PERSIST_FWD=1, VD_LSTM_PERSIST_BWD=1, VD_LSTM_STAGGER_US=40)),
                 ("persistent, 2 WG/CU grid", dict(VD_LSTM_PERSIST_FWD=1, VD_LSTM_PERSIST_BWD=1, VD_LSTM_SEQ_WGS_PER_CU=2))]
     if os.environ.get("MB_SWEEP", "1") == "0":
-        variants = variants[:2]
+        variants = variants[:5]
     for name, knobs in variants:
         ops.tune_clear()
         for k, v in knobs.items():

@@ -26,7 +26,7 @@ def _run(nproc, backend, extra_env):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'tests', 'dp_gpu_worker.py')]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.returncode == 0, out.stdout[-6000:] + out.stderr[-12000:]
     assert 'DP_GPU_OK' in out.stdout, out.stdout[-2000:]
     return out.stdout
 

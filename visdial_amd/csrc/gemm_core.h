@@ -662,7 +662,7 @@ gemm_f32_glds_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, 
 // KMAJ == true : C[M x N] (+)= epi over `splits` K ranges of A[K x M]^T * B[K x N]; M, N % 128 == 0, K % 16 == 0.
 template <class Cfg, bool KMAJ, class Epi>
 static int launch_gemm_glds(int M, int N, int K, int splits, const float* A, long lda, const float* B, long ldb,
-                            const Epi& e, hipStream_t stream) {
+                            const Epi& e, hipStream_t stream, int rotate_in = -1) {
   if (M <= 0 || N <= 0) return VD_OK;
   VD_CHECK_ARG(K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && splits >= 1,
                "launch_gemm_glds: unsupported shape M=%d N=%d K=%d", M, N, K);
@@ -682,7 +682,7 @@ static int launch_gemm_glds(int M, int N, int K, int splits, const float* A, lon
                                Cfg::LDS_BYTES));
     attr_set = true;
   }
-  const int rotate = vd_tune_get("VD_GEMM_ROTATE", 1);
+  const int rotate = rotate_in >= 0 ? rotate_in : vd_tune_get("VD_GEMM_ROTATE", 1);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, M, N, K,
                      kchunk, tiles_m, tiles_n, rotate, A, lda, B, ldb, e);
   VD_LAUNCH_CHECK();

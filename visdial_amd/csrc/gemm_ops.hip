@@ -94,24 +94,29 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
   SrcK a{A, lda}, b{B, ldb};
   EpiAtomic<4> e{C, ldc};
   const long tiles = (long)vd_cdiv(M, CfgBig::BM) * vd_cdiv(N, CfgBig::BN);
-  const int target = vd_tune_get("VD_TN_BLOCKS", 1024);
+  // LDS-DMA pipeline with k-major tiles: both operands are [k][m] rows, which IS the MFMA fragment layout along
+  // the lanes (no transposing LDS writes).  One full round of workgroups (3 per CU x 256 CUs = 768) and no K-tile
+  // rotation: 133.9 TFLOP/s on the option dWh shape (M=512, N=2048, K=380 000) vs 119.6 for the register-staged
+  // kernel at 1024 blocks (profiles/r02_dwh_sweep.txt; with 1024 blocks the ranking was the opposite in round 1:
+  // the 1.33-round tail, not the pipeline, decided).
+  const int cfg = vd_tune_get("VD_TN_CFG", 20);
+  const bool kmaj = cfg == 20 && !(flags & VD_FLAG_BF16) && M % 128 == 0 && N % 128 == 0 && K % 16 == 0 && K >= 4096;
+  const int target = vd_tune_get("VD_TN_BLOCKS", kmaj ? 768 : 1024);
   long splits = vd_cdiv(target, tiles);
   const long max_splits = vd_cdiv(K, 4 * CfgBig::BK);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   if (flags & VD_FLAG_BF16)   // opt-in reduced precision: bf16 operands, fp32 accumulation
     return launch_gemm<GemmCfg<4, 1, 4, 32, 0, 3, 0, 1>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
-  // (VD_TN_CFG=20: the LDS-DMA pipeline with k-major tiles; measured 119 vs 127 TFLOP/s for the register-staged
-  //  default on the option dWh shape, so it stays opt-in)
-  const int cfg = vd_tune_get("VD_TN_CFG", 5);
-  if (cfg == 20 && M % 128 == 0 && N % 128 == 0 && K % 16 == 0 && K >= 1024)
+  if (kmaj)
     return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 41984>, true>(M, N, K, (int)splits, A, lda, B, ldb, e,
-                                                                      (hipStream_t)stream);
+                                                                      (hipStream_t)stream, vd_tune_get("VD_TN_ROTATE", 0));
+  if (cfg == 20 || cfg == 5)   // (cfg 20 on a shape the k-major pipeline does not take: the register-staged default)
+    return launch_gemm<GemmCfg<4, 1, 4, 16, 0, 4, 41984>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
   if (cfg == 1) return launch_gemm<CfgBig>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
   if (cfg == 2) return launch_gemm<GemmCfg<4, 1, 4, 16, 0, 3>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
   if (cfg == 3) return launch_gemm<GemmCfg<4, 1, 4, 16, 2, 3>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
   if (cfg == 4) return launch_gemm<GemmCfg<4, 1, 4, 32, 2, 3>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
-  if (cfg == 5) return launch_gemm<GemmCfg<4, 1, 4, 16, 0, 4, 41984>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
   return launch_gemm<CfgBigDB>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
 }
 

@@ -20,7 +20,8 @@ extern "C" int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64
 // ---------------------------------------------------------------------------
 // forward epilogue: acc[g] = (h_prev*Wh)[row, g*H + j]
 // ---------------------------------------------------------------------------
-struct EpiLstmFwd {
+template <int SEQ>
+struct EpiLstmFwdT {
   const float* xproj;  // dense: [N x 4H] rows (ld = xld); table mode: table base [V+1 x 4H]
   long xld;
   const int* tok_gather;  // nullable; if set, x row = xproj + tok_gather[row]*xld
@@ -30,6 +31,7 @@ struct EpiLstmFwd {
   float* c_out;           // [N x H]
   float* h_out;           // [N x H]
   int H;
+  // SEQ = 1: compiler-scheduled epilogue of round 1 (A/B build, knob VD_LSTM_FWD_EPI_SEQ)
   // The four accumulator tiles are i,f,o,g of hidden units [j0, j0+32).  Each is staged through the wave's LDS
   // scratch so that a lane ends up with 4 consecutive hidden units of one row: every global access of the cell
   // update is a 16-byte one (8 lanes = one 128-byte segment of a row).
@@ -41,8 +43,59 @@ struct EpiLstmFwd {
   // latency hides under the LDS transposes, and the row loads of p+1 are issued as soon as the loaded values of p
   // have been folded into the pre-activations (one buffer of 20 VGPRs, reused), so they fly under the
   // transcendental math and the stores of p.
+  // round-1 form: one row at a time, loads / waits / math / stores in the order the compiler picks
+  __device__ __forceinline__ void sequential(const f32x16 (&acc)[4], int row0, int vcol0, int lane, int M, float* scr) const {
+    // The four accumulator tiles are i,f,o,g of hidden units [j0, j0+32).  Each is staged through the
+    // wave's LDS scratch so that a lane ends up with 4 consecutive hidden units of one row: every global
+    // access of the cell update is then a 16-byte one (8 lanes = one 128-byte segment of a row).
+    const int j = (vcol0 >> 7) * 32 + (lane & 7) * 4;
+    float4 ai[4], af[4], ao[4], ag[4];
+    tile_to_rows(acc[0], scr, lane, ai);
+    tile_to_rows(acc[1], scr, lane, af);
+    tile_to_rows(acc[2], scr, lane, ao);
+    tile_to_rows(acc[3], scr, lane, ag);
+    VD_T(3);
+    if (j >= H) return;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = row0 + p * 8 + (lane >> 3);
+      if (row >= M) continue;
+      float4 gi, gf, go, gg, c, h;
+      if (tok_mask && tok_mask[row] == 0) {
+        gi = gf = go = gg = c = h = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const float* xr = xproj + (tok_gather ? (long)tok_gather[row] : (long)row) * xld + j;
+        const float4 xi = *reinterpret_cast<const float4*>(xr);
+        const float4 xf = *reinterpret_cast<const float4*>(xr + H);
+        const float4 xo = *reinterpret_cast<const float4*>(xr + 2 * H);
+        const float4 xg = *reinterpret_cast<const float4*>(xr + 3 * H);
+        float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c_prev) cp = *reinterpret_cast<const float4*>(c_prev + (long)row * H + j);
+#define VD_CELL(E)                                        \
+        gi.E = vd_sigmoid(ai[p].E + xi.E);                \
+        gf.E = vd_sigmoid(af[p].E + xf.E);                \
+        go.E = vd_sigmoid(ao[p].E + xo.E);                \
+        gg.E = vd_tanh(ag[p].E + xg.E);                   \
+        c.E = gf.E * cp.E + gi.E * gg.E;                  \
+        h.E = go.E * vd_tanh(c.E);
+        VD_CELL(x) VD_CELL(y) VD_CELL(z) VD_CELL(w)
+#undef VD_CELL
+      }
+      float* gr = gates + (long)row * 4 * H + j;
+      *reinterpret_cast<float4*>(gr) = gi;
+      *reinterpret_cast<float4*>(gr + H) = gf;
+      *reinterpret_cast<float4*>(gr + 2 * H) = go;
+      *reinterpret_cast<float4*>(gr + 3 * H) = gg;
+      *reinterpret_cast<float4*>(c_out + (long)row * H + j) = c;
+      *reinterpret_cast<float4*>(h_out + (long)row * H + j) = h;
+    }
+  }
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int vcol0, int lane, int M,
                                              int /*Nv*/, float* scr) const {
+    if constexpr (SEQ != 0) {
+      sequential(acc, row0, vcol0, lane, M, scr);
+      return;
+    }
     const int j = (vcol0 >> 7) * 32 + (lane & 7) * 4;  // < H: H % 32 == 0 and vcol0 < 4H
     const int rl = lane >> 3;
     int rowc[4], tk[4], keep[4];
@@ -117,6 +170,8 @@ struct EpiLstmFwd {
     }
   }
 };
+
+using EpiLstmFwd = EpiLstmFwdT<0>;
 
 // ---------------------------------------------------------------------------
 // backward epilogue: acc = (da_{t+1} * Wh^T)[row, j]  (zero at the last step)
@@ -596,7 +651,7 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
     const int cfg = cfg0 == 20 ? 11 : cfg0;
     if (use_glds_bwd(N, H) && K > 0) {
       // LDS-DMA pipeline: A = da_{t+1} rows, Bt = Wh rows (both contiguous in k = the 4H gate columns)
-      if (vd_tune_get("VD_LSTM_BWD_BATCH2", 1)) {
+      if (vd_tune_get("VD_LSTM_BWD_BATCH2", 0)) {
         EpiLstmBwd<2, 2> e2b{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
         return launch_gemm_glds<CfgB12, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e2b, s);
       }
@@ -837,8 +892,14 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
       e.H = H;
       if (bf16 && hp)
         rc = launch_gemm<CfgFbf16>(nr, 4 * H, H, 1, SrcRow{hp, H}, SrcRow{WhT, H}, e, rc_.stream[ch]);
-      else if (glds && hp)
-        rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e, rc_.stream[ch]);
+      else if (glds && hp) {
+        if (vd_tune_get("VD_LSTM_FWD_EPI_SEQ", 0)) {
+          EpiLstmFwdT<1> e1{e.xproj, e.xld, e.tok_gather, e.tok_mask, e.c_prev, e.gates, e.c_out, e.h_out, e.H};
+          rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e1, rc_.stream[ch]);
+        } else {
+          rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e, rc_.stream[ch]);
+        }
+      }
       else
         rc = lstm_step_fwd(hp, Wh, nr, H, hp ? H : 0, e, rc_.stream[ch]);
       if (rc) return rc;
@@ -902,7 +963,7 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
     a.dc_has_last = dc_last ? 1 : 0;
     a.T = T; a.N = N; a.H = H; a.rotate = vd_tune_get("VD_GEMM_ROTATE", 1);
     a.sc = SeqSched{scr.sync, T, tiles_m, tiles_n, vd_tune_get("VD_LSTM_STAGGER_US", 0) * 100};
-    const int rc0 = vd_tune_get("VD_LSTM_BWD_BATCH2", 1)
+    const int rc0 = vd_tune_get("VD_LSTM_BWD_BATCH2", 0)
                         ? launch_seq(lstm_seq_bwd_kernel<CfgB12>, a, CfgB12::LDS_BYTES, CfgB12::THREADS, T * tiles_m * tiles_n, s)
                         : launch_seq(lstm_seq_bwd_kernel<CfgB11>, a, CfgB11::LDS_BYTES, CfgB11::THREADS, T * tiles_m * tiles_n, s);
     if (rc0) return rc0;

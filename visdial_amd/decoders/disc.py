@@ -75,26 +75,25 @@ class Decoder(object):
                           h_seq=self.h if fused else None, dWh=self.dWh if fused else None)
         ops.prof_end('opt_lstm_bwd', t0, 1)
         da = self.gates.view(To * NO, 4 * H)
+        # gradient of the gathered table (segmented row sums over the token-sorted rows: one HBM-bound pass over da)
+        # and its two small consumers (bias, input weights) run on the side stream BESIDE the MFMA-bound dWh
+        # contraction of the main stream; both only need the finished recurrence
+        with self.streams.fork('tab'):
+            ops.segment_rowsum_acc(da, tokf, perm, dtab)
+            ops.colsum_acc(dtab, self.db, M=V + 1, N=4 * H)
+            ops.gemm_tn_acc(self.emb, dtab, self.dWx, M=self.E, N=4 * H, K=V + 1)
         if To > 1 and not fused:
             t0 = ops.prof_begin('opt_lstm_dWh')
             ops.gemm_tn_acc(self.h.view(To * NO, H), da[NO:], self.dWh, M=H, N=4 * H, K=(To - 1) * NO,
                             flags=self.flags)
             ops.prof_end('opt_lstm_dWh', t0, 1)
-        # gradient of the gathered table: segmented row sums over the token-sorted rows
-        self.streams.join('tab')
-        ops.segment_rowsum_acc(da, tokf, perm, dtab)
-        # three small independent consumers of dtab: bias + input-weight gradients go to the side stream and
-        # run beside the embedding-gradient product of backward_embed()
-        with self.streams.fork('tab'):
-            ops.colsum_acc(dtab, self.db, M=V + 1, N=4 * H)
-            ops.gemm_tn_acc(self.emb, dtab, self.dWx, M=self.E, N=4 * H, K=V + 1)
         self.dtab = dtab
 
     def backward_embed(self):
         """dEmb += dTable * Wx^T.  Non-atomic read-modify-write of the SHARED embedding gradient: must be
         ordered after every other writer of that buffer (the encoder's atomic scatters)."""
-        ops.gemm_nt(self.dtab, self.Wx, self.demb, accumulate=True, M=self.V + 1, N=self.E, K=4 * self.H)
         self.streams.join('tab')
+        ops.gemm_nt(self.dtab, self.Wx, self.demb, accumulate=True, M=self.V + 1, N=self.E, K=4 * self.H)
 
 
 def model(params, enc, fp, ws, drop):
