@@ -47,7 +47,7 @@ def main():
     used_async_bucket = model._enc_bucket_work is not None
     model.update()
     torch.cuda.synchronize()
-    g_dp = model.wrapperdW.cpu().numpy().copy()                          # summed over ranks (scaled by 1/world in Adam)
+    g_dp = model.wrapperdW.cpu().numpy().copy()     # after update(): summed over ranks, x 1/world, clamped (clamp_adam writes it back)
     w_dp = model.wrapperW.cpu().numpy().copy()
     losses = [None] * world
     dist.all_gather_object(losses, float(loss))
@@ -62,7 +62,7 @@ def main():
         torch.cuda.synchronize()
         w_big = big.wrapperW.cpu().numpy()
         assert abs(np.mean(losses) - loss_big) < 1e-5, (losses, loss_big)
-        err = np.linalg.norm(g_dp / world - g_big) / np.linalg.norm(g_big)
+        err = np.linalg.norm(g_dp - np.clip(g_big, -5, 5)) / np.linalg.norm(g_big)
         assert err < 1e-5, err
         # Adam's first step is ~lr*sign(g): entries with |g| below the fp32 summation noise may flip sign
         settled = np.abs(g_big) > 1e-6
