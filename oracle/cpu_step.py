@@ -66,6 +66,7 @@ class CpuStep(object):
     """Holds the flat fp32 parameter / gradient / Adam vectors (layout = visdial_oracle.param_spec order)."""
 
     def __init__(self, p, spec, params):
+        assert int(p.get('numAttentionLayers', 1) or 1) == 1, "cpu_step.cpp restates the default single attention hop"
         self.p, self.spec = p, spec
         self.W = np.ascontiguousarray(np.concatenate([np.asarray(params[e[0]], np.float32).reshape(-1) for e in spec]))
         self.G = np.zeros_like(self.W)

@@ -192,6 +192,11 @@ def clamp_adam(w, g, state, lr, clip=5.0, beta1=0.9, beta2=0.999, eps=1e-8):
 
 
 # ----------------------------------------------------------------------------- parameters
+def hop_suffixes(p):
+    L = int(p.get('numAttentionLayers', 1) or 1)
+    return [''] + [str(i) for i in range(2, L + 1)]
+
+
 def param_spec(encoder, decoder, p):
     """Flat parameter layout (name, shape) shared by construction with visdial_amd/params.py.
     Tensors follow the reference modules: LSTM [(D+H) x 4H] + [4H], Linear [out x in] + [out],
@@ -207,23 +212,28 @@ def param_spec(encoder, decoder, p):
         spec.append((name + '.W', (o, i), 'lin_w'))
         spec.append((name + '.b', (o,), 'lin_b'))
 
-    if encoder == 'mn-att-ques-im-hist':
+    def san():
+        """mn-att:68-106: one img_common / ques_common / att triple PER attention hop (opts.lua:26), hop i > 1 named
+        <name><i>"""
         C, K = p['imgFeatureSize'], p.get('commonEmbeddingSize', 512)
+        lin('img_proj', C, H)
+        for sfx in hop_suffixes(p):
+            lin('img_common' + sfx, H, K); lin('ques_common' + sfx, H, K); lin('att' + sfx, K, 1)
+        lin('out', H, H)
+
+    if encoder == 'mn-att-ques-im-hist':
         lstm('hist1', E); lstm('hist2', H); lstm('ques1', E); lstm('ques2', H)
         lin('mn1', H, H); lin('mn2', H, H)
-        lin('img_proj', C, H); lin('img_common', H, K); lin('ques_common', H, K); lin('att', K, 1)
-        lin('out', H, H)
+        san()
     elif encoder in ('mn-ques-hist', 'mn-ques-im-hist'):
         lstm('hist1', E); lstm('hist2', H); lstm('ques1', E); lstm('ques2', H)
         if encoder == 'mn-ques-im-hist':
             lin('qi', p['imgFeatureSize'] + H, H)
         lin('mn1', H, H); lin('mn2', H, H)
     elif encoder == 'lf-att-ques-im-hist':
-        C, K = p['imgFeatureSize'], p.get('commonEmbeddingSize', 512)
         lstm('hist1', E); lstm('hist2', H); lstm('ques1', E); lstm('ques2', H)
         lin('qh', 2 * H, H)
-        lin('img_proj', C, H); lin('img_common', H, K); lin('ques_common', H, K); lin('att', K, 1)
-        lin('out', H, H)
+        san()
     elif encoder in ('lf-ques', 'lf-ques-im', 'lf-ques-hist', 'lf-ques-im-hist'):
         for l in range(p['numLayers']):
             lstm('ques%d' % (l + 1), E if l == 0 else H)
@@ -346,7 +356,8 @@ def _mn_block_bwd(P, G, st, dqh2, dback):
 
 
 def _san_block_fwd(P, p, batch, u0, R, d):
-    """1-hop SAN image attention + output layer (mn-att:68-106 / lf-att-ques-im-hist.lua:45-86)."""
+    """SAN image attention, numAttentionLayers hops, + output layer (mn-att:68-106 / lf-att-ques-im-hist.lua:45-86).
+    All hops attend over the same img_tr; every hop has its own Linears and its own Dropout (mask 'iqc', 'iqc2', ..)."""
     N, H = u0.shape
     B = N // R
     S2 = p['imgSpatialSize'] ** 2
@@ -354,19 +365,23 @@ def _san_block_fwd(P, p, batch, u0, R, d):
     pre = np.tanh(linear(img, P['img_proj.W'], P['img_proj.b']))            # per image
     pre_r = np.repeat(pre.reshape(B, 1, S2, H), R, 1).reshape(N, S2, H)     # model.lua:262-265 repeat
     img_tr = dropout(pre_r, d('img_tr'), 0.5)
-    img_common = linear(img_tr.reshape(N * S2, H), P['img_common.W'], P['img_common.b']).reshape(N, S2, -1)
-    qc = linear(u0, P['ques_common.W'], P['ques_common.b'])
-    t_iqc = np.tanh(img_common + qc[:, None, :])
-    iqc = dropout(t_iqc, d('iqc'), 0.5)
-    score = (iqc @ P['att.W'][0]) + P['att.b'][0]
-    score = score - score.max(1, keepdims=True)
-    e = np.exp(score)
-    patt = e / e.sum(1, keepdims=True)
-    att = np.einsum('ns,nsh->nh', patt, img_tr)
-    u1 = att + u0
-    u1_d = dropout(u1, d('u'), 0.5)
+    hops = []
+    u = u0
+    for sfx in hop_suffixes(p):
+        img_common = linear(img_tr.reshape(N * S2, H), P['img_common%s.W' % sfx], P['img_common%s.b' % sfx]).reshape(N, S2, -1)
+        qc = linear(u, P['ques_common%s.W' % sfx], P['ques_common%s.b' % sfx])
+        t_iqc = np.tanh(img_common + qc[:, None, :])
+        iqc = dropout(t_iqc, d('iqc' + sfx), 0.5)
+        score = (iqc @ P['att%s.W' % sfx][0]) + P['att%s.b' % sfx][0]
+        score = score - score.max(1, keepdims=True)
+        e = np.exp(score)
+        patt = e / e.sum(1, keepdims=True)
+        att = np.einsum('ns,nsh->nh', patt, img_tr)
+        hops.append(dict(u_in=u, t_iqc=t_iqc, iqc=iqc, patt=patt, sfx=sfx))
+        u = att + u
+    u1_d = dropout(u, d('u'), 0.5)
     out = np.tanh(linear(u1_d, P['out.W'], P['out.b']))
-    return out, dict(u0=u0, img=img, pre=pre, img_tr=img_tr, t_iqc=t_iqc, iqc=iqc, patt=patt, u1_d=u1_d, out=out, R=R)
+    return out, dict(u0=u0, img=img, pre=pre, img_tr=img_tr, hops=hops, u1_d=u1_d, out=out, R=R)
 
 
 def _san_block_bwd(P, G, p, st, denc, dback):
@@ -377,28 +392,31 @@ def _san_block_bwd(P, G, p, st, denc, dback):
     dpre_o = denc * (1 - st['out'] ** 2)
     du1d, dW, db = linear_backward(st['u1_d'], P['out.W'], dpre_o)
     G['out.W'] += dW; G['out.b'] += db
-    du1 = dback(du1d, 'u')
-    du0 = du1.copy()
-    datt = du1
-    img_tr, patt, iqc = st['img_tr'], st['patt'], st['iqc']
-    dp = np.einsum('nh,nsh->ns', datt, img_tr)
-    dimg_tr = patt[:, :, None] * datt[:, None, :]
-    dscore = patt * (dp - (patt * dp).sum(1, keepdims=True))
-    G['att.W'][0] += np.einsum('ns,nsk->k', dscore, iqc)
-    G['att.b'][0] += dscore.sum()
-    diqc = dscore[:, :, None] * P['att.W'][0][None, None, :]
-    dz = dback(diqc, 'iqc') * (1 - st['t_iqc'] ** 2)
-    dqc = dz.sum(1)
-    dimg_tr2, dW, db = linear_backward(img_tr.reshape(N * S2, H), P['img_common.W'], dz.reshape(N * S2, -1))
-    G['img_common.W'] += dW; G['img_common.b'] += db
-    dimg_tr = dimg_tr + dimg_tr2.reshape(N, S2, H)
+    du = dback(du1d, 'u')
+    img_tr = st['img_tr']
+    dimg_tr = np.zeros_like(img_tr)
+    for hp in reversed(st['hops']):
+        sfx, patt, iqc = hp['sfx'], hp['patt'], hp['iqc']
+        datt = du
+        dp = np.einsum('nh,nsh->ns', datt, img_tr)
+        dimg_tr = dimg_tr + patt[:, :, None] * datt[:, None, :]
+        dscore = patt * (dp - (patt * dp).sum(1, keepdims=True))
+        G['att%s.W' % sfx][0] += np.einsum('ns,nsk->k', dscore, iqc)
+        G['att%s.b' % sfx][0] += dscore.sum()
+        diqc = dscore[:, :, None] * P['att%s.W' % sfx][0][None, None, :]
+        dz = dback(diqc, 'iqc' + sfx) * (1 - hp['t_iqc'] ** 2)
+        dqc = dz.sum(1)
+        dimg_tr2, dW, db = linear_backward(img_tr.reshape(N * S2, H), P['img_common%s.W' % sfx], dz.reshape(N * S2, -1))
+        G['img_common%s.W' % sfx] += dW; G['img_common%s.b' % sfx] += db
+        dimg_tr = dimg_tr + dimg_tr2.reshape(N, S2, H)
+        dq, dW, db = linear_backward(hp['u_in'], P['ques_common%s.W' % sfx], dqc)
+        G['ques_common%s.W' % sfx] += dW; G['ques_common%s.b' % sfx] += db
+        du = du + dq                                                     # residual CAddTable + the ques_common path
     dpre = dback(dimg_tr, 'img_tr').reshape(B, R, S2, H).sum(1).reshape(B * S2, H)
     dpre_a = dpre * (1 - st['pre'] ** 2)
     _, dW, db = linear_backward(st['img'], P['img_proj.W'], dpre_a)
     G['img_proj.W'] += dW; G['img_proj.b'] += db
-    dq, dW, db = linear_backward(st['u0'], P['ques_common.W'], dqc)
-    G['ques_common.W'] += dW; G['ques_common.b'] += db
-    return du0 + dq
+    return du
 
 
 GRAPH_ENCODERS = ('mn-ques-hist', 'mn-ques-im-hist', 'mn-att-ques-im-hist', 'lf-att-ques-im-hist')

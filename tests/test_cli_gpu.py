@@ -33,3 +33,57 @@ def test_train_then_evaluate(tmp_path):
                         str(tmp_path / 'ranks.json')], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert e.returncode == 0, e.stdout[-2000:] + e.stderr[-2000:]
     assert 'r@1:' in e.stdout and 'meanRR:' in e.stdout and os.path.exists(str(tmp_path / 'ranks.json'))
+
+
+def test_train_evaluate_on_real_format_files(tmp_path):
+    """train.py and evaluate.py on files in the reference's dataset format (prepro.py's dataset names, here as the
+    .npz twins of visdial_data.h5 / data_img.h5 + visdial_params.json): the real `Dataloader` path end to end --
+    training lowers the loss, evaluate.py (evaluate.lua:80-81: dataloader on the chosen split) prints retrieval
+    metrics and perplexity-style loss and writes {image_id, round_id, ranks} records with the dataset's image ids and
+    only the rounds that exist (model.lua:174-184)."""
+    import json
+    import numpy as np
+    from test_dataloader_cpu import raw_dataset
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    rng = np.random.RandomState(11)
+    n, R = 12, 4
+    info, raw, img = raw_dataset(rng, n=n, R=R, MQ=6, MA=5, V=30, O=5, nopt=40, F=8, att=True)
+    # a val split = the same dialogs under the val names, with ragged round counts
+    for k in list(raw):
+        raw[k.replace('_train', '_val')] = raw[k]
+    raw['num_rounds_val'] = np.array([R, R - 1] * (n // 2), np.uint32)
+    img['images_val'] = img['images_train']
+    info['unique_img_val'] = ['VisualDialog_val2018_%012d.jpg' % (1000 + i) for i in range(n)]
+    np.savez(str(tmp_path / 'visdial_data.npz'), **raw)
+    np.savez(str(tmp_path / 'data_img.npz'), **img)
+    json.dump(info, open(str(tmp_path / 'visdial_params.json'), 'w'))
+    data = ['-inputQues', str(tmp_path / 'visdial_data.h5'), '-inputImg', str(tmp_path / 'data_img.h5'),
+            '-inputJson', str(tmp_path / 'visdial_params.json')]
+    save = str(tmp_path / "ckpt") + "/"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), '-encoder', 'mn-att-ques-im-hist', '-decoder', 'disc',
+                        '-imgFeatureSize', '8', '-imgSpatialSize', '3', '-rnnHiddenSize', '32', '-embedSize', '16',
+                        '-commonEmbeddingSize', '32', '-batchSize', '4', '-savePath', save, '-numEpochs', '100',
+                        '-saveIter', '1000', '--maxIters', '200'] + data,
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'synthetic' not in r.stdout
+    loss = [float(l.split('[Loss:')[1].split(']')[0]) for l in r.stdout.splitlines() if '[Loss:' in l]
+    assert len(loss) == 2 and loss[1] < loss[0]
+    ranks = str(tmp_path / 'logs' / 'ranks.json')
+    e = subprocess.run([sys.executable, os.path.join(ROOT, 'evaluate.py'), '-loadPath', save + 'model_final.pt',
+                        '-batchSize', '5', '-split', 'val', '-saveRanks', '1', '-saveRankPath', ranks,
+                        '-perplexity', '1'] + data, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert e.returncode == 0, e.stdout[-2000:] + e.stderr[-2000:]
+    assert 'SYNTHETIC' not in e.stdout and 'r@1:' in e.stdout and 'Perplexity' in e.stdout
+    rec = json.load(open(ranks))
+    assert len(rec) == int(raw['num_rounds_val'].sum())                       # only the rounds that exist
+    assert rec[0]['image_id'] == 1000 and rec[0]['round_id'] == 1             # tonumber(match(v, '000%d+'))
+    assert all(1 <= x['ranks'] <= 5 for x in rec)
+    # predict on the same split: all candidate ranks per round
+    e = subprocess.run([sys.executable, os.path.join(ROOT, 'evaluate.py'), '-loadPath', save + 'model_final.pt',
+                        '-batchSize', '5', '-split', 'val', '-useGt', '0', '-saveRanks', '1', '-saveRankPath', ranks] + data,
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert e.returncode == 0, e.stdout[-2000:] + e.stderr[-2000:]
+    rec = json.load(open(ranks))
+    assert sorted(rec[0]['ranks']) == [1.0, 2.0, 3.0, 4.0, 5.0]

@@ -24,6 +24,8 @@ def make_masks(p, batch, rng):
     N, H, E = B * R, p['rnnHiddenSize'], p['embedSize']
     S2, K = p['imgSpatialSize'] ** 2, p['commonEmbeddingSize']
     shp = dict(q_emb=(Tq, N, E), h_emb=(Th, N, E), hatt=(N, H), img_tr=(N, S2, H), iqc=(N, S2, K), u=(N, H))
+    for sfx in vo.hop_suffixes(p)[1:]:
+        shp['iqc' + sfx] = (N, S2, K)
     return {k: (rng.rand(*s) > 0.5).astype(np.uint8) for k, s in shp.items()}
 
 
@@ -41,12 +43,15 @@ CASES = {
     # BASELINE.json configs[4] shape (ResNet-200 7x7x2048 features), other dims reduced for the oracle
     'resnet': dict(vocabSize=120, embedSize=48, rnnHiddenSize=128, imgFeatureSize=2048, imgSpatialSize=7,
                    commonEmbeddingSize=128, maxQuesCount=4, batchSize=2, numOptions=20, maxQuesLen=8, maxAnsLen=6),
+    # numAttentionLayers = 3 (opts.lua:26; mn-att:82-104 loops): every hop has its own Linears and Dropout
+    'hops3': dict(numAttentionLayers=3, vocabSize=60, embedSize=20, rnnHiddenSize=64, imgFeatureSize=32, imgSpatialSize=4,
+                  commonEmbeddingSize=48, maxQuesCount=5, batchSize=3, numOptions=9, maxQuesLen=7, maxAnsLen=6),
     'odd': dict(vocabSize=97, embedSize=36, rnnHiddenSize=96, imgFeatureSize=40, imgSpatialSize=5,
                 commonEmbeddingSize=64, maxQuesCount=3, batchSize=5, numOptions=11, maxQuesLen=9, maxAnsLen=4),
 }
 
 
-@pytest.mark.parametrize("case", ['tiny', 'odd', 'mid', 'resnet'])
+@pytest.mark.parametrize("case", ['tiny', 'odd', 'mid', 'resnet', 'hops3'])
 @pytest.mark.parametrize("train_mode", [False, True])
 def test_mnatt_disc_step_matches_oracle(gpu, case, train_mode):
     from visdial_amd.model import Model

@@ -15,6 +15,8 @@ def make_drop(p, batch, rng):
     N, H, E = B * R, p['rnnHiddenSize'], p['embedSize']
     S2, K = p['imgSpatialSize'] ** 2, p['commonEmbeddingSize']
     shp = dict(q_emb=(Tq, N, E), h_emb=(Th, N, E), hatt=(N, H), img_tr=(N, S2, H), iqc=(N, S2, K), u=(N, H))
+    for sfx in vo.hop_suffixes(p)[1:]:
+        shp['iqc' + sfx] = (N, S2, K)
     return {k: (rng.rand(*s) > 0.5).astype(np.float64) for k, s in shp.items()}
 
 
@@ -59,11 +61,13 @@ def torch_forward(P, p, batch, drop):
     img = torch.from_numpy(batch['img_feat'].astype(np.float64)).reshape(B, S2, -1)
     img = img[:, None].expand(B, R, S2, img.shape[-1]).reshape(N, S2, -1)      # model.lua:262-265
     img_tr = dr(torch.tanh(F.linear(img, P['img_proj.W'], P['img_proj.b'])), 'img_tr')
-    ic = F.linear(img_tr, P['img_common.W'], P['img_common.b'])
-    qc = F.linear(qh2, P['ques_common.W'], P['ques_common.b'])
-    iqc = dr(torch.tanh(ic + qc[:, None, :]), 'iqc')
-    patt = torch.softmax(F.linear(iqc, P['att.W'], P['att.b']).squeeze(-1), 1)
-    u = torch.bmm(patt[:, None, :], img_tr).squeeze(1) + qh2
+    u = qh2
+    for sfx in vo.hop_suffixes(p):                                             # mn-att:82-104, one hop per iteration
+        ic = F.linear(img_tr, P['img_common%s.W' % sfx], P['img_common%s.b' % sfx])
+        qc = F.linear(u, P['ques_common%s.W' % sfx], P['ques_common%s.b' % sfx])
+        iqc = dr(torch.tanh(ic + qc[:, None, :]), 'iqc' + sfx)
+        patt = torch.softmax(F.linear(iqc, P['att%s.W' % sfx], P['att%s.b' % sfx]).squeeze(-1), 1)
+        u = torch.bmm(patt[:, None, :], img_tr).squeeze(1) + u
     enc = torch.tanh(F.linear(dr(u, 'u'), P['out.W'], P['out.b']))
     opt = batch['options']
     O = opt.shape[1]
@@ -74,9 +78,10 @@ def torch_forward(P, p, batch, drop):
     return loss, scores
 
 
+@pytest.mark.parametrize("hops", [1, 3])
 @pytest.mark.parametrize("use_drop", [False, True])
-def test_oracle_matches_torch_autograd(use_drop):
-    p = small_params()
+def test_oracle_matches_torch_autograd(use_drop, hops):
+    p = small_params(numAttentionLayers=hops)
     dl = SyntheticDataloader(p, seed=7)
     batch = dl.getTrainBatch(p)
     P = vo.init_params(p['encoder'], p['decoder'], p, seed=3)
@@ -307,3 +312,51 @@ def test_oracle_widening_matches_torch_autograd(enc, dec, use_drop):
         if k == 'embed':
             g_t, g_o = g_t[1:], g_o[1:]
         np.testing.assert_allclose(g_o, g_t, rtol=1e-7, atol=1e-9, err_msg=k)
+
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_oracle_lstm_matches_torch_nn_lstm(masked):
+    """The oracle's nn.SeqLSTM restatement against the THIRD-PARTY torch.nn.LSTM module (PyTorch's own LSTM kernel,
+    not a loop written for this repo): weights permuted from SeqLSTM's [Wx ; Wh] x (i, f, o, g) layout to PyTorch's
+    weight_ih / weight_hh with gate order (i, f, g, o).  Forward states and every gradient must agree.  maskZero is
+    checked on right-aligned inputs (leading pads), where it is equivalent to starting the recurrence at the first
+    real token with a zero state -- emulated for nn.LSTM with per-row packed sequences."""
+    rng = np.random.RandomState(4)
+    T, N, D, H = 7, 5, 6, 8
+    x = rng.randn(T, N, D)
+    W = rng.randn(D + H, 4 * H) / np.sqrt(D + H)
+    b = rng.randn(4 * H) * 0.1
+    tok = None
+    lens = np.full(N, T)
+    if masked:
+        lens = rng.randint(1, T + 1, size=N)
+        lens[0] = T
+        tok = np.zeros((T, N), np.int64)
+        for n in range(N):
+            tok[T - lens[n]:, n] = 1
+            x[:T - lens[n], n] = 0.0                                  # pad steps feed the zero vector
+    dh_seq = rng.randn(T, N, H)
+    if masked:
+        dh_seq = dh_seq * (tok != 0)[:, :, None]                      # no gradient arrives at pad steps
+    h, c, g = vo.lstm_forward(x, W, b, tok)
+    dx, dW, db, _, _ = vo.lstm_backward(x, W, g, h, c, dh_seq=dh_seq)
+    perm = np.concatenate([np.arange(0, H), np.arange(H, 2 * H), np.arange(3 * H, 4 * H), np.arange(2 * H, 3 * H)])  # i,f,o,g -> i,f,g,o
+    lstm = torch.nn.LSTM(D, H).double()
+    with torch.no_grad():
+        lstm.weight_ih_l0.copy_(torch.from_numpy(W[:D][:, perm].T.copy()))
+        lstm.weight_hh_l0.copy_(torch.from_numpy(W[D:][:, perm].T.copy()))
+        lstm.bias_ih_l0.copy_(torch.from_numpy(b[perm].copy()))
+        lstm.bias_hh_l0.zero_()
+    xt = torch.from_numpy(x.copy()).requires_grad_(True)
+    outs = []
+    for n in range(N):                                                # right-aligned row = a shorter sequence
+        o, _ = lstm(xt[T - lens[n]:, n:n + 1])
+        outs.append(torch.cat([torch.zeros(T - lens[n], 1, H, dtype=torch.float64), o], 0))
+    ht = torch.cat(outs, 1)
+    np.testing.assert_allclose(ht.detach().numpy(), h, rtol=1e-10, atol=1e-12)
+    (ht * torch.from_numpy(dh_seq)).sum().backward()
+    np.testing.assert_allclose(xt.grad.numpy(), dx, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(lstm.weight_ih_l0.grad.numpy().T[:, np.argsort(perm)], dW[:D], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(lstm.weight_hh_l0.grad.numpy().T[:, np.argsort(perm)], dW[D:], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(lstm.bias_ih_l0.grad.numpy()[np.argsort(perm)], db, rtol=1e-9, atol=1e-11)

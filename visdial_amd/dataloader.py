@@ -11,6 +11,8 @@ HDF5/JSON (no dataset offline):
   answer_ind int32 [B*R]        1-based index of the ground-truth option (prepro.py:169)
   answer_in / answer_out int32 [B, R, Ta]  <START>+tokens / tokens+<END>, left-aligned (gen)
 """
+import re
+
 import numpy as np
 
 
@@ -66,6 +68,9 @@ class SyntheticDataloader(object):
         self.numTestThreads = n
         self.startToken = self.vocabSize - 1   # <START> = V-1, <END> = V (ids as in dataloader.lua:17-22)
         self.endToken = self.vocabSize
+        for split in ('train', 'val', 'test'):  # fields Model:retrieve / predict read (model.lua:174-184, 222-241)
+            setattr(self, 'unique_img_' + split, list(range(1, n + 1)))
+            setattr(self, split + '_num_rounds', np.full(n, self.maxQuesCount, np.int64))
 
     def _tokens(self, n):
         return self.rng.randint(1, self.vocabSize - 1, size=n).astype(np.int32)
@@ -178,6 +183,8 @@ def dropout_mask_shapes(params, batch):
         if 'att' in enc:
             S2, K = params['imgSpatialSize'] ** 2, params.get('commonEmbeddingSize', 512)
             shp.update(img_tr=(N, S2, H), iqc=(N, S2, K), u=(N, H))
+            for i in range(2, int(params.get('numAttentionLayers', 1) or 1) + 1):     # one Dropout per attention hop
+                shp['iqc%d' % i] = (N, S2, K)
     return shp
 
 
@@ -263,6 +270,14 @@ class Dataloader(object):
         A = lambda name: np.asarray(ques[name])
         for dtype in subsets:
             d = {}
+            # image ids to numbers (dataloader.lua:42-45: tonumber(string.match(v, '000%d+')))
+            ids = getattr(self, 'unique_img_' + dtype, None)
+            if ids is not None:
+                conv = []
+                for v in ids:
+                    m = re.search(r'000\d+', str(v))
+                    conv.append(int(m.group()) if m else v)
+                setattr(self, 'unique_img_' + dtype, conv)
             d['ques'], d['ques_len'] = A('ques_' + dtype).astype(np.int64), A('ques_length_' + dtype).astype(np.int64)
             d['ans'], d['ans_len'] = A('ans_' + dtype).astype(np.int64), A('ans_length_' + dtype).astype(np.int64)
             if dtype != 'test':
@@ -283,6 +298,7 @@ class Dataloader(object):
             d['opt_list'] = A('opt_list_' + dtype).astype(np.int64)
             self.numOptions = d['opt'].shape[2]
             d['num_rounds'] = A('num_rounds_' + dtype).astype(np.int64)
+            setattr(self, dtype + '_num_rounds', d['num_rounds'])            # dataloader.lua:110
             self.maxQuesCount, self.maxQuesLen = d['ques'].shape[1], d['ques'].shape[2]
             self.maxAnsLen = d['ans'].shape[2]
             if self.useHistory:

@@ -124,18 +124,26 @@ class MemoryBlock(object):
 
 
 class SANBlock(object):
-    """1-hop stacked attention over the S x S image regions + output layer (mn-att:68-106;
-    lf-att-ques-im-hist.lua:45-86).  `pre` = tanh(Linear(img)) is computed once per IMAGE; the per-round
-    Dropout masks are applied by the GEMM loaders, the 10x repeat (model.lua:262-265) never materialises."""
+    """Stacked attention over the S x S image regions + output layer (mn-att:68-106; lf-att-ques-im-hist.lua:45-86),
+    `numAttentionLayers` hops (opts.lua:26, default 1): every hop has its OWN img_common / ques_common / att Linears
+    and its own Dropout on the joint embedding, all hops attend over the same img_tr (one Dropout mask), and
+    u_i = sum_s p_i[s] img_tr[s] + u_{i-1} (mn-att:82-104).  `pre` = tanh(Linear(img)) is computed once per IMAGE; the
+    per-round Dropout masks are applied by the GEMM loaders, the 10x repeat (model.lua:262-265) never materialises.
+    Parameter names: hop 1 = img_common / ques_common / att, hop i > 1 = img_common<i> / ques_common<i> / att<i>."""
+
+    @staticmethod
+    def hop_names(params):
+        L = int(params.get('numAttentionLayers', 1) or 1)
+        return [('img_common' + s, 'ques_common' + s, 'att' + s) for s in [''] + [str(i) for i in range(2, L + 1)]]
 
     @staticmethod
     def declare(params, spec):
         H, C, K = params['rnnHiddenSize'], params['imgFeatureSize'], params.get('commonEmbeddingSize', 512)
-        assert params.get('numAttentionLayers', 1) == 1, "only the default single attention hop is built"
         spec.linear('img_proj', C, H)
-        spec.linear('img_common', H, K)
-        spec.linear('ques_common', H, K)
-        spec.linear('att', K, 1)
+        for ic, qc, at in SANBlock.hop_names(params):
+            spec.linear(ic, H, K)
+            spec.linear(qc, H, K)
+            spec.linear(at, K, 1)
         spec.linear('out', H, H)
 
     def __init__(self, params, fp, ws, drop, streams):
@@ -143,9 +151,14 @@ class SANBlock(object):
         self.H, self.C = params['rnnHiddenSize'], params['imgFeatureSize']
         self.K = params.get('commonEmbeddingSize', 512)
         self.S2, self.R = params['imgSpatialSize'] ** 2, params['maxQuesCount']
+        self.hops = SANBlock.hop_names(params)
         self.img_proj = Linear(fp, 'img_proj', self.C, self.H, ws)
-        self.ques_common = Linear(fp, 'ques_common', self.H, self.K, ws)
+        self.ques_common = [Linear(fp, qc, self.H, self.K, ws) for _, qc, _ in self.hops]
         self.out = Linear(fp, 'out', self.H, self.H, ws)
+
+    @staticmethod
+    def _sfx(i):
+        return '' if i == 0 else str(i + 1)
 
     def prefetch(self, img, N):
         """per-image projection + this step's dropout masks: independent of the text branches, so it is
@@ -155,26 +168,32 @@ class SANBlock(object):
         with self.streams.fork('img'):
             self.pre = self.img_proj.forward(img, B * S2, tanh=True)             # mn-att:74-78 (pre-dropout)
             self.m1 = self.drop.mask('img_tr', N * S2 * H, P5)
-            self.m2 = self.drop.mask('iqc', N * S2 * K, P5)
+            self.m2 = [self.drop.mask('iqc' + self._sfx(i), N * S2 * K, P5) for i in range(len(self.hops))]
 
     def forward(self, u0):
         fp, ws, H, K, S2, R = self.fp, self.ws, self.H, self.K, self.S2, self.R
         N = u0.shape[0]
-        self.N, self.u0 = N, u0
+        self.N = N
         self.streams.join('img')
         sc = S5 if self.m1 is not None else 1.0
         self.sc = sc
-        qc = self.ques_common.forward(u0, N)                                     # mn-att:88
-        self.iqc = ws.get('att.iqc', (N * S2, K))
-        ops.img_common_forward(self.pre, self.m1, fp.w['img_common.W'], fp.w['img_common.b'], qc, self.m2, self.iqc, N,
-                               R, S2, H, K, sc)                                  # mn-att:83-92
-        self.patt = ws.get('att.p', (N, S2))
-        u1 = ws.get('att.u1', (N, H))
-        ops.img_att_forward(self.iqc, fp.w['att.W'], fp.w['att.b'], self.pre, self.m1, u0, self.patt, u1, N, R, S2, H,
-                            K, sc)                                               # mn-att:93-102
+        self.u_in, self.iqc, self.patt = [], [], []
+        u = u0
+        for i, (ic, _, at) in enumerate(self.hops):
+            sfx = self._sfx(i)
+            qc = self.ques_common[i].forward(u, N)                               # mn-att:88
+            iqc = ws.get('att.iqc' + sfx, (N * S2, K))
+            ops.img_common_forward(self.pre, self.m1, fp.w[ic + '.W'], fp.w[ic + '.b'], qc, self.m2[i], iqc, N, R, S2, H,
+                                   K, sc)                                        # mn-att:83-92
+            patt = ws.get('att.p' + sfx, (N, S2))
+            u1 = ws.get('att.u1' + sfx, (N, H))
+            ops.img_att_forward(iqc, fp.w[at + '.W'], fp.w[at + '.b'], self.pre, self.m1, u, patt, u1, N, R, S2, H, K,
+                                sc)                                              # mn-att:93-102
+            self.u_in.append(u); self.iqc.append(iqc); self.patt.append(patt)
+            u = u1
         self.m_u = self.drop.mask('u', N * H, P5)
-        u1_d = dropout_forward(ws, 'att.u1_d', u1, self.m_u, S5)
-        return self.out.forward(u1_d, N, tanh=True)                              # mn-att:106
+        u_d = dropout_forward(ws, 'att.u1_d', u, self.m_u, S5)
+        return self.out.forward(u_d, N, tanh=True)                               # mn-att:106
 
     def backward(self, grad_output):
         """returns d u0"""
@@ -182,19 +201,23 @@ class SANBlock(object):
         B = N // R
         G = fp.g
         du1d = self.out.backward(grad_output)
-        du1 = dropout_backward(ws, 'att.du1', du1d, self.m_u, S5)                # = d att, and the residual into u0
-        dqc = ws.get('att.dqc', (N, K))
-        ops.img_att_backward(self.iqc, fp.w['att.W'], self.pre, self.m1, self.m2, self.patt, du1, G['att.W'],
-                             G['att.b'], dqc, ws.get('att.dscore', (N, S2)), N, R, S2, H, K, sc)   # iqc now holds dz
-        dz = self.iqc
-        ops.colsum_acc(dz, G['img_common.b'], M=N * S2, N=K)
-        ops.img_common_wgrad(dz, self.pre, self.m1, G['img_common.W'], N, R, S2, H, K, sc)
+        du = dropout_backward(ws, 'att.du1', du1d, self.m_u, S5)                 # = d att of the last hop + its residual
         dpre = ws.get('att.dpre', (B * S2, H))
         ops.zero(dpre)
-        ops.img_tr_backward(dz, fp.w['img_common.W'], self.patt, du1, self.m1, dpre, N, R, S2, H, K, sc)
+        for i in range(len(self.hops) - 1, -1, -1):
+            ic, _, at = self.hops[i]
+            sfx = self._sfx(i)
+            dqc = ws.get('att.dqc' + sfx, (N, K))
+            ops.img_att_backward(self.iqc[i], fp.w[at + '.W'], self.pre, self.m1, self.m2[i], self.patt[i], du,
+                                 G[at + '.W'], G[at + '.b'], dqc, ws.get('att.dscore', (N, S2)), N, R, S2, H, K, sc)
+            dz = self.iqc[i]                                                     # iqc now holds dz
+            ops.colsum_acc(dz, G[ic + '.b'], M=N * S2, N=K)
+            ops.img_common_wgrad(dz, self.pre, self.m1, G[ic + '.W'], N, R, S2, H, K, sc)
+            ops.img_tr_backward(dz, fp.w[ic + '.W'], self.patt[i], du, self.m1, dpre, N, R, S2, H, K, sc)   # += into dpre
+            du_q = self.ques_common[i].backward(dqc)
+            du = ops.axpby(du_q, du, ws.get('att.du0' + sfx, (N, H)), 1.0, 1.0)   # residual CAddTable (mn-att:102)
         self.img_proj.backward(dpre, need_dx=False)                              # tanh' + dW, db of mn-att:77
-        du0 = self.ques_common.backward(dqc)
-        return ops.axpby(du0, du1, ws.get('att.du0', (N, H)), 1.0, 1.0)
+        return du
 
 
 class CatLinear(object):
