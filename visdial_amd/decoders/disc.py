@@ -12,6 +12,7 @@ import os
 import torch
 
 from .. import ops
+from ..criterion import DiscDecoderOutput
 from ..nn import StreamPool
 
 
@@ -49,14 +50,17 @@ class Decoder(object):
                          flags=self.flags)
         ops.prof_end('opt_lstm_fwd', t0, 1)      # one persistent launch for all To steps
         self.optH = self.h[To - 1]
-        self.output = ws.get('opt.scores', (N, O))
-        return self.output          # filled by the criterion call (scores + loss are one kernel)
+        self.output = ws.get('opt.scores', (N, O))   # filled by the criterion call (scores + loss are one kernel)
+        return DiscDecoderOutput(self.optH, enc_out, self.output, N, O, H)
 
-    def backward(self, inputs, d_optH):
-        """d_optH [N*O x H] from the fused score/CE kernel.  Accumulates the option-LSTM gradients and
-        leaves the gradient of the gathered table in self.dtab; the shared embedding gradient is added
-        by backward_embed() (kept separate so the host can order it after the encoder's scatters)."""
+    def backward(self, inputs, gradOutput):
+        """decoder:backward({options, encOut}, gradCriterionOut) (model.lua:335): gradOutput = (d optH [N*O x H],
+        d encOut [N x H]) from the fused score/CE criterion.  Accumulates the option-LSTM gradients, leaves the
+        gradient of the gathered table in self.dtab (the shared embedding gradient is added by backward_embed(), kept
+        separate so the host can order it after the encoder's scatters) and returns [None, gradEncOut] like the
+        reference's table of input gradients ({_, gradEncOut}, model.lua:335-337)."""
         otok, enc_out = inputs
+        d_optH, d_enc = gradOutput
         ws, H, V, To, NO = self.ws, self.H, self.V, self.To, self.NO
         dc = ws.get('opt.dc', (NO, H))
         # the token counting sort and the zero-fill of the table gradient depend on the inputs only:
@@ -88,6 +92,7 @@ class Decoder(object):
                             flags=self.flags)
             ops.prof_end('opt_lstm_dWh', t0, 1)
         self.dtab = dtab
+        return [None, d_enc]
 
     def backward_embed(self):
         """dEmb += dTable * Wx^T.  Non-atomic read-modify-write of the SHARED embedding gradient: must be

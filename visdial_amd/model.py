@@ -75,6 +75,10 @@ class Model(object):
         self.decoderConnect = getattr(self.decFile, 'decoderConnect', None)
         self.wrapper = Wrapper(self)
         self.wrapperW, self.wrapperdW = self.wrapper.getParameters()     # model.lua:55
+        # criterion (model.lua:32-38): disc = CrossEntropyCriterion; gen = SequencerCriterion(MaskZeroCriterion(ClassNLL)),
+        # fused into the generative decoder's vocabulary head (decoders/gen.py)
+        from .criterion import CrossEntropyCriterion
+        self.criterion = CrossEntropyCriterion(self.ws) if params['decoder'] == 'disc' else None
         self.wrapper.training()                                          # model.lua:57
         # optimiser state (model.lua:60-61; optim_updates.lua:68-77)
         self.optims = {'learningRate': float(params['learningRate']), 't': 0}
@@ -95,7 +99,7 @@ class Model(object):
         # the current step (Model.trainIteration); the loss leaves the device through a pinned buffer
         self._copy_stream = torch.cuda.Stream(device=self.device)
         self._next = None
-        self._loss_host = None
+        self._keepalive = None
 
     # ------------------------------------------------------------------ helpers
     def _dev(self, a, dtype):
@@ -180,6 +184,10 @@ class Model(object):
         if os.environ.get('VD_PREFETCH', '1') != '0':
             self._next = self._fetch(dataloader) + (dataloader,)
         curLoss = pending()
+        # The loss leaves the device right after the criterion, i.e. BEFORE this step's backward has finished reading
+        # the uploaded inputs: keep them referenced until the NEXT step's loss has arrived (stream order then
+        # guarantees this step is complete), so the allocator cannot hand their memory to a new upload early.
+        self._keepalive = (batch, prepared)
         if self.params['decoder'] == 'gen':
             numTokens = float((batch['answer_out'] > 0).sum())
             cur = curLoss / numTokens
@@ -232,8 +240,13 @@ class Model(object):
         return (lambda: loss) if deferLoss else loss
 
     def _forwardBackward_disc(self, inputs, dec_in, onlyForward):
-        """disc branch of model.lua:326-338.  The encoder (latency-bound chains) runs on a side stream
-        concurrently with the option LSTM (throughput-bound) in both directions."""
+        """disc branch of model.lua:326-338, call for call:
+            decOut  = decoder:forward({options, encOut})
+            curLoss = criterion:forward(decOut, answerInd)
+            gradCriterionOut = criterion:backward(decOut, answerInd)
+            t = decoder:backward({options, encOut}, gradCriterionOut);  encoder:backward(inputs, t[2])
+        The encoder (latency-bound chains) runs on a side stream concurrently with the option LSTM (throughput-bound)
+        in both directions.  Returns a callable that waits for the device and yields curLoss."""
         st = self.streams
         # Enqueue order matters: the option LSTM is a handful of big launches, the encoder ~200 small
         # ones -- the big chain goes to the main stream first so the GPU is busy while the host is
@@ -242,27 +255,20 @@ class Model(object):
         d_in = (dec_in['options'], enc_out_buf)
         start = torch.cuda.Event()
         start.record()
-        scores = self.decoder.forward(d_in)
+        decOut = self.decoder.forward(d_in)                                       # model.lua:329
         with st.fork('enc', after=start):
-            encOut = self.encoder.forward(inputs)
+            encOut = self.encoder.forward(inputs)                                 # model.lua:297
         assert encOut.data_ptr() == enc_out_buf.data_ptr()
         self.forwardConnect(self.encoder, self.decoder, encOut, inputs[0].shape[0])
         st.join('enc')
-        N, O, H = self.decoder.N, self.decoder.O, self.decoder.H
-        loss_rows = self.ws.get('crit.loss_rows', (N,))
-        if onlyForward:
-            ops.score_ce(self.decoder.optH, encOut, scores, N, O, H, gt=dec_in['gt'], loss_rows=loss_rows)
-        else:
-            d_optH = self.ws.get('crit.d_optH', (N * O, H))
-            d_enc = self.ws.get('crit.d_enc', (N, H))
-            # CrossEntropyCriterion forward+backward and nn.MM backward in one kernel (model.lua:330-335)
-            ops.score_ce(self.decoder.optH, encOut, scores, N, O, H, gt=dec_in['gt'], loss_rows=loss_rows,
-                         dOptH=d_optH, dEnc=d_enc, gscale=1.0 / N)
-            self._ce_event = torch.cuda.Event()
-            self._ce_event.record()
-            self.decoder.backward(d_in, d_optH)                                   # model.lua:335 (main stream)
+        crit = self.criterion.forward(decOut, dec_in['gt'], needGrad=not onlyForward)   # model.lua:330
+        pending = crit.loss_handle()
+        if not onlyForward:
+            gradCriterionOut = self.criterion.backward(decOut, dec_in['gt'])      # model.lua:334
+            self._ce_event = crit.done
+            t = self.decoder.backward(d_in, gradCriterionOut)                     # model.lua:335 (main stream)
             with st.fork('enc', after=self._ce_done()):
-                self.encoder.backward(inputs, d_enc)                              # model.lua:337
+                self.encoder.backward(inputs, t[1])                               # model.lua:337 (t[2] in Lua)
                 if self._dp_active() and st.enabled:
                     # gradient bucket 1: the encoder's own tensors are final here -> start their RCCL
                     # all-reduce now, overlapped with the option-LSTM backward on the main stream
@@ -271,17 +277,6 @@ class Model(object):
                     _, self._enc_bucket_work = reduce_gradients(self.wrapperdW[lo:hi], self.dist_group, async_op=True)
             st.join('enc')
             self.decoder.backward_embed()
-        # the per-round losses leave through a pinned buffer; the host waits only when the value is asked for
-        if self._loss_host is None or self._loss_host.numel() < N:
-            self._loss_host = torch.empty(N, dtype=torch.float32).pin_memory()
-        host = self._loss_host[:N]
-        host.copy_(loss_rows, non_blocking=True)
-        done = torch.cuda.Event()
-        done.record()
-
-        def pending():
-            done.synchronize()
-            return float(host.numpy().astype(np.float64).mean())
         return pending
 
     def _ce_done(self):
@@ -297,9 +292,7 @@ class Model(object):
                                                  inputs[0].shape[0])
             self.scores = scores
         else:
-            scores = self.decoder.forward((dec_in['options'], encOut))
-            N, O, H = self.decoder.N, self.decoder.O, self.decoder.H
-            ops.score_ce(self.decoder.optH, encOut, scores, N, O, H)
+            scores = self.decoder.forward((dec_in['options'], encOut)).materialize()
             self.scores = scores
         gt = dec_in.get('gt') if self.params.get('useGt') else None
         return utils.computeRanks(scores, gt, self.ws)
