@@ -89,6 +89,9 @@ def main():
     ap.add_argument('--batch', type=int, default=20, help='dialogs per GPU (headline: 20)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--same-batch', action='store_true', help='reuse one resident batch (round-1 behaviour; A/B only)')
+    ap.add_argument('--host', choices=['python', 'native'], default=os.environ.get('VD_BENCH_HOST', 'python'),
+                    help='python = visdial_amd.Model composing the operator-level ABI; native = the model-level ABI '
+                         '(csrc/runtime.hip: the orchestration a Lua host would get)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -116,7 +119,12 @@ def main():
     from visdial_amd.model import Model
 
     p = headline_params(rank=rank, batch=args.batch)
-    model = Model(p, dist_group=group)
+    if args.host == 'native':
+        assert world == 1, "the native host leaves the gradient all-reduce to its caller; bench it single-GPU"
+        from visdial_amd.native import NativeModel
+        model = NativeModel(p)
+    else:
+        model = Model(p, dist_group=group)
     dl = SyntheticDataloader(p, seed=1234 + rank, fast=True)
     N = p['batchSize'] * p['maxQuesCount']
     if args.same_batch:
@@ -143,6 +151,12 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ops.prof_summary()
     ops.PROFILE = None
+    if args.host == 'native':       # HIP events recorded by the library around the three families in the LAST step
+        f = model.family_ms()
+        prof = {'opt_lstm_fwd': (f[0], 1), 'opt_lstm_bwd': (f[1], 1), 'opt_lstm_dWh': (f[2], 1)}
+        args_steps_for_prof = 1
+    else:
+        args_steps_for_prof = args.steps
     if group is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -161,7 +175,7 @@ def main():
                 ('opt_lstm_dWh', 2.0 * NO * (To - 1) * H * 4 * H, 2.0 * NO * (To - 1) * H * 4 * H, 1)):
             if tag in prof:
                 ms, n = prof[tag]
-                fams[tag] = dict(ms_total_per_step=ms / args.steps, avg_launch_ms=ms / n, launches_per_step=n / args.steps,
+                fams[tag] = dict(ms_total_per_step=ms / args_steps_for_prof, avg_launch_ms=ms / n, launches_per_step=n / args_steps_for_prof,
                                  gflop_executed_per_launch=executed / 1e9,
                                  tflops_nominal=nominal / (ms / n) / 1e9, tflops_executed=executed / (ms / n) / 1e9)
         dom = max(fams, key=lambda k: fams[k]['ms_total_per_step']) if fams else None
@@ -199,7 +213,7 @@ def main():
             "config": {"workload": "mn-att-ques-im-hist + disc, B=%d dialogs/GPU x 10 rounds x 100 options, "
                                    "14x14x512 pool5 map, V=11322, E=300, H=512 (BASELINE.json configs[3])" % args.batch,
                        "global_batch_dialogs": world * args.batch, "parallelism": "dp%d" % world,
-                       "dropout": "on (device generator)", "loss": round(float(loss), 5)},
+                       "dropout": "on (device generator)", "loss": round(float(loss), 5), "host": args.host},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

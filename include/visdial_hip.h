@@ -5,7 +5,7 @@
  * op on its training hot path lives in un-vendored Lua rocks (nn, rnn, cunn).  This header is
  * the operator-level boundary that replaces those calls: each entry point names the reference
  * module call it stands in for (file:line under /root/reference).  A host (LuaJIT ffi.cdef,
- * Python ctypes, ...) composes them exactly as encoders/*.lua / decoders/*.lua compose nn
+ * Python ctypes, ...) composes them exactly as encoders/<name>.lua / decoders/<name>.lua compose nn
  * modules; see INTEGRATION.md for the Lua-side binding.
  *
  * Conventions
@@ -221,6 +221,60 @@ int vd_ranks(const float* scores, int32_t* ranks, int N, int O, void* stream);
 /* ---- wrapperdW:clamp(-5,5) + adam (model.lua:96-99; model_utils/optim_updates.lua:62-91) ---- */
 int vd_clamp_adam(float* w, float* g, float* m, float* v, int64_t n, float gscale, float clip, float beta1,
                   float beta2, float eps, float step, void* stream);
+
+/* ======================================================================================================
+ * Model-level entry points (csrc/runtime.hip): the whole training step of the headline pair behind the ABI.
+ * A LuaJIT host's model.lua needs only these: stream fork/join, the skewed two-layer wavefront,
+ * the length sort, workspaces and launch order live in the library.  Covered pair: encoder 'mn-att-ques-im-hist'
+ * (encoders/mn-att-ques-im-hist.lua:5-115) + decoder 'disc' (decoders/disc.lua:3-38); vd_model_create refuses others
+ * (they run through the operator-level entry points above).  One host thread per model; calls enqueue on
+ * library-owned streams and block only where a host value is returned (loss, scores, ranks, tensors).
+ * ====================================================================================================== */
+typedef struct vd_model vd_model;
+typedef struct vd_model_params {   /* the `params` keys Model() consumes: opts.lua:15-40, train.lua:55-59 */
+  int32_t vocabSize, embedSize, rnnHiddenSize, imgFeatureSize, imgSpatialSize, commonEmbeddingSize,
+          numAttentionLayers, maxQuesCount, numOptions;
+  float learningRate, lrDecayRate, minLRate;     /* opts.lua:35-38 */
+  uint64_t seed;                                 /* dropout noise stream */
+  int32_t lstmBf16;                              /* opt-in bf16 operands of the option recurrence (configs[4]) */
+  int32_t useStreams;                            /* 0 = everything on one stream (debug) */
+} vd_model_params;
+typedef struct vd_batch {          /* HOST pointers, dataloader layout (dataloader.lua:324-339, 378-475) */
+  int32_t B, Tq, Th, To;           /* dialogs; trimmed question / history / option lengths */
+  const int32_t* ques_fwd;         /* [B*R x Tq] right-aligned, 0 = pad */
+  const int32_t* hist;             /* [B*R x Th] right-aligned */
+  const float* img_feat;           /* [B x S*S x C] */
+  const int32_t* options;          /* [B*R x O x To] left-aligned */
+  const int32_t* answer_ind;       /* [B*R] 1-based, or NULL (test split) */
+} vd_batch;
+/* Model:__init (model.lua:10-63): parameter vectors (zeroed), optimiser state, streams */
+int vd_model_create(const vd_model_params* p, const char* encoder, const char* decoder, vd_model** out);
+void vd_model_destroy(vd_model* m);
+/* wrapper:getParameters() (model.lua:55): flat layout = embed | encoder tensors | decoder tensors, every tensor
+ * 16-byte aligned; tensor i = name, element offset, rows x cols */
+int64_t vd_model_num_tensors(const vd_model* m);
+int64_t vd_model_flat_size(const vd_model* m);
+int vd_model_tensor_info(const vd_model* m, int64_t i, char* name64, int64_t* offset, int64_t* rows, int64_t* cols);
+/* device pointers of wrapperW, wrapperdW and the Adam moments (for a host-side RCCL all-reduce of wrapperdW) */
+int vd_model_flat_pointers(vd_model* m, float** W, float** dW, float** adam_m, float** adam_v);
+void* vd_model_stream(vd_model* m);                       /* the main hipStream_t */
+int vd_model_init_params(vd_model* m, uint64_t seed);     /* library-default init */
+int vd_model_set_tensor(vd_model* m, const char* name, const float* host, int64_t n);   /* wrapperW:copy(...) */
+int vd_model_get_tensor(vd_model* m, const char* name, int which /*0 W, 1 dW, 2 m, 3 v*/, float* host, int64_t n);
+int vd_model_set_training(vd_model* m, int on);           /* wrapper:training() / :evaluate() (model.lua:57,111) */
+int vd_model_set_dropout_mask(vd_model* m, const char* site, const uint8_t* host_keep, int64_t n); /* NULL host = clear */
+/* batch re-layout + upload (model.lua:255-294, dataloader.lua:410-475), asynchronous, double-buffered */
+int vd_model_upload_batch(vd_model* m, const vd_batch* host_batch);
+/* Model:forwardBackward on the uploaded batch (model.lua:249-342); zeroes the gradients first unless only_forward */
+int vd_model_forward_backward(vd_model* m, int only_forward);
+int vd_model_loss(vd_model* m, float* loss);              /* curLoss of the last forward (waits for it) */
+/* wrapperdW*gscale -> clamp(-5,5) -> adam -> lr decay (model.lua:96-105; optim_updates.lua:62-91) */
+int vd_model_update(vd_model* m, float gscale);
+int vd_model_learning_rate(vd_model* m, double* lr, int set);
+int vd_model_scores(vd_model* m, float* host_scores, int64_t n);        /* [N x O] of the last forward */
+int vd_model_ranks(vd_model* m, int use_gt, int32_t* host_ranks);       /* utils.computeRanks (utils.lua:106-128) */
+int vd_model_family_ms(vd_model* m, float* ms3);          /* device ms of option-LSTM fwd, bwd, dWh in the last step */
+int vd_model_synchronize(vd_model* m);
 
 #ifdef __cplusplus
 }

@@ -133,17 +133,17 @@ void gemm(int M, int N, int K, const float* A, long rsa, long csa, const float* 
   const Kernel& kr = kernel();
   const int MR = kr.MR, NR = kr.NR;
   const int nth = omp_get_max_threads();
-  // C tile = MC x NC; shrink until there are enough tiles for the threads
+  // C tile = MC x NC.  Shrink (never below 2 x 2 register tiles: smaller tiles spend more time packing than
+  // multiplying) until every thread has a tile; small problems simply use fewer threads.
   int MC = MR * 8, NC = NR * 16;
   auto tiles = [&](int mc, int nc) { return (long)((M + mc - 1) / mc) * ((N + nc - 1) / nc); };
-  while (tiles(MC, NC) < 3L * nth && (MC > MR || NC > NR)) {
-    if (NC > NR && (NC / NR >= MC / MR || MC == MR)) NC /= 2;
+  while (tiles(MC, NC) < 2L * nth && (MC > 2 * MR || NC > 2 * NR)) {
+    if (NC > 2 * NR && (NC / NR >= MC / MR || MC <= 2 * MR)) NC /= 2;
     else MC /= 2;
-    if (NC < NR) NC = NR;
-    if (MC < MR) MC = MR;
   }
   const int tm = (M + MC - 1) / MC, tn = (N + NC - 1) / NC;
-#pragma omp parallel
+  const int use = (int)std::min<long>(nth, (long)tm * tn);
+#pragma omp parallel num_threads(use)
   {
     std::vector<float> Ap((size_t)MC * KC), Bp((size_t)NC * KC);
 #pragma omp for collapse(2) schedule(dynamic, 1)

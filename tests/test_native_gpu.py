@@ -1,0 +1,103 @@
+"""The model-level C ABI (csrc/runtime.hip, the calls a LuaJIT model.lua proxy makes -- INTEGRATION.md) against the
+CPU oracle and against the Python host that composes the operator-level entry points: same step, same numbers."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import small_params
+from oracle import visdial_oracle as vo
+from test_model_gpu import CASES, make_masks, rel
+from visdial_amd.dataloader import SyntheticDataloader
+from visdial_amd.opts import derive
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+@pytest.mark.parametrize("case", ['tiny', 'odd', 'hops3', 'mid'])
+@pytest.mark.parametrize("train_mode", [False, True])
+def test_native_step_matches_oracle(gpu, case, train_mode):
+    from visdial_amd.native import NativeModel
+    p = derive(small_params(**CASES[case]))
+    batch = SyntheticDataloader(p, seed=11).getTrainBatch(p)
+    model = NativeModel(p, init_seed=5)
+    masks = None
+    if train_mode:
+        masks = make_masks(p, batch, np.random.RandomState(5))
+        model.set_dropout_masks(masks)
+    else:
+        model.training(False)
+    P0 = {k: v.astype(np.float64) for k, v in model.get_parameters_dict().items()}
+    assert set(P0) == {e[0] for e in vo.param_spec(p['encoder'], p['decoder'], p)}
+    loss = model.forwardBackward(batch)
+    drop = {k: v.astype(np.float64) for k, v in masks.items()} if masks else None
+    ref = vo.forward_backward(p['encoder'], p['decoder'], P0, p, batch, drop)
+    assert abs(loss - ref['loss']) < 1e-4
+    g = model.get_gradients_dict()
+    bad = [(rel(g[k], ref['grads'][k]), k) for k in ref['grads']
+           if rel(g[k], ref['grads'][k]) >= 1e-4 and np.abs(g[k] - ref['grads'][k]).max() >= 1e-6]
+    assert not bad, bad
+    N, O = batch['options'].shape[0], batch['options'].shape[1]
+    assert rel(model.scores(N, O), ref['scores']) < 1e-4
+    model.update()
+    after = model.get_parameters_dict()
+    for k in P0:
+        w2, _ = vo.clamp_adam(P0[k].reshape(-1), g[k].astype(np.float64).reshape(-1), {}, p['learningRate'])
+        assert np.abs(after[k].reshape(-1) - w2).max() < 1e-6, k
+    model.close()
+
+
+def test_native_equals_python_host(gpu):
+    """same parameters, same batch, same pinned dropout masks: the two hosts launch the same kernels"""
+    from visdial_amd.model import Model
+    from visdial_amd.native import NativeModel
+    p = derive(small_params(**CASES['odd']))
+    batch = SyntheticDataloader(p, seed=3).getTrainBatch(p)
+    masks = make_masks(p, batch, np.random.RandomState(1))
+    py = Model(p)
+    py.set_dropout_masks(masks)
+    nat = NativeModel(p)
+    nat.set_parameters_dict(py.get_parameters_dict())
+    nat.set_dropout_masks(masks)
+    py.wrapper.zeroGradParameters()
+    l1 = py.forwardBackward(batch)
+    l2 = nat.forwardBackward(batch)
+    assert abs(l1 - l2) < 1e-6
+    g1, g2 = py.get_gradients_dict(), nat.get_gradients_dict()
+    for k in g1:
+        assert rel(g2[k], g1[k]) < 2e-6 or np.abs(g2[k] - g1[k]).max() < 1e-7, k     # float atomics: order-dependent sums
+    nat.close()
+
+
+def test_native_training_loop_and_ranks(gpu):
+    from visdial_amd.native import NativeModel
+    p = derive(small_params(**CASES['tiny']))
+    dl = SyntheticDataloader(p, seed=9)
+    fixed = dl.getTrainBatch(p)
+    dl.getTrainBatch = lambda params, **kw: fixed        # overfit one batch: the loss must fall
+    model = NativeModel(p)
+    losses = [model.trainIteration(dl) for _ in range(60)]
+    assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0]
+    model.training(False)
+    ranks = model.retrieveBatch(fixed, useGt=True)
+    P = {k: v.astype(np.float64) for k, v in model.get_parameters_dict().items()}
+    ref = vo.retrieve(p['encoder'], p['decoder'], P, p, fixed)
+    N, O = fixed['options'].shape[0], fixed['options'].shape[1]
+    dev = model.scores(N, O)
+    assert rel(dev, ref) < 1e-4
+    np.testing.assert_array_equal(ranks, vo.compute_ranks(dev, fixed['answer_ind'].reshape(-1) - 1))
+    allr = model.retrieveBatch(fixed, useGt=False)
+    assert np.all(np.sort(allr, 1) == np.arange(1, O + 1)[None, :])
+    model.close()
+
+
+def test_native_refuses_other_pairs(gpu):
+    from visdial_amd import _lib
+    from visdial_amd.native import NativeModel
+    with pytest.raises(_lib.VisdialHipError):
+        NativeModel(derive(small_params(encoder='lf-ques', decoder='gen')))

@@ -29,6 +29,18 @@ class Lstm2Bwd(C.Structure):
                 ("nact", C.c_void_p)]
 
 
+class ModelParams(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ('vocabSize', 'embedSize', 'rnnHiddenSize', 'imgFeatureSize', 'imgSpatialSize',
+                                         'commonEmbeddingSize', 'numAttentionLayers', 'maxQuesCount', 'numOptions')] + \
+               [(k, C.c_float) for k in ('learningRate', 'lrDecayRate', 'minLRate')] + \
+               [('seed', C.c_uint64), ('lstmBf16', C.c_int32), ('useStreams', C.c_int32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ('B', 'Tq', 'Th', 'To')] + \
+               [(k, C.c_void_p) for k in ('ques_fwd', 'hist', 'img_feat', 'options', 'answer_ind')]
+
+
 # name -> argtypes  (return type is int unless listed in _RESTYPE)
 PROTOTYPES = {
     "vd_last_error": [],
@@ -82,8 +94,31 @@ PROTOTYPES = {
     "vd_score_ce": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "vd_ranks": [_p, _p, _i, _i, _p],
     "vd_clamp_adam": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _p],
+    # model-level entry points (csrc/runtime.hip)
+    "vd_model_create": [C.POINTER(ModelParams), C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)],
+    "vd_model_destroy": [_p],
+    "vd_model_num_tensors": [_p],
+    "vd_model_flat_size": [_p],
+    "vd_model_tensor_info": [_p, _l, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+    "vd_model_flat_pointers": [_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
+    "vd_model_stream": [_p],
+    "vd_model_init_params": [_p, _u64],
+    "vd_model_set_tensor": [_p, C.c_char_p, _p, _l],
+    "vd_model_get_tensor": [_p, C.c_char_p, _i, _p, _l],
+    "vd_model_set_training": [_p, _i],
+    "vd_model_set_dropout_mask": [_p, C.c_char_p, _p, _l],
+    "vd_model_upload_batch": [_p, C.POINTER(Batch)],
+    "vd_model_forward_backward": [_p, _i],
+    "vd_model_loss": [_p, C.POINTER(C.c_float)],
+    "vd_model_update": [_p, _f],
+    "vd_model_learning_rate": [_p, C.POINTER(C.c_double), _i],
+    "vd_model_scores": [_p, _p, _l],
+    "vd_model_ranks": [_p, _i, _p],
+    "vd_model_family_ms": [_p, C.POINTER(C.c_float)],
+    "vd_model_synchronize": [_p],
 }
-_RESTYPE = {"vd_last_error": C.c_char_p}
+_RESTYPE = {"vd_last_error": C.c_char_p, "vd_model_destroy": None, "vd_model_num_tensors": C.c_int64,
+            "vd_model_flat_size": C.c_int64, "vd_model_stream": C.c_void_p}
 
 
 class VisdialHipError(RuntimeError):

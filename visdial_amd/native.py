@@ -1,0 +1,143 @@
+"""`NativeModel` -- the training step of the headline pair (mn-att-ques-im-hist + disc) driven entirely through the
+MODEL-LEVEL C ABI (include/visdial_hip.h, csrc/runtime.hip): the same handful of calls a LuaJIT `model.lua` proxy
+makes.  Python only converts numpy batches to host pointers; streams, the skewed LSTM wavefront,
+the length sort, workspaces and launch order live in the library.  Same method names as visdial_amd.model.Model /
+the reference's Model (model.lua): trainIteration, forwardBackward, update, retrieveBatch."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+call = _lib.call
+
+
+class NativeModel(object):
+    def __init__(self, params, init_seed=1234):
+        p = params
+        mp = _lib.ModelParams(
+            vocabSize=p['vocabSize'], embedSize=p['embedSize'], rnnHiddenSize=p['rnnHiddenSize'],
+            imgFeatureSize=p['imgFeatureSize'], imgSpatialSize=p['imgSpatialSize'],
+            commonEmbeddingSize=p.get('commonEmbeddingSize', 512), numAttentionLayers=int(p.get('numAttentionLayers', 1) or 1),
+            maxQuesCount=p['maxQuesCount'], numOptions=p.get('numOptions', 100),
+            learningRate=p.get('learningRate', 1e-3), lrDecayRate=p.get('lrDecayRate', 0.9997592083),
+            minLRate=p.get('minLRate', 5e-5), seed=int(p.get('seed', 1234)) + 7919 * int(p.get('rank', 0)),
+            lstmBf16=1 if p.get('lstmPrecision', 'fp32') == 'bf16' else 0, useStreams=int(p.get('useStreams', 1)))
+        self.params = p
+        h = C.c_void_p()
+        call("vd_model_create", C.byref(mp), p['encoder'].encode(), p['decoder'].encode(), C.byref(h))
+        self.h = h
+        lib = _lib.load()
+        self.tensors = []
+        name = C.create_string_buffer(64)
+        off, r, c = C.c_int64(), C.c_int64(), C.c_int64()
+        for i in range(lib.vd_model_num_tensors(h)):
+            call("vd_model_tensor_info", h, i, name, C.byref(off), C.byref(r), C.byref(c))
+            self.tensors.append((name.value.decode(), int(off.value), int(r.value), int(c.value)))
+        call("vd_model_init_params", h, int(init_seed))
+        self._keep = None
+
+    def close(self):
+        if self.h:
+            _lib.load().vd_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ parameters
+    def _shape(self, name, r, c):
+        return (c,) if name.endswith('.b') else (r, c)
+
+    def set_parameters_dict(self, d):
+        for name, _, r, c in self.tensors:
+            a = np.ascontiguousarray(d[name], dtype=np.float32)
+            assert a.size == r * c, name
+            call("vd_model_set_tensor", self.h, name.encode(), a.ctypes.data, a.size)
+
+    def _get(self, which):
+        out = {}
+        for name, _, r, c in self.tensors:
+            a = np.empty(self._shape(name, r, c), np.float32)
+            call("vd_model_get_tensor", self.h, name.encode(), which, a.ctypes.data, a.size)
+            out[name] = a
+        return out
+
+    def get_parameters_dict(self):
+        return self._get(0)
+
+    def get_gradients_dict(self):
+        return self._get(1)
+
+    def training(self, on=True):
+        call("vd_model_set_training", self.h, int(on))
+
+    def set_dropout_masks(self, masks):
+        call("vd_model_set_dropout_mask", self.h, None, None, 0)
+        for k, v in (masks or {}).items():
+            a = np.ascontiguousarray(np.asarray(v) != 0, dtype=np.uint8).reshape(-1)
+            call("vd_model_set_dropout_mask", self.h, k.encode(), a.ctypes.data, a.size)
+
+    # ------------------------------------------------------------------ step
+    def upload(self, batch):
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        q = i32(batch['ques_fwd'].reshape(-1, batch['ques_fwd'].shape[2]))
+        h = i32(batch['hist'].reshape(-1, batch['hist'].shape[2]))
+        o = i32(batch['options'])
+        img = np.ascontiguousarray(batch['img_feat'], dtype=np.float32)
+        ans = i32(batch['answer_ind'].reshape(-1)) if 'answer_ind' in batch else None
+        hb = _lib.Batch(B=batch['ques_fwd'].shape[0], Tq=q.shape[1], Th=h.shape[1], To=o.shape[2], ques_fwd=q.ctypes.data,
+                        hist=h.ctypes.data, img_feat=img.ctypes.data, options=o.ctypes.data,
+                        answer_ind=ans.ctypes.data if ans is not None else None)
+        call("vd_model_upload_batch", self.h, C.byref(hb))      # host buffers are consumed before it returns
+
+    def forwardBackward(self, batch=None, onlyForward=False, deferLoss=False):
+        if batch is not None:
+            self.upload(batch)
+        call("vd_model_forward_backward", self.h, int(onlyForward))
+        return self.loss if deferLoss else self.loss()
+
+    def loss(self):
+        v = C.c_float()
+        call("vd_model_loss", self.h, C.byref(v))
+        return float(v.value)
+
+    def update(self, gscale=1.0):
+        call("vd_model_update", self.h, float(gscale))
+
+    def trainIteration(self, dataloader):
+        """model.lua:66-106, software-pipelined like Model.trainIteration: enqueue the step, upload the next batch
+        (copy stream, second slot) while the device executes, then wait for this step's loss."""
+        if self._keep is None or self._keep is not dataloader:
+            self.upload(dataloader.getTrainBatch(self.params))
+            self._keep = dataloader
+        call("vd_model_forward_backward", self.h, 0)
+        self.update()
+        self.upload(dataloader.getTrainBatch(self.params))
+        return self.loss()
+
+    def scores(self, N, O):
+        a = np.empty((N, O), np.float32)
+        call("vd_model_scores", self.h, a.ctypes.data, a.size)
+        return a
+
+    def retrieveBatch(self, batch, useGt=True):
+        """model.lua:344-430: ground-truth ranks [N] (useGt) or all ranks [N x O]"""
+        self.upload(batch)
+        call("vd_model_forward_backward", self.h, 1)
+        N = batch['ques_fwd'].shape[0] * batch['ques_fwd'].shape[1]
+        O = batch['options'].shape[1]
+        out = np.empty(N if useGt else (N, O), np.int32)
+        call("vd_model_ranks", self.h, int(useGt), out.ctypes.data)
+        return out
+
+    def family_ms(self):
+        a = (C.c_float * 3)()
+        call("vd_model_family_ms", self.h, a)
+        return [float(x) for x in a]
+
+    def synchronize(self):
+        call("vd_model_synchronize", self.h)
