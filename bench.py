@@ -89,9 +89,9 @@ def main():
     ap.add_argument('--batch', type=int, default=20, help='dialogs per GPU (headline: 20)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--same-batch', action='store_true', help='reuse one resident batch (round-1 behaviour; A/B only)')
-    ap.add_argument('--host', choices=['python', 'native'], default=os.environ.get('VD_BENCH_HOST', 'python'),
-                    help='python = visdial_amd.Model composing the operator-level ABI; native = the model-level ABI '
-                         '(csrc/runtime.hip: the orchestration a Lua host would get)')
+    ap.add_argument('--host', choices=['python', 'native'], default=os.environ.get('VD_BENCH_HOST', 'native'),
+                    help='native (default) = the model-level ABI (csrc/runtime.hip: the orchestration a Lua host gets); '
+                         'python = visdial_amd.Model composing the operator-level ABI')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -120,9 +120,8 @@ def main():
 
     p = headline_params(rank=rank, batch=args.batch)
     if args.host == 'native':
-        assert world == 1, "the native host leaves the gradient all-reduce to its caller; bench it single-GPU"
         from visdial_amd.native import NativeModel
-        model = NativeModel(p)
+        model = NativeModel(p, dist_group=group)
     else:
         model = Model(p, dist_group=group)
     dl = SyntheticDataloader(p, seed=1234 + rank, fast=True)

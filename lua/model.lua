@@ -1,0 +1,197 @@
+-- model.lua -- drop-in for the reference's model.lua (class Model, model.lua:8-615) on the MI355X-native library.
+--
+-- Same surface the reference's train.lua / evaluate.lua use: Model(params), model:trainIteration(dataloader),
+-- model:forwardBackward(batch, onlyForward), model:retrieveBatch(batch), model:retrieve / model:predict(dataloader,
+-- dtype), model.optims.learningRate, model:getFlatParameters() / model:setFlatParameters(t) (wrapperW:copy / :float()).
+-- The encoder / decoder are still resolved by plug-in FILE (model.lua:19-26): encoders/<name>.lua returns a table
+-- with model(params), decoders/<name>.lua a table with model(params, enc), forwardConnect, backwardConnect -- here
+-- those tables describe the native graph instead of building nn modules, and the whole step (stream fork/join,
+-- skewed LSTM wavefront, length sort, workspaces) runs behind the model-level C ABI (include/visdial_hip.h,
+-- csrc/runtime.hip).  Host code stays Lua; no cutorch / cunn / rnn is needed, torch only for the dataloader's
+-- CPU tensors.  UNTESTED HERE: no Lua/LuaJIT/Torch7 exists in the build container (DESIGN.md); the Python host
+-- visdial_amd/native.py makes exactly these calls and is what the GPU tests drive.
+local ffi = require 'ffi'
+local vd = dofile('visdial_ffi.lua')
+local C = vd.C
+local utils = dofile('utils.lua')          -- the reference's own utils.lua (processRanks, writeJSON, ...)
+
+local Model = torch.class('Model')
+
+local function as_int(t)   return t:int():contiguous() end      -- Long/Float/Cuda tensor -> IntTensor (token ids)
+local function as_float(t) return t:float():contiguous() end
+
+function Model:__init(params)
+    print('Setting up model (MI355X-native)..')
+    self.params = params
+    -- build the model - encoder, decoder (model.lua:19-26): the plug-in files name the native graph
+    local encFile = string.format('encoders/%s.lua', params.encoder)
+    local decFile = string.format('decoders/%s.lua', params.decoder)
+    print('Encoder: ', params.encoder); print('Decoder: ', params.decoder)
+    self.encoder = dofile(encFile).model(params)
+    local decoderNet = dofile(decFile)
+    self.decoder = decoderNet.model(params, self.encoder)
+    self.forwardConnect = decoderNet.forwardConnect
+    self.backwardConnect = decoderNet.backwardConnect
+
+    local p = ffi.new('vd_model_params')
+    p.vocabSize = params.vocabSize;           p.embedSize = params.embedSize
+    p.rnnHiddenSize = params.rnnHiddenSize;   p.imgFeatureSize = params.imgFeatureSize
+    p.imgSpatialSize = params.imgSpatialSize or 14
+    p.commonEmbeddingSize = params.commonEmbeddingSize or 512
+    p.numAttentionLayers = params.numAttentionLayers or 1
+    p.maxQuesCount = params.maxQuesCount;     p.numOptions = params.numOptions or 100
+    p.learningRate = params.learningRate;     p.lrDecayRate = params.lrDecayRate
+    p.minLRate = params.minLRate;             p.seed = 1234
+    p.lstmBf16 = 0;                           p.useStreams = 1
+    if params.gpuid and params.gpuid >= 0 then vd.call('vd_set_device', params.gpuid) end
+    local h = ffi.new('vd_model*[1]')
+    vd.call('vd_model_create', p, self.encoder.native, self.decoder.native, h)
+    self.h = ffi.gc(h[0], C.vd_model_destroy)
+    vd.call('vd_model_init_params', self.h, 1234)                      -- library-default init (weight-init.lua is a no-op)
+    -- optimiser state lives in the library; the learning rate is mirrored for train.lua's log line / checkpoints
+    self.optims = {learningRate = params.learningRate}
+    self.runningLoss = 0
+    self.havePrefetched = false
+end
+
+-- batch tables of dataloader.lua:324-339,378-475 -> vd_batch (host pointers; consumed before the call returns)
+function Model:upload(batch)
+    local ques = as_int(batch['ques_fwd']);  local hist = as_int(batch['hist'])
+    local img = as_float(batch['img_feat']); local opts = as_int(batch['options'])
+    local b = ffi.new('vd_batch')
+    b.B = ques:size(1); b.Tq = ques:size(3); b.Th = hist:size(3); b.To = opts:size(opts:dim())
+    b.ques_fwd = ques:data(); b.hist = hist:data(); b.img_feat = img:data(); b.options = opts:data()
+    local ans
+    if batch['answer_ind'] then ans = as_int(batch['answer_ind']); b.answer_ind = ans:data() end
+    vd.call('vd_model_upload_batch', self.h, b)
+end
+
+function Model:loss()
+    local v = ffi.new('float[1]')
+    vd.call('vd_model_loss', self.h, v)
+    return tonumber(v[0])
+end
+
+-- model.lua:66-106, software-pipelined: enqueue the step, upload the NEXT batch while the device runs, read the loss
+function Model:trainIteration(dataloader)
+    if not self.havePrefetched then
+        self:upload(dataloader:getTrainBatch(self.params)); self.havePrefetched = true
+    end
+    vd.call('vd_model_forward_backward', self.h, 0)
+    local lr = ffi.new('double[1]', self.optims.learningRate)
+    vd.call('vd_model_learning_rate', self.h, lr, 1)
+    vd.call('vd_model_update', self.h, 1.0)                            -- clamp(-5,5) + adam + lr decay (model.lua:96-105)
+    vd.call('vd_model_learning_rate', self.h, lr, 0)
+    self.optims.learningRate = tonumber(lr[0])
+    self:upload(dataloader:getTrainBatch(self.params))
+    local curLoss = self:loss()
+    if self.runningLoss > 0 then self.runningLoss = 0.95 * self.runningLoss + 0.05 * curLoss
+    else self.runningLoss = curLoss end
+    return curLoss
+end
+
+-- model.lua:249-342 (disc branch)
+function Model:forwardBackward(batch, onlyForward)
+    self:upload(batch); self.havePrefetched = false
+    vd.call('vd_model_forward_backward', self.h, onlyForward and 1 or 0)
+    return self:loss()
+end
+
+-- model.lua:344-430 + utils.computeRanks (utils.lua:106-128)
+function Model:retrieveBatch(batch)
+    self:upload(batch); self.havePrefetched = false
+    vd.call('vd_model_forward_backward', self.h, 1)
+    local N = batch['ques_fwd']:size(1) * batch['ques_fwd']:size(2)
+    local O = self.params.numOptions or 100
+    local useGt = self.params.useGt and 1 or 0
+    local out = torch.IntTensor(useGt == 1 and N or N * O)
+    vd.call('vd_model_ranks', self.h, useGt, out:data())
+    if useGt == 1 then return out:double():view(-1, self.params.maxQuesCount) end
+    return out:double():view(N, O)
+end
+
+function Model:setMode(training)
+    vd.call('vd_model_set_training', self.h, training and 1 or 0)
+end
+
+-- rank every dialog of a split batch by batch; perRound = number of rank values kept per round (1 or numOptions)
+function Model:rankSplit(dataloader, dtype, useGt)
+    self:setMode(false)
+    self.params.useGt = useGt
+    self.params.numOptions = 100
+    local O, R = self.params.numOptions, self.params.maxQuesCount
+    local total = dataloader.numThreads[dtype]
+    local ranks = useGt and torch.Tensor(total, R) or torch.Tensor(total, R, O)
+    ranks:fill(O + 1)                                                  -- rounds never ranked keep rank 101
+    local first = 1
+    while first <= total do
+        local batch, nxt = dataloader:getTestBatch(first, self.params, dtype)
+        local got = self:retrieveBatch(batch)
+        if useGt then ranks:narrow(1, first, nxt - first):copy(got)
+        else ranks:narrow(1, first, nxt - first):copy(got:view(nxt - first, R, O)) end
+        first = nxt
+    end
+    self:setMode(true)
+    return ranks
+end
+
+-- {image_id, round_id, ranks} records: real image ids, only the rounds a dialog has; lastOnly = test split of
+-- predict (one record per dialog, its last round) -- the EvalAI format
+local function records(dataloader, dtype, ranks, lastOnly)
+    local ids, rounds = dataloader['unique_img_' .. dtype], dataloader[dtype .. '_num_rounds']
+    local tab, out = torch.totable(ranks:double()), {}
+    for i = 1, #ids do
+        local from = lastOnly and rounds[i] or 1
+        for j = from, rounds[i] do
+            out[#out + 1] = {image_id = ids[i], round_id = j, ranks = tab[i][j]}
+        end
+    end
+    return out
+end
+
+-- Model:retrieve (model.lua:142-189): ground-truth ranks + R@k / MRR
+function Model:retrieve(dataloader, dtype)
+    local ranks = self:rankSplit(dataloader, dtype, true)
+    print(string.format('\n%s - Retrieval:', dtype))
+    utils.processRanks(ranks)
+    return records(dataloader, dtype, ranks, false)
+end
+
+-- Model:predict (model.lua:192-246): all 100 ranks per round; the test split keeps the last round only
+function Model:predict(dataloader, dtype)
+    return records(dataloader, dtype, self:rankSplit(dataloader, dtype, false), dtype == 'test')
+end
+
+-- wrapperW:float() / wrapperW:copy(savedModel.modelW) (train.lua:79,99-102,120-121; evaluate.lua:91): the flat
+-- vector in THIS library's layout (embed | encoder tensors | decoder tensors, no padding), tensor by tensor
+function Model:tensors()
+    local out, name = {}, ffi.new('char[64]')
+    local off, rows, cols = ffi.new('int64_t[1]'), ffi.new('int64_t[1]'), ffi.new('int64_t[1]')
+    for i = 0, tonumber(C.vd_model_num_tensors(self.h)) - 1 do
+        vd.call('vd_model_tensor_info', self.h, i, name, off, rows, cols)
+        table.insert(out, {name = ffi.string(name), numel = tonumber(rows[0] * cols[0])})
+    end
+    return out
+end
+
+function Model:getFlatParameters()
+    local ts, total = self:tensors(), 0
+    for _, t in ipairs(ts) do total = total + t.numel end
+    local flat, o = torch.FloatTensor(total), 0
+    for _, t in ipairs(ts) do
+        vd.call('vd_model_get_tensor', self.h, t.name, 0, flat:narrow(1, o + 1, t.numel):data(), t.numel)
+        o = o + t.numel
+    end
+    return flat
+end
+
+function Model:setFlatParameters(flat)
+    flat = flat:float():contiguous()
+    local o = 0
+    for _, t in ipairs(self:tensors()) do
+        vd.call('vd_model_set_tensor', self.h, t.name, flat:narrow(1, o + 1, t.numel):data(), t.numel)
+        o = o + t.numel
+    end
+end
+
+return Model

@@ -39,28 +39,51 @@ def main():
     R = p['maxQuesCount']
     mine = {'ques_fwd': full['ques_fwd'][lo:hi], 'hist': full['hist'][lo:hi], 'img_feat': full['img_feat'][lo:hi],
             'options': full['options'][lo * R:hi * R], 'answer_ind': full['answer_ind'][lo * R:hi * R]}
-    model = Model(p, dist_group=dist.group.WORLD)
-    assert model._dp_active(), "the data-parallel branch must be live (world > 1 or VD_FORCE_ALLREDUCE=1)"
-    model.wrapper.evaluate()                                             # no dropout noise: deterministic comparison
-    model.wrapper.zeroGradParameters()
-    loss = model.forwardBackward(mine)
-    used_async_bucket = model._enc_bucket_work is not None
-    model.update()
-    torch.cuda.synchronize()
-    g_dp = model.wrapperdW.cpu().numpy().copy()     # after update(): summed over ranks, x 1/world, clamped (clamp_adam writes it back)
-    w_dp = model.wrapperW.cpu().numpy().copy()
+    native = os.environ.get('VD_TEST_HOST', 'python') == 'native'
+    flat = lambda d, names: np.concatenate([np.asarray(d[k], np.float32).reshape(-1) for k in names])
+    if native:
+        from visdial_amd.native import NativeModel
+        model = NativeModel(p, dist_group=dist.group.WORLD)
+        names = [t[0] for t in model.tensors]
+        assert model._dp_active()
+        model.training(False)
+        loss = model.forwardBackward(mine)
+        used_async_bucket = False
+        model.update()
+        model.synchronize()
+        g_dp, w_dp = flat(model.get_gradients_dict(), names), flat(model.get_parameters_dict(), names)
+    else:
+        model = Model(p, dist_group=dist.group.WORLD)
+        assert model._dp_active(), "the data-parallel branch must be live (world > 1 or VD_FORCE_ALLREDUCE=1)"
+        model.wrapper.evaluate()                                             # no dropout noise: deterministic comparison
+        model.wrapper.zeroGradParameters()
+        loss = model.forwardBackward(mine)
+        used_async_bucket = model._enc_bucket_work is not None
+        model.update()
+        torch.cuda.synchronize()
+        g_dp = model.wrapperdW.cpu().numpy().copy()     # after update(): summed over ranks, x 1/world, clamped (clamp_adam writes it back)
+        w_dp = model.wrapperW.cpu().numpy().copy()
     losses = [None] * world
     dist.all_gather_object(losses, float(loss))
     if rank == 0:
         pb = derive(small_params(batchSize=per_rank * world, gpuid=0, rank=0))
-        big = Model(pb)
-        big.wrapper.evaluate()
-        big.wrapper.zeroGradParameters()
-        loss_big = big.forwardBackward(full)
-        g_big = big.wrapperdW.cpu().numpy().copy()
-        big.update()
-        torch.cuda.synchronize()
-        w_big = big.wrapperW.cpu().numpy()
+        if native:
+            big = NativeModel(pb)
+            big.training(False)
+            loss_big = big.forwardBackward(full)
+            g_big = flat(big.get_gradients_dict(), names)
+            big.update()
+            big.synchronize()
+            w_big = flat(big.get_parameters_dict(), names)
+        else:
+            big = Model(pb)
+            big.wrapper.evaluate()
+            big.wrapper.zeroGradParameters()
+            loss_big = big.forwardBackward(full)
+            g_big = big.wrapperdW.cpu().numpy().copy()
+            big.update()
+            torch.cuda.synchronize()
+            w_big = big.wrapperW.cpu().numpy()
         assert abs(np.mean(losses) - loss_big) < 1e-5, (losses, loss_big)
         err = np.linalg.norm(g_dp - np.clip(g_big, -5, 5)) / np.linalg.norm(g_big)
         assert err < 1e-5, err
@@ -68,7 +91,8 @@ def main():
         settled = np.abs(g_big) > 1e-6
         assert np.abs(w_dp - w_big)[settled].max() < 1e-6
         assert np.mean(np.abs(w_dp - w_big) < 1e-6) > 0.999
-        print("DP_GPU_OK world=%d backend=%s async_encoder_bucket=%s grad_rel_err=%.2e" % (world, backend, used_async_bucket, err))
+        print("DP_GPU_OK world=%d backend=%s host=%s async_encoder_bucket=%s grad_rel_err=%.2e" % (
+            world, backend, 'native' if native else 'python', used_async_bucket, err))
     dist.barrier()
     dist.destroy_process_group()
 

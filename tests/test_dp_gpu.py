@@ -39,3 +39,15 @@ def test_world1_rccl_forced_allreduce():
 def test_world2_shared_gpu_gloo():
     out = _run(2, 'gloo', {})
     assert 'world=2' in out
+
+
+def test_native_host_world1_rccl_forced_allreduce():
+    """the model-level ABI host (visdial_amd.native): the library hands out wrapperdW + its stream, the collective is
+    torch.distributed's (RCCL), ordered behind the step through an external-stream wrapper"""
+    out = _run(1, 'nccl', dict(VD_FORCE_ALLREDUCE='1', VD_TEST_HOST='native'))
+    assert 'host=native' in out
+
+
+def test_native_host_world2_shared_gpu_gloo():
+    out = _run(2, 'gloo', dict(VD_TEST_HOST='native'))
+    assert 'world=2' in out and 'host=native' in out

@@ -12,9 +12,18 @@ from . import _lib
 call = _lib.call
 
 
+class _DevArray(object):
+    """a raw device pointer as something torch.as_tensor understands (plumbing for torch.distributed only)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '<f4', 'data': (ptr, False), 'version': 2}
+
+
 class NativeModel(object):
-    def __init__(self, params, init_seed=1234):
+    def __init__(self, params, init_seed=1234, dist_group=None):
         p = params
+        self.dist_group = dist_group
+        self._dW = None
         mp = _lib.ModelParams(
             vocabSize=p['vocabSize'], embedSize=p['embedSize'], rnnHiddenSize=p['rnnHiddenSize'],
             imgFeatureSize=p['imgFeatureSize'], imgSpatialSize=p['imgSpatialSize'],
@@ -105,7 +114,27 @@ class NativeModel(object):
         call("vd_model_loss", self.h, C.byref(v))
         return float(v.value)
 
+    def _dp_active(self):
+        import os
+        if self.dist_group is None:
+            return False
+        import torch.distributed as dist
+        return dist.get_world_size(self.dist_group) > 1 or os.environ.get('VD_FORCE_ALLREDUCE') == '1'
+
     def update(self, gscale=1.0):
+        """[all-reduce of the flat gradient over the group] -> clamp -> adam -> lr decay.  The collective is the
+        host's: the library hands out the device pointer of wrapperdW and its main stream."""
+        if self._dp_active():
+            import torch
+            from .parallel import reduce_gradients
+            if self._dW is None:
+                ptrs = [C.c_void_p() for _ in range(4)]
+                call("vd_model_flat_pointers", self.h, *[C.byref(x) for x in ptrs])
+                n = int(_lib.load().vd_model_flat_size(self.h))
+                self._dW = torch.as_tensor(_DevArray(ptrs[1].value, n), device='cuda')
+                self._stream = torch.cuda.ExternalStream(_lib.load().vd_model_stream(self.h))
+            with torch.cuda.stream(self._stream):          # ordered behind the step on the library's main stream
+                gscale, _ = reduce_gradients(self._dW, self.dist_group)
         call("vd_model_update", self.h, float(gscale))
 
     def trainIteration(self, dataloader):
