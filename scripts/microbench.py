@@ -53,6 +53,7 @@ def main():
     variants = [("per-step, bwd epilogue batch 1 (<=128 VGPR)", dict(VD_LSTM_BWD_BATCH2=0)),
                 ("per-step launches", dict()),
                 ("per-step, fwd epilogue compiler-scheduled (r1)", dict(VD_LSTM_FWD_EPI_SEQ=1)),
+                ("per-step, fwd K LOOP ONLY (diagnostic, no epilogue)", dict(VD_LSTM_FWD_EPI_SEQ=2)),
                 ("per-step launches (repeat)", dict()),
                 ("per-step, bwd batch 2 (<=168 VGPR)", dict(VD_LSTM_BWD_BATCH2=1)),
                 ("persistent", dict(VD_LSTM_PERSIST_FWD=1, VD_LSTM_PERSIST_BWD=1)),
@@ -60,7 +61,7 @@ def main():
                 ("persistent, stagger 40us", dict(VD_LSTM_PERSIST_FWD=1, VD_LSTM_PERSIST_BWD=1, VD_LSTM_STAGGER_US=40)),
                 ("persistent, 2 WG/CU grid", dict(VD_LSTM_PERSIST_FWD=1, VD_LSTM_PERSIST_BWD=1, VD_LSTM_SEQ_WGS_PER_CU=2))]
     if os.environ.get("MB_SWEEP", "1") == "0":
-        variants = variants[:5]
+        variants = variants[:6]
     for name, knobs in variants:
         ops.tune_clear()
         for k, v in knobs.items():

@@ -92,7 +92,21 @@ struct EpiLstmFwdT {
   }
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int vcol0, int lane, int M,
                                              int /*Nv*/, float* scr) const {
-    if constexpr (SEQ != 0) {
+    if constexpr (SEQ == 2) {
+      // DIAGNOSTIC build (knob VD_LSTM_FWD_EPI_SEQ=2, scripts/microbench.py): no epilogue loads, no gate math, one
+      // 16-byte store per row -- isolates the K loop of the step kernel.  Results are garbage by construction.
+      float4 a0[4];
+      const f32x16 sum = acc[0] + acc[1] + acc[2] + acc[3];   // keeps every MFMA of the K loop live
+      tile_to_rows(sum, scr, lane, a0);
+      const int j0 = (vcol0 >> 7) * 32 + (lane & 7) * 4;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = row0 + p * 8 + (lane >> 3);
+        if (row < M) *reinterpret_cast<float4*>(h_out + (long)row * H + j0) = a0[p];
+      }
+      return;
+    }
+    if constexpr (SEQ == 1) {
       sequential(acc, row0, vcol0, lane, M, scr);
       return;
     }
@@ -893,9 +907,13 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
       if (bf16 && hp)
         rc = launch_gemm<CfgFbf16>(nr, 4 * H, H, 1, SrcRow{hp, H}, SrcRow{WhT, H}, e, rc_.stream[ch]);
       else if (glds && hp) {
-        if (vd_tune_get("VD_LSTM_FWD_EPI_SEQ", 0)) {
+        const int epi = vd_tune_get("VD_LSTM_FWD_EPI_SEQ", 0);
+        if (epi == 1) {
           EpiLstmFwdT<1> e1{e.xproj, e.xld, e.tok_gather, e.tok_mask, e.c_prev, e.gates, e.c_out, e.h_out, e.H};
           rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e1, rc_.stream[ch]);
+        } else if (epi == 2) {
+          EpiLstmFwdT<2> e2{e.xproj, e.xld, e.tok_gather, e.tok_mask, e.c_prev, e.gates, e.c_out, e.h_out, e.H};
+          rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e2, rc_.stream[ch]);
         } else {
           rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e, rc_.stream[ch]);
         }
