@@ -145,7 +145,11 @@ void gemm(int M, int N, int K, const float* A, long rsa, long csa, const float* 
   const int use = (int)std::min<long>(nth, (long)tm * tn);
 #pragma omp parallel num_threads(use)
   {
-    std::vector<float> Ap((size_t)MC * KC), Bp((size_t)NC * KC);
+    // packing buffers live for the life of the thread (a fresh 600 KB vector per thread per call is an mmap + page
+    // faults every time: it dominated the step on a 128-core host)
+    static thread_local std::vector<float> Ap, Bp;
+    if (Ap.size() < (size_t)MC * KC) Ap.resize((size_t)MC * KC);
+    if (Bp.size() < (size_t)NC * KC) Bp.resize((size_t)NC * KC);
 #pragma omp for collapse(2) schedule(dynamic, 1)
     for (int im = 0; im < tm; ++im)
       for (int in = 0; in < tn; ++in) {
@@ -199,7 +203,8 @@ inline float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 // column sums: out[j] += sum_i X[i][j]
 void colsum_acc(const float* X, long M, int N, float* out) {
   const int nth = omp_get_max_threads();
-  std::vector<double> part((size_t)nth * N, 0.0);
+  static std::vector<double> part;
+  part.assign((size_t)nth * N, 0.0);
 #pragma omp parallel
   {
     double* p = part.data() + (size_t)omp_get_thread_num() * N;
@@ -228,9 +233,14 @@ void lstm_forward(const float* x, const float* W, const float* b, const int32_t*
                   LstmState& S) {
   S.T = T; S.N = N; S.D = D; S.H = H;
   const long NH = (long)N * H;
-  S.gates.assign((size_t)T * N * 4 * H, 0.f);
-  S.h.assign((size_t)T * NH, 0.f);
-  S.c.assign((size_t)T * NH, 0.f);
+  auto pzero = [](std::vector<float>& v, size_t n) {   // zero fill on all cores (steady state: no reallocation)
+    if (v.size() != n) v.resize(n);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; ++i) v[i] = 0.f;
+  };
+  pzero(S.gates, (size_t)T * N * 4 * H);
+  pzero(S.h, (size_t)T * NH);
+  pzero(S.c, (size_t)T * NH);
   const float *Wx = W, *Wh = W + (long)D * 4 * H;
   std::vector<float> a((size_t)N * 4 * H);
   for (int t = 0; t < T; ++t) {
