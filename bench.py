@@ -29,11 +29,14 @@ FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2
 STEP_GFLOP_PER_ROUND = 21.934          # nominal dense math of the reference graph per QA round
 
 
-def headline_params(rank=0, batch=20):
+def headline_params(rank=0, batch=20, config=3):
+    """config 3 = BASELINE.json configs[3] (the headline: 14x14x512 pool5 map, fp32); config 4 = configs[4]
+    (ResNet-200 7x7x2048 features, bf16 operands for the option recurrence; informative, never the default)"""
     from visdial_amd.opts import default_params
-    return default_params(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=512, imgSpatialSize=14,
-                          batchSize=batch, vocabSize=11322, gpuid=int(os.environ.get('LOCAL_RANK', 0)), rank=rank,
-                          maxHistoryLenPerRound=40)
+    kw = dict(imgFeatureSize=512, imgSpatialSize=14) if config == 3 else dict(imgFeatureSize=2048, imgSpatialSize=7,
+                                                                              lstmPrecision='bf16')
+    return default_params(encoder='mn-att-ques-im-hist', decoder='disc', batchSize=batch, vocabSize=11322,
+                          gpuid=int(os.environ.get('LOCAL_RANK', 0)), rank=rank, maxHistoryLenPerRound=40, **kw)
 
 
 def cpu_baseline(seconds_budget=30.0, batch=20):
@@ -89,6 +92,8 @@ def main():
     ap.add_argument('--batch', type=int, default=20, help='dialogs per GPU (headline: 20)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--same-batch', action='store_true', help='reuse one resident batch (round-1 behaviour; A/B only)')
+    ap.add_argument('--config', type=int, choices=[3, 4], default=3,
+                    help='BASELINE.json configs index: 3 = headline (fp32, 14x14x512); 4 = 7x7x2048 features + bf16 option recurrence')
     ap.add_argument('--host', choices=['python', 'native'], default=os.environ.get('VD_BENCH_HOST', 'native'),
                     help='native (default) = the model-level ABI (csrc/runtime.hip: the orchestration a Lua host gets); '
                          'python = visdial_amd.Model composing the operator-level ABI')
@@ -118,7 +123,7 @@ def main():
     from visdial_amd.dataloader import SyntheticDataloader
     from visdial_amd.model import Model
 
-    p = headline_params(rank=rank, batch=args.batch)
+    p = headline_params(rank=rank, batch=args.batch, config=args.config)
     if args.host == 'native':
         from visdial_amd.native import NativeModel
         model = NativeModel(p, dist_group=group)
@@ -186,7 +191,17 @@ def main():
             except Exception:
                 traffic = None
         roof = None
-        if dom:
+        if dom and args.config == 4:
+            # bf16 operands make the matrix work 16x cheaper: the recurrence is priced by its bytes
+            alg = {'opt_lstm_fwd': 19 * 496e6 + 410e6, 'opt_lstm_bwd': 19 * 660e6 + 250e6, 'opt_lstm_dWh': 3.9e9}[dom]
+            gbs = alg / (fams[dom]['avg_launch_ms'] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(gbs / 8000.0, 4), "traffic": None, "avg_launch_ms": round(fams[dom]['avg_launch_ms'], 4),
+                    "note": "bf16 operands / fp32 accumulation in the option recurrence: bound by HBM bytes (fp32 gates, h, c, "
+                            "table gather), algorithmic bytes per direction / HIP-event time; MFMA side: %.0f TFLOP/s of the "
+                            "2 500 TFLOP/s dense bf16 peak" % fams[dom]['tflops_executed'],
+                    "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
+        elif dom:
             a = fams[dom]['tflops_executed']
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(a, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(a / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -206,11 +221,13 @@ def main():
             "ms_per_step_median": round(float(np.median(ps)), 3), "ms_per_step_p10_p90": [round(float(np.percentile(ps, 10)), 3),
                                                                                             round(float(np.percentile(ps, 90)), 3)],
             "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.config == 3 else "bf16 operands / f32 accumulate (option recurrence only), f32 elsewhere",
             "data": "synthetic" + (" (one resident batch reused)" if args.same_batch else
                                    " (a fresh batch every step: host generation + length sort + H2D upload inside the timed region, overlapped)"),
             "config": {"workload": "mn-att-ques-im-hist + disc, B=%d dialogs/GPU x 10 rounds x 100 options, "
-                                   "14x14x512 pool5 map, V=11322, E=300, H=512 (BASELINE.json configs[3])" % args.batch,
+                                   "%s, V=11322, E=300, H=512 (BASELINE.json configs[%d])"
+                                   % (args.batch, "14x14x512 pool5 map" if args.config == 3 else "7x7x2048 ResNet-200 map", args.config),
                        "global_batch_dialogs": world * args.batch, "parallelism": "dp%d" % world,
                        "dropout": "on (device generator)", "loss": round(float(loss), 5), "host": args.host},
             "roofline": roof,

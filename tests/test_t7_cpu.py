@@ -68,3 +68,47 @@ def test_flat_vector_mapping():
     back = t7.flat_to_named(flat, spec.entries)
     for n in named:
         np.testing.assert_array_equal(back[n], named[n])
+
+
+def test_reference_parameter_order_per_encoder_family():
+    """getParameters() order of a reference checkpoint: lf-* = declaration order; hre-* puts the
+    image Linear BEFORE the history LSTMs (concat = wordBranch, imageBranch, histBranch: hre-ques-im-hist.lua:56-60);
+    nngraph encoders (mn-*, lf-att) are refused because their order cannot be derived."""
+    import pytest
+    from visdial_amd import encoders, decoders
+    from visdial_amd.opts import default_params
+
+    def spec_for(enc, dec):
+        p = default_params(encoder=enc, decoder=dec, vocabSize=20, embedSize=8, rnnHiddenSize=32, imgFeatureSize=12,
+                           imgEmbedSize=8, imgSpatialSize=2, commonEmbeddingSize=16)
+        spec = ParamSpec()
+        spec.embed('embed', p['vocabSize'] + 1, p['embedSize'])
+        encoders.load(enc).declare(p, spec)
+        decoders.load(dec).declare(p, spec)
+        return spec.entries
+
+    names = lambda entries: [e[0] for e in entries]
+    e = spec_for('lf-ques-im-hist', 'gen')
+    assert names(t7.reference_order('lf-ques-im-hist', e)) == names(e)
+    assert names(e)[:3] == ['embed', 'ques1.W', 'ques1.b'] and 'fuse.W' in names(e)
+    for enc in ('hre-ques-im-hist', 'hrea-ques-im-hist'):
+        e = spec_for(enc, 'disc')
+        ref = names(t7.reference_order(enc, e))
+        assert ref[:3] == ['embed', 'img_embed.W', 'img_embed.b'] and ref[3] == 'hist1.W'
+        assert sorted(ref) == sorted(names(e)) and ref.index('ques1.W') > ref.index('hist2.b')
+        # a flat vector written in reference order comes back tensor by tensor
+        named = {n: np.random.RandomState(len(n)).randn(*s).astype(np.float32) for n, s, _ in e}
+        flat = t7.named_to_flat(named, e, enc)
+        back = t7.flat_to_named(flat, e, enc)
+        for n in named:
+            np.testing.assert_array_equal(back[n], named[n])
+        # ... and differs from declaration order exactly where the image Linear moved
+        assert not np.array_equal(flat, t7.named_to_flat(named, e))
+    e = spec_for('hre-ques-hist', 'disc')
+    assert names(t7.reference_order('hre-ques-hist', e)) == names(e)
+    for enc in ('mn-att-ques-im-hist', 'mn-ques-hist', 'lf-att-ques-im-hist'):
+        e = spec_for(enc, 'disc')
+        flat = np.zeros(sum(int(np.prod(s)) for _, s, _ in e), np.float32)
+        with pytest.raises(ValueError):
+            t7.flat_to_named(flat, e, enc)
+        t7.flat_to_named(flat, e, enc, allow_unverified=True)
