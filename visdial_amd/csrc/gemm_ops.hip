@@ -101,9 +101,11 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
   // the 1.33-round tail, not the pipeline, decided).
   const int cfg = vd_tune_get("VD_TN_CFG", 20);
   const bool kmaj = cfg == 20 && !(flags & VD_FLAG_BF16) && M % 128 == 0 && N % 128 == 0 && K % 16 == 0 && K >= 4096;
-  const int target = vd_tune_get("VD_TN_BLOCKS", kmaj ? 768 : 1024);
+  // split-K target: one full round of workgroups for the big k-major shape; the register-staged shapes (encoder weight
+  // gradients, K <= 11 323) take fewer, longer slices -- every slice ends in 64 KB of float atomics per tile
+  const int target = kmaj ? vd_tune_get("VD_TN_BLOCKS", 768) : vd_tune_get("VD_TN_BLOCKS_SMALL", 768);
   long splits = vd_cdiv(target, tiles);
-  const long max_splits = vd_cdiv(K, 4 * CfgBig::BK);
+  const long max_splits = vd_cdiv(K, vd_tune_get("VD_TN_MIN_KCHUNK", 1024));   // (sweep in the full step: 26.03 -> 25.70 ms vs 1024 blocks / 64-row slices)
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   if (flags & VD_FLAG_BF16)   // opt-in reduced precision: bf16 operands, fp32 accumulation
