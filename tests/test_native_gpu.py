@@ -101,3 +101,41 @@ def test_native_refuses_other_pairs(gpu):
     from visdial_amd.native import NativeModel
     with pytest.raises(_lib.VisdialHipError):
         NativeModel(derive(small_params(encoder='lf-ques', decoder='gen')))
+
+
+def test_native_full_size_step_matches_cpp_restatement(gpu):
+    """The bench's own path at the bench's own size: BASELINE.json configs[3] (20 dialogs x 10 rounds x 100 options,
+    14x14x512, V = 11322, H = 512), dropout on with pinned masks, through the MODEL-LEVEL ABI, against
+    oracle/cpu_step.cpp (fp32 on the host cores).  Bounds as in test_full_size_step_matches_cpp_restatement."""
+    from oracle import cpu_step
+    from visdial_amd.native import NativeModel
+    from visdial_amd.opts import default_params
+    p = default_params(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=512, imgSpatialSize=14,
+                       batchSize=20, vocabSize=11322, gpuid=0, maxHistoryLenPerRound=40)
+    batch = SyntheticDataloader(p, seed=4321, fast=True).getTrainBatch(p)
+    model = NativeModel(p, init_seed=99)
+    masks = make_masks(p, batch, np.random.RandomState(6))
+    model.set_dropout_masks(masks)
+    P0 = model.get_parameters_dict()
+    loss = model.forwardBackward(batch)
+    g = model.get_gradients_dict()
+    N, O = batch['options'].shape[0], batch['options'].shape[1]
+    scores = model.scores(N, O)
+    cs = cpu_step.CpuStep(p, vo.param_spec(p['encoder'], p['decoder'], p), P0)
+    ref_loss, ref_scores = cs.step(batch, masks, want_scores=True)
+    G = cs.named(cs.G)
+    assert abs(loss - ref_loss) < 1e-4, (loss, ref_loss)
+    assert rel(scores, ref_scores) < 1e-4
+    bad = [(rel(g[k], G[k]), k) for k in G if rel(g[k], G[k]) >= 5e-4 and np.abs(g[k] - G[k]).max() >= 1e-6]
+    assert not bad, bad
+    gt = batch['answer_ind'].reshape(-1) - 1
+    assert (vo.compute_ranks(scores, gt) == vo.compute_ranks(ref_scores, gt)).mean() >= 0.99
+    # one Adam step on both sides, then the parameters
+    model.update()
+    cs.step(batch, masks, update=True, lr=p['learningRate'])
+    W1, W2 = model.get_parameters_dict(), cs.named(cs.W)
+    settled = {k: np.abs(G[k]) > 1e-6 for k in G}          # Adam's first step is ~lr*sign(g): skip entries at the noise floor
+    for k in W1:
+        d = np.abs(W1[k].reshape(-1) - W2[k].reshape(-1))[settled[k].reshape(-1)]
+        assert d.size == 0 or d.max() < 2e-6, (k, float(d.max()))
+    model.close()

@@ -70,6 +70,13 @@ struct BatchSlot {
   std::map<std::string, DevBuf> pinned; // per-slot pinned staging
 };
 
+struct EncState {  // what the encoder backward needs from the forward of the same step
+  uint8_t *m_q = nullptr, *m_h = nullptr, *m_hatt = nullptr, *m1 = nullptr, *m_u = nullptr;
+  std::vector<uint8_t*> m2;
+  float *xs_q = nullptr, *xs_h = nullptr;
+  float sc = 1.f;
+};
+
 }  // namespace
 
 struct vd_model {
@@ -96,6 +103,7 @@ struct vd_model {
   int causal_B = 0;
   // saved by forward for backward
   int N = 0, NO = 0;
+  EncState enc;
 };
 
 namespace {
@@ -313,13 +321,6 @@ int text_branch_prepare(vd_model* m, const Dims& d, const SeqSort& ss, const cha
   *xs_out = xs;
   return VD_OK;
 }
-
-struct EncState {  // what backward needs from forward
-  uint8_t *m_q = nullptr, *m_h = nullptr, *m_hatt = nullptr, *m1 = nullptr, *m_u = nullptr;
-  std::vector<uint8_t*> m2;
-  float *xs_q = nullptr, *xs_h = nullptr;
-  float sc = 1.f;
-};
 
 int lstm2_desc_fwd(vd_model* m, const Dims& d, const SeqSort& ss, const char* l, vd_lstm2_fwd_t* o) {
   const std::string p(l);
@@ -566,8 +567,6 @@ int encoder_backward(vd_model* m, BatchSlot& b, EncState& st, const float* grad_
 }
 
 }  // namespace
-
-static thread_local EncState g_enc_state;  // state of the last forward on this host thread (one model per thread)
 
 extern "C" {
 
@@ -845,7 +844,7 @@ int vd_model_forward_backward(vd_model* m, int only_forward) {
   VD_TRY(vd_lstm_forward(table, 0, 4L * H, b.options, nullptr, Wopt + (long)E * 4 * H, nullptr, nullptr, gates, h, c, To, NO, H, flags, s));
   VD_HIP(hipEventRecord(m->ev_prof[1], s));
   float* enc_out = nullptr;
-  VD_TRY(encoder_forward(m, b, g_enc_state, &enc_out, se));
+  VD_TRY(encoder_forward(m, b, m->enc, &enc_out, se));
   VD_TRY(join_stream(m, se, s));
   // ---- criterion (+ nn.MM backward) in one kernel (model.lua:330-335)
   const float* optH = h + (long)(To - 1) * NO * H;
@@ -882,7 +881,7 @@ int vd_model_forward_backward(vd_model* m, int only_forward) {
   VD_HIP(hipEventRecord(m->ev_prof[2], s));
   VD_TRY(vd_lstm_backward(Wopt + (long)E * 4 * H, gates, c, nullptr, nullptr, d_optH, nullptr, dc, nullptr, nullptr, nullptr, To, NO, H, flags, s));
   VD_HIP(hipEventRecord(m->ev_prof[3], s));
-  VD_TRY(encoder_backward(m, b, g_enc_state, d_enc, se));
+  VD_TRY(encoder_backward(m, b, m->enc, d_enc, se));
   // table gradient + its consumers beside the dWh contraction
   VD_TRY(fork_stream(m, s, st));
   VD_TRY(vd_segment_rowsum_acc(gates, 4L * H, b.options, perm, (long)To * NO, 4 * H, dtab, 4L * H, st));
