@@ -382,15 +382,20 @@ def test_beam_search_matches_oracle(gpu, enc):
     assert all(a['answer'].startswith(' <START>') for a in smp[0]['dialog'])
 
 
-def test_full_size_step_is_additive_over_dialogs(gpu):
-    """BASELINE.json configs[3] sizes (20 dialogs x 10 rounds x 100 options, 14x14x512, V=11322, H=512):
+@pytest.mark.parametrize("config", [3, 4])
+def test_full_size_step_is_additive_over_dialogs(gpu, config):
+    """BASELINE.json configs[3] sizes (20 dialogs x 10 rounds x 100 options, 14x14x512, V=11322, H=512) and configs[4]
+    (7x7x2048 ResNet-200 features, bf16 operands in the option recurrence -- operand rounding is per element, so the
+    identity below holds for it as well):
     the oracle is too slow there, so the step is checked through a size-independent property -- dialogs are
     independent, hence loss and every gradient of the 20-dialog batch equal the mean over its two 10-dialog
     halves (the identity data parallelism relies on).  Exercises the throughput kernels at full shapes."""
     from visdial_amd.model import Model
     from visdial_amd.opts import default_params
-    p = default_params(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=512, imgSpatialSize=14,
-                       batchSize=20, vocabSize=11322, gpuid=0, maxHistoryLenPerRound=40)
+    kw = dict(imgFeatureSize=512, imgSpatialSize=14) if config == 3 else dict(imgFeatureSize=2048, imgSpatialSize=7,
+                                                                              lstmPrecision='bf16')
+    p = default_params(encoder='mn-att-ques-im-hist', decoder='disc', batchSize=20, vocabSize=11322, gpuid=0,
+                       maxHistoryLenPerRound=40, **kw)
     dl = SyntheticDataloader(p, seed=77)
     full = dl.getTrainBatch(p)
     R, O = p['maxQuesCount'], p['numOptions']

@@ -139,3 +139,36 @@ def test_native_full_size_step_matches_cpp_restatement(gpu):
         d = np.abs(W1[k].reshape(-1) - W2[k].reshape(-1))[settled[k].reshape(-1)]
         assert d.size == 0 or d.max() < 2e-6, (k, float(d.max()))
     model.close()
+
+
+@pytest.mark.parametrize("train_mode", [False, True])
+def test_native_ragged_empty_and_max_length_inputs(gpu, train_mode):
+    """edge cases of the batch contract through the model-level ABI (its own host-side length sort and uploads):
+    pad-only questions / history rounds / options, a dialog of empty questions, full-length rows, ties, collisions"""
+    from test_model_gpu import _make_ragged
+    from visdial_amd.native import NativeModel
+    p = derive(small_params(**CASES['odd']))
+    batch = _make_ragged(SyntheticDataloader(p, seed=23).getTrainBatch(p), p, np.random.RandomState(3))
+    model = NativeModel(p, init_seed=8)
+    masks = None
+    if train_mode:
+        masks = make_masks(p, batch, np.random.RandomState(9))
+        model.set_dropout_masks(masks)
+    else:
+        model.training(False)
+    P0 = {k: v.astype(np.float64) for k, v in model.get_parameters_dict().items()}
+    loss = model.forwardBackward(batch)
+    drop = {k: v.astype(np.float64) for k, v in masks.items()} if masks else None
+    ref = vo.forward_backward(p['encoder'], p['decoder'], P0, p, batch, drop)
+    assert np.isfinite(loss) and abs(loss - ref['loss']) < 1e-4
+    g = model.get_gradients_dict()
+    bad = [(rel(g[k], ref['grads'][k]), k) for k in ref['grads']
+           if rel(g[k], ref['grads'][k]) >= 1e-4 and np.abs(g[k] - ref['grads'][k]).max() >= 1e-6]
+    assert not bad, bad
+    N, O = batch['options'].shape[0], batch['options'].shape[1]
+    dev = model.scores(N, O)
+    assert rel(dev, ref['scores']) < 1e-4
+    ranks = model.retrieveBatch(batch, useGt=False) if not train_mode else None
+    if ranks is not None:        # ties (identical options) resolve like utils.computeRanks: lower index first
+        np.testing.assert_array_equal(ranks, vo.compute_ranks(model.scores(N, O)))
+    model.close()
