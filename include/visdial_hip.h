@@ -223,12 +223,14 @@ int vd_clamp_adam(float* w, float* g, float* m, float* v, int64_t n, float gscal
                   float beta2, float eps, float step, void* stream);
 
 /* ======================================================================================================
- * Model-level entry points (csrc/runtime.hip): the whole training step of the headline pair behind the ABI.
- * A LuaJIT host's model.lua needs only these: stream fork/join, the skewed two-layer wavefront,
- * the length sort, workspaces and launch order live in the library.  Covered pair: encoder 'mn-att-ques-im-hist'
- * (encoders/mn-att-ques-im-hist.lua:5-115) + decoder 'disc' (decoders/disc.lua:3-38); vd_model_create refuses others
- * (they run through the operator-level entry points above).  One host thread per model; calls enqueue on
- * library-owned streams and block only where a host value is returned (loss, scores, ranks, tensors).
+ * Model-level entry points (csrc/runtime.hip): the whole training / retrieval step behind the ABI, for every plug-in
+ * pair of the reference: encoders lf-ques, lf-ques-im, lf-ques-hist, lf-ques-im-hist, lf-att-ques-im-hist,
+ * hre-ques-hist, hre-ques-im-hist, hrea-ques-im-hist, mn-ques-hist, mn-ques-im-hist, mn-att-ques-im-hist
+ * (encoders/<name>.lua) x decoders disc, gen (decoders/<name>.lua).  A LuaJIT host's model.lua needs only these
+ * (INTEGRATION.md): stream fork/join, the skewed two-layer wavefront, the length sort, workspaces, forwardConnect /
+ * backwardConnect and launch order live in the library.  One host thread per model; calls enqueue on library-owned
+ * streams and block only where a host value is returned (loss, scores, ranks, tensors).  Sampling / beam search
+ * (Model:generateAnswers, model.lua:432-613) is host-driven over the operator-level entry points.
  * ====================================================================================================== */
 typedef struct vd_model vd_model;
 typedef struct vd_model_params {   /* the `params` keys Model() consumes: opts.lua:15-40, train.lua:55-59 */
@@ -238,14 +240,23 @@ typedef struct vd_model_params {   /* the `params` keys Model() consumes: opts.l
   uint64_t seed;                                 /* dropout noise stream */
   int32_t lstmBf16;                              /* opt-in bf16 operands of the option recurrence (configs[4]) */
   int32_t useStreams;                            /* 0 = everything on one stream (debug) */
+  int32_t numLayers;                             /* -numLayers (opts.lua:27): lf-*, hre-* encoders and the gen decoder; <1 = 2 */
+  int32_t imgEmbedSize;                          /* -imgEmbedSize (opts.lua:24): hre-ques-im-hist, hrea-ques-im-hist */
+  float dropout;                                 /* -dropout (opts.lua:29): the fusion Dropout of lf-ques* */
 } vd_model_params;
 typedef struct vd_batch {          /* HOST pointers, dataloader layout (dataloader.lua:324-339, 378-475) */
-  int32_t B, Tq, Th, To;           /* dialogs; trimmed question / history / option lengths */
+  int32_t B, Tq, Th, To;           /* dialogs; trimmed question / history / option lengths (To: columns of options,
+                                      or of option_in / option_out for gen retrieval) */
   const int32_t* ques_fwd;         /* [B*R x Tq] right-aligned, 0 = pad */
-  const int32_t* hist;             /* [B*R x Th] right-aligned */
-  const float* img_feat;           /* [B x S*S x C] */
-  const int32_t* options;          /* [B*R x O x To] left-aligned */
+  const int32_t* hist;             /* [B*R x Th] right-aligned                      (encoders with `hist`) */
+  const float* img_feat;           /* [B x S*S x C] attention encoders, [B x F] otherwise (encoders with `im`) */
+  const int32_t* options;          /* [B*R x O x To] left-aligned                   (decoder disc) */
   const int32_t* answer_ind;       /* [B*R] 1-based, or NULL (test split) */
+  int32_t Ta;                      /* trimmed answer length + 1 */
+  const int32_t* answer_in;        /* [B*R x Ta] <START>+tokens, left-aligned       (decoder gen, training) */
+  const int32_t* answer_out;       /* [B*R x Ta] tokens+<END> */
+  const int32_t* option_in;        /* [B*R x O x To] <START>+tokens                 (decoder gen, retrieval) */
+  const int32_t* option_out;       /* [B*R x O x To] tokens+<END> */
 } vd_batch;
 /* Model:__init (model.lua:10-63): parameter vectors (zeroed), optimiser state, streams */
 int vd_model_create(const vd_model_params* p, const char* encoder, const char* decoder, vd_model** out);
@@ -267,11 +278,15 @@ int vd_model_set_dropout_mask(vd_model* m, const char* site, const uint8_t* host
 int vd_model_upload_batch(vd_model* m, const vd_batch* host_batch);
 /* Model:forwardBackward on the uploaded batch (model.lua:249-342); zeroes the gradients first unless only_forward */
 int vd_model_forward_backward(vd_model* m, int only_forward);
-int vd_model_loss(vd_model* m, float* loss);              /* curLoss of the last forward (waits for it) */
+int vd_model_loss(vd_model* m, float* loss);              /* curLoss of the last forward (waits for it): disc = mean
+                                                             cross-entropy, gen = summed NLL (model.lua:309-311,330) */
+/* Model:retrieveBatch up to the option scores (model.lua:344-425): disc = scores of a forward pass, gen = candidate
+ * log-likelihoods (utils.computeLhood, utils.lua:86-102); read with vd_model_scores / vd_model_ranks */
+int vd_model_retrieve(vd_model* m);
 /* wrapperdW*gscale -> clamp(-5,5) -> adam -> lr decay (model.lua:96-105; optim_updates.lua:62-91) */
 int vd_model_update(vd_model* m, float gscale);
 int vd_model_learning_rate(vd_model* m, double* lr, int set);
-int vd_model_scores(vd_model* m, float* host_scores, int64_t n);        /* [N x O] of the last forward */
+int vd_model_scores(vd_model* m, float* host_scores, int64_t n);        /* [N x O] of the last forward / retrieve */
 int vd_model_ranks(vd_model* m, int use_gt, int32_t* host_ranks);       /* utils.computeRanks (utils.lua:106-128) */
 int vd_model_family_ms(vd_model* m, float* ms3);          /* device ms of option-LSTM fwd, bwd, dWh in the last step */
 int vd_model_synchronize(vd_model* m);

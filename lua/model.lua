@@ -35,7 +35,7 @@ function Model:__init(params)
 
     local p = ffi.new('vd_model_params')
     p.vocabSize = params.vocabSize;           p.embedSize = params.embedSize
-    p.rnnHiddenSize = params.rnnHiddenSize;   p.imgFeatureSize = params.imgFeatureSize
+    p.rnnHiddenSize = params.rnnHiddenSize;   p.imgFeatureSize = params.imgFeatureSize or 0
     p.imgSpatialSize = params.imgSpatialSize or 14
     p.commonEmbeddingSize = params.commonEmbeddingSize or 512
     p.numAttentionLayers = params.numAttentionLayers or 1
@@ -43,6 +43,8 @@ function Model:__init(params)
     p.learningRate = params.learningRate;     p.lrDecayRate = params.lrDecayRate
     p.minLRate = params.minLRate;             p.seed = 1234
     p.lstmBf16 = 0;                           p.useStreams = 1
+    p.numLayers = params.numLayers or 2;      p.imgEmbedSize = params.imgEmbedSize or 300
+    p.dropout = params.dropout or 0.5
     if params.gpuid and params.gpuid >= 0 then vd.call('vd_set_device', params.gpuid) end
     local h = ffi.new('vd_model*[1]')
     vd.call('vd_model_create', p, self.encoder.native, self.decoder.native, h)
@@ -56,13 +58,24 @@ end
 
 -- batch tables of dataloader.lua:324-339,378-475 -> vd_batch (host pointers; consumed before the call returns)
 function Model:upload(batch)
-    local ques = as_int(batch['ques_fwd']);  local hist = as_int(batch['hist'])
-    local img = as_float(batch['img_feat']); local opts = as_int(batch['options'])
+    local keep = {}                                                    -- converted tensors stay alive until the call returns
+    local function ints(t)   local x = as_int(t);   keep[#keep + 1] = x; return x end
+    local function floats(t) local x = as_float(t); keep[#keep + 1] = x; return x end
     local b = ffi.new('vd_batch')
-    b.B = ques:size(1); b.Tq = ques:size(3); b.Th = hist:size(3); b.To = opts:size(opts:dim())
-    b.ques_fwd = ques:data(); b.hist = hist:data(); b.img_feat = img:data(); b.options = opts:data()
-    local ans
-    if batch['answer_ind'] then ans = as_int(batch['answer_ind']); b.answer_ind = ans:data() end
+    local ques = ints(batch['ques_fwd'])
+    b.B = ques:size(1); b.Tq = ques:size(3); b.ques_fwd = ques:data()
+    if batch['hist'] then local x = ints(batch['hist']); b.Th = x:size(3); b.hist = x:data() end
+    if batch['img_feat'] then b.img_feat = floats(batch['img_feat']):data() end
+    if batch['options'] then local x = ints(batch['options']); b.To = x:size(x:dim()); b.options = x:data() end
+    if batch['answer_ind'] then b.answer_ind = ints(batch['answer_ind']):data() end
+    if batch['answer_in'] then                                         -- decoder gen, training (dataloader.lua:330-334)
+        local x = ints(batch['answer_in']); b.Ta = x:size(x:dim()); b.answer_in = x:data()
+        b.answer_out = ints(batch['answer_out']):data()
+    end
+    if batch['option_in'] then                                         -- decoder gen, retrieval (dataloader.lua:437-462)
+        local x = ints(batch['option_in']); b.To = x:size(x:dim()); b.option_in = x:data()
+        b.option_out = ints(batch['option_out']):data()
+    end
     vd.call('vd_model_upload_batch', self.h, b)
 end
 
@@ -90,7 +103,7 @@ function Model:trainIteration(dataloader)
     return curLoss
 end
 
--- model.lua:249-342 (disc branch)
+-- model.lua:249-342 (both decoder branches; forwardConnect / backwardConnect run inside the library)
 function Model:forwardBackward(batch, onlyForward)
     self:upload(batch); self.havePrefetched = false
     vd.call('vd_model_forward_backward', self.h, onlyForward and 1 or 0)
@@ -100,7 +113,7 @@ end
 -- model.lua:344-430 + utils.computeRanks (utils.lua:106-128)
 function Model:retrieveBatch(batch)
     self:upload(batch); self.havePrefetched = false
-    vd.call('vd_model_forward_backward', self.h, 1)
+    vd.call('vd_model_retrieve', self.h)                               -- disc: option scores; gen: candidate log-likelihoods
     local N = batch['ques_fwd']:size(1) * batch['ques_fwd']:size(2)
     local O = self.params.numOptions or 100
     local useGt = self.params.useGt and 1 or 0

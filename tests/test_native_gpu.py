@@ -6,7 +6,7 @@ import torch
 
 from conftest import small_params
 from oracle import visdial_oracle as vo
-from test_model_gpu import CASES, make_masks, rel
+from test_model_gpu import ALL_ENC, CASES, WIDE, fuse_masks, make_masks, rel
 from visdial_amd.dataloader import SyntheticDataloader
 from visdial_amd.opts import derive
 
@@ -96,11 +96,98 @@ def test_native_training_loop_and_ranks(gpu):
     model.close()
 
 
-def test_native_refuses_other_pairs(gpu):
+def test_native_refuses_unknown_plugins(gpu):
     from visdial_amd import _lib
     from visdial_amd.native import NativeModel
     with pytest.raises(_lib.VisdialHipError):
-        NativeModel(derive(small_params(encoder='lf-ques', decoder='gen')))
+        NativeModel(derive(small_params(encoder='lf-ques', decoder='gen')) | {'encoder': 'lf-quesX'})
+    with pytest.raises(_lib.VisdialHipError):
+        NativeModel(derive(small_params(encoder='lf-ques', decoder='gen')) | {'decoder': 'ctc'})
+
+
+@pytest.mark.parametrize("enc,dec", [(e, d) for e in ALL_ENC for d in ('disc', 'gen')
+                                     if (e, d) != ('mn-att-ques-im-hist', 'disc')])     # that pair: tests above
+@pytest.mark.parametrize("case", ['tiny', 'mid'])
+def test_native_all_pairs_match_oracle(gpu, enc, dec, case):
+    """every encoder x decoder plug-in pair through the MODEL-LEVEL ABI (what lua/model.lua calls): loss, every gradient
+    tensor, forward-only mode, one Adam step -- against the fp64 oracle.  tiny: training mode with pinned dropout masks;
+    mid: evaluate mode at H = 512 / 100 options."""
+    from visdial_amd.native import NativeModel
+    kw = dict(WIDE[case])
+    if 'att' in enc:
+        kw.update(imgFeatureSize=32 if case == 'tiny' else 512, imgSpatialSize=3 if case == 'tiny' else 7)
+    p = derive(small_params(encoder=enc, decoder=dec, **kw))
+    batch = SyntheticDataloader(p, seed=21).getTrainBatch(p)
+    model = NativeModel(p, init_seed=17)
+    assert [t[0] for t in model.tensors] == [e[0] for e in vo.param_spec(enc, dec, p)]
+    masks = fuse_masks(p, batch, np.random.RandomState(8)) if case == 'tiny' else None
+    if masks is not None:
+        model.set_dropout_masks(masks)
+    else:
+        model.training(False)
+    P0 = {k: v.astype(np.float64) for k, v in model.get_parameters_dict().items()}
+    loss = model.forwardBackward(batch)
+    drop = {k: v.astype(np.float64) for k, v in masks.items()} if masks else None
+    ref = vo.forward_backward(enc, dec, P0, p, batch, drop)
+    assert abs(loss - ref['loss']) < 1e-4 * max(1.0, abs(ref['loss']))
+    g = model.get_gradients_dict()
+    gnorm = max(np.abs(v).max() for v in ref['grads'].values())
+    bad = [(rel(g[k], ref['grads'][k]), k) for k in ref['grads']
+           if rel(g[k], ref['grads'][k]) >= 1e-4 and np.abs(g[k] - ref['grads'][k]).max() >= 1e-6 * max(1.0, gnorm)]
+    assert not bad, bad
+    # forward-only (Model:evaluate path, model.lua:128): same loss, gradients untouched
+    loss2 = model.forwardBackward(batch, onlyForward=True)
+    assert abs(loss2 - loss) < 1e-5 * max(1.0, abs(loss))
+    g2 = model.get_gradients_dict()
+    assert all(np.array_equal(g[k], g2[k]) for k in g)
+    model.update()
+    after = model.get_parameters_dict()
+    for k in P0:
+        w2, _ = vo.clamp_adam(P0[k].reshape(-1), g[k].astype(np.float64).reshape(-1), {}, p['learningRate'])
+        assert np.abs(after[k].reshape(-1) - w2).max() < 1e-6, k
+    model.close()
+
+
+@pytest.mark.parametrize("enc", ['lf-ques', 'lf-ques-im-hist', 'mn-att-ques-im-hist', 'hre-ques-im-hist', 'hrea-ques-im-hist'])
+def test_native_gen_retrieval_matches_oracle(gpu, enc):
+    """gen-decoder candidate ranking (model.lua:392-420, utils.computeLhood) through vd_model_retrieve / vd_model_ranks"""
+    from visdial_amd.native import NativeModel
+    kw = dict(imgNorm=1, dropout=0.5, numOptions=12, batchSize=2)
+    if 'att' in enc:
+        kw.update(imgFeatureSize=32, imgSpatialSize=3)
+    p = derive(small_params(encoder=enc, decoder='gen', **kw))
+    batch, _ = SyntheticDataloader(p, seed=31, num_threads=4).getTestBatch(1, p, 'val')
+    batch['option_in'][0, 0, 1, 1:] = 0           # an EMPTY candidate scores log-likelihood 0
+    batch['option_out'][0, 0, 1, :] = 0
+    if batch['answer_ind'][0] == 2:
+        batch['answer_ind'][0] = 1
+    model = NativeModel(p, init_seed=3)
+    model.training(False)
+    gt_ranks = model.retrieveBatch(batch, useGt=True)
+    N, O = batch['option_in'].shape[0] * batch['option_in'].shape[1], batch['option_in'].shape[2]
+    dev = model.scores(N, O)
+    assert np.isfinite(dev).all()
+    P = {k: v.astype(np.float64) for k, v in model.get_parameters_dict().items()}
+    ref = vo.retrieve(enc, 'gen', P, p, batch)
+    assert np.abs(dev - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    np.testing.assert_array_equal(gt_ranks, vo.compute_ranks(dev, batch['answer_ind'].reshape(-1) - 1))
+    allr = model.retrieveBatch(batch, useGt=False)
+    np.testing.assert_array_equal(allr, vo.compute_ranks(dev))
+    model.close()
+
+
+@pytest.mark.parametrize("enc,dec", [('lf-ques-im-hist', 'gen'), ('hre-ques-im-hist', 'disc'), ('mn-ques-im-hist', 'gen')])
+def test_native_pairs_train(gpu, enc, dec):
+    """pipelined trainIteration (upload of the next batch overlapped) on a fixed batch: the loss must fall"""
+    from visdial_amd.native import NativeModel
+    p = derive(small_params(encoder=enc, decoder=dec, **WIDE['tiny']))
+    dl = SyntheticDataloader(p, seed=9)
+    fixed = dl.getTrainBatch(p)
+    dl.getTrainBatch = lambda params, **kw: fixed
+    model = NativeModel(p)
+    losses = [model.trainIteration(dl) for _ in range(60)]
+    assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
+    model.close()
 
 
 def test_native_full_size_step_matches_cpp_restatement(gpu):

@@ -33,12 +33,14 @@ class ModelParams(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ('vocabSize', 'embedSize', 'rnnHiddenSize', 'imgFeatureSize', 'imgSpatialSize',
                                          'commonEmbeddingSize', 'numAttentionLayers', 'maxQuesCount', 'numOptions')] + \
                [(k, C.c_float) for k in ('learningRate', 'lrDecayRate', 'minLRate')] + \
-               [('seed', C.c_uint64), ('lstmBf16', C.c_int32), ('useStreams', C.c_int32)]
+               [('seed', C.c_uint64), ('lstmBf16', C.c_int32), ('useStreams', C.c_int32), ('numLayers', C.c_int32),
+                ('imgEmbedSize', C.c_int32), ('dropout', C.c_float)]
 
 
 class Batch(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ('B', 'Tq', 'Th', 'To')] + \
-               [(k, C.c_void_p) for k in ('ques_fwd', 'hist', 'img_feat', 'options', 'answer_ind')]
+               [(k, C.c_void_p) for k in ('ques_fwd', 'hist', 'img_feat', 'options', 'answer_ind')] + [('Ta', C.c_int32)] + \
+               [(k, C.c_void_p) for k in ('answer_in', 'answer_out', 'option_in', 'option_out')]
 
 
 # name -> argtypes  (return type is int unless listed in _RESTYPE)
@@ -110,6 +112,7 @@ PROTOTYPES = {
     "vd_model_upload_batch": [_p, C.POINTER(Batch)],
     "vd_model_forward_backward": [_p, _i],
     "vd_model_loss": [_p, C.POINTER(C.c_float)],
+    "vd_model_retrieve": [_p],
     "vd_model_update": [_p, _f],
     "vd_model_learning_rate": [_p, C.POINTER(C.c_double), _i],
     "vd_model_scores": [_p, _p, _l],

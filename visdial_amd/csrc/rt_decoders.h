@@ -1,0 +1,253 @@
+// Native step runtime, part 3: the decoder plug-ins (reference decoders/disc.lua, decoders/gen.lua) and the two
+// branches of Model:forwardBackward / Model:retrieveBatch they select (model.lua:306-338, 344-430).  Mirrors
+// visdial_amd/decoders/disc.py, gen.py and visdial_amd/model.py.  Included by runtime.hip only.
+#pragma once
+#include "rt_encoders.h"
+
+namespace vdrt {
+
+struct Decoder {
+  virtual ~Decoder() {}
+  virtual void declare(vd_model* m) = 0;
+  // Model:forwardBackward on slot b: encoder + decoder forward, criterion, and (unless only_forward) both backwards
+  virtual int forward_backward(vd_model* m, BatchSlot& b, bool only_forward) = 0;
+  // Model:retrieveBatch up to the scores: leaves [N x O] option scores in m->scores
+  virtual int retrieve(vd_model* m, BatchSlot& b) = 0;
+};
+
+inline int stage_loss(vd_model* m, const float* loss_rows, long n, bool is_sum, hipStream_t s) {
+  if (m->loss_cap < n) {
+    if (m->loss_host) VD_HIP(hipHostFree(m->loss_host));
+    m->loss_host = nullptr;
+    VD_HIP(hipHostMalloc((void**)&m->loss_host, (size_t)n * sizeof(float), hipHostMallocDefault));
+    m->loss_cap = n;
+  }
+  m->loss_n = n;
+  m->loss_is_sum = is_sum;
+  VD_HIP(hipMemcpyAsync(m->loss_host, loss_rows, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
+  VD_HIP(hipEventRecord(m->ev_loss, s));
+  return VD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Discriminative decoder (decoders/disc.lua:3-38): the 100 candidate answers of a round share one embedding and one
+// LSTM; option scores = <last hidden state, encoder output>; criterion = CrossEntropy over the options.
+//   * 100 clones under nn.Concat(2) -> ONE recurrence over N*O rows
+//   * LookupTable + Wx*x + b -> a [V+1 x 4H] table gathered by token id inside the step kernel
+//   * nn.MM + CrossEntropyCriterion (+ their backward) -> vd_score_ce
+// The option LSTM (a handful of big launches) runs on the main stream, the encoder (~200 small ones) beside it.
+// ------------------------------------------------------------------------------------------------------------
+struct Disc : Decoder {
+  void declare(vd_model* m) override { add_lstm(m, "opt", m->p.embedSize, m->p.rnnHiddenSize); }
+  int forward_backward(vd_model* m, BatchSlot& b, bool only_forward) override {
+    VD_CHECK_ARG(b.opt.present, "decoder 'disc' needs batch.options");
+    VD_CHECK_ARG(only_forward || b.has_gt, "training decoder 'disc' needs batch.answer_ind");
+    const int N = b.q.N, O = m->p.numOptions, NO = N * O, To = b.opt.T;
+    const long H = m->p.rnnHiddenSize, E = m->p.embedSize, V = m->p.vocabSize;
+    hipStream_t s = m->s_main;
+    hipStream_t se = side_stream(m, m->s_enc, s);
+    hipStream_t st = side_stream(m, m->s_tab, s);
+    float *table, *gates, *h, *c, *scores, *loss_rows;
+    VD_TRY(ws_get(m, "opt.table", (size_t)(V + 1) * 4 * H, &table));
+    VD_TRY(ws_get(m, "opt.gates", (size_t)To * NO * 4 * H, &gates));
+    VD_TRY(ws_get(m, "opt.h", (size_t)To * NO * H, &h));
+    VD_TRY(ws_get(m, "opt.c", (size_t)To * NO * H, &c));
+    VD_TRY(ws_get(m, "opt.scores", (size_t)N * O, &scores));
+    VD_TRY(ws_get(m, "crit.loss_rows", (size_t)N, &loss_rows));
+    float* Wopt = Wp(m, "opt.W");
+    const int flags = m->p.lstmBf16 ? VD_FLAG_BF16 : 0;
+    VD_TRY(fork_stream(m, s, se));
+    VD_TRY(vd_gemm_nn(Wp(m, "embed"), E, Wopt, 4 * H, Wp(m, "opt.b"), table, 4 * H, (int)V + 1, (int)(4 * H), (int)E, 0, s));
+    VD_HIP(hipEventRecord(m->ev_prof[0], s));
+    VD_TRY(vd_lstm_forward(table, 0, 4 * H, b.opt.tok, nullptr, Wopt + E * 4 * H, nullptr, nullptr, gates, h, c, To, NO, (int)H, flags, s));
+    VD_HIP(hipEventRecord(m->ev_prof[1], s));
+    float* enc_out = nullptr;
+    VD_TRY(m->enc->forward(m, se, b, &enc_out));                                   // model.lua:297
+    VD_TRY(join_stream(m, se, s));
+    // criterion (+ nn.MM backward) in one kernel (model.lua:330-335)
+    const float* optH = h + (long)(To - 1) * NO * H;
+    float *d_optH = nullptr, *d_enc = nullptr;
+    if (!only_forward) {
+      VD_TRY(ws_get(m, "crit.d_optH", (size_t)NO * H, &d_optH));
+      VD_TRY(ws_get(m, "crit.d_enc", (size_t)N * H, &d_enc));
+    }
+    VD_TRY(vd_score_ce(optH, enc_out, b.gt, scores, loss_rows, d_optH, d_enc, N, O, (int)H, 1.0f / N, s));
+    VD_TRY(stage_loss(m, loss_rows, N, false, s));
+    m->scores = scores;
+    m->prof_valid = !only_forward;
+    if (only_forward) return VD_OK;
+    // decoder backward on the main stream, encoder backward beside it (model.lua:335-337)
+    VD_TRY(fork_stream(m, s, se));
+    float *dc, *dtab;
+    int32_t *offset, *work, *perm;
+    VD_TRY(ws_get(m, "opt.dc", (size_t)NO * H, &dc));
+    VD_TRY(ws_get(m, "opt.dtable", (size_t)(V + 1) * 4 * H, &dtab));
+    VD_TRY(ws_get(m, "opt.sort_off", (size_t)V + 2, &offset));
+    VD_TRY(ws_get(m, "opt.sort_work", (size_t)2 * (V + 1), &work));
+    VD_TRY(ws_get(m, "opt.sort_perm", (size_t)To * NO, &perm));
+    VD_TRY(fork_stream(m, s, st));
+    VD_TRY(vd_token_sort(b.opt.tok, (long)To * NO, (int)V + 1, offset, work, perm, st));
+    VD_TRY(vd_memset(dtab, 0, (V + 1) * 4 * H * 4, st));
+    VD_HIP(hipEventRecord(m->ev_prof[2], s));
+    VD_TRY(vd_lstm_backward(Wopt + E * 4 * H, gates, c, nullptr, nullptr, d_optH, nullptr, dc, nullptr, nullptr, nullptr, To, NO, (int)H, flags,
+                            s));
+    VD_HIP(hipEventRecord(m->ev_prof[3], s));
+    VD_TRY(m->enc->backward(m, se, b, d_enc));
+    // table gradient + its consumers beside the dWh contraction
+    VD_TRY(fork_stream(m, s, st));
+    VD_TRY(vd_segment_rowsum_acc(gates, 4 * H, b.opt.tok, perm, (long)To * NO, (int)(4 * H), dtab, 4 * H, st));
+    VD_TRY(vd_colsum_acc(dtab, 4 * H, (int)V + 1, (int)(4 * H), Gp(m, "opt.b"), st));
+    VD_TRY(vd_gemm_tn_acc(Wp(m, "embed"), E, dtab, 4 * H, Gp(m, "opt.W"), 4 * H, (int)E, (int)(4 * H), (int)V + 1, 0, st));
+    VD_HIP(hipEventRecord(m->ev_prof[4], s));
+    if (To > 1)
+      VD_TRY(vd_gemm_tn_acc(h, H, gates + (long)NO * 4 * H, 4 * H, Gp(m, "opt.W") + E * 4 * H, 4 * H, (int)H, (int)(4 * H), (To - 1) * NO, flags,
+                            s));
+    VD_HIP(hipEventRecord(m->ev_prof[5], s));
+    VD_TRY(join_stream(m, se, s));
+    VD_TRY(join_stream(m, st, s));
+    // dEmb += dTable * Wx^T: non-atomic read-modify-write of the SHARED embedding gradient, after every other writer
+    return vd_gemm_nt(dtab, 4 * H, Wopt, 4 * H, nullptr, Gp(m, "embed"), E, (int)V + 1, (int)E, (int)(4 * H), VD_ACT_NONE, 1, s);
+  }
+  int retrieve(vd_model* m, BatchSlot& b) override { return forward_backward(m, b, true); }   // model.lua:421-425
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// Generative decoder (decoders/gen.lua:3-68):
+//   answer_in -> shared embedding -> numLayers x SeqLSTM(maskZero) -> Linear(H, V) -> LogSoftMax,
+//   criterion = sum over non-pad steps of -log p(answer_out)            (model.lua:32-36, 306-324)
+// The encoder's per-layer final (h, c) seed the decoder layers and the encoder output replaces the top layer's initial
+// h (forwardConnect, gen.lua:30-42); backwardConnect hands the gradients w.r.t. those states back (gen.lua:45-60).
+// ------------------------------------------------------------------------------------------------------------
+struct Gen : Decoder {
+  std::vector<SeqLSTM> rnn;
+  long E = 0, H = 0, V = 0, Vp = 0;
+  void declare(vd_model* m) override {
+    E = m->p.embedSize; H = m->p.rnnHiddenSize; V = m->p.vocabSize; Vp = (V + 3) / 4 * 4;
+    rnn.resize(m->p.numLayers);
+    for (int l = 0; l < m->p.numLayers; ++l) {
+      add_lstm(m, "dec" + std::to_string(l + 1), l == 0 ? E : H, H);              // gen.lua:17-22
+      rnn[l].init("dec" + std::to_string(l + 1), l == 0 ? E : H, H);
+    }
+    add_linear(m, "vocab", H, V);                                                   // gen.lua:23
+  }
+  // gen.lua:30-42; `rep` (retrieval) replicates every encoder state row over the chunk's options
+  int forwardConnect(vd_model* m, hipStream_t s, const float* encOut, int seqLen, const int32_t* rep, long rows) {
+    auto put = [&](const float* x, const std::string& key, const float** dst) -> int {
+      if (!rep) {
+        *dst = x;
+        return VD_OK;
+      }
+      float* r;
+      VD_TRY(ws_get(m, key, (size_t)rows * H, &r));
+      VD_TRY(vd_embed_gather(x, rep, nullptr, r, rows, (int)H, 1.f, s));
+      *dst = r;
+      return VD_OK;
+    };
+    std::vector<SeqLSTM>* layers = m->enc->rnnLayers();
+    if (layers) {
+      for (size_t i = 0; i < layers->size(); ++i) {
+        VD_TRY(put((*layers)[i].out_at(seqLen - 1), "ret.h0_" + std::to_string(i), &rnn[i].userPrevOutput));
+        VD_TRY(put((*layers)[i].cell_at(seqLen - 1), "ret.c0_" + std::to_string(i), &rnn[i].userPrevCell));
+      }
+      return put(encOut, "ret.enc", &rnn[layers->size() - 1].userPrevOutput);
+    }
+    return put(encOut, "ret.enc", &rnn.back().userPrevOutput);
+  }
+  // gen.lua:45-60: returns dL/d encOut
+  const float* backwardConnect(vd_model* m) {
+    std::vector<SeqLSTM>* layers = m->enc->rnnLayers();
+    if (layers) {
+      const size_t n = rnn.size();
+      for (size_t i = 0; i < n; ++i) {
+        (*layers)[i].userNextGradCell = rnn[i].userGradPrevCell;
+        if (i != n - 1) (*layers)[i].gradPrevOutput = rnn[i].userGradPrevOutput;
+      }
+      return rnn[layers->size() - 1].userGradPrevOutput;
+    }
+    return rnn.back().userGradPrevOutput;
+  }
+  int forward_backward(vd_model* m, BatchSlot& b, bool only_forward) override {
+    VD_CHECK_ARG(b.ain.present && b.aout.present, "decoder 'gen' needs batch.answer_in / answer_out");
+    hipStream_t s = m->s_main;
+    const int N = b.q.N, Ta = b.ain.T;
+    const long rows = (long)Ta * N;
+    float* encOut;
+    VD_TRY(m->enc->forward(m, s, b, &encOut));                                      // model.lua:297
+    VD_TRY(forwardConnect(m, s, encOut, m->enc->seqLen(b), nullptr, N));            // model.lua:300
+    float *x, *h, *logits, *loss_rows;
+    VD_TRY(ws_get(m, "dec.x", (size_t)rows * E, &x));
+    VD_TRY(ws_get(m, "dec.logits", (size_t)rows * Vp, &logits));
+    VD_TRY(ws_get(m, "dec.loss_rows", (size_t)rows, &loss_rows));
+    VD_TRY(vd_embed_gather(Wp(m, "embed"), b.ain.tok, nullptr, x, rows, (int)E, 1.f, s));
+    VD_TRY(lstm_stack_forward(m, s, rnn, {x}, Ta, N, b.ain.tok, &h));
+    VD_TRY(vd_gemm_nt(h, H, Wp(m, "vocab.W"), H, Wp(m, "vocab.b"), logits, Vp, (int)rows, (int)V, (int)H, VD_ACT_NONE, 0, s));
+    VD_TRY(vd_logsoftmax_nll(logits, Vp, rows, (int)V, b.ain.tok, b.aout.tok, loss_rows, only_forward ? 0 : 1, s));   // model.lua:309-311
+    VD_TRY(stage_loss(m, loss_rows, rows, true, s));
+    m->prof_valid = false;
+    if (only_forward) return VD_OK;
+    float* dh;                                                                      // logits now hold d loss / d logits
+    VD_TRY(ws_get(m, "dec.dh", (size_t)rows * H, &dh));
+    VD_TRY(vd_gemm_tn_acc(logits, Vp, h, H, Gp(m, "vocab.W"), H, (int)V, (int)H, (int)rows, 0, s));
+    VD_TRY(vd_colsum_acc(logits, Vp, (int)rows, (int)V, Gp(m, "vocab.b"), s));
+    VD_TRY(vd_gemm_nn(logits, Vp, Wp(m, "vocab.W"), H, nullptr, dh, H, (int)rows, (int)H, (int)V, 0, s));
+    std::vector<float*> dx;
+    VD_TRY(lstm_stack_backward(m, s, rnn, nullptr, dh, &dx));                       // model.lua:316
+    VD_TRY(vd_embed_scatter_acc(Gp(m, "embed"), b.ain.tok, nullptr, dx[0], rows, (int)E, 1.f, s));
+    const float* gradDecOut = backwardConnect(m);                                   // model.lua:319
+    VD_CHECK_ARG(gradDecOut, "backwardConnect produced no gradient");
+    return m->enc->backward(m, s, b, gradDecOut);                                   // model.lua:322
+  }
+  // Model:retrieveBatch gen branch (model.lua:392-420) + utils.computeLhood (utils.lua:86-102).  The reference loops
+  // over the 100 options; here chunks of options are ONE decoder batch (rows = round x option) seeded by the replicated
+  // encoder state, and the [rows x V] logits only ever exist for one chunk.
+  int retrieve(vd_model* m, BatchSlot& b) override {
+    VD_CHECK_ARG(b.oin.present && b.oout.present, "retrieval with decoder 'gen' needs batch.option_in / option_out");
+    hipStream_t s = m->s_main;
+    const int N = b.q.N, O = m->p.numOptions, T = b.oin.T;
+    float* encOut;
+    VD_TRY(m->enc->forward(m, s, b, &encOut));
+    const int seqLen = m->enc->seqLen(b);
+    float* lhood;
+    VD_TRY(ws_get(m, "ret.lhood", (size_t)N * O, &lhood));
+    const long per_opt = (long)T * N * Vp;
+    const int oc = (int)std::max<long>(1, std::min<long>(O, (1L << 30) / std::max<long>(1, per_opt)));   // <= 4 GiB of logits
+    for (int o0 = 0; o0 < O; o0 += oc) {
+      const int C = std::min(O, o0 + oc) - o0;
+      const long rows = (long)N * C;
+      int32_t *cin, *cout, *idx;
+      VD_TRY(ws_get(m, "ret.cin", (size_t)T * rows, &cin));
+      VD_TRY(ws_get(m, "ret.cout", (size_t)T * rows, &cout));
+      // [T*N x O] int32 -> columns [o0, o0+C): a strided dword copy
+      VD_TRY(vd_copy_2d((float*)cin, C, (const float*)(b.oin.tok + o0), O, (long)T * N, C, s));
+      VD_TRY(vd_copy_2d((float*)cout, C, (const float*)(b.oout.tok + o0), O, (long)T * N, C, s));
+      std::vector<int32_t> hidx(rows);
+      for (long r = 0; r < rows; ++r) hidx[r] = (int32_t)(r / C);
+      VD_TRY(index_array(m, "idx.ret." + std::to_string(rows) + "." + std::to_string(C), hidx, &idx));
+      VD_TRY(forwardConnect(m, s, encOut, seqLen, idx, rows));
+      float *x, *h, *logits, *nll, *acc;
+      VD_TRY(ws_get(m, "ret.x", (size_t)T * rows * E, &x));
+      VD_TRY(ws_get(m, "ret.logits", (size_t)T * rows * Vp, &logits));
+      VD_TRY(ws_get(m, "ret.nll", (size_t)T * rows, &nll));
+      VD_TRY(ws_get(m, "ret.acc", (size_t)rows, &acc));
+      VD_TRY(vd_embed_gather(Wp(m, "embed"), cin, nullptr, x, T * rows, (int)E, 1.f, s));
+      VD_TRY(lstm_stack_forward(m, s, rnn, {x}, T, (int)rows, cin, &h));
+      VD_TRY(vd_gemm_nt(h, H, Wp(m, "vocab.W"), H, Wp(m, "vocab.b"), logits, Vp, (int)(T * rows), (int)V, (int)H, VD_ACT_NONE, 0, s));
+      VD_TRY(vd_logsoftmax_nll(logits, Vp, T * rows, (int)V, cin, cout, nll, 0, s));
+      VD_TRY(vd_memset(acc, 0, rows * 4, s));
+      VD_TRY(vd_colsum_acc(nll, rows, T, (int)rows, acc, s));                       // sum over time (utils.lua:98)
+      VD_TRY(vd_copy_2d(lhood + o0, O, acc, C, N, C, s));
+    }
+    VD_TRY(vd_axpby(lhood, nullptr, lhood, (long)N * O, -1.f, 0.f, s));             // log-likelihood = -NLL
+    m->scores = lhood;
+    m->prof_valid = false;
+    return VD_OK;
+  }
+};
+
+inline std::unique_ptr<Decoder> make_decoder(const std::string& n) {
+  if (n == "disc") return std::unique_ptr<Decoder>(new Disc());
+  if (n == "gen") return std::unique_ptr<Decoder>(new Gen());
+  return nullptr;
+}
+
+}  // namespace vdrt

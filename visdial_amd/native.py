@@ -1,4 +1,4 @@
-"""`NativeModel` -- the training step of the headline pair (mn-att-ques-im-hist + disc) driven entirely through the
+"""`NativeModel` -- the training / retrieval step of any encoder x decoder plug-in pair driven entirely through the
 MODEL-LEVEL C ABI (include/visdial_hip.h, csrc/runtime.hip): the same handful of calls a LuaJIT `model.lua` proxy
 makes.  Python only converts numpy batches to host pointers; streams, the skewed LSTM wavefront,
 the length sort, workspaces and launch order live in the library.  Same method names as visdial_amd.model.Model /
@@ -26,12 +26,14 @@ class NativeModel(object):
         self._dW = None
         mp = _lib.ModelParams(
             vocabSize=p['vocabSize'], embedSize=p['embedSize'], rnnHiddenSize=p['rnnHiddenSize'],
-            imgFeatureSize=p['imgFeatureSize'], imgSpatialSize=p['imgSpatialSize'],
+            imgFeatureSize=p.get('imgFeatureSize', 0), imgSpatialSize=p.get('imgSpatialSize', 1),
             commonEmbeddingSize=p.get('commonEmbeddingSize', 512), numAttentionLayers=int(p.get('numAttentionLayers', 1) or 1),
             maxQuesCount=p['maxQuesCount'], numOptions=p.get('numOptions', 100),
             learningRate=p.get('learningRate', 1e-3), lrDecayRate=p.get('lrDecayRate', 0.9997592083),
             minLRate=p.get('minLRate', 5e-5), seed=int(p.get('seed', 1234)) + 7919 * int(p.get('rank', 0)),
-            lstmBf16=1 if p.get('lstmPrecision', 'fp32') == 'bf16' else 0, useStreams=int(p.get('useStreams', 1)))
+            lstmBf16=1 if p.get('lstmPrecision', 'fp32') == 'bf16' else 0, useStreams=int(p.get('useStreams', 1)),
+            numLayers=int(p.get('numLayers', 2)), imgEmbedSize=int(p.get('imgEmbedSize', 300)),
+            dropout=float(p.get('dropout', 0.5)))
         self.params = p
         h = C.c_void_p()
         call("vd_model_create", C.byref(mp), p['encoder'].encode(), p['decoder'].encode(), C.byref(h))
@@ -93,15 +95,31 @@ class NativeModel(object):
     # ------------------------------------------------------------------ step
     def upload(self, batch):
         i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        keep = []                                   # host buffers stay alive until the call returns
+
+        def ptr(a):
+            keep.append(a)
+            return a.ctypes.data
         q = i32(batch['ques_fwd'].reshape(-1, batch['ques_fwd'].shape[2]))
-        h = i32(batch['hist'].reshape(-1, batch['hist'].shape[2]))
-        o = i32(batch['options'])
-        img = np.ascontiguousarray(batch['img_feat'], dtype=np.float32)
-        ans = i32(batch['answer_ind'].reshape(-1)) if 'answer_ind' in batch else None
-        hb = _lib.Batch(B=batch['ques_fwd'].shape[0], Tq=q.shape[1], Th=h.shape[1], To=o.shape[2], ques_fwd=q.ctypes.data,
-                        hist=h.ctypes.data, img_feat=img.ctypes.data, options=o.ctypes.data,
-                        answer_ind=ans.ctypes.data if ans is not None else None)
+        hb = _lib.Batch(B=batch['ques_fwd'].shape[0], Tq=q.shape[1], ques_fwd=ptr(q))
+        if 'hist' in batch:
+            h = i32(batch['hist'].reshape(-1, batch['hist'].shape[2]))
+            hb.Th, hb.hist = h.shape[1], ptr(h)
+        if 'img_feat' in batch:
+            hb.img_feat = ptr(np.ascontiguousarray(batch['img_feat'], dtype=np.float32))
+        if 'options' in batch:
+            o = i32(batch['options'])
+            hb.To, hb.options = o.shape[-1], ptr(o)
+        if 'answer_ind' in batch:
+            hb.answer_ind = ptr(i32(batch['answer_ind'].reshape(-1)))
+        if 'answer_in' in batch:
+            a = i32(batch['answer_in'])
+            hb.Ta, hb.answer_in, hb.answer_out = a.shape[-1], ptr(a), ptr(i32(batch['answer_out']))
+        if 'option_in' in batch:
+            a = i32(batch['option_in'])
+            hb.To, hb.option_in, hb.option_out = a.shape[-1], ptr(a), ptr(i32(batch['option_out']))
         call("vd_model_upload_batch", self.h, C.byref(hb))      # host buffers are consumed before it returns
+        self._N = batch['ques_fwd'].shape[0] * batch['ques_fwd'].shape[1]
 
     def forwardBackward(self, batch=None, onlyForward=False, deferLoss=False):
         if batch is not None:
@@ -156,9 +174,8 @@ class NativeModel(object):
     def retrieveBatch(self, batch, useGt=True):
         """model.lua:344-430: ground-truth ranks [N] (useGt) or all ranks [N x O]"""
         self.upload(batch)
-        call("vd_model_forward_backward", self.h, 1)
-        N = batch['ques_fwd'].shape[0] * batch['ques_fwd'].shape[1]
-        O = batch['options'].shape[1]
+        call("vd_model_retrieve", self.h)
+        N, O = self._N, int(self.params.get('numOptions', 100))
         out = np.empty(N if useGt else (N, O), np.int32)
         call("vd_model_ranks", self.h, int(useGt), out.ctypes.data)
         return out
