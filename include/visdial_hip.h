@@ -269,6 +269,11 @@ int vd_model_tensor_info(const vd_model* m, int64_t i, char* name64, int64_t* of
 /* device pointers of wrapperW, wrapperdW and the Adam moments (for a host-side RCCL all-reduce of wrapperdW) */
 int vd_model_flat_pointers(vd_model* m, float** W, float** dW, float** adam_m, float** adam_v);
 void* vd_model_stream(vd_model* m);                       /* the main hipStream_t */
+/* data-parallel bucketing (new relative to the single-GPU reference): flat element range [lo, hi) of the
+ * encoder's own tensors, and "make `stream` wait until those gradients of the last forward_backward are final" -- under
+ * a disc decoder that is the end of the encoder backward, well before the option-LSTM backward ends */
+int vd_model_encoder_range(const vd_model* m, int64_t* lo, int64_t* hi);
+int vd_model_wait_encoder_grads(vd_model* m, void* stream);
 int vd_model_init_params(vd_model* m, uint64_t seed);     /* library-default init */
 int vd_model_set_tensor(vd_model* m, const char* name, const float* host, int64_t n);   /* wrapperW:copy(...) */
 int vd_model_get_tensor(vd_model* m, const char* name, int which /*0 W, 1 dW, 2 m, 3 v*/, float* host, int64_t n);

@@ -386,7 +386,9 @@ def test_beam_search_matches_oracle(gpu, enc):
 def test_full_size_step_is_additive_over_dialogs(gpu, config):
     """BASELINE.json configs[3] sizes (20 dialogs x 10 rounds x 100 options, 14x14x512, V=11322, H=512) and configs[4]
     (7x7x2048 ResNet-200 features, bf16 operands in the option recurrence -- operand rounding is per element, so the
-    identity below holds for it as well):
+    identity below holds for it too, but only to ~1e-3: the 10 000-row and 20 000-row recurrences run different tile
+    configurations, their fp32 states differ in the last bit, and a last-bit difference can flip a bf16 rounding of
+    an operand, i.e. a 4e-3 relative change of that element; measured 1.3e-4):
     the oracle is too slow there, so the step is checked through a size-independent property -- dialogs are
     independent, hence loss and every gradient of the 20-dialog batch equal the mean over its two 10-dialog
     halves (the identity data parallelism relies on).  Exercises the throughput kernels at full shapes."""
@@ -414,7 +416,7 @@ def test_full_size_step_is_additive_over_dialogs(gpu, config):
     assert np.isfinite(lf) and abs(lf - 0.5 * (l1 + l2)) < 1e-5 * max(1.0, abs(lf))
     gm = 0.5 * (g1 + g2)
     err = float((gf - gm).norm() / gm.norm())
-    assert err < 1e-4, err
+    assert err < (1e-4 if config == 3 else 1e-3), err
     p['useGt'] = False
     ranks = model.retrieveBatch(part(0, 20))
     assert ranks.shape == (200, 100) and np.all(np.sort(ranks, 1) == np.arange(1, 101)[None, :])

@@ -104,6 +104,8 @@ PROTOTYPES = {
     "vd_model_tensor_info": [_p, _l, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "vd_model_flat_pointers": [_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
     "vd_model_stream": [_p],
+    "vd_model_encoder_range": [_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+    "vd_model_wait_encoder_grads": [_p, _p],
     "vd_model_init_params": [_p, _u64],
     "vd_model_set_tensor": [_p, C.c_char_p, _p, _l],
     "vd_model_get_tensor": [_p, C.c_char_p, _i, _p, _l],

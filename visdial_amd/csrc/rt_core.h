@@ -80,6 +80,8 @@ struct vd_model {
   hipStream_t s_main = nullptr, s_enc = nullptr, s_img = nullptr, s_hist = nullptr, s_tab = nullptr, s_copy = nullptr;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_next = 0;
+  hipEvent_t ev_enc_grads = nullptr;  // recorded behind the encoder backward: its gradient tensors are final
+  bool enc_grads_recorded = false;
   hipEvent_t ev_loss = nullptr, ev_prof[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool training = true, streams = true, prof_valid = false;
   long step = 0;

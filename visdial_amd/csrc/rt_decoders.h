@@ -93,6 +93,8 @@ struct Disc : Decoder {
                             s));
     VD_HIP(hipEventRecord(m->ev_prof[3], s));
     VD_TRY(m->enc->backward(m, se, b, d_enc));
+    VD_HIP(hipEventRecord(m->ev_enc_grads, se));                                    // encoder tensors final (data-parallel bucket 1)
+    m->enc_grads_recorded = true;
     // table gradient + its consumers beside the dWh contraction
     VD_TRY(fork_stream(m, s, st));
     VD_TRY(vd_segment_rowsum_acc(gates, 4 * H, b.opt.tok, perm, (long)To * NO, (int)(4 * H), dtab, 4 * H, st));
@@ -195,7 +197,10 @@ struct Gen : Decoder {
     VD_TRY(vd_embed_scatter_acc(Gp(m, "embed"), b.ain.tok, nullptr, dx[0], rows, (int)E, 1.f, s));
     const float* gradDecOut = backwardConnect(m);                                   // model.lua:319
     VD_CHECK_ARG(gradDecOut, "backwardConnect produced no gradient");
-    return m->enc->backward(m, s, b, gradDecOut);                                   // model.lua:322
+    VD_TRY(m->enc->backward(m, s, b, gradDecOut));                                  // model.lua:322
+    VD_HIP(hipEventRecord(m->ev_enc_grads, s));
+    m->enc_grads_recorded = true;
+    return VD_OK;
   }
   // Model:retrieveBatch gen branch (model.lua:392-420) + utils.computeLhood (utils.lua:86-102).  The reference loops
   // over the 100 options; here chunks of options are ONE decoder batch (rows = round x option) seeded by the replicated

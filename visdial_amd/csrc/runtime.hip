@@ -159,6 +159,7 @@ int vd_model_create(const vd_model_params* p, const char* encoder, const char* d
   for (auto& e : m->ev_pool)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(VD_ERR_HIP);
   if (hipEventCreateWithFlags(&m->ev_loss, hipEventDisableTiming) != hipSuccess) return fail(VD_ERR_HIP);
+  if (hipEventCreateWithFlags(&m->ev_enc_grads, hipEventDisableTiming) != hipSuccess) return fail(VD_ERR_HIP);
   for (auto& e : m->ev_prof)
     if (hipEventCreate(&e) != hipSuccess) return fail(VD_ERR_HIP);
   for (auto& sl : m->slot)
@@ -190,6 +191,7 @@ void vd_model_destroy(vd_model* m) {
   for (auto& e : m->ev_pool)
     if (e) (void)hipEventDestroy(e);
   if (m->ev_loss) (void)hipEventDestroy(m->ev_loss);
+  if (m->ev_enc_grads) (void)hipEventDestroy(m->ev_enc_grads);
   for (auto& e : m->ev_prof)
     if (e) (void)hipEventDestroy(e);
   for (hipStream_t s : {m->s_main, m->s_enc, m->s_img, m->s_hist, m->s_tab, m->s_copy})
@@ -223,6 +225,23 @@ int vd_model_flat_pointers(vd_model* m, float** W, float** dW, float** adam_m, f
 }
 
 void* vd_model_stream(vd_model* m) { return m ? (void*)m->s_main : nullptr; }
+
+// Data-parallel gradient bucketing: the encoder's own tensors occupy the flat element range [lo, hi)
+// (everything between the shared embedding and the decoder's tensors).  Under a `disc` decoder they are final when
+// the encoder backward ends on its side stream, long before the option-LSTM backward does: a host makes its
+// communication stream wait for that point and all-reduces the range underneath the rest of the step.
+int vd_model_encoder_range(const vd_model* m, int64_t* lo, int64_t* hi) {
+  VD_CHECK_ARG(m && lo && hi, "vd_model_encoder_range: null");
+  const char* first_dec = m->dec_name == "disc" ? "opt.W" : "dec1.W";
+  *lo = m->spec[1].off;
+  *hi = m->spec[m->index.at(first_dec)].off;
+  return VD_OK;
+}
+int vd_model_wait_encoder_grads(vd_model* m, void* stream) {
+  VD_CHECK_ARG(m && m->enc_grads_recorded, "vd_model_wait_encoder_grads: no backward pass has been enqueued");
+  VD_HIP(hipStreamWaitEvent((hipStream_t)stream, m->ev_enc_grads, 0));
+  return VD_OK;
+}
 
 // Library-default initialisation (weight-init.lua is a no-op in the reference): SeqLSTM weight ~
 // N(0, 1/sqrt(D+H)), bias 0 with the forget gate at 1; Linear weight and bias ~ U(+-1/sqrt(in)); LookupTable ~ N(0,1)
@@ -358,6 +377,7 @@ int vd_model_upload_batch(vd_model* m, const vd_batch* hb) {
 static int begin_step(vd_model* m, bool zero_grads, BatchSlot** out) {
   VD_CHECK_ARG(m && m->uploaded >= 0, "no batch uploaded");
   m->cur = m->uploaded;
+  m->enc_grads_recorded = false;
   BatchSlot& b = m->slot[m->cur];
   m->N = b.q.N;
   m->O = m->p.numOptions;

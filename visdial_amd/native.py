@@ -141,7 +141,10 @@ class NativeModel(object):
 
     def update(self, gscale=1.0):
         """[all-reduce of the flat gradient over the group] -> clamp -> adam -> lr decay.  The collective is the
-        host's: the library hands out the device pointer of wrapperdW and its main stream."""
+        host's: the library hands out the device pointer of wrapperdW, its main stream, the encoder's flat range and a
+        "encoder gradients are final" wait.  Two buckets: the encoder's tensors start reducing on a
+        communication stream as soon as the encoder backward has ended -- underneath the option-LSTM backward --
+        the shared embedding and the decoder's tensors follow behind the step on the library's main stream."""
         if self._dp_active():
             import torch
             from .parallel import reduce_gradients
@@ -151,8 +154,22 @@ class NativeModel(object):
                 n = int(_lib.load().vd_model_flat_size(self.h))
                 self._dW = torch.as_tensor(_DevArray(ptrs[1].value, n), device='cuda')
                 self._stream = torch.cuda.ExternalStream(_lib.load().vd_model_stream(self.h))
+                self._comm = torch.cuda.Stream()
+                lo, hi = C.c_int64(), C.c_int64()
+                call("vd_model_encoder_range", self.h, C.byref(lo), C.byref(hi))
+                self._enc_range = (int(lo.value), int(hi.value))
+            lo, hi = self._enc_range
+            work = None
+            if hi > lo:
+                call("vd_model_wait_encoder_grads", self.h, C.c_void_p(self._comm.cuda_stream))
+                with torch.cuda.stream(self._comm):
+                    _, work = reduce_gradients(self._dW[lo:hi], self.dist_group, async_op=True)
             with torch.cuda.stream(self._stream):          # ordered behind the step on the library's main stream
-                gscale, _ = reduce_gradients(self._dW, self.dist_group)
+                for sl in (self._dW[:lo], self._dW[hi:]):
+                    gscale, _ = reduce_gradients(sl, self.dist_group)
+                if work is not None:
+                    work.wait()                            # the main stream waits for bucket 1
+                    self._stream.wait_stream(self._comm)
         call("vd_model_update", self.h, float(gscale))
 
     def trainIteration(self, dataloader):
