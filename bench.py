@@ -25,6 +25,24 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _host_arg(argv):
+    for i, a in enumerate(argv):
+        if a == '--host' and i + 1 < len(argv):
+            return argv[i + 1]
+        if a.startswith('--host='):
+            return a.split('=', 1)[1]
+    return 'native'
+
+
+# The native host issues the whole step from one thread onto five library-owned HIP streams.  HIP multiplexes streams
+# onto GPU_MAX_HW_QUEUES hardware queues (default 4); with all of them on ONE queue the cross-stream event waits
+# resolve inside the command processor and the step is 3-4 % faster (profiles/r02_hw_queues.txt).
+# Must be in the environment before HIP initialises, i.e. before torch touches the device; an explicit setting wins.
+# (The Python operator-level host is slower that way -- 29.0 vs 26.8 ms -- so it keeps the default.)
+if _host_arg(sys.argv[1:]) == 'native':
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '1')
+
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 STEP_GFLOP_PER_ROUND = 21.934          # nominal dense math of the reference graph per QA round
 
@@ -92,6 +110,7 @@ def main():
     ap.add_argument('--batch', type=int, default=20, help='dialogs per GPU (headline: 20)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--same-batch', action='store_true', help='reuse one resident batch (round-1 behaviour; A/B only)')
+    ap.add_argument('--no-streams', action='store_true', help='whole step on one HIP stream (A/B only)')
     ap.add_argument('--config', type=int, choices=[3, 4], default=3,
                     help='BASELINE.json configs index: 3 = headline (fp32, 14x14x512); 4 = 7x7x2048 features + bf16 option recurrence')
     ap.add_argument('--host', choices=['python', 'native'], default=os.environ.get('VD_BENCH_HOST', 'native'),
@@ -124,6 +143,8 @@ def main():
     from visdial_amd.model import Model
 
     p = headline_params(rank=rank, batch=args.batch, config=args.config)
+    if args.no_streams:
+        p['useStreams'] = 0
     if args.host == 'native':
         from visdial_amd.native import NativeModel
         model = NativeModel(p, dist_group=group)
@@ -229,7 +250,8 @@ def main():
                                    "%s, V=11322, E=300, H=512 (BASELINE.json configs[%d])"
                                    % (args.batch, "14x14x512 pool5 map" if args.config == 3 else "7x7x2048 ResNet-200 map", args.config),
                        "global_batch_dialogs": world * args.batch, "parallelism": "dp%d" % world,
-                       "dropout": "on (device generator)", "loss": round(float(loss), 5), "host": args.host},
+                       "dropout": "on (device generator)", "loss": round(float(loss), 5), "host": args.host,
+                       "GPU_MAX_HW_QUEUES": os.environ.get('GPU_MAX_HW_QUEUES', 'default')},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

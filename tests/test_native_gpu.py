@@ -259,3 +259,42 @@ def test_native_ragged_empty_and_max_length_inputs(gpu, train_mode):
     if ranks is not None:        # ties (identical options) resolve like utils.computeRanks: lower index first
         np.testing.assert_array_equal(ranks, vo.compute_ranks(model.scores(N, O)))
     model.close()
+
+
+@pytest.mark.parametrize("config", [1, 2])
+def test_native_full_size_other_configs_are_additive_over_dialogs(gpu, config):
+    """BASELINE.json configs[1] (lf-ques-im-hist + gen, fc7 4096-d features, batch 20, concatenated history up to 300
+    steps) and configs[2] (hre-ques-im-hist + disc, batch 20 x 10 rounds x 100 options) at their FULL sizes through the
+    model-level ABI.  The oracle is too slow there, so the step is checked through the size-independent property data
+    parallelism relies on: dialogs are independent, hence loss and every gradient of the 20-dialog batch equal the sum
+    (gen: summed NLL) / the mean (disc: mean cross-entropy) over its two 10-dialog halves."""
+    from visdial_amd.native import NativeModel
+    from visdial_amd.opts import default_params
+    kw = (dict(encoder='lf-ques-im-hist', decoder='gen') if config == 1 else dict(encoder='hre-ques-im-hist', decoder='disc'))
+    p = default_params(imgFeatureSize=4096, batchSize=20, vocabSize=11322, gpuid=0, maxHistoryLenPerRound=40, **kw)
+    full = SyntheticDataloader(p, seed=77, fast=True).getTrainBatch(p)
+    R = p['maxQuesCount']
+    if config == 1:
+        assert full["hist"].shape[2] >= 150           # the concatenated-history recurrence really is long
+
+    def part(lo, hi):
+        out = {}
+        for k, v in full.items():
+            rows = v.shape[0] // 20                   # leading dim is dialogs (B) or rounds (B*R)
+            out[k] = v[lo * rows:hi * rows]
+        return out
+    model = NativeModel(p, init_seed=3)
+    model.training(False)                             # no dropout noise: the three runs must see the same function
+    names = [t[0] for t in model.tensors]
+    out = []
+    for lo, hi in ((0, 20), (0, 10), (10, 20)):
+        loss = model.forwardBackward(part(lo, hi))
+        g = model.get_gradients_dict()
+        out.append((loss, np.concatenate([g[k].reshape(-1) for k in names]).astype(np.float64)))
+    (lf, gf), (l1, g1), (l2, g2) = out
+    w = 1.0 if config == 1 else 0.5
+    assert np.isfinite(lf) and abs(lf - w * (l1 + l2)) < 2e-5 * max(1.0, abs(lf)), (lf, l1, l2)
+    gm = w * (g1 + g2)
+    err = float(np.linalg.norm(gf - gm) / np.linalg.norm(gm))
+    assert err < 1e-4, err
+    model.close()

@@ -57,12 +57,14 @@ struct Disc : Decoder {
     float* Wopt = Wp(m, "opt.W");
     const int flags = m->p.lstmBf16 ? VD_FLAG_BF16 : 0;
     VD_TRY(fork_stream(m, s, se));
+    float* enc_out = nullptr;
+    const bool enc_first = vd_tune_get("VD_RT_ENC_FIRST", 0) != 0;     // host enqueue order (A/B knob)
+    if (enc_first) VD_TRY(m->enc->forward(m, se, b, &enc_out));
     VD_TRY(vd_gemm_nn(Wp(m, "embed"), E, Wopt, 4 * H, Wp(m, "opt.b"), table, 4 * H, (int)V + 1, (int)(4 * H), (int)E, 0, s));
     VD_HIP(hipEventRecord(m->ev_prof[0], s));
     VD_TRY(vd_lstm_forward(table, 0, 4 * H, b.opt.tok, nullptr, Wopt + E * 4 * H, nullptr, nullptr, gates, h, c, To, NO, (int)H, flags, s));
     VD_HIP(hipEventRecord(m->ev_prof[1], s));
-    float* enc_out = nullptr;
-    VD_TRY(m->enc->forward(m, se, b, &enc_out));                                   // model.lua:297
+    if (!enc_first) VD_TRY(m->enc->forward(m, se, b, &enc_out));                   // model.lua:297
     VD_TRY(join_stream(m, se, s));
     // criterion (+ nn.MM backward) in one kernel (model.lua:330-335)
     const float* optH = h + (long)(To - 1) * NO * H;
@@ -92,9 +94,14 @@ struct Disc : Decoder {
     VD_TRY(vd_lstm_backward(Wopt + E * 4 * H, gates, c, nullptr, nullptr, d_optH, nullptr, dc, nullptr, nullptr, nullptr, To, NO, (int)H, flags,
                             s));
     VD_HIP(hipEventRecord(m->ev_prof[3], s));
-    VD_TRY(m->enc->backward(m, se, b, d_enc));
-    VD_HIP(hipEventRecord(m->ev_enc_grads, se));                                    // encoder tensors final (data-parallel bucket 1)
-    m->enc_grads_recorded = true;
+    const bool dwh_first = vd_tune_get("VD_RT_DWH_FIRST", 0) != 0;   // host enqueue order (matters when streams share a hardware queue)
+    auto enc_bwd = [&]() -> int {
+      VD_TRY(m->enc->backward(m, se, b, d_enc));
+      VD_HIP(hipEventRecord(m->ev_enc_grads, se));                                  // encoder tensors final (data-parallel bucket 1)
+      m->enc_grads_recorded = true;
+      return VD_OK;
+    };
+    if (!dwh_first) VD_TRY(enc_bwd());
     // table gradient + its consumers beside the dWh contraction
     VD_TRY(fork_stream(m, s, st));
     VD_TRY(vd_segment_rowsum_acc(gates, 4 * H, b.opt.tok, perm, (long)To * NO, (int)(4 * H), dtab, 4 * H, st));
@@ -105,6 +112,7 @@ struct Disc : Decoder {
       VD_TRY(vd_gemm_tn_acc(h, H, gates + (long)NO * 4 * H, 4 * H, Gp(m, "opt.W") + E * 4 * H, 4 * H, (int)H, (int)(4 * H), (To - 1) * NO, flags,
                             s));
     VD_HIP(hipEventRecord(m->ev_prof[5], s));
+    if (dwh_first) VD_TRY(enc_bwd());
     VD_TRY(join_stream(m, se, s));
     VD_TRY(join_stream(m, st, s));
     // dEmb += dTable * Wx^T: non-atomic read-modify-write of the SHARED embedding gradient, after every other writer

@@ -13,8 +13,8 @@
 //   rt_encoders.h  the 11 encoder plug-ins        rt_decoders.h  disc, gen + the forwardBackward / retrieve branches
 //
 // Streams: main (option LSTM, criterion, decoder, optimiser), enc (encoder chains under a disc decoder), img (per-image
-// projection + masks), hist (history branch of lf-* / hre-*), tab (token sort + table gradient), copy (H2D uploads of
-// the NEXT batch; two batch slots).
+// projection + masks; also the history branch of lf-* / hre-*), tab (token sort + table gradient), copy (H2D uploads
+// of the NEXT batch; two batch slots).
 #include "rt_decoders.h"
 
 using namespace vdrt;
@@ -150,11 +150,20 @@ int vd_model_create(const vd_model_params* p, const char* encoder, const char* d
     }
     (void)hipMemset(*v, 0, off * sizeof(float));
   }
-  int lo = 0, hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // numerically lower = higher priority
-  if (hipStreamCreateWithPriority(&m->s_main, hipStreamNonBlocking, lo) != hipSuccess) return fail(VD_ERR_HIP);
-  for (hipStream_t* s : {&m->s_enc, &m->s_img, &m->s_hist, &m->s_tab, &m->s_copy})
-    if (hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi) != hipSuccess) return fail(VD_ERR_HIP);
+  // throughput work (option LSTM, criterion, optimiser) at the LEAST priority, the latency-bound encoder chains and
+  // uploads at the GREATEST: their small workgroups take free slots ahead of the next big-kernel workgroup
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (hipStreamCreateWithPriority(&m->s_main, hipStreamNonBlocking, least) != hipSuccess) return fail(VD_ERR_HIP);
+  for (hipStream_t* s : {&m->s_enc, &m->s_img, &m->s_tab, &m->s_copy})
+    if (hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest) != hipSuccess) return fail(VD_ERR_HIP);
+  // No encoder uses both side branches, so the history branch of lf-* / hre-* shares the image-branch stream: HIP
+  // multiplexes streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, default 4), and a sixth stream put the
+  // table-gradient stream on the main stream's queue (measured: +0.75 ms per headline step).  Hosts that own the
+  // process should go further and export GPU_MAX_HW_QUEUES=1 before HIP initialises (bench.py does): with every stream
+  // of the step multiplexed onto ONE hardware queue the cross-stream event waits resolve inside the command processor
+  // and the headline step is 0.75-1.0 ms (3-4 %) faster (profiles/r02_hw_queues.txt).
+  m->s_hist = m->s_img;
   m->ev_pool.resize(64);
   for (auto& e : m->ev_pool)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(VD_ERR_HIP);
@@ -194,7 +203,7 @@ void vd_model_destroy(vd_model* m) {
   if (m->ev_enc_grads) (void)hipEventDestroy(m->ev_enc_grads);
   for (auto& e : m->ev_prof)
     if (e) (void)hipEventDestroy(e);
-  for (hipStream_t s : {m->s_main, m->s_enc, m->s_img, m->s_hist, m->s_tab, m->s_copy})
+  for (hipStream_t s : {m->s_main, m->s_enc, m->s_img, m->s_tab, m->s_copy})
     if (s) (void)hipStreamDestroy(s);
   delete m;
 }
@@ -483,7 +492,7 @@ int vd_model_family_ms(vd_model* m, float* ms3) {
 
 int vd_model_synchronize(vd_model* m) {
   VD_CHECK_ARG(m, "vd_model_synchronize: null model");
-  for (hipStream_t s : {m->s_copy, m->s_enc, m->s_img, m->s_hist, m->s_tab, m->s_main}) VD_HIP(hipStreamSynchronize(s));
+  for (hipStream_t s : {m->s_copy, m->s_enc, m->s_img, m->s_tab, m->s_main}) VD_HIP(hipStreamSynchronize(s));
   return VD_OK;
 }
 
