@@ -190,19 +190,22 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * N * args.steps / elapsed
-        # dominant kernel family = the option-LSTM recurrence (fused recurrent GEMM + cell update).  Per direction it
-        # is ONE persistent launch covering all To steps; figures below are per launch and per step-equivalent.
+        # dominant kernel family = the option-LSTM recurrence (fused recurrent GEMM + cell update): To-1 kernel launches
+        # per direction and step (the first step has h0 = 0 and no recurrent product), one launch for dWh.  The HIP
+        # events bracket the whole family on its stream; figures are per KERNEL LAUNCH so they can be compared with
+        # the rocprofv3 average duration of the same kernel (profiles/r02_kernel_stats_bench.txt).
         NO, E, H, To = N * p['numOptions'], p['embedSize'], p['rnnHiddenSize'], p['maxAnsLen']
         fams = {}
-        for tag, nominal, executed, nlaunch in (
-                ('opt_lstm_fwd', 2.0 * NO * (E + H) * 4 * H * To, 2.0 * NO * H * 4 * H * (To - 1), 1),
-                ('opt_lstm_bwd', 2.0 * NO * (E + H) * 4 * H * To, 2.0 * NO * H * 4 * H * (To - 1), 1),
+        for tag, nominal, executed, klaunch in (
+                ('opt_lstm_fwd', 2.0 * NO * (E + H) * 4 * H * To, 2.0 * NO * H * 4 * H * (To - 1), To - 1),
+                ('opt_lstm_bwd', 2.0 * NO * (E + H) * 4 * H * To, 2.0 * NO * H * 4 * H * (To - 1), To - 1),
                 ('opt_lstm_dWh', 2.0 * NO * (To - 1) * H * 4 * H, 2.0 * NO * (To - 1) * H * 4 * H, 1)):
             if tag in prof:
-                ms, n = prof[tag]
-                fams[tag] = dict(ms_total_per_step=ms / args_steps_for_prof, avg_launch_ms=ms / n, launches_per_step=n / args_steps_for_prof,
-                                 gflop_executed_per_launch=executed / 1e9,
-                                 tflops_nominal=nominal / (ms / n) / 1e9, tflops_executed=executed / (ms / n) / 1e9)
+                ms, n = prof[tag]                       # n family invocations (one per step) took ms in total
+                per_family = ms / n
+                fams[tag] = dict(ms_total_per_step=ms / args_steps_for_prof, kernel_launches_per_step=klaunch * n / args_steps_for_prof,
+                                 avg_launch_ms=per_family / klaunch, gflop_executed_per_launch=executed / klaunch / 1e9,
+                                 tflops_nominal=nominal / per_family / 1e9, tflops_executed=executed / per_family / 1e9)
         dom = max(fams, key=lambda k: fams[k]['ms_total_per_step']) if fams else None
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
@@ -215,7 +218,7 @@ def main():
         if dom and args.config == 4:
             # bf16 operands make the matrix work 16x cheaper: the recurrence is priced by its bytes
             alg = {'opt_lstm_fwd': 19 * 496e6 + 410e6, 'opt_lstm_bwd': 19 * 660e6 + 250e6, 'opt_lstm_dWh': 3.9e9}[dom]
-            gbs = alg / (fams[dom]['avg_launch_ms'] * 1e-3) / 1e9
+            gbs = alg / (fams[dom]['ms_total_per_step'] * 1e-3) / 1e9      # bytes of the whole family / its event time
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(gbs / 8000.0, 4), "traffic": None, "avg_launch_ms": round(fams[dom]['avg_launch_ms'], 4),
                     "note": "bf16 operands / fp32 accumulation in the option recurrence: bound by HBM bytes (fp32 gates, h, c, "
