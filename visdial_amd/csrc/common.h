@@ -55,12 +55,16 @@ int vd_num_cus();  // compute units of the current device (cached)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Gate nonlinearities on the hardware exp (v_exp_f32, ~1 ulp in 2^x): absolute error ~1e-7, two orders
-// below the 1e-5 per-op / 1e-4 end-to-end parity budget, and ~4x fewer VALU ops than libm expf/tanhf.
-__device__ __forceinline__ float vd_sigmoid(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
+// Gate nonlinearities on the hardware exp and reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each): absolute error ~1e-7,
+// two orders below the 1e-5 per-op / 1e-4 end-to-end parity budget.  The reciprocal is the bare instruction on
+// purpose: `__fdividef` / `1.0f / x` expand to the IEEE division sequence (2 v_div_scale, v_rcp, 4 v_fma, v_div_fmas,
+// v_div_fixup = ~10 VALU instructions), which was HALF of the LSTM step epilogue's 1 550 VALU instructions -- and VALU
+// issue in the epilogue comes straight out of the co-resident waves' matrix-pipe time.
+__device__ __forceinline__ float vd_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float vd_sigmoid(float x) { return vd_rcp(1.0f + __expf(-x)); }
 __device__ __forceinline__ float vd_tanh(float x) {
   const float e = __expf(-2.0f * fabsf(x));          // in (0, 1]: no overflow
-  const float t = __fdividef(1.0f - e, 1.0f + e);
+  const float t = (1.0f - e) * vd_rcp(1.0f + e);
   return copysignf(t, x);
 }
 
