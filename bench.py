@@ -57,6 +57,33 @@ def headline_params(rank=0, batch=20, config=3):
                           gpuid=int(os.environ.get('LOCAL_RANK', 0)), rank=rank, maxHistoryLenPerRound=40, **kw)
 
 
+def dominant_kernel_alone(p, N, iters=3):
+    """The dominant kernel family (option-LSTM backward, To-1 timestep launches) run by itself on the same shapes, HIP
+    events on its stream: the rate the kernel reaches when it does not share the matrix pipe with the encoder."""
+    import torch
+    from visdial_amd import ops
+    NO, H, To = N * p['numOptions'], p['rnnHiddenSize'], p['maxAnsLen']
+    g = torch.Generator(device='cuda').manual_seed(0)
+    Wh = torch.randn(H, 4 * H, device='cuda', generator=g) * 0.04
+    gates = torch.rand(To, NO, 4 * H, device='cuda', generator=g)
+    c = torch.randn(To, NO, H, device='cuda', generator=g) * 0.1
+    dcw = torch.empty(NO, H, device='cuda')
+    dh_last = torch.randn(NO, H, device='cuda', generator=g) * 0.01
+    run = lambda: ops.lstm_backward(Wh, gates, c, dcw, To, NO, H, dh_last=dh_last)
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters / (To - 1)
+    tf = 2.0 * NO * H * 4 * H / ms / 1e9
+    del gates, c
+    return {"avg_launch_ms": round(ms, 4), "achieved": round(tf, 2), "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+
+
 def cpu_baseline(seconds_budget=30.0, batch=20):
     """oracle/cpu_step.cpp -- the repo's C++17/OpenMP fp32 restatement of the same training step, organised like the
     reference's CPU path (per-timestep GEMMs, 10x image replication, no table hoist) -- timed on all host cores on
@@ -237,6 +264,11 @@ def main():
                             "that this build replaces by an exact table gather (SURVEY 8d)",
                     "step_tflops_nominal": round(STEP_GFLOP_PER_ROUND * value / 1e3, 2),
                     "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
+        if roof and roof.get("bound") == "mfma" and world == 1:
+            try:
+                roof["alone"] = dominant_kernel_alone(p, N)     # same kernel, same shapes, nothing else on the chip
+            except Exception as exc:                            # never let the extra figure break the bench line
+                roof["alone"] = {"error": str(exc)[:120]}
         ps = np.array(per_step) * 1e3
         out = {
             "metric": "QA-rounds/sec training mn-att-ques-im-hist+disc (batch 20x10x100)",
