@@ -123,6 +123,29 @@ function Model:retrieveBatch(batch)
     return out:double():view(N, O)
 end
 
+-- Model:evaluate (model.lua:109-139): validation loss / perplexity over a split (train.lua:105-107)
+function Model:evaluate(dataloader, dtype)
+    self:setMode(false)
+    local total = dataloader.numThreads[dtype]
+    local curLoss, count, first = 0, 0, 1
+    while first <= total do
+        local batch, nxt = dataloader:getTestBatch(first, self.params, dtype)
+        if self.params.decoder == 'gen' then
+            count = count + batch['answer_out']:gt(0):sum()            -- non-pad target tokens
+            curLoss = curLoss + self:forwardBackward(batch, true)      -- summed token NLL
+        else
+            local rounds = batch['answer_ind']:nElement()
+            count = count + rounds
+            curLoss = curLoss + self:forwardBackward(batch, true) * rounds
+        end
+        first = nxt
+    end
+    curLoss = curLoss / math.max(count, 1)
+    print(string.format('\n%s\tLoss: %f\t Perplexity: %f\n', dtype, curLoss, math.exp(curLoss)))
+    self:setMode(true)
+    return curLoss
+end
+
 function Model:setMode(training)
     vd.call('vd_model_set_training', self.h, training and 1 or 0)
 end

@@ -298,3 +298,22 @@ def test_native_full_size_other_configs_are_additive_over_dialogs(gpu, config):
     err = float(np.linalg.norm(gf - gm) / np.linalg.norm(gm))
     assert err < 1e-4, err
     model.close()
+
+
+@pytest.mark.parametrize("enc,dec", [('lf-ques-im-hist', 'gen'), ('mn-att-ques-im-hist', 'disc')])
+def test_native_evaluate_equals_python_host(gpu, enc, dec):
+    """Model:evaluate (model.lua:109-139) over a split through the model-level ABI = the operator-level host's, same
+    parameters, same batches (two loaders with the same seed)"""
+    from visdial_amd.model import Model
+    from visdial_amd.native import NativeModel
+    kw = dict(WIDE['tiny'])
+    if 'att' in enc:
+        kw.update(imgFeatureSize=32, imgSpatialSize=3)
+    p = derive(small_params(encoder=enc, decoder=dec, **kw))
+    py = Model(p)
+    nat = NativeModel(p)
+    nat.set_parameters_dict(py.get_parameters_dict())
+    l1, ppl1 = py.evaluate(SyntheticDataloader(p, seed=5, num_threads=5), 'val')
+    l2, ppl2 = nat.evaluate(SyntheticDataloader(p, seed=5, num_threads=5), 'val')
+    assert np.isfinite(l1) and abs(l1 - l2) < 1e-5 * max(1.0, abs(l1)) and abs(ppl1 - ppl2) < 1e-4 * max(1.0, ppl1)
+    nat.close()

@@ -197,6 +197,27 @@ class NativeModel(object):
         call("vd_model_ranks", self.h, int(useGt), out.ctypes.data)
         return out
 
+    def evaluate(self, dataloader, dtype):
+        """model.lua:109-139: validation loss / perplexity over a split (see visdial_amd.model.Model.evaluate)."""
+        import math
+        self.training(False)
+        n = dataloader.numThreads[dtype]
+        cur, count, start = 0.0, 0.0, 1
+        while start <= n:
+            batch, nxt = dataloader.getTestBatch(start, self.params, dtype)
+            if self.params['decoder'] == 'gen':
+                count += float((batch['answer_out'] > 0).sum())
+                cur += self.forwardBackward(batch, onlyForward=True)
+            else:
+                rounds = float(np.asarray(batch['answer_ind']).size)
+                count += rounds
+                cur += self.forwardBackward(batch, onlyForward=True) * rounds
+            start = nxt
+        cur /= max(count, 1.0)
+        print('\n%s\tLoss: %f\t Perplexity: %f\n' % (dtype, cur, math.exp(cur)))
+        self.training(True)
+        return cur, math.exp(cur)
+
     def family_ms(self):
         a = (C.c_float * 3)()
         call("vd_model_family_ms", self.h, a)
