@@ -28,6 +28,8 @@ def main():
     ap.add_argument('-saveRankPath', '--saveRankPath', default='logs/ranks.json')
     ap.add_argument('-perplexity', '--perplexity', type=int, default=0, help='also run Model:evaluate (model.lua:109-139)')
     ap.add_argument('--numThreads', type=int, default=100, help='synthetic fallback only')
+    ap.add_argument('-host', '--host', default='python', choices=['python', 'native'],
+                    help="'native' drives the model-level C ABI (what lua/model.lua calls)")
     a = ap.parse_args()
     saved = load_checkpoint(a.loadPath)
     p = opts.derive(saved['modelParams'])                    # sets useHistory / useIm / concatHistory (evaluate.lua:69-75)
@@ -41,7 +43,11 @@ def main():
     else:
         print('no dataset at %s: ranking SYNTHETIC batches (plumbing check, the metrics mean nothing)' % a.inputQues)
         dl = SyntheticDataloader(p, seed=4321, num_threads=a.numThreads)
-    model = Model(p)
+    if a.host == 'native':
+        from visdial_amd.native import NativeModel
+        model = NativeModel(p)
+    else:
+        model = Model(p)
     restore_weights(model, saved)          # evaluate.lua:91
     print('Evaluating..')
     if a.perplexity:

@@ -12,13 +12,16 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_train_then_evaluate(tmp_path):
+@pytest.mark.parametrize("host", ['python', 'native'])
+def test_train_then_evaluate(tmp_path, host):
+    """host = which layer of the C ABI drives the library: operator-level (visdial_amd/model.py) or model-level
+    (visdial_amd/native.py = the calls lua/model.lua makes); checkpoints are interchangeable (evaluated by the OTHER host)"""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     save = str(tmp_path / "ckpt") + "/"
     common = ['-encoder', 'mn-att-ques-im-hist', '-decoder', 'disc', '-imgFeatureSize', '64', '-imgSpatialSize', '4',
               '-rnnHiddenSize', '64', '-embedSize', '32', '-commonEmbeddingSize', '64', '-batchSize', '4',
-              '--vocabSize', '100', '--numTrainThreads', '40']
+              '--vocabSize', '100', '--numTrainThreads', '40', '-host', host]
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py')] + common +
                        ['-savePath', save, '-numEpochs', '20', '-saveIter', '10', '--maxIters', '200'],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
@@ -30,7 +33,8 @@ def test_train_then_evaluate(tmp_path):
     assert os.path.exists(save + 'model_final.pt') and os.path.exists(save + 'model_epoch_10.pt')
     e = subprocess.run([sys.executable, os.path.join(ROOT, 'evaluate.py'), '-loadPath', save + 'model_final.pt',
                         '-batchSize', '4', '--numThreads', '8', '-saveRanks', '1', '-saveRankPath',
-                        str(tmp_path / 'ranks.json')], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        str(tmp_path / 'ranks.json'), '-perplexity', '1', '-host', 'native' if host == 'python' else 'python'],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert e.returncode == 0, e.stdout[-2000:] + e.stderr[-2000:]
     assert 'r@1:' in e.stdout and 'meanRR:' in e.stdout and os.path.exists(str(tmp_path / 'ranks.json'))
 

@@ -64,7 +64,11 @@ def main():
     os.makedirs(opt['savePath'], exist_ok=True)
     opt['numIterPerEpoch'] = int(math.ceil(opt['numTrainThreads'] / float(opt['batchSize'])))
     print('\n%d iter per epoch.' % opt['numIterPerEpoch'])
-    model = Model(opt)
+    if opt.get('host', 'python') == 'native':     # model-level C ABI (the calls lua/model.lua makes)
+        from visdial_amd.native import NativeModel
+        model = NativeModel(opt)
+    else:
+        model = Model(opt)
     if saved is not None:                                        # train.lua:78-81
         restore_weights(model, saved)
         model.optims['learningRate'] = saved['optims']['learningRate']
@@ -77,16 +81,19 @@ def main():
         model.trainIteration(dataloader)
         if it % (opt['saveIter'] * opt['numIterPerEpoch']) == 0:      # train.lua:95-102
             ep = it // opt['numIterPerEpoch']
-            torch.save({'modelW': model.wrapperW.cpu(), 'optims': dict(model.optims), 'modelParams': _plain(opt)},
+            torch.save({'modelW': model.wrapperW.cpu(), 'optims': {k: model.optims[k] for k in model.optims.keys()},
+                        'modelParams': _plain(opt)},
                        os.path.join(opt['savePath'], 'model_epoch_%d.pt' % ep))
         if it % 100 == 0:                                            # train.lua:108-115
             torch.cuda.synchronize()
+            getattr(model, 'synchronize', lambda: None)()
             rounds = 100 * opt['batchSize'] * opt['maxQuesCount']
             print('[%s][Epoch:%.02f][Iter:%d][Loss:%.05f][lr:%f][%.0f QA-rounds/s]' % (
                 time.ctime(), it / float(opt['numIterPerEpoch']), it, model.runningLoss,
                 model.optims['learningRate'], rounds / (time.time() - t0)))
             t0 = time.time()
-    torch.save({'modelW': model.wrapperW.float().cpu(), 'modelParams': _plain(opt), 'optims': dict(model.optims)},
+    torch.save({'modelW': model.wrapperW.float().cpu(), 'modelParams': _plain(opt),
+                'optims': {k: model.optims[k] for k in model.optims.keys()}},
                os.path.join(opt['savePath'], 'model_final.pt'))     # train.lua:120-121
 
 

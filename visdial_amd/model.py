@@ -15,6 +15,7 @@ import os
 from . import decoders, encoders, ops, utils
 from .nn import DropoutState, SeqSort, StreamPool, Workspace
 from .params import FlatParams, ParamSpec, init_host
+from .split_eval import SplitEval
 
 
 class Wrapper(object):
@@ -40,7 +41,7 @@ class Wrapper(object):
         return self._m.encoder if i == 1 else self._m.decoder
 
 
-class Model(object):
+class Model(SplitEval):
     def __init__(self, params, dist_group=None):
         self.params = params
         if not torch.cuda.is_available():
@@ -297,79 +298,9 @@ class Model(object):
         gt = dec_in.get('gt') if self.params.get('useGt') else None
         return utils.computeRanks(scores, gt, self.ws)
 
-    def evaluate(self, dataloader, dtype):
-        """model.lua:109-139: validation loss / perplexity over a split (generative decoder: summed token NLL over
-        the number of non-pad target tokens; for the discriminative decoder, whose batches carry no answer_out, the
-        reference would fail -- here the mean cross-entropy over rounds is reported instead).  Returns (loss, ppl)."""
-        self.wrapper.evaluate()
-        n = dataloader.numThreads[dtype]
-        cur, count, start = 0.0, 0.0, 1
-        while start <= n:
-            batch, nxt = dataloader.getTestBatch(start, self.params, dtype)
-            if self.params['decoder'] == 'gen':
-                count += float((batch['answer_out'] > 0).sum())
-                cur += self.forwardBackward(batch, onlyForward=True)
-            else:
-                rounds = float(np.asarray(batch['answer_ind']).size)
-                count += rounds
-                cur += self.forwardBackward(batch, onlyForward=True) * rounds
-            start = nxt
-        cur /= max(count, 1.0)
-        print('\n%s\tLoss: %f\t Perplexity: %f\n' % (dtype, cur, math.exp(cur)))
-        self.wrapper.training()
-        return cur, math.exp(cur)
-
-    def _rank_records(self, dataloader, dtype, ranks, last_round_only):
-        """{image_id, round_id, ranks} records as model.lua:174-184 / :222-241 builds them: real image ids, only the
-        rounds that exist (num_rounds), and for the test split of predict() the last round only."""
-        ids = getattr(dataloader, 'unique_img_' + dtype, None)
-        rounds = getattr(dataloader, dtype + '_num_rounds', None)
-        n, R = ranks.shape[0], ranks.shape[1]
-        out = []
-        for i in range(n):
-            iid = ids[i] if ids is not None and i < len(ids) else i + 1
-            nr = int(rounds[i]) if rounds is not None else R
-            if last_round_only:
-                out.append({'image_id': iid, 'round_id': nr, 'ranks': ranks[i, nr - 1].tolist()})
-            else:
-                for j in range(nr):
-                    r = ranks[i, j]
-                    out.append({'image_id': iid, 'round_id': j + 1, 'ranks': r.tolist() if np.ndim(r) else float(r)})
-        return out
-
-    def retrieve(self, dataloader, dtype):
-        """model.lua:142-189: ground-truth ranks + metrics.  Returns (metrics, records)."""
-        self.wrapper.evaluate()
-        self.params['useGt'] = True
-        n = dataloader.numThreads[dtype]
-        R = int(self.params['maxQuesCount'])
-        O = int(self.params.get('numOptions', 100))
-        ranks = np.full((n, R), O + 1.0)                               # model.lua:153-154
-        start = 1
-        while start <= n:
-            batch, nxt = dataloader.getTestBatch(start, self.params, dtype)
-            ranks[start - 1:nxt - 1] = self.retrieveBatch(batch).reshape(-1, R)
-            start = nxt
-        print('\n%s - Retrieval:' % dtype)
-        metrics = utils.processRanks(ranks)
-        self.wrapper.training()
-        return metrics, self._rank_records(dataloader, dtype, ranks, False)
-
-    def predict(self, dataloader, dtype):
-        """model.lua:192-246: all 100 ranks per round (val: every existing round; test: the last round only)."""
-        self.wrapper.evaluate()
-        self.params['useGt'] = False
-        n = dataloader.numThreads[dtype]
-        R = int(self.params['maxQuesCount'])
-        O = int(self.params.get('numOptions', 100))
-        ranks = np.full((n, R, O), O + 1.0)
-        start = 1
-        while start <= n:
-            batch, nxt = dataloader.getTestBatch(start, self.params, dtype)
-            ranks[start - 1:nxt - 1] = self.retrieveBatch(batch).reshape(-1, R, O)
-            start = nxt
-        self.wrapper.training()
-        return self._rank_records(dataloader, dtype, ranks, dtype == 'test')
+    # Model:evaluate / retrieve / predict (model.lua:109-246): visdial_amd/split_eval.py, shared with the native host
+    def _set_training(self, on):
+        self.wrapper.training() if on else self.wrapper.evaluate()
 
     # ------------------------------------------------------------------ generation (model.lua:432-613)
     def generateAnswers(self, dataloader, dtype, params=None):

@@ -8,6 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from .split_eval import SplitEval
 
 call = _lib.call
 
@@ -19,7 +20,33 @@ class _DevArray(object):
         self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '<f4', 'data': (ptr, False), 'version': 2}
 
 
-class NativeModel(object):
+class _Optims(object):
+    """`model.optims` of the reference (model.lua:58-63): only learningRate is host-visible; the Adam moments live in
+    the library"""
+
+    def __init__(self, model):
+        self._m = model
+
+    def _lr(self, value=None):
+        v = C.c_double(0.0 if value is None else float(value))
+        call("vd_model_learning_rate", self._m.h, C.byref(v), 0 if value is None else 1)
+        return float(v.value)
+
+    def __getitem__(self, k):
+        if k != 'learningRate':
+            raise KeyError(k)
+        return self._lr()
+
+    def __setitem__(self, k, v):
+        if k != 'learningRate':
+            raise KeyError(k)
+        self._lr(v)
+
+    def keys(self):
+        return ['learningRate']
+
+
+class NativeModel(SplitEval):
     def __init__(self, params, init_seed=1234, dist_group=None):
         p = params
         self.dist_group = dist_group
@@ -47,6 +74,9 @@ class NativeModel(object):
             self.tensors.append((name.value.decode(), int(off.value), int(r.value), int(c.value)))
         call("vd_model_init_params", h, int(init_seed))
         self._keep = None
+        self.runningLoss = 0.0
+        self._W = None
+        self.optims = _Optims(self)
 
     def close(self):
         if self.h:
@@ -82,6 +112,36 @@ class NativeModel(object):
 
     def get_gradients_dict(self):
         return self._get(1)
+
+    @property
+    def wrapperW(self):
+        """the flat parameter vector (device tensor aliasing the library's buffer; same aligned layout as
+        visdial_amd.model.Model.wrapperW, so `.pt` checkpoints are interchangeable between the two hosts)"""
+        if self._W is None:
+            import torch
+            ptrs = [C.c_void_p() for _ in range(4)]
+            call("vd_model_flat_pointers", self.h, *[C.byref(x) for x in ptrs])
+            n = int(_lib.load().vd_model_flat_size(self.h))
+            self._W = torch.as_tensor(_DevArray(ptrs[0].value, n), device='cuda')
+        self.synchronize()
+        return self._W
+
+    def _entries(self):
+        kind = lambda n: 'embed' if n == 'embed' else ('lstm' if n.split('.')[0].rstrip('0123456789') in
+                                                        ('hist', 'ques', 'opt', 'dec', 'dialog') else 'lin') + \
+            ('_w' if n.endswith('.W') else '_b')
+        return [(n, self._shape(n, r, c), kind(n)) for n, _, r, c in self.tensors]
+
+    def load_flat_parameters(self, modelW, allow_unverified=False):
+        """`model.wrapperW:copy(savedModel.modelW)` for a flat vector in the REFERENCE's getParameters() layout
+        (see visdial_amd.model.Model.load_flat_parameters)"""
+        from . import t7
+        self.set_parameters_dict(t7.flat_to_named(np.asarray(modelW), self._entries(), self.params['encoder'],
+                                                  allow_unverified))
+
+    def flat_parameters(self):
+        from . import t7
+        return t7.named_to_flat(self.get_parameters_dict(), self._entries(), self.params['encoder'])
 
     def training(self, on=True):
         call("vd_model_set_training", self.h, int(on))
@@ -181,15 +241,19 @@ class NativeModel(object):
         call("vd_model_forward_backward", self.h, 0)
         self.update()
         self.upload(dataloader.getTrainBatch(self.params))
-        return self.loss()
+        cur = self.loss()
+        self.runningLoss = 0.95 * self.runningLoss + 0.05 * cur if self.runningLoss > 0 else cur   # model.lua:88-92
+        return cur
 
     def scores(self, N, O):
         a = np.empty((N, O), np.float32)
         call("vd_model_scores", self.h, a.ctypes.data, a.size)
         return a
 
-    def retrieveBatch(self, batch, useGt=True):
-        """model.lua:344-430: ground-truth ranks [N] (useGt) or all ranks [N x O]"""
+    def retrieveBatch(self, batch, useGt=None):
+        """model.lua:344-430: ground-truth ranks [N] (useGt; default params['useGt']) or all ranks [N x O]"""
+        if useGt is None:
+            useGt = bool(self.params.get('useGt', True))
         self.upload(batch)
         call("vd_model_retrieve", self.h)
         N, O = self._N, int(self.params.get('numOptions', 100))
@@ -197,26 +261,9 @@ class NativeModel(object):
         call("vd_model_ranks", self.h, int(useGt), out.ctypes.data)
         return out
 
-    def evaluate(self, dataloader, dtype):
-        """model.lua:109-139: validation loss / perplexity over a split (see visdial_amd.model.Model.evaluate)."""
-        import math
-        self.training(False)
-        n = dataloader.numThreads[dtype]
-        cur, count, start = 0.0, 0.0, 1
-        while start <= n:
-            batch, nxt = dataloader.getTestBatch(start, self.params, dtype)
-            if self.params['decoder'] == 'gen':
-                count += float((batch['answer_out'] > 0).sum())
-                cur += self.forwardBackward(batch, onlyForward=True)
-            else:
-                rounds = float(np.asarray(batch['answer_ind']).size)
-                count += rounds
-                cur += self.forwardBackward(batch, onlyForward=True) * rounds
-            start = nxt
-        cur /= max(count, 1.0)
-        print('\n%s\tLoss: %f\t Perplexity: %f\n' % (dtype, cur, math.exp(cur)))
-        self.training(True)
-        return cur, math.exp(cur)
+    # Model:evaluate / retrieve / predict (model.lua:109-246): visdial_amd/split_eval.py, shared with the Python host
+    def _set_training(self, on):
+        self.training(on)
 
     def family_ms(self):
         a = (C.c_float * 3)()

@@ -35,6 +35,8 @@ OPTIONS = [
     ('backend', 'cudnn', 'accepted for CLI compatibility; ignored'),
     # not a reference flag: the bf16 LSTM step of BASELINE.json configs[4] (option recurrence only; default exact fp32)
     ('lstmPrecision', 'fp32', "arithmetic of the option-LSTM recurrence GEMMs: 'fp32' | 'bf16' (fp32 accumulation)"),
+    ('host', 'python', "which host drives the library: 'python' (operator-level C ABI, visdial_amd/model.py) | 'native' "
+                       "(model-level C ABI, the calls lua/model.lua makes; visdial_amd/native.py)"),
 ]
 
 
