@@ -68,6 +68,11 @@ int vd_gemm_nn(const float* A, int64_t lda, const float* B, int64_t ldb, const f
 /* C[MxN] += A[KxM]^T * B[KxN]                  -- accGradParameters of nn.Linear / nn.SeqLSTM */
 int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
                    int N, int K, int flags, void* stream);
+/* C[MxN] += sum_k A[a_rows[k], :M]^T * B[b_rows[k], :N], k < K  -- the same accGradParameters contraction over an
+ * explicit list of (row of A, row of B) pairs: nn.SeqLSTM:maskZero() zeroes the gradient of padded (timestep, row)
+ * pairs (encoders/mn-att-ques-im-hist.lua:27-41), so only the non-pad pairs are contracted (~55 % of T*N) */
+int vd_gemm_tn_rows_acc(const float* A, int64_t lda, const int32_t* a_rows, const float* B, int64_t ldb,
+                        const int32_t* b_rows, float* C, int64_t ldc, int M, int N, int K, void* stream);
 /* out[N] += column sums of X[MxN]              -- gradBias */
 int vd_colsum_acc(const float* X, int64_t ld, int M, int N, float* out, void* stream);
 

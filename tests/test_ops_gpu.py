@@ -72,6 +72,23 @@ def test_gemm_tn_acc(ops, M, N, K):
     assert relerr(C, C0 + A.astype(np.float64).T @ B.astype(np.float64)) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,R,K", [(512, 2048, 8000, 4431), (300, 2048, 8000, 4431), (36, 384, 135, 77), (96, 384, 60, 1),
+                                     (512, 2048, 4000, 4000)])
+def test_gemm_tn_rows_acc(ops, M, N, R, K):
+    """the weight-gradient contraction over an explicit list of (row of A, row of B) pairs (non-pad (t, row) pairs of
+    a maskZero recurrence): ordered and repeated indices, different lists for the two operands, ragged K"""
+    import torch
+    rng = np.random.RandomState(M + N + K)
+    A, B = f32(rng, R, M), f32(rng, R, N) * 0.1
+    ra = np.sort(rng.choice(R, size=K, replace=K > R)).astype(np.int32)
+    rb = np.maximum(ra - rng.randint(0, 3), 0).astype(np.int32)
+    C0 = f32(rng, M, N)
+    C = dev(C0)
+    ops.gemm_tn_rows_acc(dev(A), torch.from_numpy(ra).cuda(), dev(B), torch.from_numpy(rb).cuda(), C)
+    ref = C0 + A[ra].astype(np.float64).T @ B[rb].astype(np.float64)
+    assert relerr(C, ref) < 1e-5
+
+
 def test_colsum(ops):
     rng = np.random.RandomState(0)
     X = f32(rng, 8001, 2048)

@@ -68,6 +68,7 @@ PROTOTYPES = {
     "vd_gemm_nt": [_p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _i, _p],
     "vd_gemm_nn": [_p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _p],
     "vd_gemm_tn_acc": [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p],
+    "vd_gemm_tn_rows_acc": [_p, _l, _p, _p, _l, _p, _p, _l, _i, _i, _i, _p],
     "vd_colsum_acc": [_p, _l, _i, _i, _p, _p],
     "vd_lstm_forward": [_p, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "vd_lstm_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],

@@ -96,6 +96,18 @@ struct SrcK {
     return *reinterpret_cast<const float4*>(p + (long)k * ld + r);
   }
 };
+// k-major rows picked through an index list: element (r, k) = p[rows[k]*ld + r].  Weight gradients of the masked
+// (maskZero) encoder recurrences contract only the (timestep, row) pairs that are not padding.
+struct SrcKRows {
+  static constexpr bool KMAJOR = true;
+  static constexpr bool PLAIN = false;
+  const float* p;
+  long ld;
+  const int* rows;
+  __device__ __forceinline__ float4 ld4(int r, int k) const {
+    return *reinterpret_cast<const float4*>(p + (long)rows[k] * ld + r);
+  }
+};
 // LSTM recurrent weight Wh [H x 4H] (gate order i,f,o,g) seen through "virtual"
 // columns vc = jb*128 + gate*32 + jj  ->  real column gate*H + jb*32 + jj, so one
 // wave strip holds all four gates of 32 hidden units.

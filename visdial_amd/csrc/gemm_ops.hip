@@ -122,6 +122,27 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
   return launch_gemm<CfgBigDB>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
 }
 
+// C[M x N] += sum_k A[a_rows[k], :M]^T * B[b_rows[k], :N]: the weight-gradient contraction over an explicit list of K
+// (row of A, row of B) pairs instead of all rows -- the non-pad (timestep, row) pairs of a maskZero recurrence.
+int vd_gemm_tn_rows_acc(const float* A, int64_t lda, const int32_t* a_rows, const float* B, int64_t ldb,
+                        const int32_t* b_rows, float* C, int64_t ldc, int M, int N, int K, void* stream) {
+  VD_CHECK_ARG(A && B && C && a_rows && b_rows && M >= 0 && N >= 0 && K >= 0 && (M % 4 == 0 || lda >= (M + 3) / 4 * 4) &&
+                   (N % 4 == 0 || ldb >= (N + 3) / 4 * 4),
+               "vd_gemm_tn_rows_acc: bad args M=%d N=%d K=%d", M, N, K);
+  if (int rc = check_align(A, lda, "vd_gemm_tn_rows_acc A")) return rc;
+  if (int rc = check_align(B, ldb, "vd_gemm_tn_rows_acc B")) return rc;
+  if (K == 0) return VD_OK;
+  SrcKRows a{A, lda, a_rows}, b{B, ldb, b_rows};
+  EpiAtomic<4> e{C, ldc};
+  using Cfg = GemmCfg<4, 1, 4, 16, 0, 4, 41984>;
+  const long tiles = (long)vd_cdiv(M, Cfg::BM) * vd_cdiv(N, Cfg::BN);
+  long splits = vd_cdiv(vd_tune_get("VD_TN_BLOCKS_SMALL", 768), tiles);
+  const long max_splits = vd_cdiv(K, vd_tune_get("VD_TN_MIN_KCHUNK", 1024));
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  return launch_gemm<Cfg>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
+}
+
 // out[N] += column sums of X[M x N]  (bias gradients)
 int vd_colsum_acc(const float* X, int64_t ld, int M, int N, float* out, void* stream) {
   VD_CHECK_ARG(X && out && M >= 0 && N >= 0, "vd_colsum_acc: bad args");

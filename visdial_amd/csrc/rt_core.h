@@ -48,6 +48,10 @@ struct SeqTok {
   int32_t* tok = nullptr;
   std::vector<int32_t> nact;  // host [T]
   int32_t *tok_sorted = nullptr, *fwd_idx = nullptr, *inv_idx = nullptr, *perm = nullptr, *inv = nullptr, *nact_dev = nullptr;
+  // the non-pad (t, row) pairs as linear row indices of the sorted [T*N x .] tensors, in step order; act1 / prev1 =
+  // the pairs with t >= 1 and their previous-step rows (weight gradients contract these only)
+  int32_t *act = nullptr, *act1 = nullptr, *prev1 = nullptr;
+  int n_act = 0, n_act1 = 0;
 };
 
 struct BatchSlot {
@@ -323,6 +327,7 @@ struct SeqLSTM {
   const int32_t* tok_mask = nullptr;
   const float *h0 = nullptr, *c0 = nullptr;
   float *gates = nullptr, *h = nullptr, *c = nullptr;
+  const SeqTok* rows = nullptr;   // set for length-sorted stacks: weight gradients skip the pad (t, row) pairs
 
   void init(const std::string& n, long D_, long H_, const std::vector<long>& p = {}) {
     name = n; D = D_; H = H_;
@@ -356,7 +361,7 @@ struct SeqLSTM {
       h0 = z;
     }
     VD_TRY(alloc(m, T_, N_));
-    xs = x; tok_mask = tok;
+    xs = x; tok_mask = tok; rows = nullptr;
     // hoisted input projection, written straight into the gates buffer (the recurrence runs in place)
     long roff = 0;
     for (size_t i = 0; i < parts.size(); ++i) {
@@ -373,13 +378,25 @@ struct SeqLSTM {
     const long TN = (long)T * N;
     float* dW = Gp(m, name + ".W");
     float* dWh = dW + D * 4 * H;
-    if (T > 1) VD_TRY(vd_gemm_tn_acc(h, H, gates + (long)N * 4 * H, 4 * H, dWh, 4 * H, (int)H, (int)(4 * H), (T - 1) * N, 0, s));
+    const bool by_rows = rows && rows->act && vd_tune_get("VD_SKIP_PAD_WGRAD", 1) != 0;
+    if (by_rows) {
+      if (rows->n_act1 > 0)
+        VD_TRY(vd_gemm_tn_rows_acc(h, H, rows->prev1, gates, 4 * H, rows->act1, dWh, 4 * H, (int)H, (int)(4 * H), rows->n_act1, s));
+    } else if (T > 1) {
+      VD_TRY(vd_gemm_tn_acc(h, H, gates + (long)N * 4 * H, 4 * H, dWh, 4 * H, (int)H, (int)(4 * H), (T - 1) * N, 0, s));
+    }
     if (h0) VD_TRY(vd_gemm_tn_acc(h0, H, gates, 4 * H, dWh, 4 * H, (int)H, (int)(4 * H), N, 0, s));
     VD_TRY(vd_colsum_acc(gates, 4 * H, (int)TN, (int)(4 * H), Gp(m, name + ".b"), s));
     if (dxs) dxs->assign(parts.size(), nullptr);
     long roff = 0;
     for (size_t i = 0; i < parts.size(); ++i) {
-      VD_TRY(vd_gemm_tn_acc(xs[i], parts[i], gates, 4 * H, dW + roff * 4 * H, 4 * H, (int)parts[i], (int)(4 * H), (int)TN, 0, s));
+      if (by_rows) {
+        if (rows->n_act > 0)
+          VD_TRY(vd_gemm_tn_rows_acc(xs[i], parts[i], rows->act, gates, 4 * H, rows->act, dW + roff * 4 * H, 4 * H, (int)parts[i],
+                                     (int)(4 * H), rows->n_act, s));
+      } else {
+        VD_TRY(vd_gemm_tn_acc(xs[i], parts[i], gates, 4 * H, dW + roff * 4 * H, 4 * H, (int)parts[i], (int)(4 * H), (int)TN, 0, s));
+      }
       if (need_dx.empty() || need_dx[i]) {
         float* dx;
         VD_TRY(ws_get(m, name + ".dx" + std::to_string(i), (size_t)TN * parts[i], &dx));

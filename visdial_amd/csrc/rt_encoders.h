@@ -76,6 +76,7 @@ struct TextBranches {
     VD_TRY(vd_memset(l2.gates, 0, TN * 4 * H * 4, s));
     l1.xs = {xs};
     l2.xs = {l1.h};
+    l1.rows = l2.rows = ss.sorted ? &ss : nullptr;
     *mask_out = mk;
     *xs_out = xs;
     return VD_OK;

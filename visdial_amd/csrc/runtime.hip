@@ -31,7 +31,7 @@ int upload_tokens(BatchSlot& sl, SeqTok& ss, const std::string& tag, const int32
   ss.present = true;
   ss.sorted = sorted;
   const size_t TN = (size_t)T * N;
-  const size_t total = sorted ? 4 * TN + 2 * (size_t)N + T : TN;
+  const size_t total = sorted ? 7 * TN + 2 * (size_t)N + T : TN;   // (+ up to 3 x T*N row-list entries)
   int32_t* stage = nullptr;
   VD_TRY(pin_get(sl.pinned, tag + ".stage", total * sizeof(int32_t), (void**)&stage));
   int32_t* tok = stage;
@@ -71,6 +71,16 @@ int upload_tokens(BatchSlot& sl, SeqTok& ss, const std::string& tag, const int32
         inv_idx[(size_t)t * N + i] = t * N + inv[i];
       }
     }
+    // non-pad (t, row) pairs of the sorted layout, in step order (rows [0, nact[t]) of step t)
+    int32_t* act = nact + T;
+    int na = 0;
+    for (int t = 0; t < T; ++t)
+      for (int i = 0; i < ss.nact[t]; ++i) act[na++] = t * N + i;
+    const int n0 = T > 0 ? ss.nact[0] : 0;
+    int32_t* prev1 = act + TN;
+    for (int k = n0; k < na; ++k) prev1[k - n0] = act[k] - N;
+    ss.n_act = na;
+    ss.n_act1 = na - n0;
   }
   int32_t* dev = nullptr;
   VD_TRY(dev_get(sl.bufs, tag + ".dev", total * sizeof(int32_t), (void**)&dev));
@@ -83,6 +93,9 @@ int upload_tokens(BatchSlot& sl, SeqTok& ss, const std::string& tag, const int32
     ss.perm = dev + 4 * TN;
     ss.inv = ss.perm + N;
     ss.nact_dev = ss.inv + N;
+    ss.act = ss.nact_dev + T;
+    ss.act1 = ss.act + (T > 0 ? ss.nact[0] : 0);
+    ss.prev1 = ss.act + TN;
   }
   return VD_OK;
 }

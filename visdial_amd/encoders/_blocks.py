@@ -53,7 +53,7 @@ class TextBranches(object):
         if srt is None:
             return (l1, l2, x, T, N, tok), None, m
         xs = ops.embed_gather(x, srt.fwd_idx, self.ws.get(name + '.xs', (T * N, self.E)))   # permute rows per step
-        return (l1, l2, xs, T, N, srt.tok_sorted, srt.nact, srt.nact_dev), srt, m
+        return (l1, l2, xs, T, N, srt.tok_sorted, srt.nact, srt.nact_dev, srt.rows), srt, m
 
     def forward(self, ques, hist):
         N, H = ques.shape[1], self.H

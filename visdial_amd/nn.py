@@ -6,6 +6,8 @@ decoders/*.lua: they own no arithmetic -- every forward/backward is a call into 
 """
 import zlib
 
+import os
+
 import torch
 
 from . import ops
@@ -162,6 +164,7 @@ class SeqLSTM(object):
             h0 = self.ws.get(k + '.h0zero', (N, H))
             ops.zero(h0)
         self.T, self.N, self.xs, self.tok_mask, self.h0, self.c0 = T, N, xs, tok_mask, h0, c0
+        self.rows = None
         self.gates = self.ws.get(k + '.gates', (T, N, 4 * H))
         self.h = self.ws.get(k + '.h', (T, N, H))
         self.c = self.ws.get(k + '.c', (T, N, H))
@@ -198,7 +201,12 @@ class SeqLSTM(object):
         T, N, H, k = self.T, self.N, self.H, self.key
         da = self.gates.view(T * N, 4 * H)
         h2 = self.h.view(T * N, H)
-        if T > 1:
+        rows = getattr(self, 'rows', None)          # (act, act1, prev1): contract the non-pad (t, row) pairs only
+        if rows is not None:
+            act, act1, prev1 = rows
+            if act1.numel():
+                ops.gemm_tn_rows_acc(h2, prev1, da, act1, self.dWh, M=H, N=4 * H)
+        elif T > 1:
             ops.gemm_tn_acc(h2, da[N:], self.dWh, M=H, N=4 * H, K=(T - 1) * N)
         if self.h0 is not None:
             ops.gemm_tn_acc(self.h0, da, self.dWh, M=H, N=4 * H, K=N)
@@ -207,7 +215,10 @@ class SeqLSTM(object):
         dxs = []
         for i, (xi, wi, dwi, d) in enumerate(zip(self.xs, self._wx_blocks(self.Wx), self._wx_blocks(self.dWx),
                                                 self.part_dims)):
-            ops.gemm_tn_acc(xi, da, dwi, M=d, N=4 * H, K=T * N)
+            if rows is not None:
+                ops.gemm_tn_rows_acc(xi, rows[0], da, rows[0], dwi, M=d, N=4 * H)
+            else:
+                ops.gemm_tn_acc(xi, da, dwi, M=d, N=4 * H, K=T * N)
             if need[i]:
                 dx = self.ws.get('%s.dx%d' % (k, i), (T * N, d))
                 ops.gemm_nt(da, wi, dx, M=T * N, N=d, K=4 * H)
@@ -242,18 +253,29 @@ class SeqSort(object):
         self.inv_idx = dev((base + inv[None, :]).reshape(-1))
         self.perm, self.inv, self.nact_dev = dev(perm), dev(inv), dev(self.nact)
         self.T, self.N = T, N
+        # the non-pad (t, row) pairs as linear row indices of the sorted [T*N x .] tensors, in step order: the
+        # weight-gradient contractions run over these only (vd_gemm_tn_rows_acc).  act1 / prev1 = the pairs with
+        # t >= 1 and their previous-step rows (dWh = sum_t h_{t-1}^T da_t).
+        act = np.concatenate([t * N + np.arange(self.nact[t], dtype=np.int32) for t in range(T)]).astype(np.int32) \
+            if T else np.zeros(0, np.int32)
+        n0 = int(self.nact[0]) if T else 0
+        self.rows = None
+        if os.environ.get('VD_SKIP_PAD_WGRAD', '1') != '0' and act.size:
+            self.rows = (dev(act), dev(act[n0:]), dev(act[n0:] - N))
 
 
 def lstm2_bundle_forward(bundle):
     """bundle: list of (l1, l2, x, T, N, tok_mask[, nact, nact_dev]) -- two-layer maskZero stacks advanced
     together as a skewed wavefront (vd_lstm2_forward): one grouped launch per tick for ALL stacks.  With
-    nact (rows sorted by length) pad rows are skipped and zero-filled.  Returns the top layers' h tensors.
+    nact (rows sorted by length) pad rows are skipped and zero-filled; an optional 9th item `rows` = (act, act1, prev1)
+    row lists (SeqSort.rows) lets the weight-gradient contractions skip the pad pairs too.  Returns the top layers' h tensors.
     Fills the same saved-state fields SeqLSTM.forward does."""
     H = bundle[0][0].H
     descs = []
     for item in bundle:
         l1, l2, x, T, N, tok = item[:6]
         nact, nact_dev = (item[6], item[7]) if len(item) > 6 else (None, None)
+        l1.rows = l2.rows = item[8] if len(item) > 8 else None
         assert l1.H == H and l2.H == H and l2.D == H and len(l1.part_dims) == 1
         for l, xs in ((l1, [x]), (l2, None)):
             l.T, l.N, l.tok_mask, l.h0, l.c0 = T, N, tok, None, None

@@ -91,6 +91,17 @@ def gemm_tn_acc(A, B, C_acc, M=None, N=None, K=None, lda=None, ldb=None, ldc=Non
     return C_acc
 
 
+def gemm_tn_rows_acc(A, a_rows, B, b_rows, C_acc, M=None, N=None, lda=None, ldb=None, ldc=None):
+    """C[MxN] += sum_k A[a_rows[k], :M].T @ B[b_rows[k], :N]  (K = len(a_rows) = len(b_rows) row pairs)"""
+    K = a_rows.numel()
+    assert b_rows.numel() == K
+    M = A.shape[1] if M is None else M
+    N = B.shape[1] if N is None else N
+    call("vd_gemm_tn_rows_acc", _p(A, F32), lda or A.stride(0), _p(a_rows, I32), _p(B, F32), ldb or B.stride(0),
+         _p(b_rows, I32), _p(C_acc, F32), ldc or C_acc.stride(0), M, N, K, _stream())
+    return C_acc
+
+
 def colsum_acc(X, out, M=None, N=None, ld=None):
     M = X.shape[0] if M is None else M
     N = X.shape[1] if N is None else N
