@@ -27,13 +27,21 @@ def main():
     ap.add_argument('-temperature', '--temperature', type=float, default=1.0)
     ap.add_argument('-maxThreads', '--maxThreads', type=int, default=50)
     ap.add_argument('-gpuid', '--gpuid', type=int, default=0)
+    ap.add_argument('-host', '--host', default='python', choices=['python', 'native'],
+                    help="'native' drives the model-level C ABI (what lua/model.lua calls)")
     a = vars(ap.parse_args())
     saved = load_checkpoint(a['loadPath'])
     p = opts.derive(saved['modelParams'])                      # generate.lua:57-70
     p['gpuid'] = a['gpuid']
     p.update(inputImg=a['inputImg'], inputQues=a['inputQues'], inputJson=a['inputJson'])
     dl = Dataloader(seed=1234).initialize(p, ['val'])
-    model = Model(p)
+    for k in ('vocabSize', 'maxQuesCount', 'maxQuesLen', 'maxAnsLen'):
+        p[k] = getattr(dl, k)
+    if a['host'] == 'native':
+        from visdial_amd.native import NativeModel
+        model = NativeModel(p)
+    else:
+        model = Model(p)
     restore_weights(model, saved)
     answers = model.generateAnswers(dl, 'val', dict(beamSize=a['beamSize'], beamLen=a['beamLen'],
                                                     maxThreads=a['maxThreads'], sampleWords=a['sampleWords'],

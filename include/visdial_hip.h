@@ -234,8 +234,7 @@ int vd_clamp_adam(float* w, float* g, float* m, float* v, int64_t n, float gscal
  * (encoders/<name>.lua) x decoders disc, gen (decoders/<name>.lua).  A LuaJIT host's model.lua needs only these
  * (INTEGRATION.md): stream fork/join, the skewed two-layer wavefront, the length sort, workspaces, forwardConnect /
  * backwardConnect and launch order live in the library.  One host thread per model; calls enqueue on library-owned
- * streams and block only where a host value is returned (loss, scores, ranks, tensors).  Sampling / beam search
- * (Model:generateAnswers, model.lua:432-613) is host-driven over the operator-level entry points.
+ * streams and block only where a host value is returned (loss, scores, ranks, tensors, log-probabilities).
  * ====================================================================================================== */
 typedef struct vd_model vd_model;
 typedef struct vd_model_params {   /* the `params` keys Model() consumes: opts.lua:15-40, train.lua:55-59 */
@@ -296,6 +295,17 @@ int vd_model_retrieve(vd_model* m);
 /* wrapperdW*gscale -> clamp(-5,5) -> adam -> lr decay (model.lua:96-105; optim_updates.lua:62-91) */
 int vd_model_update(vd_model* m, float gscale);
 int vd_model_learning_rate(vd_model* m, double* lr, int set);
+/* Model:generateAnswers, device side (model.lua:432-613; generative decoder).  The host keeps the candidate
+ * bookkeeping exactly as the reference's Lua does; each call advances all live hypotheses together.
+ *   encode        encoder forward of the uploaded batch = forwardBackward(batch, true, true) (model.lua:464)
+ *   decode_begin  hiddenBeams (model.lua:478-503): hypothesis i starts from the encoder state of QA round rounds[i] (0-based)
+ *   decode_step   one decoder step (model.lua:518-522, 590-596): tokens[n] in, log-probabilities [n x vocabSize] out (host)
+ *   decode_select hypothesis i continues from the stepped state of hypothesis src[i] (model.lua:560-575); slots >= n_keep
+ *                 keep their previous state; sampling passes the identity */
+int vd_model_encode(vd_model* m);
+int vd_model_decode_begin(vd_model* m, const int32_t* rounds, int n);
+int vd_model_decode_step(vd_model* m, const int32_t* tokens, float* host_logprobs);
+int vd_model_decode_select(vd_model* m, const int32_t* src, int n_keep);
 int vd_model_scores(vd_model* m, float* host_scores, int64_t n);        /* [N x O] of the last forward / retrieve */
 int vd_model_ranks(vd_model* m, int use_gt, int32_t* host_ranks);       /* utils.computeRanks (utils.lua:106-128) */
 int vd_model_family_ms(vd_model* m, float* ms3);          /* device ms of option-LSTM fwd, bwd, dWh in the last step */

@@ -200,6 +200,97 @@ end
 
 -- wrapperW:float() / wrapperW:copy(savedModel.modelW) (train.lua:79,99-102,120-121; evaluate.lua:91): the flat
 -- vector in THIS library's layout (embed | encoder tensors | decoder tensors, no padding), tensor by tensor
+-- Model:generateAnswers (model.lua:432-613): beam search (default) or temperature sampling with the generative decoder,
+-- one dialog at a time.  Candidate bookkeeping is host control flow as in the reference; the device side is four calls:
+-- vd_model_encode (encoder forward), vd_model_decode_begin (hiddenBeams), vd_model_decode_step (one decoder step for all
+-- live hypotheses -> log-probabilities on the host), vd_model_decode_select (beam back-pointers).
+function Model:generateAnswers(dataloader, dtype, params)
+    if self.params.decoder == 'disc' then error('Sampling/beam search only for generative model') end
+    params = params or {}
+    local sampleWords = params.sampleWords == 1
+    local temperature = params.temperature or 1.0
+    local beamSize, beamLen = params.beamSize or 5, params.beamLen or 20
+    local startToken, endToken = dataloader.word2ind['<START>'], dataloader.word2ind['<END>']
+    local numThreads = params.maxThreads or dataloader.numThreads[dtype]
+    local V = self.params.vocabSize
+    local answerTable = {}
+    self:setMode(false)
+    for convId = 1, numThreads do
+        local batch = dataloader:getIndexData(torch.LongTensor{convId}, self.params, dtype)
+        local R = batch['ques_fwd']:size(2)
+        self:upload({ques_fwd = batch['ques_fwd'], hist = batch['hist'], img_feat = batch['img_feat']})
+        self.havePrefetched = false
+        vd.call('vd_model_encode', self.h)                             -- forwardBackward(batch, true, true)
+        local threadAnswers = {}
+        local function words(ids) return utils.idToWords(ids, dataloader.ind2word) end
+        if not sampleWords then
+            local n = beamSize
+            local rounds, toks, src = ffi.new('int32_t[?]', n), ffi.new('int32_t[?]', n), ffi.new('int32_t[?]', n)
+            local logp = ffi.new('float[?]', n * V)
+            for iter = 1, R do
+                for i = 0, n - 1 do rounds[i] = iter - 1 end
+                vd.call('vd_model_decode_begin', self.h, rounds, n)    -- hiddenBeams (model.lua:478-503)
+                local beams, scores, finish = {}, {}, {}
+                for i = 1, n do beams[i] = {startToken}; scores[i] = 0 end
+                for step = 2, beamLen do
+                    local explore = (step == 2) and 1 or n             -- all beams are <START> at first
+                    for i = 1, n do toks[i - 1] = beams[i][step - 1] or 0 end
+                    vd.call('vd_model_decode_step', self.h, toks, logp)
+                    local cands = {}
+                    for w = 1, explore do
+                        local row = {}
+                        for c = 1, V do row[c] = {c, logp[(w - 1) * V + c - 1]} end
+                        table.sort(row, function(a, b) if a[2] ~= b[2] then return a[2] > b[2] end return a[1] < b[1] end)
+                        for k = 1, math.min(n, V) do
+                            local cid, lp = row[k][1], row[k][2]
+                            local cb = {}
+                            for t = 1, step - 1 do cb[t] = beams[w][t] end
+                            cb[step] = cid
+                            if cid == endToken then finish[#finish + 1] = {beam = cb, score = scores[w] + lp, order = #finish}
+                            else cands[#cands + 1] = {beam = cb, score = scores[w] + lp, src = w - 1, order = #cands} end
+                        end
+                    end
+                    table.sort(cands, function(a, b) if a.score ~= b.score then return a.score > b.score end return a.order < b.order end)
+                    local keep = math.min(n, #cands)
+                    if keep > 0 then
+                        for i = 1, keep do src[i - 1] = cands[i].src end
+                        vd.call('vd_model_decode_select', self.h, src, keep)   -- untouched slots keep their old state
+                    end
+                    for i = 1, keep do beams[i] = cands[i].beam; scores[i] = cands[i].score end
+                end
+                table.sort(finish, function(a, b) if a.score ~= b.score then return a.score > b.score end return a.order < b.order end)
+                local best = (#finish > 0) and finish[1].beam or beams[1]
+                threadAnswers[#threadAnswers + 1] = {question = words(batch['ques_fwd'][{1, iter}]), answer = words(torch.LongTensor(best))}
+            end
+        else
+            local n = R
+            local rounds, toks, src = ffi.new('int32_t[?]', n), ffi.new('int32_t[?]', n), ffi.new('int32_t[?]', n)
+            local logp = ffi.new('float[?]', n * V)
+            for i = 0, n - 1 do rounds[i] = i; src[i] = i; toks[i] = startToken end
+            vd.call('vd_model_decode_begin', self.h, rounds, n)
+            local answer = {}
+            for i = 1, n do answer[i] = {startToken} end
+            for _ = 1, beamLen do
+                vd.call('vd_model_decode_step', self.h, toks, logp)
+                vd.call('vd_model_decode_select', self.h, src, n)
+                for i = 1, n do
+                    local pr = torch.FloatTensor(V)
+                    for c = 1, V do pr[c] = math.exp(logp[(i - 1) * V + c - 1] / temperature) end
+                    local nxt = torch.multinomial(pr:div(pr:sum()), 1)[1]
+                    answer[i][#answer[i] + 1] = nxt; toks[i - 1] = nxt
+                end
+            end
+            for iter = 1, R do
+                threadAnswers[#threadAnswers + 1] = {question = words(batch['ques_fwd'][{1, iter}]), answer = words(torch.LongTensor(answer[iter]))}
+            end
+        end
+        local ids = dataloader['unique_img_' .. dtype]
+        answerTable[#answerTable + 1] = {image_id = ids and ids[convId] or convId, dialog = threadAnswers}
+    end
+    self:setMode(true)
+    return answerTable
+end
+
 function Model:tensors()
     local out, name = {}, ffi.new('char[64]')
     local off, rows, cols = ffi.new('int64_t[1]'), ffi.new('int64_t[1]'), ffi.new('int64_t[1]')

@@ -317,3 +317,43 @@ def test_native_evaluate_equals_python_host(gpu, enc, dec):
     l2, ppl2 = nat.evaluate(SyntheticDataloader(p, seed=5, num_threads=5), 'val')
     assert np.isfinite(l1) and abs(l1 - l2) < 1e-5 * max(1.0, abs(l1)) and abs(ppl1 - ppl2) < 1e-4 * max(1.0, ppl1)
     nat.close()
+
+
+@pytest.mark.parametrize("enc", ['lf-ques-im-hist', 'mn-ques-hist', 'hre-ques-im-hist'])
+def test_native_beam_search_matches_oracle(gpu, enc):
+    """Model:generateAnswers (model.lua:432-613) through vd_model_encode / decode_begin / decode_step / decode_select on a
+    tiny real-format dataset: beam-search token sequences equal the fp64 oracle's and the operator-level host's;
+    sampling with the same seed gives the same sentences as the operator-level host."""
+    from test_dataloader_cpu import raw_dataset
+    from visdial_amd import utils
+    from visdial_amd.dataloader import Dataloader
+    from visdial_amd.model import Model
+    from visdial_amd.native import NativeModel
+    from visdial_amd.opts import default_params
+    rng = np.random.RandomState(2)
+    info, raw, img = raw_dataset(rng, n=3, R=3, MQ=5, MA=4, V=20, O=4, nopt=12, F=8)
+    raw = {k.replace('_train', '_val'): v for k, v in raw.items()}
+    img = {k.replace('_train', '_val'): v for k, v in img.items()}
+    info['unique_img_val'] = info.pop('unique_img_train')
+    p = derive(default_params(encoder=enc, decoder='gen', embedSize=12, rnnHiddenSize=32, imgFeatureSize=8, imgEmbedSize=8,
+                              numLayers=2, batchSize=1, learningRate=1e-3, gpuid=0))
+    dl = Dataloader(seed=1).from_arrays(info, raw, img, p, ['val'])
+    for k in ('vocabSize', 'maxQuesCount', 'maxQuesLen', 'maxAnsLen'):
+        p[k] = getattr(dl, k)
+    nat = NativeModel(p, init_seed=4)
+    py = Model(p)
+    py.set_parameters_dict(nat.get_parameters_dict())
+    cfg = dict(beamSize=3, beamLen=6, maxThreads=2)
+    out = nat.generateAnswers(dl, 'val', cfg)
+    assert out == py.generateAnswers(dl, 'val', cfg)
+    P = {k: v.astype(np.float64) for k, v in nat.get_parameters_dict().items()}
+    START, END = dl.word2ind['<START>'], dl.word2ind['<END>']
+    for conv in (1, 2):
+        batch = dl.getIndexData(np.array([conv]), p, 'val')
+        ref = vo.generate_beam(enc, P, p, batch, 3, 6, START, END)
+        for it, (beam, score) in enumerate(ref):
+            assert out[conv - 1]['dialog'][it]['answer'] == utils.idToWords(beam, dl.ind2word), (conv, it)
+    smp = dict(sampleWords=1, temperature=0.7, beamLen=5, maxThreads=2, seed=7)
+    a, b = nat.generateAnswers(dl, 'val', smp), py.generateAnswers(dl, 'val', smp)
+    assert a == b and all(x['answer'].startswith(' <START>') for x in a[0]['dialog'])
+    nat.close()

@@ -116,6 +116,10 @@ PROTOTYPES = {
     "vd_model_forward_backward": [_p, _i],
     "vd_model_loss": [_p, C.POINTER(C.c_float)],
     "vd_model_retrieve": [_p],
+    "vd_model_encode": [_p],
+    "vd_model_decode_begin": [_p, _p, _i],
+    "vd_model_decode_step": [_p, _p, _p],
+    "vd_model_decode_select": [_p, _p, _i],
     "vd_model_update": [_p, _f],
     "vd_model_learning_rate": [_p, C.POINTER(C.c_double), _i],
     "vd_model_scores": [_p, _p, _l],

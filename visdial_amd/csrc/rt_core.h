@@ -99,6 +99,8 @@ struct vd_model {
   std::unique_ptr<vdrt::Encoder> enc;
   std::unique_ptr<vdrt::Decoder> dec;
   float* scores = nullptr;  // [N x O] of the last forward / retrieval
+  float* gen_enc_out = nullptr;  // encoder output of the last vd_model_encode (generation)
+  int gen_seq_len = 0;
   int N = 0, O = 0;
   // capability flags from the encoder NAME (opts.lua:54-67)
   bool use_im = false, use_hist = false, is_att = false, is_graph = false;

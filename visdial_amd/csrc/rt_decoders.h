@@ -13,6 +13,14 @@ struct Decoder {
   virtual int forward_backward(vd_model* m, BatchSlot& b, bool only_forward) = 0;
   // Model:retrieveBatch up to the scores: leaves [N x O] option scores in m->scores
   virtual int retrieve(vd_model* m, BatchSlot& b) = 0;
+  // Model:generateAnswers device steps (model.lua:432-613); generative decoder only
+  virtual int gen_begin(vd_model*, const int32_t*, int) { return no_gen(); }
+  virtual int gen_step(vd_model*, const int32_t*, float*) { return no_gen(); }
+  virtual int gen_select(vd_model*, const int32_t*, int) { return no_gen(); }
+  static int no_gen() {
+    vd_set_error("sampling / beam search only for the generative decoder (model.lua:436-438)");
+    return VD_ERR_STATE;
+  }
 };
 
 inline int stage_loss(vd_model* m, const float* loss_rows, long n, bool is_sum, hipStream_t s) {
@@ -128,9 +136,18 @@ struct Disc : Decoder {
 // The encoder's per-layer final (h, c) seed the decoder layers and the encoder output replaces the top layer's initial
 // h (forwardConnect, gen.lua:30-42); backwardConnect hands the gradients w.r.t. those states back (gen.lua:45-60).
 // ------------------------------------------------------------------------------------------------------------
+struct Gen;
+int Gen_begin(Gen* g, vd_model* m, const int32_t* rounds, int n);
+int Gen_step(Gen* g, vd_model* m, const int32_t* tokens, float* host_logp);
+int Gen_select(Gen* g, vd_model* m, const int32_t* src, int n_keep);
+
 struct Gen : Decoder {
+  int gen_begin(vd_model* m, const int32_t* r, int n) override { return Gen_begin(this, m, r, n); }
+  int gen_step(vd_model* m, const int32_t* t, float* lp) override { return Gen_step(this, m, t, lp); }
+  int gen_select(vd_model* m, const int32_t* src, int k) override { return Gen_select(this, m, src, k); }
   std::vector<SeqLSTM> rnn;
   long E = 0, H = 0, V = 0, Vp = 0;
+  int gen_n = 0;                                     // live hypotheses of the running generation
   void declare(vd_model* m) override {
     E = m->p.embedSize; H = m->p.rnnHiddenSize; V = m->p.vocabSize; Vp = (V + 3) / 4 * 4;
     rnn.resize(m->p.numLayers);
@@ -256,6 +273,100 @@ struct Gen : Decoder {
     return VD_OK;
   }
 };
+
+// ---- Model:generateAnswers (model.lua:432-613): the device side of sampling / beam search.  The host keeps the
+// candidate bookkeeping (as the reference does in Lua); one call = one decoder step for all live hypotheses.
+inline int gen_rows(vd_model* m, const char* key, const int32_t* host, int n, int32_t** out) {
+  VD_TRY(ws_get(m, key, (size_t)std::max(n, 1), out));
+  VD_HIP(hipMemcpyAsync(*out, host, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, m->s_main));
+  VD_HIP(hipStreamSynchronize(m->s_main));           // `host` may be a temporary of the caller
+  return VD_OK;
+}
+// hiddenBeams (model.lua:478-503): hypothesis i starts from the encoder state of QA round rounds[i]
+inline int Gen_begin(Gen* g, vd_model* m, const int32_t* rounds, int n) {
+  VD_CHECK_ARG(m->gen_enc_out && rounds && n > 0, "vd_model_decode_begin: call vd_model_encode first");
+  for (int i = 0; i < n; ++i) VD_CHECK_ARG(rounds[i] >= 0 && rounds[i] < m->N, "vd_model_decode_begin: round %d out of range", rounds[i]);
+  hipStream_t s = m->s_main;
+  int32_t* idx;
+  VD_TRY(gen_rows(m, "gen.idx", rounds, n, &idx));
+  std::vector<SeqLSTM>* layers = m->enc->rnnLayers();
+  const int L = (int)g->rnn.size(), seqLen = m->gen_seq_len;
+  const long H = g->H;
+  for (int l = 0; l < L; ++l) {
+    float *h, *c, *hn, *cn;
+    VD_TRY(ws_get(m, "gen.h" + std::to_string(l), (size_t)n * H, &h));
+    VD_TRY(ws_get(m, "gen.c" + std::to_string(l), (size_t)n * H, &c));
+    VD_TRY(ws_get(m, "gen.hn" + std::to_string(l), (size_t)n * H, &hn));
+    VD_TRY(ws_get(m, "gen.cn" + std::to_string(l), (size_t)n * H, &cn));
+    if (layers) {
+      VD_CHECK_ARG(l < (int)layers->size(), "decoder has more layers than the encoder's recurrence");
+      const float* hs = l == (int)layers->size() - 1 ? m->gen_enc_out : (*layers)[l].out_at(seqLen - 1);
+      VD_TRY(vd_embed_gather(hs, idx, nullptr, h, n, (int)H, 1.f, s));
+      VD_TRY(vd_embed_gather((*layers)[l].cell_at(seqLen - 1), idx, nullptr, c, n, (int)H, 1.f, s));
+    } else {
+      VD_TRY(vd_memset(c, 0, (long)n * H * 4, s));
+      if (l == L - 1) VD_TRY(vd_embed_gather(m->gen_enc_out, idx, nullptr, h, n, (int)H, 1.f, s));
+      else VD_TRY(vd_memset(h, 0, (long)n * H * 4, s));
+    }
+  }
+  g->gen_n = n;
+  return VD_OK;
+}
+// model.lua:518-522 / :590-596: one decoder step for the n live hypotheses -> log-probabilities [n x V] on the host
+inline int Gen_step(Gen* g, vd_model* m, const int32_t* tokens, float* host_logp) {
+  const int n = g->gen_n;
+  VD_CHECK_ARG(n > 0 && tokens && host_logp, "vd_model_decode_step: call vd_model_decode_begin first");
+  hipStream_t s = m->s_main;
+  const long H = g->H, E = g->E, V = g->V, Vp = g->Vp;
+  int32_t* tok;
+  VD_TRY(gen_rows(m, "gen.tok", tokens, n, &tok));
+  VD_TRY(vd_memset(Wp(m, "embed"), 0, E * 4, s));                                   // LookupTableMaskZero pad row
+  const int L = (int)g->rnn.size();
+  std::vector<float*> h(L), c(L), hn(L), cn(L);
+  for (int l = 0; l < L; ++l) {
+    VD_TRY(ws_get(m, "gen.h" + std::to_string(l), (size_t)n * H, &h[l]));
+    VD_TRY(ws_get(m, "gen.c" + std::to_string(l), (size_t)n * H, &c[l]));
+    VD_TRY(ws_get(m, "gen.hn" + std::to_string(l), (size_t)n * H, &hn[l]));
+    VD_TRY(ws_get(m, "gen.cn" + std::to_string(l), (size_t)n * H, &cn[l]));
+    g->rnn[l].userPrevOutput = h[l];
+    g->rnn[l].userPrevCell = c[l];
+  }
+  float *x, *top, *logits;
+  VD_TRY(ws_get(m, "gen1.x", (size_t)n * E, &x));
+  VD_TRY(ws_get(m, "gen1.logits", (size_t)n * Vp, &logits));
+  VD_TRY(vd_embed_gather(Wp(m, "embed"), tok, nullptr, x, n, (int)E, 1.f, s));
+  VD_TRY(lstm_stack_forward(m, s, g->rnn, {x}, 1, n, tok, &top));
+  VD_TRY(vd_gemm_nt(top, H, Wp(m, "vocab.W"), H, Wp(m, "vocab.b"), logits, Vp, n, (int)V, (int)H, VD_ACT_NONE, 0, s));
+  VD_TRY(vd_log_softmax_rows(logits, Vp, n, (int)V, s));
+  for (int l = 0; l < L; ++l) {                                                      // the stepped state (decoderConnect, gen.lua:63-68)
+    VD_TRY(vd_memcpy_d2d(hn[l], g->rnn[l].out_at(0), (long)n * H * 4, s));
+    VD_TRY(vd_memcpy_d2d(cn[l], g->rnn[l].cell_at(0), (long)n * H * 4, s));
+  }
+  VD_HIP(hipMemcpy2DAsync(host_logp, (size_t)V * 4, logits, (size_t)Vp * 4, (size_t)V * 4, (size_t)n, hipMemcpyDeviceToHost, s));
+  VD_HIP(hipStreamSynchronize(s));
+  return VD_OK;
+}
+// model.lua:560-575: hypothesis i continues from the stepped state of hypothesis src[i]; slots >= n_keep keep theirs
+inline int Gen_select(Gen* g, vd_model* m, const int32_t* src, int n_keep) {
+  const int n = g->gen_n;
+  VD_CHECK_ARG(n > 0 && src && n_keep >= 0 && n_keep <= n, "vd_model_decode_select: bad arguments");
+  for (int i = 0; i < n_keep; ++i) VD_CHECK_ARG(src[i] >= 0 && src[i] < n, "vd_model_decode_select: src[%d] = %d out of range", i, src[i]);
+  if (n_keep == 0) return VD_OK;
+  hipStream_t s = m->s_main;
+  int32_t* idx;
+  VD_TRY(gen_rows(m, "gen.idx", src, n_keep, &idx));
+  const long H = g->H;
+  for (size_t l = 0; l < g->rnn.size(); ++l) {
+    float *h, *c, *hn, *cn;
+    VD_TRY(ws_get(m, "gen.h" + std::to_string(l), (size_t)n * H, &h));
+    VD_TRY(ws_get(m, "gen.c" + std::to_string(l), (size_t)n * H, &c));
+    VD_TRY(ws_get(m, "gen.hn" + std::to_string(l), (size_t)n * H, &hn));
+    VD_TRY(ws_get(m, "gen.cn" + std::to_string(l), (size_t)n * H, &cn));
+    VD_TRY(vd_embed_gather(hn, idx, nullptr, h, n_keep, (int)H, 1.f, s));
+    VD_TRY(vd_embed_gather(cn, idx, nullptr, c, n_keep, (int)H, 1.f, s));
+  }
+  return VD_OK;
+}
 
 inline std::unique_ptr<Decoder> make_decoder(const std::string& n) {
   if (n == "disc") return std::unique_ptr<Decoder>(new Disc());

@@ -349,8 +349,7 @@ int vd_model_upload_batch(vd_model* m, const vd_batch* hb) {
   VD_CHECK_ARG(!m->use_im || hb->img_feat, "vd_model_upload_batch: encoder '%s' needs img_feat", m->enc_name.c_str());
   const bool disc = m->dec_name == "disc";
   VD_CHECK_ARG(!disc || (hb->options && hb->To > 0), "vd_model_upload_batch: decoder 'disc' needs options");
-  VD_CHECK_ARG(disc || (hb->answer_in && hb->answer_out && hb->Ta > 0) || (hb->option_in && hb->option_out && hb->To > 0),
-               "vd_model_upload_batch: decoder 'gen' needs answer_in/answer_out (training) or option_in/option_out (retrieval)");
+  // (decoder gen: answer_in/answer_out for training, option_in/option_out for retrieval, neither for generation)
   BatchSlot& sl = m->slot[m->cur < 0 ? 0 : (m->cur ^ 1)];   // the slot the running step does not read
   hipStream_t s = m->s_copy;
   // the step that last read this slot may still be executing (the host runs ahead of the device)
@@ -429,6 +428,34 @@ int vd_model_retrieve(vd_model* m) {
   const int rc = m->dec->retrieve(m, *b);
   VD_HIP(hipEventRecord(b->done, m->s_main));
   return rc;
+}
+
+// Model:generateAnswers, device side (model.lua:432-613).  vd_model_encode = `forwardBackward(batch, true, true)`
+// (model.lua:464): encoder forward of the uploaded batch, state kept for vd_model_decode_begin.
+int vd_model_encode(vd_model* m) {
+  BatchSlot* b = nullptr;
+  VD_TRY(begin_step(m, false, &b));
+  m->gen_enc_out = nullptr;
+  float* out = nullptr;
+  const int rc = m->enc->forward(m, m->s_main, *b, &out);
+  VD_HIP(hipEventRecord(b->done, m->s_main));
+  if (rc == VD_OK) {
+    m->gen_enc_out = out;
+    m->gen_seq_len = m->enc->seqLen(*b);
+  }
+  return rc;
+}
+int vd_model_decode_begin(vd_model* m, const int32_t* rounds, int n) {
+  VD_CHECK_ARG(m, "vd_model_decode_begin: null model");
+  return m->dec->gen_begin(m, rounds, n);
+}
+int vd_model_decode_step(vd_model* m, const int32_t* tokens, float* host_logprobs) {
+  VD_CHECK_ARG(m, "vd_model_decode_step: null model");
+  return m->dec->gen_step(m, tokens, host_logprobs);
+}
+int vd_model_decode_select(vd_model* m, const int32_t* src, int n_keep) {
+  VD_CHECK_ARG(m, "vd_model_decode_select: null model");
+  return m->dec->gen_select(m, src, n_keep);
 }
 
 // waits for the loss of the last vd_model_forward_backward: disc = mean cross-entropy over the rounds, gen = summed

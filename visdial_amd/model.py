@@ -303,115 +303,47 @@ class Model(SplitEval):
         self.wrapper.training() if on else self.wrapper.evaluate()
 
     # ------------------------------------------------------------------ generation (model.lua:432-613)
-    def generateAnswers(self, dataloader, dtype, params=None):
-        """Beam search (default) or temperature sampling with the generative decoder, one dialog at a time,
-        exactly as the reference drives it from the host: the decoder step (embedding, LSTM stack, vocabulary
-        projection, log-softmax) runs on the device for all hypotheses at once, candidate bookkeeping is host
-        control flow.  Returns [{image_id, dialog: [{question, answer}...]}]."""
-        if self.params['decoder'] == 'disc':
-            raise SystemExit('Sampling/beam search only for generative model')
-        params = params or {}
-        sampleWords = bool(params.get('sampleWords', 0) == 1)
-        temperature = float(params.get('temperature', 1.0))
-        beamSize, beamLen = int(params.get('beamSize', 5)), int(params.get('beamLen', 20))
-        startToken, endToken = dataloader.word2ind['<START>'], dataloader.word2ind['<END>']
-        numThreads = int(params.get('maxThreads') or dataloader.numThreads[dtype])
-        rng = np.random.RandomState(int(params.get('seed', 1234)))
-        ind2word = dataloader.ind2word
-        H = self.params['rnnHiddenSize']
-        dec = self.decoder
-        L = len(dec.rnnLayers)
-        answerTable = []
-        self.wrapper.evaluate()
-        for convId in range(1, numThreads + 1):
-            batch = dataloader.getIndexData(np.array([convId]), self.params, dtype)
-            R = batch['ques_fwd'].shape[1]
-            Tq = batch['ques_fwd'].shape[2]
-            inputs, _ = self.prepare_inputs(batch)
-            ops.zero(self.fp.w['embed'][0])
-            encOut = self.encoder.forward(inputs)                                   # forwardBackward(batch, true, true)
-            encLayers = getattr(self.encoder, 'rnnLayers', None)
-            threadAnswers = []
+    # host loop: split_eval.SplitEval.generateAnswers; the four device steps over the operator-level entry points:
+    def _gen_encode(self, batch):
+        inputs, _ = self.prepare_inputs(batch)
+        ops.zero(self.fp.w['embed'][0])
+        encOut = self.encoder.forward(inputs)                                   # forwardBackward(batch, true, true)
+        self._gen = dict(encOut=encOut, encLayers=getattr(self.encoder, 'rnnLayers', None), Tq=batch['ques_fwd'].shape[2])
 
-            def init_hidden(rows, K):
-                """hiddenBeams of model.lua:478-503 for the given QA rounds, each repeated K times"""
-                idx = torch.tensor(np.repeat(rows, K).astype(np.int32), device=self.device)
-                hid = []
-                for level in range(L):
-                    if encLayers is not None:
-                        h = encOut if level == len(encLayers) - 1 else encLayers[level].output[Tq - 1]
-                        c = encLayers[level].cell[Tq - 1]
-                        hid.append((ops.embed_gather(h, idx, torch.empty(len(idx), H, device=self.device)),
-                                    ops.embed_gather(c, idx, torch.empty(len(idx), H, device=self.device))))
-                    else:
-                        z = torch.zeros(len(idx), H, device=self.device)
-                        h = ops.embed_gather(encOut, idx, torch.empty(len(idx), H, device=self.device)) if level == L - 1 else z
-                        hid.append((h, z.clone()))
-                return hid
-
-            if not sampleWords:
-                for it in range(R):
-                    beams = np.zeros((beamLen, beamSize), np.int64)
-                    hidden = init_hidden(np.array([it]), beamSize)
-                    beams[0] = startToken
-                    scores = np.zeros(beamSize)
-                    finish = []
-                    for step in range(1, beamLen):
-                        exploreSize = 1 if step == 1 else beamSize                    # all beams are <START> at first
-                        tok = torch.tensor(beams[step - 1:step].astype(np.int32), device=self.device)
-                        logp, newh = dec.step_logprobs(tok, hidden)
-                        cands = []
-                        for wordId in range(exploreSize):
-                            top = np.argsort(-logp[wordId], kind='stable')[:beamSize]  # torch.topk(..., true)
-                            for cid in top:
-                                cb = beams[:, wordId].copy()
-                                cb[step] = cid + 1                                     # vocabulary ids are 1-based
-                                sc = scores[wordId] + float(logp[wordId, cid])
-                                if cid + 1 == endToken:
-                                    finish.append(dict(beam=cb, length=step + 1, score=sc))
-                                else:
-                                    cands.append(dict(score=sc, beam=cb, src=wordId))
-                        cands.sort(key=lambda a: -a['score'])                         # (stable; Lua's table.sort is not)
-                        keep = cands[:beamSize]
-                        if keep:
-                            src = torch.tensor([c['src'] for c in keep] + [0] * (beamSize - len(keep)), dtype=torch.int32,
-                                               device=self.device)
-                            old = hidden
-                            hidden = []
-                            for level in range(L):
-                                h = ops.embed_gather(newh[level][0], src, torch.empty(beamSize, H, device=self.device))
-                                c = ops.embed_gather(newh[level][1], src, torch.empty(beamSize, H, device=self.device))
-                                if len(keep) < beamSize:                                # untouched slots keep their old state
-                                    h[len(keep):] = old[level][0][len(keep):]
-                                    c[len(keep):] = old[level][1][len(keep):]
-                                hidden.append((h, c))
-                        for i, c in enumerate(keep):
-                            beams[:, i] = c['beam']
-                            scores[i] = c['score']
-                    finish.sort(key=lambda a: -a['score'])
-                    best = finish[0]['beam'] if finish else beams[:, 0]               # (the reference errors if none ended)
-                    threadAnswers.append({'question': utils.idToWords(batch['ques_fwd'][0, it], ind2word),
-                                          'answer': utils.idToWords(best, ind2word)})
+    def _gen_begin(self, rounds):
+        """hiddenBeams of model.lua:478-503: hypothesis i starts from the encoder state of QA round rounds[i]"""
+        g, H, L = self._gen, self.params['rnnHiddenSize'], len(self.decoder.rnnLayers)
+        idx = torch.tensor(np.asarray(rounds, np.int32), device=self.device)
+        encOut, encLayers, Tq = g['encOut'], g['encLayers'], g['Tq']
+        hid = []
+        for level in range(L):
+            if encLayers is not None:
+                h = encOut if level == len(encLayers) - 1 else encLayers[level].output[Tq - 1]
+                c = encLayers[level].cell[Tq - 1]
+                hid.append((ops.embed_gather(h, idx, torch.empty(len(idx), H, device=self.device)),
+                            ops.embed_gather(c, idx, torch.empty(len(idx), H, device=self.device))))
             else:
-                numQues = R
-                hidden = init_hidden(np.arange(R), 1)
-                answerIn = np.full((1, numQues), startToken, np.int64)
-                answer = [answerIn.T.copy()]
-                for timeStep in range(beamLen):
-                    logp, hidden = dec.step_logprobs(torch.tensor(answerIn.astype(np.int32), device=self.device), hidden)
-                    pr = np.exp(logp.astype(np.float64) / temperature)
-                    pr /= pr.sum(1, keepdims=True)
-                    nxt = np.array([rng.choice(pr.shape[1], p=pr[i]) + 1 for i in range(numQues)], np.int64)
-                    answer.append(nxt[:, None])
-                    answerIn = nxt[None, :]
-                answer = np.concatenate(answer, 1)
-                for it in range(R):
-                    threadAnswers.append({'question': utils.idToWords(batch['ques_fwd'][0, it], ind2word),
-                                          'answer': utils.idToWords(answer[it], ind2word)})
-            img_ids = getattr(dataloader, 'unique_img_' + dtype, None)
-            answerTable.append({'image_id': img_ids[convId - 1] if img_ids else convId, 'dialog': threadAnswers})
-        self.wrapper.training()
-        return answerTable
+                z = torch.zeros(len(idx), H, device=self.device)
+                h = ops.embed_gather(encOut, idx, torch.empty(len(idx), H, device=self.device)) if level == L - 1 else z
+                hid.append((h, z.clone()))
+        g['hidden'] = hid
+
+    def _gen_step(self, tokens):
+        g = self._gen
+        tok = torch.tensor(np.asarray(tokens, np.int32)[None, :], device=self.device)
+        logp, g['stepped'] = self.decoder.step_logprobs(tok, g['hidden'])
+        return logp
+
+    def _gen_select(self, src, n_keep):
+        g, H = self._gen, self.params['rnnHiddenSize']
+        idx = torch.tensor(np.asarray(src, np.int32)[:n_keep], device=self.device)
+        hidden = []
+        for (h_old, c_old), (h_new, c_new) in zip(g['hidden'], g['stepped']):
+            h, c = h_old.clone(), c_old.clone()                                   # slots >= n_keep keep their old state
+            h[:n_keep] = ops.embed_gather(h_new, idx, torch.empty(n_keep, H, device=self.device))
+            c[:n_keep] = ops.embed_gather(c_new, idx, torch.empty(n_keep, H, device=self.device))
+            hidden.append((h, c))
+        g['hidden'] = hidden
 
     # ------------------------------------------------------------------ test / checkpoint helpers
     def get_parameters_dict(self):

@@ -265,6 +265,27 @@ class NativeModel(SplitEval):
     def _set_training(self, on):
         self.training(on)
 
+    # Model:generateAnswers (host loop in split_eval.py); the four device steps through the model-level ABI
+    def _gen_encode(self, batch):
+        self.upload({k: v for k, v in batch.items() if k in ('ques_fwd', 'hist', 'img_feat')})
+        call("vd_model_encode", self.h)
+
+    def _gen_begin(self, rounds):
+        r = np.ascontiguousarray(rounds, dtype=np.int32)
+        call("vd_model_decode_begin", self.h, r.ctypes.data, r.size)
+        self._gen_n = r.size
+
+    def _gen_step(self, tokens):
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        assert t.size == self._gen_n
+        out = np.empty((t.size, int(self.params['vocabSize'])), np.float32)
+        call("vd_model_decode_step", self.h, t.ctypes.data, out.ctypes.data)
+        return out
+
+    def _gen_select(self, src, n_keep):
+        s_ = np.ascontiguousarray(src, dtype=np.int32)
+        call("vd_model_decode_select", self.h, s_.ctypes.data, int(n_keep))
+
     def family_ms(self):
         a = (C.c_float * 3)()
         call("vd_model_family_ms", self.h, a)
