@@ -109,6 +109,34 @@ def test_process_ranks_matches_oracle():
         assert a[k] == b[k]
 
 
+def test_seqsort_metadata_and_non_pad_row_lists():
+    """host-side length sort of a right-aligned [T x N] token matrix (nn.SeqSort; the native runtime builds the same
+    arrays in upload_tokens): permutations are inverse of each other, step t owns the prefix [0, nact[t]), and the row
+    lists the masked weight gradients contract (vd_gemm_tn_rows_acc) are exactly the non-pad (t, row) pairs"""
+    import torch
+    from visdial_amd.nn import SeqSort
+    rng = np.random.RandomState(0)
+    T, N = 7, 13
+    lens = rng.randint(0, T + 1, size=N)
+    lens[3], lens[5] = 0, T                                   # an empty row and a full-length row
+    tok = np.zeros((T, N), np.int32)
+    for n, l in enumerate(lens):
+        tok[T - l:, n] = rng.randint(1, 50, size=l)
+    s = SeqSort(tok, torch.device('cpu'))
+    perm, inv = s.perm.numpy(), s.inv.numpy()
+    assert np.array_equal(perm[inv], np.arange(N)) and np.all(np.diff(lens[perm]) <= 0)
+    ts = s.tok_sorted.numpy()
+    assert np.array_equal(ts, tok[:, perm])
+    for t in range(T):
+        assert np.all(ts[t, :s.nact[t]] != 0) and np.all(ts[t, s.nact[t]:] == 0)
+    assert np.array_equal(ts.reshape(-1)[s.inv_idx.numpy()].reshape(T, N), tok)      # sorted -> original layout
+    assert np.array_equal(tok.reshape(-1)[s.fwd_idx.numpy()].reshape(T, N), ts)
+    act, act1, prev1 = (a.numpy() for a in s.rows)
+    assert np.array_equal(act, np.flatnonzero(ts.reshape(-1) != 0))                  # all non-pad pairs, in step order
+    assert np.array_equal(act1, act[act >= N]) and np.array_equal(prev1, act1 - N)
+    assert act.size == lens.sum()
+
+
 def test_shard_dialogs_partition():
     from visdial_amd.parallel import shard_dialogs
     for n, w in ((20, 8), (160, 8), (7, 3), (5, 1)):
