@@ -59,7 +59,9 @@ int vd_copy_2d(float* dst, int64_t dst_ld, const float* src, int64_t src_ld, int
 
 /* ---- dense contractions (nn.Linear / hoisted SeqLSTM input projection / weight grads) -- */
 /* C[MxN] (+)= act(A[MxK] * W[NxK]^T + bias)   -- nn.Linear:updateOutput (+nn.Tanh),
- * e.g. encoders/mn-att-ques-im-hist.lua:64-65,77,88,106; also dX = dA * Wh^T style products. */
+ * e.g. encoders/mn-att-ques-im-hist.lua:64-65,77,88,106; also dX = dA * Wh^T style products.
+ * accumulate: 0 = overwrite, 1 = C += (plain read-modify-write), 2 = C += with float atomics (C has other
+ * concurrent atomic writers: the shared embedding gradient) */
 int vd_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C,
                int64_t ldc, int M, int N, int K, int act, int accumulate, void* stream);
 /* C[MxN] (+)= A[MxK] * B[KxN] + bias           -- x*Wx+b of nn.SeqLSTM (mn-att:27-41), nn.Linear:updateGradInput */

@@ -777,6 +777,10 @@ struct EpiStore {
         float v = acc[j][r] + bv;
         if (act == VD_ACT_TANH) v = tanhf(v);
         float* d = C + (long)row * ldc + col;
+        if (accumulate == 2) {   // C += ... with a hardware float atomic: safe beside other (atomic) writers of C
+          atomicAdd(d, v);
+          continue;
+        }
         if (accumulate) v += *d;
         *d = v;
       }

@@ -121,10 +121,11 @@ struct Disc : Decoder {
                             s));
     VD_HIP(hipEventRecord(m->ev_prof[5], s));
     if (dwh_first) VD_TRY(enc_bwd());
+    // dEmb += dTable * Wx^T on the table stream, with float atomics: the SHARED embedding gradient has concurrent atomic
+    // writers (the encoder's scatters), and the product is off the main stream's critical path this way
+    VD_TRY(vd_gemm_nt(dtab, 4 * H, Wopt, 4 * H, nullptr, Gp(m, "embed"), E, (int)V + 1, (int)E, (int)(4 * H), VD_ACT_NONE, 2, st));
     VD_TRY(join_stream(m, se, s));
-    VD_TRY(join_stream(m, st, s));
-    // dEmb += dTable * Wx^T: non-atomic read-modify-write of the SHARED embedding gradient, after every other writer
-    return vd_gemm_nt(dtab, 4 * H, Wopt, 4 * H, nullptr, Gp(m, "embed"), E, (int)V + 1, (int)E, (int)(4 * H), VD_ACT_NONE, 1, s);
+    return join_stream(m, st, s);
   }
   int retrieve(vd_model* m, BatchSlot& b) override { return forward_backward(m, b, true); }   // model.lua:421-425
 };

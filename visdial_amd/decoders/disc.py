@@ -86,6 +86,9 @@ class Decoder(object):
             ops.segment_rowsum_acc(da, tokf, perm, dtab)
             ops.colsum_acc(dtab, self.db, M=V + 1, N=4 * H)
             ops.gemm_tn_acc(self.emb, dtab, self.dWx, M=self.E, N=4 * H, K=V + 1)
+            # dEmb += dTable * Wx^T with float atomics (accumulate = 2): the SHARED embedding gradient has concurrent
+            # atomic writers (the encoder's scatters); off the main stream's critical path here
+            ops.gemm_nt(dtab, self.Wx, self.demb, accumulate=2, M=V + 1, N=self.E, K=4 * H)
         if To > 1 and not fused:
             t0 = ops.prof_begin('opt_lstm_dWh')
             ops.gemm_tn_acc(self.h.view(To * NO, H), da[NO:], self.dWh, M=H, N=4 * H, K=(To - 1) * NO,
@@ -95,10 +98,8 @@ class Decoder(object):
         return [None, d_enc]
 
     def backward_embed(self):
-        """dEmb += dTable * Wx^T.  Non-atomic read-modify-write of the SHARED embedding gradient: must be
-        ordered after every other writer of that buffer (the encoder's atomic scatters)."""
+        """the table-gradient stream (incl. dEmb += dTable * Wx^T) joins the main stream"""
         self.streams.join('tab')
-        ops.gemm_nt(self.dtab, self.Wx, self.demb, accumulate=True, M=self.V + 1, N=self.E, K=4 * self.H)
 
 
 def model(params, enc, fp, ws, drop):
