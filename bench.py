@@ -92,6 +92,8 @@ def cpu_baseline(seconds_budget=30.0, batch=20):
     from oracle import cpu_step, visdial_oracle as vo          # checker / baseline only
     from visdial_amd.dataloader import SyntheticDataloader
     p = headline_params(batch=batch)
+    threads = cpu_step.fit_threads_to_quota()       # the boxes run the container under a CPU quota (see cpu_step.cpu_quota)
+    quota = cpu_step.cpu_quota()
     dl = SyntheticDataloader(p, seed=1234, fast=True)
     b = dl.getTrainBatch(p)
     P = vo.init_params(p['encoder'], p['decoder'], p, seed=1234, dtype=np.float32)
@@ -112,13 +114,14 @@ def cpu_baseline(seconds_budget=30.0, batch=20):
         cs.step(b, drop, update=True)
         times.append(time.time() - t0)
     dt = float(np.median(times)) if times else first
-    return {"value": round(N / dt, 3), "unit": "QA-rounds/s", "cores": cpu_step.num_threads(), "kind": "port",
+    return {"value": round(N / dt, 3), "unit": "QA-rounds/s", "cores": threads, "kind": "port",
             "sample": "oracle/cpu_step.cpp: C++17/OpenMP fp32 restatement of the step (per-timestep GEMMs on the %s "
                       "kernel, 10x image replication, clamp+adam), identical shape B=%d dialogs x 10 rounds x 100 "
-                      "options, %s, %.2f s/step; os.cpu_count=%d; restated CPU baseline, not Torch7"
+                      "options, %s, %.2f s/step; %d OpenMP threads, os.cpu_count=%d, container CPU quota=%s; restated "
+                      "CPU baseline, not Torch7"
                       % (cpu_step.gemm_kernel(), batch,
                          ("median of %d timed steps after 1 warm-up" % n) if times else "the single warm-up step only",
-                         dt, os.cpu_count() or 0)}
+                         dt, threads, os.cpu_count() or 0, ("%.0f CPUs" % quota) if quota else "none")}
 
 
 def respawn_under_torchrun(args):

@@ -409,6 +409,7 @@ struct vdcpu_dims {
 };
 
 int vdcpu_num_threads(void) { return omp_get_max_threads(); }
+void vdcpu_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 const char* vdcpu_gemm_kernel(void) { return kernel().name; }
 int64_t vdcpu_num_params(const vdcpu_dims* dd) {
   Dims d{dd->B, dd->R, dd->Tq, dd->Th, dd->To, dd->O, dd->V, dd->E, dd->H, dd->S2, dd->C, dd->K};

@@ -34,6 +34,8 @@ def load():
         lib.vdcpu_num_params.restype = C.c_int64
         lib.vdcpu_num_params.argtypes = [C.POINTER(Dims)]
         lib.vdcpu_num_threads.restype = C.c_int
+        lib.vdcpu_set_num_threads.restype = None
+        lib.vdcpu_set_num_threads.argtypes = [C.c_int]
         lib.vdcpu_gemm_kernel.restype = C.c_char_p
         lib.vdcpu_gemm.restype = None
         lib.vdcpu_gemm.argtypes = [C.c_int] * 3 + [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
@@ -42,8 +44,36 @@ def load():
     return _lib
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited.  The GPU
+    boxes expose 256 logical CPUs but run the container under a 16-CPU quota: 128 OpenMP threads are throttled to a
+    third of the rate 32 threads reach (scripts/cpu_probe.py: 570 vs 1 650 GFLOP/s on the 20 000 x 512 x 2 048 GEMM)."""
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        return None if q == 'max' else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def num_threads():
     return int(load().vdcpu_num_threads())
+
+
+def fit_threads_to_quota():
+    """OpenMP threads = 2 x the CPU quota (the best of the 8..256 sweep), never more than the default.  Returns the
+    thread count in use."""
+    lib = load()
+    q = cpu_quota()
+    if q:
+        want = max(1, min(num_threads(), int(round(2 * q))))
+        lib.vdcpu_set_num_threads(want)
+    return num_threads()
 
 
 def gemm_kernel():
