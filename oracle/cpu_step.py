@@ -41,6 +41,9 @@ def load():
         lib.vdcpu_gemm.argtypes = [C.c_int] * 3 + [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                                    C.c_void_p, C.c_int64, C.c_int]
         _lib = lib
+        q = cpu_quota()
+        if q:       # never run more OpenMP threads than twice the container's CPU quota (they would only be throttled)
+            lib.vdcpu_set_num_threads(max(1, min(int(lib.vdcpu_num_threads()), int(round(2 * q)))))
     return _lib
 
 
