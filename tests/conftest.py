@@ -8,6 +8,29 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _cpu_quota():
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        return None if q == 'max' else float(q) / float(per)
+    except Exception:
+        return None
+
+
+# The GPU boxes show 256 logical CPUs but run the container under a 16-CPU quota: BLAS / OpenMP pools sized by
+# cpu_count are throttled to a fraction of what 2 x quota threads reach (the numpy fp64 oracle dominates the -m gpu
+# suite's wall time).  Size the pools to the quota; an explicit OMP_NUM_THREADS wins.
+_q = _cpu_quota()
+if _q and 'OMP_NUM_THREADS' not in os.environ:
+    _n = str(max(1, int(round(2 * _q))))
+    for _k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        os.environ.setdefault(_k, _n)                 # for libraries not loaded yet
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=int(_n))             # for the ones that already are
+    except Exception:
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
