@@ -32,7 +32,7 @@ def _host_arg(argv):
             return argv[i + 1]
         if a.startswith('--host='):
             return a.split('=', 1)[1]
-    return 'native'
+    return os.environ.get('VD_BENCH_HOST', 'native')
 
 
 # The native host issues the whole step from one thread onto five library-owned HIP streams.  HIP multiplexes streams
