@@ -321,4 +321,15 @@ function Model:setFlatParameters(flat)
     end
 end
 
+-- `model.wrapperW` as train.lua:100,120 reads it (torch.save of {modelW = model.wrapperW, ...}, `model.wrapperW:float()`):
+-- a host FloatTensor snapshot of the flat parameter vector, built on access.  (Writing goes through
+-- model:setFlatParameters(t): the three `model.wrapperW:copy(savedModel.modelW)` lines of train.lua:79,
+-- evaluate.lua:91 and generate.lua:83 are the only edits those scripts need.)
+local methods = Model.__index
+Model.__index = function(self, key)
+    if key == 'wrapperW' then return self:getFlatParameters() end
+    if type(methods) == 'function' then return methods(self, key) end
+    return methods[key]
+end
+
 return Model
