@@ -45,15 +45,27 @@ function Model:__init(params)
     p.lstmBf16 = 0;                           p.useStreams = 1
     p.numLayers = params.numLayers or 2;      p.imgEmbedSize = params.imgEmbedSize or 300
     p.dropout = params.dropout or 0.5
-    if params.gpuid and params.gpuid >= 0 then vd.call('vd_set_device', params.gpuid) end
+    -- device: VD_DEVICE wins (lets the UNCHANGED train.lua run with `-gpuid -1`, i.e. without its
+    -- `require 'cutorch'` branch, train.lua:15-20, while the library still computes on a GPU), else -gpuid, else 0
+    local dev = tonumber(os.getenv('VD_DEVICE') or '') or ((params.gpuid and params.gpuid >= 0) and params.gpuid or 0)
+    vd.call('vd_set_device', dev)
     local h = ffi.new('vd_model*[1]')
     vd.call('vd_model_create', p, self.encoder.native, self.decoder.native, h)
     self.h = ffi.gc(h[0], C.vd_model_destroy)
     vd.call('vd_model_init_params', self.h, 1234)                      -- library-default init (weight-init.lua is a no-op)
     -- optimiser state lives in the library; the learning rate is mirrored for train.lua's log line / checkpoints
     self.optims = {learningRate = params.learningRate}
-    self.runningLoss = 0
     self.havePrefetched = false
+    self.numTokens = 0
+end
+
+-- `model.wrapperW` (train.lua:79,100,120; evaluate.lua:91; generate.lua:83) is a real host FloatTensor: checked out
+-- of the library on access (Model.__index at the end of this file) and written back before the next device call, so
+-- `model.wrapperW:copy(savedModel.modelW)`, `torch.save({modelW = model.wrapperW, ...})` and `model.wrapperW:float()`
+-- all work on the reference's scripts as they are.
+function Model:commitW()
+    local w = rawget(self, 'checkedOutW')
+    if w then self:setFlatParameters(w); rawset(self, 'checkedOutW', nil) end
 end
 
 -- batch tables of dataloader.lua:324-339,378-475 -> vd_batch (host pointers; consumed before the call returns)
@@ -77,6 +89,8 @@ function Model:upload(batch)
         b.option_out = ints(batch['option_out']):data()
     end
     vd.call('vd_model_upload_batch', self.h, b)
+    -- non-pad target tokens of THIS batch: the gen loss EMA divides by it (model.lua:76-85)
+    self.numTokens = batch['answer_out'] and batch['answer_out']:gt(0):sum() or 0
 end
 
 function Model:loss()
@@ -87,9 +101,11 @@ end
 
 -- model.lua:66-106, software-pipelined: enqueue the step, upload the NEXT batch while the device runs, read the loss
 function Model:trainIteration(dataloader)
+    self:commitW()
     if not self.havePrefetched then
         self:upload(dataloader:getTrainBatch(self.params)); self.havePrefetched = true
     end
+    local numTokens = self.numTokens                                   -- of the batch this step trains on
     vd.call('vd_model_forward_backward', self.h, 0)
     local lr = ffi.new('double[1]', self.optims.learningRate)
     vd.call('vd_model_learning_rate', self.h, lr, 1)
@@ -98,13 +114,18 @@ function Model:trainIteration(dataloader)
     self.optims.learningRate = tonumber(lr[0])
     self:upload(dataloader:getTrainBatch(self.params))
     local curLoss = self:loss()
-    if self.runningLoss > 0 then self.runningLoss = 0.95 * self.runningLoss + 0.05 * curLoss
-    else self.runningLoss = curLoss end
+    -- model.lua:73-93: the EMA lives in the GLOBAL `runningLoss` that train.lua:89 initialises and train.lua:113 prints;
+    -- gen feeds curLoss / numTokens (the criterion sums over tokens), disc curLoss
+    local cur = curLoss
+    if self.params.decoder == 'gen' then cur = curLoss / math.max(numTokens, 1) end
+    if (runningLoss or 0) > 0 then runningLoss = 0.95 * runningLoss + 0.05 * cur
+    else runningLoss = cur end
     return curLoss
 end
 
 -- model.lua:249-342 (both decoder branches; forwardConnect / backwardConnect run inside the library)
 function Model:forwardBackward(batch, onlyForward)
+    self:commitW()
     self:upload(batch); self.havePrefetched = false
     vd.call('vd_model_forward_backward', self.h, onlyForward and 1 or 0)
     return self:loss()
@@ -112,6 +133,7 @@ end
 
 -- model.lua:344-430 + utils.computeRanks (utils.lua:106-128)
 function Model:retrieveBatch(batch)
+    self:commitW()
     self:upload(batch); self.havePrefetched = false
     vd.call('vd_model_retrieve', self.h)                               -- disc: option scores; gen: candidate log-likelihoods
     local N = batch['ques_fwd']:size(1) * batch['ques_fwd']:size(2)
@@ -214,6 +236,7 @@ function Model:generateAnswers(dataloader, dtype, params)
     local numThreads = params.maxThreads or dataloader.numThreads[dtype]
     local V = self.params.vocabSize
     local answerTable = {}
+    self:commitW()
     self:setMode(false)
     for convId = 1, numThreads do
         local batch = dataloader:getIndexData(torch.LongTensor{convId}, self.params, dtype)
@@ -321,13 +344,20 @@ function Model:setFlatParameters(flat)
     end
 end
 
--- `model.wrapperW` as train.lua:100,120 reads it (torch.save of {modelW = model.wrapperW, ...}, `model.wrapperW:float()`):
--- a host FloatTensor snapshot of the flat parameter vector, built on access.  (Writing goes through
--- model:setFlatParameters(t): the three `model.wrapperW:copy(savedModel.modelW)` lines of train.lua:79,
--- evaluate.lua:91 and generate.lua:83 are the only edits those scripts need.)
+-- `model.wrapperW`: every access checks the flat vector out of the library into a host FloatTensor (a fresh D2H
+-- snapshot, 57 MB for the headline pair) and remembers it; commitW() -- first thing in every method that touches the
+-- device -- writes it back, so both directions of the reference's uses work on the unchanged scripts:
+--   model.wrapperW:copy(savedModel.modelW)                    train.lua:79, evaluate.lua:91, generate.lua:83
+--   torch.save(path, {modelW = model.wrapperW, ...})          train.lua:100   (a plain FloatTensor is serialised)
+--   model.wrapperW:float()                                    train.lua:120
+-- (a read-only access costs one redundant H2D of identical values before the next step.)
 local methods = Model.__index
 Model.__index = function(self, key)
-    if key == 'wrapperW' then return self:getFlatParameters() end
+    if key == 'wrapperW' then
+        local w = rawget(self, 'checkedOutW')
+        if not w then w = self:getFlatParameters(); rawset(self, 'checkedOutW', w) end
+        return w
+    end
     if type(methods) == 'function' then return methods(self, key) end
     return methods[key]
 end

@@ -30,13 +30,31 @@ def test_train_then_evaluate(tmp_path, host):
     assert len(lines) == 2 and '[lr:' in lines[0]
     loss = [float(l.split('[Loss:')[1].split(']')[0]) for l in lines]
     assert loss[1] < loss[0] < 6.0
-    assert os.path.exists(save + 'model_final.pt') and os.path.exists(save + 'model_epoch_10.pt')
-    e = subprocess.run([sys.executable, os.path.join(ROOT, 'evaluate.py'), '-loadPath', save + 'model_final.pt',
+    # checkpoints under the reference's names, in the Torch7 binary format (train.lua:99-102,120-121)
+    assert os.path.exists(save + 'model_final.t7') and os.path.exists(save + 'model_epoch_10.t7')
+    from visdial_amd import t7
+    ck = t7.load(save + 'model_epoch_10.t7')
+    assert set(ck) >= {'modelW', 'optims', 'modelParams'} and ck['optims']['learningRate'] < 1e-3
+    assert ck['vdLayout'] == 'declaration'                 # nngraph encoder: own order, marked (never guessed)
+    e = subprocess.run([sys.executable, os.path.join(ROOT, 'evaluate.py'), '-loadPath', save + 'model_final.t7',
                         '-batchSize', '4', '--numThreads', '8', '-saveRanks', '1', '-saveRankPath',
                         str(tmp_path / 'ranks.json'), '-perplexity', '1', '-host', 'native' if host == 'python' else 'python'],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert e.returncode == 0, e.stdout[-2000:] + e.stderr[-2000:]
     assert 'r@1:' in e.stdout and 'meanRR:' in e.stdout and os.path.exists(str(tmp_path / 'ranks.json'))
+    # resume from the epoch checkpoint (train.lua:32-41,78-81): weights + learning rate come back, the run continues
+    # on the host named on the COMMAND LINE (not the one stored in the checkpoint)
+    other = 'native' if host == 'python' else 'python'
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py')] + common[:-1] + [other] +
+                        ['-loadPath', save + 'model_epoch_10.t7', '-synthetic', '1', '-savePath', save + 'resumed/',
+                         '-numEpochs', '10', '-saveIter', '100', '--maxIters', '100', '-saveFormat', 'pt'],
+                        capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    l2 = [float(l.split('[Loss:')[1].split(']')[0]) for l in r2.stdout.splitlines() if '[Loss:' in l]
+    lr2 = [float(l.split('[lr:')[1].split(']')[0]) for l in r2.stdout.splitlines() if '[lr:' in l]
+    assert len(l2) == 1 and l2[0] < loss[0]                 # it starts from trained weights, not from scratch
+    assert lr2[0] < ck['optims']['learningRate']           # the decayed learning rate was restored and kept decaying
+    assert os.path.exists(save + 'resumed/model_final.pt')
 
 
 def test_train_evaluate_on_real_format_files(tmp_path):
@@ -68,7 +86,7 @@ def test_train_evaluate_on_real_format_files(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), '-encoder', 'mn-att-ques-im-hist', '-decoder', 'disc',
                         '-imgFeatureSize', '8', '-imgSpatialSize', '3', '-rnnHiddenSize', '32', '-embedSize', '16',
                         '-commonEmbeddingSize', '32', '-batchSize', '4', '-savePath', save, '-numEpochs', '100',
-                        '-saveIter', '1000', '--maxIters', '200'] + data,
+                        '-saveIter', '1000', '--maxIters', '200', '-saveFormat', 'pt'] + data,
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'synthetic' not in r.stdout

@@ -58,3 +58,31 @@ def test_model_lua_calls_only_exported_symbols():
     body = h[h.index('typedef struct vd_model_params'):h.index('} vd_batch;')]
     for field in set(re.findall(r'\b[pb]\.([A-Za-z_]+)\s*=', src)):
         assert re.search(r'\b%s\b' % field, body), field
+
+
+def test_model_lua_keeps_the_reference_script_contract():
+    """What the reference's UNCHANGED train.lua / evaluate.lua / generate.lua read and write on the model object
+    (train.lua:79-81,89,100-102,113,120; evaluate.lua:91; generate.lua:83) must exist in lua/model.lua."""
+    src = open(os.path.join(ROOT, 'lua', 'model.lua')).read()
+    code = '\n'.join(l.split('--')[0] for l in src.splitlines())          # comments stripped
+    # the loss EMA is the GLOBAL `runningLoss` (train.lua:89 sets it, train.lua:113 prints it; model.lua:81-92)
+    assert re.search(r'(?m)^\s*(if .* then )?runningLoss\s*=', code), "trainIteration must assign the global runningLoss"
+    assert 'self.runningLoss' not in code and not re.search(r'local\s+runningLoss', code)
+    # gen: the EMA is fed curLoss / numTokens (model.lua:76-85)
+    assert re.search(r"decoder\s*==\s*'gen'\s*then\s*cur\s*=\s*curLoss\s*/", code)
+    assert ":gt(0):sum()" in code
+    # model.wrapperW is a real tensor that can be read AND written; written back before any device call
+    assert "key == 'wrapperW'" in code and 'function Model:commitW()' in code
+    for method in ('trainIteration', 'forwardBackward', 'retrieveBatch', 'generateAnswers'):
+        body = code[code.index('function Model:%s(' % method):]
+        body = body[:body.index('\nend\n')]
+        assert 'self:commitW()' in body, method
+        first_call = re.search(r"vd\.call\(", body)
+        assert body.index('self:commitW()') < first_call.start(), method
+    # fields / methods the scripts use
+    for needle in ('self.optims = {learningRate', 'function Model:retrieve(', 'function Model:predict(',
+                   'function Model:evaluate(', 'function Model:generateAnswers(', 'self.optims.learningRate = '):
+        assert needle in code, needle
+    # the three scripts need no edit: INTEGRATION.md must not tell the user to edit them any more
+    integ = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    assert 'setFlatParameters(savedModel.modelW)' not in integ

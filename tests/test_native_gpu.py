@@ -357,3 +357,53 @@ def test_native_beam_search_matches_oracle(gpu, enc):
     a, b = nat.generateAnswers(dl, 'val', smp), py.generateAnswers(dl, 'val', smp)
     assert a == b and all(x['answer'].startswith(' <START>') for x in a[0]['dialog'])
     nat.close()
+
+
+@pytest.mark.parametrize("enc,dec", [('lf-ques-im-hist', 'gen'), ('mn-att-ques-im-hist', 'disc')])
+def test_running_loss_is_the_same_through_both_hosts(gpu, enc, dec):
+    """model.lua:73-93: the loss EMA is fed curLoss / numTokens for gen (the criterion SUMS over tokens) and curLoss for
+    disc.  Same parameters, same dataloader stream, dropout off: the two hosts must log the same `[Loss:...]`."""
+    from visdial_amd.model import Model
+    from visdial_amd.native import NativeModel
+    p = derive(small_params(encoder=enc, decoder=dec, **CASES['tiny']))
+    py, nat = Model(dict(p)), NativeModel(dict(p))
+    nat.set_parameters_dict(py.get_parameters_dict())
+    py.wrapper.evaluate()
+    nat.training(False)
+    d1, d2 = SyntheticDataloader(p, seed=21), SyntheticDataloader(p, seed=21)
+    cur = []
+    for _ in range(3):
+        a, b = py.trainIteration(d1), nat.trainIteration(d2)
+        assert abs(a - b) < 1e-4 * max(1.0, abs(a)), (a, b)          # curLoss itself (gen: the un-normalised sum)
+        cur.append(a)
+    assert py.runningLoss > 0 and abs(py.runningLoss - nat.runningLoss) < 1e-5 * max(1.0, py.runningLoss)
+    if dec == 'gen':      # the EMA is per token: far below the summed NLL the criterion returns
+        assert nat.runningLoss < 0.2 * min(cur)
+    nat.close()
+
+
+def test_retrieve_between_training_steps_does_not_train_on_the_eval_batch(gpu):
+    """trainIteration prefetches the next training batch into the library's second slot; evaluate / retrieve / predict
+    between two steps replace it.  The next trainIteration must notice and fetch a training batch again (lua/model.lua:
+    havePrefetched = false on those paths) -- same parameters as the Python host after the same interleaving."""
+    from visdial_amd.model import Model
+    from visdial_amd.native import NativeModel
+    p = derive(small_params(**CASES['tiny']))
+    py, nat = Model(dict(p)), NativeModel(dict(p))
+    nat.set_parameters_dict(py.get_parameters_dict())
+    py.wrapper.evaluate()
+    nat.training(False)
+    d1, d2 = SyntheticDataloader(p, seed=5), SyntheticDataloader(p, seed=5)
+    val = SyntheticDataloader(p, seed=77).getTrainBatch(p)
+    for it in range(4):
+        a, b = py.trainIteration(d1), nat.trainIteration(d2)
+        assert abs(a - b) < 1e-4, (it, a, b)
+        if it % 2 == 0:
+            py.params['useGt'] = True
+            r1, r2 = py.retrieveBatch(val), nat.retrieveBatch(val, useGt=True)
+            r1 = r1.cpu().numpy() if hasattr(r1, 'cpu') else np.asarray(r1)
+            np.testing.assert_array_equal(r1.reshape(-1), np.asarray(r2).reshape(-1))
+    w1, w2 = py.get_parameters_dict(), nat.get_parameters_dict()
+    for k in w1:
+        assert np.abs(w1[k] - w2[k]).max() < 2e-5, k
+    nat.close()

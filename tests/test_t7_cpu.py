@@ -112,3 +112,52 @@ def test_reference_parameter_order_per_encoder_family():
         with pytest.raises(ValueError):
             t7.flat_to_named(flat, e, enc)
         t7.flat_to_named(flat, e, enc, allow_unverified=True)
+
+
+class _FakeModel(object):
+    """the three things checkpoint.save_t7 / restore_weights use of a host model"""
+
+    def __init__(self, encoder, named):
+        self.params = {'encoder': encoder}
+        self.optims = {'learningRate': 7e-4}
+        self.named = named
+
+    def _entries(self):
+        return [(k, v.shape, 'lin_w') for k, v in self.named.items()]
+
+    def get_parameters_dict(self):
+        return self.named
+
+    def set_parameters_dict(self, d):
+        self.named = {k: np.array(v) for k, v in d.items()}
+
+    def load_flat_parameters(self, w, allow_unverified=False):
+        self.set_parameters_dict(t7.flat_to_named(w, self._entries(), self.params['encoder'], allow_unverified))
+
+
+def test_cli_checkpoint_t7_roundtrip_marks_unverified_layouts(tmp_path):
+    """train.py's model_epoch_%d.t7 / model_final.t7 (train.lua:99-102,120-121): Sequential encoders are written in the
+    reference's getParameters() order; nngraph encoders in this library's declaration order WITH a marker, and
+    restore_weights follows the marker instead of guessing (a Torch7-written file without it stays refused)."""
+    import pytest
+    from visdial_amd import checkpoint
+    rng = np.random.RandomState(3)
+    named = {'embed': rng.randn(5, 4).astype(np.float32), 'hist1.W': rng.randn(6, 8).astype(np.float32),
+             'img_embed.W': rng.randn(3, 4).astype(np.float32), 'ques1.W': rng.randn(6, 8).astype(np.float32)}
+    for enc, marked in (('hre-ques-im-hist', False), ('mn-att-ques-im-hist', True)):
+        m = _FakeModel(enc, dict(named))
+        p = str(tmp_path / (enc + '.t7'))
+        checkpoint.save_t7(p, m, {'encoder': enc, 'decoder': 'disc', 'rnnHiddenSize': 8})
+        ck = checkpoint.load_checkpoint(p)
+        assert ('vdLayout' in ck) == marked and abs(ck['optims']['learningRate'] - 7e-4) < 1e-12
+        if not marked:     # reference order: the image Linear sits between embed and the history LSTM
+            np.testing.assert_array_equal(ck['modelW'][20:32], named['img_embed.W'].reshape(-1))
+        m2 = _FakeModel(enc, {k: np.zeros_like(v) for k, v in named.items()})
+        checkpoint.restore_weights(m2, ck)
+        for k in named:
+            np.testing.assert_array_equal(m2.named[k], named[k])
+    # the same vector WITHOUT the marker is what Torch7 would have written: refused unless the caller insists
+    ck.pop('vdLayout')
+    with pytest.raises(ValueError):
+        checkpoint.restore_weights(m2, ck)
+    checkpoint.restore_weights(m2, ck, allow_unverified=True)

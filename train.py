@@ -16,7 +16,7 @@ import torch
 from visdial_amd import opts
 from visdial_amd.dataloader import Dataloader, SyntheticDataloader
 from visdial_amd.model import Model
-from visdial_amd.checkpoint import load_checkpoint, restore_weights
+from visdial_amd.checkpoint import load_checkpoint, restore_weights, save_t7
 
 
 def _plain(d):
@@ -44,7 +44,9 @@ def main():
         for k in ('imgNorm', 'encoder', 'decoder'):              # the only three options taken from the checkpoint
             opt[k] = mp[k]
         mp['gpuid'], mp['batchSize'] = opt['gpuid'], opt['batchSize']
-        for k in ('numEpochs', 'maxIters', 'savePath', 'saveIter'):   # run control stays with the command line
+        # run control and runtime (non-architectural) choices stay with the command line
+        for k in ('numEpochs', 'maxIters', 'savePath', 'saveIter', 'host', 'lstmPrecision', 'saveFormat',
+                  'allowUnverifiedOrder', 'synthetic'):
             mp[k] = opt.get(k)
     # the dataloader is built from the CURRENT command line (train.lua:47-48), never from paths stored in a checkpoint
     have = lambda p: os.path.exists(p) or os.path.exists(p[:-3] + '.npz')
@@ -70,7 +72,7 @@ def main():
     else:
         model = Model(opt)
     if saved is not None:                                        # train.lua:78-81
-        restore_weights(model, saved)
+        restore_weights(model, saved, allow_unverified=bool(opt.get('allowUnverifiedOrder')))
         model.optims['learningRate'] = saved['optims']['learningRate']
     print('Training..')
     total = opt['numEpochs'] * opt['numIterPerEpoch']
@@ -81,9 +83,12 @@ def main():
         model.trainIteration(dataloader)
         if it % (opt['saveIter'] * opt['numIterPerEpoch']) == 0:      # train.lua:95-102
             ep = it // opt['numIterPerEpoch']
-            torch.save({'modelW': model.wrapperW.cpu(), 'optims': {k: model.optims[k] for k in model.optims.keys()},
-                        'modelParams': _plain(opt)},
-                       os.path.join(opt['savePath'], 'model_epoch_%d.pt' % ep))
+            if opt.get('saveFormat', 't7') == 't7':
+                save_t7(os.path.join(opt['savePath'], 'model_epoch_%d.t7' % ep), model, _plain(opt))
+            else:
+                torch.save({'modelW': model.wrapperW.cpu(), 'optims': {k: model.optims[k] for k in model.optims.keys()},
+                            'modelParams': _plain(opt)},
+                           os.path.join(opt['savePath'], 'model_epoch_%d.pt' % ep))
         if it % 100 == 0:                                            # train.lua:108-115
             torch.cuda.synchronize()
             getattr(model, 'synchronize', lambda: None)()
@@ -92,9 +97,12 @@ def main():
                 time.ctime(), it / float(opt['numIterPerEpoch']), it, model.runningLoss,
                 model.optims['learningRate'], rounds / (time.time() - t0)))
             t0 = time.time()
-    torch.save({'modelW': model.wrapperW.float().cpu(), 'modelParams': _plain(opt),
-                'optims': {k: model.optims[k] for k in model.optims.keys()}},
-               os.path.join(opt['savePath'], 'model_final.pt'))     # train.lua:120-121
+    if opt.get('saveFormat', 't7') == 't7':                          # train.lua:120-121
+        save_t7(os.path.join(opt['savePath'], 'model_final.t7'), model, _plain(opt))
+    else:
+        torch.save({'modelW': model.wrapperW.float().cpu(), 'modelParams': _plain(opt),
+                    'optims': {k: model.optims[k] for k in model.optims.keys()}},
+                   os.path.join(opt['savePath'], 'model_final.pt'))
 
 
 if __name__ == '__main__':

@@ -63,7 +63,8 @@ struct BatchSlot {
   bool has_gt = false;
   hipEvent_t ready = nullptr;  // recorded on the copy stream when the upload has landed
   hipEvent_t done = nullptr;   // recorded on the main stream behind the last reader of this slot
-  bool used = false;
+  bool used = false;      // a step has read this slot (done is recorded)
+  bool uploaded = false;  // ready is recorded (an upload has been issued into this slot)
   std::map<std::string, DevBuf> bufs, pinned;
 };
 

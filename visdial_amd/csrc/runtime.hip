@@ -354,6 +354,11 @@ int vd_model_upload_batch(vd_model* m, const vd_batch* hb) {
   hipStream_t s = m->s_copy;
   // the step that last read this slot may still be executing (the host runs ahead of the device)
   if (sl.used) VD_HIP(hipStreamWaitEvent(s, sl.done, 0));
+  // ... and the previous upload INTO this slot may still be queued behind that wait, reading the slot's pinned staging
+  // buffers: a host that runs two or more steps ahead without reading a loss (forward_backward loops, deferred loss)
+  // would otherwise overwrite them under the copy.  In the pipelined training loop this returns at once.
+  if (sl.uploaded) VD_HIP(hipEventSynchronize(sl.ready));
+  sl.uploaded = true;
   sl.B = hb->B;
   const int R = m->p.maxQuesCount, N = hb->B * R, O = m->p.numOptions;
   const long NO = (long)N * O;

@@ -180,6 +180,11 @@ class NativeModel(SplitEval):
             hb.To, hb.option_in, hb.option_out = a.shape[-1], ptr(a), ptr(i32(batch['option_out']))
         call("vd_model_upload_batch", self.h, C.byref(hb))      # host buffers are consumed before it returns
         self._N = batch['ques_fwd'].shape[0] * batch['ques_fwd'].shape[1]
+        # non-pad target tokens of THIS batch: the gen loss EMA divides by it (model.lua:76-85)
+        self._numTokens = float((np.asarray(batch['answer_out']) > 0).sum()) if 'answer_out' in batch else 0.0
+        # whatever was prefetched for trainIteration has just been replaced (evaluate / retrieve / predict / generate
+        # between two training steps): the next trainIteration must fetch its own batch
+        self._keep = None
 
     def forwardBackward(self, batch=None, onlyForward=False, deferLoss=False):
         if batch is not None:
@@ -237,13 +242,16 @@ class NativeModel(SplitEval):
         (copy stream, second slot) while the device executes, then wait for this step's loss."""
         if self._keep is None or self._keep is not dataloader:
             self.upload(dataloader.getTrainBatch(self.params))
-            self._keep = dataloader
+        numTokens = self._numTokens                             # of the batch this step trains on
         call("vd_model_forward_backward", self.h, 0)
         self.update()
-        self.upload(dataloader.getTrainBatch(self.params))
-        cur = self.loss()
-        self.runningLoss = 0.95 * self.runningLoss + 0.05 * cur if self.runningLoss > 0 else cur   # model.lua:88-92
-        return cur
+        self.upload(dataloader.getTrainBatch(self.params))      # prefetch: the second slot, on the copy stream
+        self._keep = dataloader                                 # (upload() clears it: set AFTER the prefetch)
+        curLoss = self.loss()
+        # model.lua:73-93: gen feeds curLoss / numTokens into the EMA (the criterion sums over tokens), disc curLoss
+        cur = curLoss / max(numTokens, 1.0) if self.params['decoder'] == 'gen' else curLoss
+        self.runningLoss = 0.95 * self.runningLoss + 0.05 * cur if self.runningLoss > 0 else cur
+        return curLoss
 
     def scores(self, N, O):
         a = np.empty((N, O), np.float32)

@@ -35,6 +35,10 @@ OPTIONS = [
     ('backend', 'cudnn', 'accepted for CLI compatibility; ignored'),
     # not a reference flag: the bf16 LSTM step of BASELINE.json configs[4] (option recurrence only; default exact fp32)
     ('lstmPrecision', 'fp32', "arithmetic of the option-LSTM recurrence GEMMs: 'fp32' | 'bf16' (fp32 accumulation)"),
+    ('saveFormat', 't7', "checkpoint files: 't7' = model_epoch_%d.t7 / model_final.t7 in the Torch7 binary format "
+                         "(train.lua:99-102,120-121) | 'pt' = torch.save of the same three fields"),
+    ('allowUnverifiedOrder', 0, "1 = accept a Torch7-written .t7 for the nngraph encoders (mn-*, lf-att-*), assuming "
+                                "their getParameters() order equals this library's declaration order (unverifiable offline)"),
     ('host', 'python', "which host drives the library: 'python' (operator-level C ABI, visdial_amd/model.py) | 'native' "
                        "(model-level C ABI, the calls lua/model.lua makes; visdial_amd/native.py)"),
 ]
@@ -69,6 +73,8 @@ def parse(argv=None):
     ap.add_argument('--vocabSize', type=int, default=11322)
     ap.add_argument('--numTrainThreads', type=int, default=2000)
     ap.add_argument('--maxIters', type=int, default=0, help='stop after this many iterations (0 = numEpochs)')
+    ap.add_argument('-synthetic', '--synthetic', type=int, default=0,
+                    help='1 = allow resuming (-loadPath) on synthetic batches when no dataset files exist')
     opt = vars(ap.parse_args(argv))
     opt.update(maxQuesCount=10, maxQuesLen=20, maxAnsLen=20, numOptions=100)
     if opt['savePath'] == 'checkpoints/':
