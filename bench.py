@@ -35,12 +35,24 @@ def _host_arg(argv):
     return os.environ.get('VD_BENCH_HOST', 'native')
 
 
+def _world_arg(argv):
+    w = int(os.environ.get('WORLD_SIZE', '1') or 1)
+    for i, a in enumerate(argv):
+        if a == '--gpus' and i + 1 < len(argv):
+            w = max(w, int(argv[i + 1]))
+        elif a.startswith('--gpus='):
+            w = max(w, int(a.split('=', 1)[1]))
+    return w
+
+
 # The native host issues the whole step from one thread onto five library-owned HIP streams.  HIP multiplexes streams
 # onto GPU_MAX_HW_QUEUES hardware queues (default 4); with all of them on ONE queue the cross-stream event waits
 # resolve inside the command processor and the step is 3-4 % faster (profiles/r02_hw_queues.txt).
 # Must be in the environment before HIP initialises, i.e. before torch touches the device; an explicit setting wins.
 # (The Python operator-level host is slower that way -- 29.0 vs 26.8 ms -- so it keeps the default.)
-if _host_arg(sys.argv[1:]) == 'native':
+# Only for ONE GPU: with peers, RCCL's kernels would share that single hardware queue with the five compute streams --
+# never measured on an 8-GPU node (none is available to the builder), so multi-GPU runs keep HIP's default.
+if _host_arg(sys.argv[1:]) == 'native' and _world_arg(sys.argv[1:]) == 1:
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '1')
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
@@ -114,7 +126,8 @@ def cpu_baseline(seconds_budget=30.0, batch=20):
         cs.step(b, drop, update=True)
         times.append(time.time() - t0)
     dt = float(np.median(times)) if times else first
-    return {"value": round(N / dt, 3), "unit": "QA-rounds/s", "cores": threads, "kind": "port",
+    cores = int(round(quota)) if quota else (os.cpu_count() or threads)   # what the container may actually use
+    return {"value": round(N / dt, 3), "unit": "QA-rounds/s", "cores": cores, "threads": threads, "kind": "port",
             "sample": "oracle/cpu_step.cpp: C++17/OpenMP fp32 restatement of the step (per-timestep GEMMs on the %s "
                       "kernel, 10x image replication, clamp+adam), identical shape B=%d dialogs x 10 rounds x 100 "
                       "options, %s, %.2f s/step; %d OpenMP threads, os.cpu_count=%d, container CPU quota=%s; restated "
@@ -143,6 +156,8 @@ def main():
     ap.add_argument('--no-streams', action='store_true', help='whole step on one HIP stream (A/B only)')
     ap.add_argument('--config', type=int, choices=[3, 4], default=3,
                     help='BASELINE.json configs index: 3 = headline (fp32, 14x14x512); 4 = 7x7x2048 features + bf16 option recurrence')
+    ap.add_argument('--collective', choices=['library', 'torch'], default='library',
+                    help='native host, N > 1: library = RCCL behind the C ABI (default); torch = host-side torch.distributed')
     ap.add_argument('--host', choices=['python', 'native'], default=os.environ.get('VD_BENCH_HOST', 'native'),
                     help='native (default) = the model-level ABI (csrc/runtime.hip: the orchestration a Lua host gets); '
                          'python = visdial_amd.Model composing the operator-level ABI')
@@ -161,11 +176,43 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs a GPU"
     torch.cuda.set_device(local)
     group = None
+    collective = None
+    lib_comm = False
     if 'RANK' in os.environ:      # launched by torch.distributed.run (any world size, incl. 1)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))   # nccl == RCCL on ROCm
-        group = dist.group.WORLD
+        if args.host == 'native' and args.collective == 'library':
+            # The gradient all-reduce is the LIBRARY's: RCCL communicator + communication stream behind the C ABI
+            # (csrc/comm.hip, vd_model_allreduce_grads).  torch.distributed (gloo) is only the courier of the 128-byte
+            # rendezvous token, the barriers and the max-over-ranks of the wall time.
+            dist.init_process_group(backend='gloo')
+            group = dist.group.WORLD
+            from visdial_amd.parallel import init_library_comm_over
+            ok = 1
+            try:
+                from visdial_amd import _lib
+                _lib.call("vd_set_device", local)
+                init_library_comm_over(group)
+            except Exception as exc:     # agree on the outcome: either every rank uses the library or none does
+                print('rank %d: library communicator failed (%s); falling back to torch.distributed nccl' % (rank, exc),
+                      file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            lib_comm = bool(flag.item())
+            collective = 'library RCCL (vd_model_allreduce_grads; 2 buckets, library comm stream)'
+            if not lib_comm:
+                from visdial_amd.parallel import destroy_library_comm
+                try:
+                    destroy_library_comm()
+                except Exception:
+                    pass
+                group = dist.new_group(backend='nccl', device_id=torch.device('cuda', local))
+                collective = 'torch.distributed nccl (fallback: library communicator failed)'
+        else:
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))   # nccl == RCCL on ROCm
+            group = dist.group.WORLD
+            collective = 'torch.distributed nccl (host-side, 2 buckets)'
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
     from visdial_amd import ops
@@ -177,7 +224,7 @@ def main():
         p['useStreams'] = 0
     if args.host == 'native':
         from visdial_amd.native import NativeModel
-        model = NativeModel(p, dist_group=group)
+        model = NativeModel(p, dist_group=None if lib_comm else group, library_comm=lib_comm)
     else:
         model = Model(p, dist_group=group)
     dl = SyntheticDataloader(p, seed=1234 + rank, fast=True)
@@ -190,7 +237,7 @@ def main():
         loss = model.trainIteration(dl)
     torch.cuda.synchronize()
     if group is not None:
-        dist.barrier()
+        dist.barrier(group=group)
     torch.cuda.synchronize()
     ops.PROFILE = {}
     per_step = []
@@ -200,8 +247,9 @@ def main():
         loss = model.trainIteration(dl)        # returns after this step's loss has left the device
         per_step.append(time.perf_counter() - ts)
     torch.cuda.synchronize()
+    getattr(model, 'synchronize', lambda: None)()     # the native host's streams are not torch's
     if group is not None:
-        dist.barrier()
+        dist.barrier(group=group)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = ops.prof_summary()
@@ -213,8 +261,8 @@ def main():
     else:
         args_steps_for_prof = args.steps
     if group is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if dist.get_backend(group) == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(t.item())
 
     if rank == 0:
@@ -289,7 +337,8 @@ def main():
                                    % (args.batch, "14x14x512 pool5 map" if args.config == 3 else "7x7x2048 ResNet-200 map", args.config),
                        "global_batch_dialogs": world * args.batch, "parallelism": "dp%d" % world,
                        "dropout": "on (device generator)", "loss": round(float(loss), 5), "host": args.host,
-                       "GPU_MAX_HW_QUEUES": os.environ.get('GPU_MAX_HW_QUEUES', 'default')},
+                       "GPU_MAX_HW_QUEUES": os.environ.get('GPU_MAX_HW_QUEUES', 'default'),
+                       "collective": collective},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -297,7 +346,11 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if group is not None:
+    if lib_comm:
+        from visdial_amd.parallel import destroy_library_comm
+        model.synchronize()
+        destroy_library_comm()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -280,6 +280,18 @@ void* vd_model_stream(vd_model* m);                       /* the main hipStream_
  * a disc decoder that is the end of the encoder backward, well before the option-LSTM backward ends */
 int vd_model_encoder_range(const vd_model* m, int64_t* lo, int64_t* hi);
 int vd_model_wait_encoder_grads(vd_model* m, void* stream);
+/* ---- data-parallel gradient exchange inside the library (csrc/comm.hip).  The reference is
+ * single-GPU (train.lua:19); a host that wants N GPUs runs one process per GPU and makes three extra calls: rank 0
+ * creates the 128-byte rendezvous token and the host hands it to the peers by any channel it has; every rank joins the
+ * RCCL communicator on its current device; then once per step, between forward_backward and update(1/world),
+ * vd_model_allreduce_grads sums wrapperdW over all ranks in two buckets -- the encoder's own tensors on a library-owned
+ * communication stream underneath the option-LSTM backward, the shared embedding + decoder tensors behind the step --
+ * and makes the main stream wait for both.  RCCL (librccl.so.1) is loaded at run time on first use. ---- */
+int vd_comm_unique_id(void* out128);                      /* ncclGetUniqueId: 128 bytes */
+int vd_comm_init(int rank, int world, const void* id128); /* ncclCommInitRank on the current device (collective) */
+int vd_comm_info(int* rank, int* world);                  /* world = 0: no communicator */
+int vd_comm_destroy(void);
+int vd_model_allreduce_grads(vd_model* m);                /* enqueue only; every rank, once per step */
 int vd_model_init_params(vd_model* m, uint64_t seed);     /* library-default init */
 int vd_model_set_tensor(vd_model* m, const char* name, const float* host, int64_t n);   /* wrapperW:copy(...) */
 int vd_model_get_tensor(vd_model* m, const char* name, int which /*0 W, 1 dW, 2 m, 3 v*/, float* host, int64_t n);

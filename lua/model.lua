@@ -68,6 +68,23 @@ function Model:commitW()
     if w then self:setFlatParameters(w); rawset(self, 'checkedOutW', nil) end
 end
 
+-- Data parallelism (new relative to the reference, which is single-GPU: train.lua:19): one `th` process per GPU.  Rank 0
+-- calls Model.commUniqueId() and hands the 128-byte string to its peers by any channel the launcher has (a file, a
+-- socket, an environment variable written by a wrapper script); every rank then calls model:initComm(rank, world, id).
+-- From then on trainIteration sums the gradient over RCCL inside the library (two buckets, the encoder's under the
+-- option-LSTM backward) and applies the 1/world average before clamp + adam -- the update of the concatenated batch.
+function Model.commUniqueId()
+    local id = ffi.new('char[128]')
+    vd.call('vd_comm_unique_id', id)
+    return ffi.string(id, 128)
+end
+
+function Model:initComm(rank, world, id)
+    assert(#id == 128, 'initComm: the rendezvous token is 128 bytes')
+    vd.call('vd_comm_init', rank, world, ffi.cast('const void*', id))
+    self.world = world
+end
+
 -- batch tables of dataloader.lua:324-339,378-475 -> vd_batch (host pointers; consumed before the call returns)
 function Model:upload(batch)
     local keep = {}                                                    -- converted tensors stay alive until the call returns
@@ -109,7 +126,9 @@ function Model:trainIteration(dataloader)
     vd.call('vd_model_forward_backward', self.h, 0)
     local lr = ffi.new('double[1]', self.optims.learningRate)
     vd.call('vd_model_learning_rate', self.h, lr, 1)
-    vd.call('vd_model_update', self.h, 1.0)                            -- clamp(-5,5) + adam + lr decay (model.lua:96-105)
+    local world = self.world or 1
+    if world > 1 then vd.call('vd_model_allreduce_grads', self.h) end  -- RCCL sum over the ranks (enqueue only)
+    vd.call('vd_model_update', self.h, 1.0 / world)                    -- [average] clamp(-5,5) + adam + lr decay (model.lua:96-105)
     vd.call('vd_model_learning_rate', self.h, lr, 0)
     self.optims.learningRate = tonumber(lr[0])
     self:upload(dataloader:getTrainBatch(self.params))

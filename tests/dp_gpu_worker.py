@@ -39,13 +39,24 @@ def main():
     R = p['maxQuesCount']
     mine = {'ques_fwd': full['ques_fwd'][lo:hi], 'hist': full['hist'][lo:hi], 'img_feat': full['img_feat'][lo:hi],
             'options': full['options'][lo * R:hi * R], 'answer_ind': full['answer_ind'][lo * R:hi * R]}
-    native = os.environ.get('VD_TEST_HOST', 'python') == 'native'
+    host = os.environ.get('VD_TEST_HOST', 'python')
+    native = host in ('native', 'native-lib')
     flat = lambda d, names: np.concatenate([np.asarray(d[k], np.float32).reshape(-1) for k in names])
     if native:
         from visdial_amd.native import NativeModel
-        model = NativeModel(p, dist_group=dist.group.WORLD)
+        if host == 'native-lib':
+            # the collective behind the C ABI (csrc/comm.hip): the library owns the RCCL communicator and its stream;
+            # the process group (gloo) only carries the 128-byte rendezvous token -- what a Lua host would do by file
+            from visdial_amd import _lib
+            from visdial_amd.parallel import init_library_comm_over, library_comm_world
+            _lib.call("vd_set_device", 0)
+            init_library_comm_over(dist.group.WORLD)
+            assert library_comm_world() == world
+            model = NativeModel(p, library_comm=True)
+        else:
+            model = NativeModel(p, dist_group=dist.group.WORLD)
+            assert model._dp_active()
         names = [t[0] for t in model.tensors]
-        assert model._dp_active()
         model.training(False)
         loss = model.forwardBackward(mine)
         used_async_bucket = False
@@ -92,7 +103,11 @@ def main():
         assert np.abs(w_dp - w_big)[settled].max() < 1e-6
         assert np.mean(np.abs(w_dp - w_big) < 1e-6) > 0.999
         print("DP_GPU_OK world=%d backend=%s host=%s async_encoder_bucket=%s grad_rel_err=%.2e" % (
-            world, backend, 'native' if native else 'python', used_async_bucket, err))
+            world, backend, host, used_async_bucket, err))
+    if host == 'native-lib':
+        from visdial_amd.parallel import destroy_library_comm
+        model.synchronize()
+        destroy_library_comm()
     dist.barrier()
     dist.destroy_process_group()
 

@@ -5,6 +5,9 @@ so these are ORACLE outputs (fp64) for seeded inputs: they freeze the restated s
 edit of the oracle that changes a number fails tests/test_golden.py) and give the GPU path a fixed,
 file-based target.  Data only: inputs (parameters, batch, dropout masks) and expected outputs
 (loss, every gradient tensor, scores/ranks/metrics).        Run:  python tests/golden/make_golden.py
+
+`python tests/golden/make_golden.py --full` writes the FULL-SIZE fixture of BASELINE.json configs[3] (SURVEY.md 8c:
+"one at full B=20 stored as checksums/slices"): see full_case() / full_outputs() below.  ~20 GB of RAM, minutes.
 """
 import os
 import sys
@@ -47,7 +50,95 @@ def masks_for(p, batch, rng):
     return {k: (rng.rand(*s) > pd).astype(np.uint8) for k, s in shp.items()}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Full-size fixture: mn-att-ques-im-hist + disc, 20 dialogs x 10 rounds x 100 options, 14x14x512, V = 11 322, H = 512,
+# dropout ON with pinned masks (model.lua:249-342, decoders/disc.lua:3-32, utils.lua:106-160).  Inputs are
+# seed-reproducible (numpy RandomState / default_rng), so the file stores only their SHA-256 -- a drift of a generator
+# is reported as such, not as a parity failure -- and the oracle's fp64 OUTPUTS: loss, the whole [200 x 100] score
+# matrix (training-mode forward and evaluate-mode forward), ranks, R@k / MRR, and for each of the 14.2 M gradient
+# values' tensors: L2 norm, sum, a strided sample of <= 16 384 entries, and a 64-row random-sign sketch
+# <g, r_j> (E[<d, r>^2] = |d|^2, so the sketch of a difference estimates the FULL tensor's L2 error).
+FULL_NAME = 'full__mn-att-ques-im-hist__disc.npz'
+SAMPLE, SKETCH = 16384, 64
+
+
+def full_case():
+    """(p, batch, masks, P) of the full-size fixture; every array deterministic in the seeds below"""
+    from visdial_amd.opts import default_params
+    p = default_params(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=512, imgSpatialSize=14,
+                       batchSize=20, vocabSize=11322, gpuid=0, maxHistoryLenPerRound=40)
+    batch = SyntheticDataloader(p, seed=1234, fast=True).getTrainBatch(p)
+    masks = masks_for(p, batch, np.random.RandomState(5))
+    P = vo.init_params(p['encoder'], p['decoder'], p, seed=77, dtype=np.float32)
+    return p, batch, masks, P
+
+
+def digest(d):
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(d):
+        a = np.ascontiguousarray(d[k])
+        h.update(k.encode()); h.update(str(a.dtype).encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def sample_index(n):
+    """<= SAMPLE entries of a flat tensor: a fixed stride over the whole tensor"""
+    return np.arange(0, n, max(1, n // SAMPLE))[:SAMPLE]
+
+
+def sketch(name, flat):
+    """64 random-sign projections of a flat fp64 vector (signs seeded by the tensor name and size)"""
+    import zlib
+    rng = np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff)
+    out = np.empty(SKETCH)
+    for j in range(SKETCH):
+        r = rng.randint(0, 2, flat.size).astype(np.int8) * 2 - 1
+        out[j] = float(np.dot(flat, r))
+    return out
+
+
+def full_outputs():
+    p, batch, masks, P = full_case()
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    drop = {k: v.astype(np.float64) for k, v in masks.items()}
+    out = {'digest.params': np.array(digest(P)), 'digest.batch': np.array(digest(batch)),
+           'digest.masks': np.array(digest(masks))}
+    r = vo.forward_backward(p['encoder'], p['decoder'], P64, p, batch, drop)
+    gt = batch['answer_ind'].reshape(-1) - 1
+    out['loss'] = np.float64(r['loss'])
+    out['scores'] = r['scores']
+    out['gt_ranks'] = vo.compute_ranks(r['scores'], gt)
+    for k, g in r['grads'].items():
+        f = g.reshape(-1)
+        out['gnorm.' + k] = np.float64(np.linalg.norm(f))
+        out['gsum.' + k] = np.float64(f.sum())
+        out['gsample.' + k] = f[sample_index(f.size)].copy()
+        out['gsketch.' + k] = sketch(k, f)
+    del r
+    ev = vo.forward_backward(p['encoder'], p['decoder'], P64, p, batch, None, only_forward=True)   # evaluate(): no dropout
+    out['eval.loss'] = np.float64(ev['loss'])
+    out['eval.scores'] = ev['scores']
+    out['eval.ranks'] = vo.compute_ranks(ev['scores']).astype(np.int16)
+    out['eval.gt_ranks'] = vo.compute_ranks(ev['scores'], gt)
+    m = vo.process_ranks(out['eval.gt_ranks'])
+    out['eval.metrics'] = np.array([m[k] for k in ('r@1', 'r@5', 'r@10', 'medianR', 'meanR', 'meanRR')])
+    return out
+
+
+def main_full():
+    import time
+    t0 = time.time()
+    out = full_outputs()
+    path = os.path.join(HERE, FULL_NAME)
+    np.savez_compressed(path, **out)
+    print('%s  loss %.12f  eval loss %.12f  %d arrays  %.1f KB  (%.0f s)' % (
+        FULL_NAME, out['loss'], out['eval.loss'], len(out), os.path.getsize(path) / 1024.0, time.time() - t0))
+
+
 def main():
+    if '--full' in sys.argv:
+        return main_full()
     for enc, dec, kw in CASES:
         p = derive(small_params(encoder=enc, decoder=dec, **kw))
         dl = SyntheticDataloader(p, seed=2024)

@@ -51,3 +51,13 @@ def test_native_host_world1_rccl_forced_allreduce():
 def test_native_host_world2_shared_gpu_gloo():
     out = _run(2, 'gloo', dict(VD_TEST_HOST='native'))
     assert 'world=2' in out and 'host=native' in out
+
+
+def test_native_host_library_rccl_world1():
+    """the collective BEHIND the C ABI (include/visdial_hip.h: vd_comm_unique_id / vd_comm_init /
+    vd_model_allreduce_grads, csrc/comm.hip): the library dlopens librccl, owns the communicator and the communication
+    stream, reduces the encoder bucket behind ev_enc_grads and the tail behind the main stream; the host (here Python,
+    in production lua/model.lua:initComm) only carries the 128-byte token.  World 1 with the all-reduce forced: the
+    RCCL kernels really run on the gradient buffer and the step must equal the plain single-process step."""
+    out = _run(1, 'gloo', dict(VD_FORCE_ALLREDUCE='1', VD_TEST_HOST='native-lib', NCCL_DEBUG='VERSION'))
+    assert 'host=native-lib' in out

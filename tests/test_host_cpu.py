@@ -195,3 +195,20 @@ def test_data_parallel_step_equals_big_batch_step_gloo(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "DP_OK" in outs[0]
+
+
+def test_library_comm_surface_without_a_gpu():
+    """csrc/comm.hip: the communicator entry points exist, report "no communicator" (world 0) before vd_comm_init, refuse
+    to reduce without one -- and the library carries no link-time dependency on RCCL (it is dlopen'ed on first use, so a
+    single-GPU Lua host never loads it)."""
+    import ctypes as C
+    import subprocess
+    from visdial_amd import _lib
+    from visdial_amd.parallel import library_comm_world
+    assert library_comm_world() == 0
+    lib = _lib.load()
+    assert lib.vd_model_allreduce_grads(None) != 0 and b'null model' in lib.vd_last_error()
+    assert lib.vd_comm_init(3, 2, C.create_string_buffer(128)) != 0          # rank outside the world
+    assert lib.vd_comm_destroy() == 0                                        # nothing to destroy is not an error
+    needed = subprocess.run(['readelf', '-d', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert 'rccl' not in needed.lower() and 'torch' not in needed.lower()

@@ -107,6 +107,11 @@ PROTOTYPES = {
     "vd_model_stream": [_p],
     "vd_model_encoder_range": [_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "vd_model_wait_encoder_grads": [_p, _p],
+    "vd_comm_unique_id": [_p],
+    "vd_comm_init": [_i, _i, _p],
+    "vd_comm_info": [C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "vd_comm_destroy": [],
+    "vd_model_allreduce_grads": [_p],
     "vd_model_init_params": [_p, _u64],
     "vd_model_set_tensor": [_p, C.c_char_p, _p, _l],
     "vd_model_get_tensor": [_p, C.c_char_p, _i, _p, _l],

@@ -47,9 +47,13 @@ class _Optims(object):
 
 
 class NativeModel(SplitEval):
-    def __init__(self, params, init_seed=1234, dist_group=None):
+    def __init__(self, params, init_seed=1234, dist_group=None, library_comm=False):
+        """library_comm=True: the gradient all-reduce is the library's own (vd_comm_init has been called in this process,
+        visdial_amd.parallel.init_library_comm): RCCL behind the ABI, no Python in the reduce path.  dist_group: the
+        older host-side path over torch.distributed (kept as the gloo test vehicle and for the operator-level host)."""
         p = params
         self.dist_group = dist_group
+        self.library_comm = bool(library_comm)
         self._dW = None
         mp = _lib.ModelParams(
             vocabSize=p['vocabSize'], embedSize=p['embedSize'], rnnHiddenSize=p['rnnHiddenSize'],
@@ -210,7 +214,15 @@ class NativeModel(SplitEval):
         "encoder gradients are final" wait.  Two buckets: the encoder's tensors start reducing on a
         communication stream as soon as the encoder backward has ended -- underneath the option-LSTM backward --
         the shared embedding and the decoder's tensors follow behind the step on the library's main stream."""
-        if self._dp_active():
+        if self.library_comm:
+            import os
+            from .parallel import library_comm_world
+            world = library_comm_world()
+            assert world > 0, "library_comm=True but no communicator: call visdial_amd.parallel.init_library_comm first"
+            if world > 1 or os.environ.get('VD_FORCE_ALLREDUCE') == '1':
+                call("vd_model_allreduce_grads", self.h)        # two buckets, library-owned communication stream
+                gscale = 1.0 / world
+        elif self._dp_active():
             import torch
             from .parallel import reduce_gradients
             if self._dW is None:

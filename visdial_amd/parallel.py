@@ -7,6 +7,8 @@ Dialogs are independent in forward and backward, so the step shards by dialog: e
 Adam on every rank -- which equals the single-process step on the concatenated batch because the
 loss is a mean over rows (model.lua:38).  No other collective exists on the path.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -49,3 +51,43 @@ def rank_loss_mean(local_loss, group=None):
         t = t.cuda()
     dist.all_reduce(t, group=group)
     return float(t.item()) / dist.get_world_size(group)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The collective behind the C ABI (csrc/comm.hip): the library owns the RCCL communicator and its stream; the host only
+# carries the 128-byte rendezvous token from rank 0 to the peers.  This is the path a Lua host uses too
+# (lua/model.lua:initComm); torch.distributed below is nothing but the courier of those 128 bytes.
+def library_comm_world():
+    """world size of the library's communicator; 0 = none"""
+    from . import _lib
+    r, w = C.c_int(), C.c_int()
+    _lib.call("vd_comm_info", C.byref(r), C.byref(w))
+    return int(w.value)
+
+
+def init_library_comm(rank, world, exchange):
+    """Join the library's RCCL communicator on the current device.  `exchange(token_or_None) -> token`: called with
+    the 128-byte token on rank 0 and None elsewhere, returns rank 0's token on every rank (any channel will do)."""
+    from . import _lib
+    buf = C.create_string_buffer(128)
+    if rank == 0:
+        _lib.call("vd_comm_unique_id", buf)
+    token = exchange(bytes(buf.raw) if rank == 0 else None)
+    assert isinstance(token, (bytes, bytearray)) and len(token) == 128
+    _lib.call("vd_comm_init", int(rank), int(world), C.create_string_buffer(bytes(token), 128))
+
+
+def init_library_comm_over(group=None):
+    """the same with a torch.distributed group (any backend, gloo is enough) as the courier"""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+    def exchange(token):
+        box = [token]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return box[0]
+    init_library_comm(rank, world, exchange)
+
+
+def destroy_library_comm():
+    from . import _lib
+    _lib.call("vd_comm_destroy")
