@@ -49,3 +49,44 @@ def small_params(**kw):
 @pytest.fixture
 def params_small():
     return small_params()
+
+
+def grad_mismatches(g, ref, tol=1e-4):
+    """[(rel-L2 error, tensor name)] of every gradient tensor that misses the bound.  The bound is RELATIVE (north_star:
+    1e-4 in fp32) for every tensor with a gradient; only a tensor whose reference gradient is identically zero
+    (|ref| < 1e-12: e.g. 'att.b', which feeds a softmax over the regions, or the weights of a branch that saw only
+    padding) gets an absolute bound instead -- a relative error is undefined there."""
+    import numpy as np
+    bad = []
+    for k in ref:
+        a, b = np.asarray(g[k], np.float64), np.asarray(ref[k], np.float64)
+        nb = float(np.linalg.norm(b))
+        if nb < 1e-12:
+            if np.abs(a).max() >= 1e-6:
+                bad.append((float(np.abs(a).max()), k + ' (reference gradient is zero)'))
+            continue
+        err = float(np.linalg.norm(a - b)) / nb
+        if err >= tol:
+            bad.append((err, k))
+    return bad
+
+
+def unexplained_rank_flips(dev_scores, ref_scores, tol=1e-4):
+    """(flipped pairs, unexplained ones): option pairs whose ORDER differs between the device scores and the fp64 oracle's
+    scores; a flip is explained only if the fp64 scores are a near tie, |s_a - s_b| < tol * max(1, |s_a|, |s_b|).  Ties
+    break by lower index first on both sides (utils.lua:106-128)."""
+    import numpy as np
+    dev, ref = np.asarray(dev_scores, np.float64), np.asarray(ref_scores, np.float64)
+    idx = np.arange(ref.shape[1])
+    flipped, bad = 0, []
+    before = lambda s: (s[:, None] > s[None, :]) | ((s[:, None] == s[None, :]) & (idx[:, None] < idx[None, :]))
+    for r in range(ref.shape[0]):
+        f = before(dev[r]) != before(ref[r])
+        if not f.any():
+            continue
+        a, b = np.nonzero(np.triu(f, 1))
+        flipped += a.size
+        margin = np.abs(ref[r, a] - ref[r, b])
+        scale = np.maximum(1.0, np.maximum(np.abs(ref[r, a]), np.abs(ref[r, b])))
+        bad += [(r, int(a[k]), int(b[k]), float(margin[k])) for k in np.nonzero(margin >= tol * scale)[0]]
+    return flipped, bad

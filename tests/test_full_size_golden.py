@@ -1,0 +1,169 @@
+"""BASELINE.json configs[3] at FULL size against the fp64 oracle, at north_star's tolerance ("one at full
+B=20 stored as checksums/slices").
+
+Fixture: tests/golden/full__mn-att-ques-im-hist__disc.npz, written by `python tests/golden/make_golden.py --full` from
+oracle/visdial_oracle.py (numpy fp64; model.lua:249-342, decoders/disc.lua:3-32, utils.lua:106-160) on
+seed-reproducible inputs -- 20 dialogs x 10 rounds x 100 options, 14x14x512, V = 11 322, H = 512, dropout on with
+pinned masks.  It holds the inputs' SHA-256 and the oracle's OUTPUTS: loss, the whole [200 x 100] score matrix of the
+training-mode forward and of the evaluate-mode forward, ranks, R@k / MRR, and per gradient tensor its L2 norm, sum, a
+strided sample of <= 16 384 entries and a 64-row random-sign sketch (E<d, r>^2 = |d|^2: the sketch of the difference
+estimates the FULL tensor's L2 error without storing 57 MB).
+
+Bounds (north_star: 1e-4 in fp32): |loss diff| < 1e-4; scores rel-L2 < 1e-4; every gradient tensor: sketch-estimated
+rel-L2 < 1e-4 AND sample rel-L2 < 1e-4 AND norm within 1e-4; ranks: every mismatch against the fp64 ranks must be a
+near tie in the fp64 scores (|s_a - s_b| < 1e-4 max(1, |s|)); R@k / MRR within 1e-4 (+ 1/N per explained near tie)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, unexplained_rank_flips
+
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+import make_golden as mg                                     # noqa: E402  (input generators + digest / sketch helpers)
+from oracle import visdial_oracle as vo                      # noqa: E402  (checker only: compute_ranks / process_ranks)
+
+PATH = os.path.join(ROOT, 'tests', 'golden', mg.FULL_NAME)
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def case():
+    z = np.load(PATH)
+    p, batch, masks, P = mg.full_case()
+    return z, p, batch, masks, P
+
+
+def test_full_size_fixture_inputs_are_reproducible(case):
+    """the fixture stores only a digest of its inputs: a drift of a generator must show up HERE, not as a parity failure"""
+    z, p, batch, masks, P = case
+    assert str(z['digest.params']) == mg.digest(P)
+    assert str(z['digest.batch']) == mg.digest(batch)
+    assert str(z['digest.masks']) == mg.digest(masks)
+    spec = vo.param_spec(p['encoder'], p['decoder'], p)
+    assert {'gnorm.' + e[0] for e in spec} == {k for k in z.files if k.startswith('gnorm.')}
+    assert z['scores'].shape == (200, 100) and z['eval.ranks'].shape == (200, 100)
+    # internal consistency of the stored outputs (oracle-side, fp64)
+    gt = batch['answer_ind'].reshape(-1) - 1
+    np.testing.assert_array_equal(vo.compute_ranks(z['eval.scores'], gt), z['eval.gt_ranks'])
+    m = vo.process_ranks(z['eval.gt_ranks'])
+    np.testing.assert_allclose([m[k] for k in ('r@1', 'r@5', 'r@10', 'medianR', 'meanR', 'meanRR')], z['eval.metrics'])
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+unexplained_rank_mismatches = unexplained_rank_flips
+
+
+def check_step(z, loss, scores, grads, gt):
+    assert abs(loss - float(z['loss'])) < TOL, (loss, float(z['loss']))
+    assert rel(scores, z['scores']) < TOL, rel(scores, z['scores'])
+    worst = []
+    for key in [k for k in z.files if k.startswith('gnorm.')]:
+        name = key[len('gnorm.'):]
+        g = np.asarray(grads[name], np.float64).reshape(-1)
+        norm = float(z[key])
+        if norm < 1e-12:                      # a tensor whose exact gradient is 0 ('att.b' feeds a softmax)
+            assert np.abs(g).max() < 1e-6, name
+            continue
+        # (1) full-tensor L2 error estimated from the 64 random-sign projections
+        d = mg.sketch(name, g) - z['gsketch.' + name]
+        est = float(np.sqrt(np.mean(d * d))) / norm
+        # (2) exact comparison on the strided sample, relative to the sample's own norm
+        s_ref = z['gsample.' + name]
+        s_err = rel(g[mg.sample_index(g.size)], s_ref) if np.linalg.norm(s_ref) > 1e-9 * norm else 0.0
+        # (3) norm and sum
+        n_err = abs(float(np.linalg.norm(g)) - norm) / norm
+        sum_err = abs(float(g.sum()) - float(z['gsum.' + name])) / (norm * np.sqrt(g.size))
+        worst.append((max(est, s_err, n_err, sum_err), name, est, s_err, n_err, sum_err))
+    worst.sort(reverse=True)
+    assert worst[0][0] < TOL, worst[:5]
+    # ranks of the ground truth from the device scores vs the fp64 ranks: every difference must be a near tie
+    dev_ranks = vo.compute_ranks(scores, gt)
+    flipped, bad = unexplained_rank_mismatches(scores, z['scores'])
+    assert not bad, bad[:10]
+    assert (dev_ranks != z['gt_ranks']).sum() <= flipped
+    return worst[0], flipped
+
+
+def check_eval(z, scores, all_ranks, gt_ranks, gt):
+    from visdial_amd import utils
+    assert rel(scores, z['eval.scores']) < TOL
+    np.testing.assert_array_equal(all_ranks, vo.compute_ranks(scores))        # the device kernel on the device scores: exact
+    np.testing.assert_array_equal(gt_ranks, vo.compute_ranks(scores, gt))
+    flipped, bad = unexplained_rank_mismatches(scores, z['eval.scores'])
+    assert not bad, bad[:10]
+    mism = int((np.asarray(all_ranks) != z['eval.ranks']).sum())
+    assert mism <= 2 * flipped                                                 # a flipped pair moves two ranks by one
+    m = utils.processRanks(np.asarray(gt_ranks), verbose=False)
+    n_gt_mism = int((np.asarray(gt_ranks).reshape(-1) != z['eval.gt_ranks']).sum())
+    for k, ref in zip(('r@1', 'r@5', 'r@10', 'meanRR'), z['eval.metrics'][[0, 1, 2, 5]]):
+        assert abs(m[k] - ref) < TOL + n_gt_mism / 200.0, (k, m[k], ref)       # n_gt_mism == 0 unless near ties exist
+    return flipped, n_gt_mism
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("host", ['python', 'native'])
+def test_full_size_step_matches_fp64_golden(case, host):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    z, p, batch, masks, P = case
+    gt = batch['answer_ind'].reshape(-1) - 1
+    N, O = 200, 100
+    if host == 'python':
+        from visdial_amd.model import Model
+        model = Model(dict(p))
+        model.set_parameters_dict(P)
+        model.set_dropout_masks(masks)
+        model.wrapper.zeroGradParameters()
+        loss = model.forwardBackward(batch)
+        scores = model.decoder.output.cpu().numpy()
+        grads = model.get_gradients_dict()
+        worst, flipped = check_step(z, loss, scores, grads, gt)
+        model.wrapper.evaluate()
+        model.params['useGt'] = False
+        all_ranks = model.retrieveBatch(batch)
+        ev_scores = model.decoder.output.cpu().numpy()
+        model.params['useGt'] = True
+        gt_ranks = model.retrieveBatch(batch)
+        tonp = lambda t: t.cpu().numpy() if hasattr(t, 'cpu') else np.asarray(t)
+        ef, egm = check_eval(z, ev_scores, tonp(all_ranks), tonp(gt_ranks), gt)
+    else:
+        from visdial_amd.native import NativeModel
+        model = NativeModel(dict(p))
+        model.set_parameters_dict(P)
+        model.set_dropout_masks(masks)
+        loss = model.forwardBackward(batch)
+        scores = model.scores(N, O)
+        grads = model.get_gradients_dict()
+        worst, flipped = check_step(z, loss, scores, grads, gt)
+        model.training(False)
+        all_ranks = model.retrieveBatch(batch, useGt=False)
+        ev_scores = model.scores(N, O)
+        gt_ranks = model.retrieveBatch(batch, useGt=True)
+        ef, egm = check_eval(z, ev_scores, all_ranks, gt_ranks, gt)
+        model.close()
+    print('full-size fp64 golden (%s host): |dloss| %.2e  worst gradient tensor %s (sketch %.2e, sample %.2e, norm %.2e)  '
+          'near-tie flips: train %d, eval %d (gt ranks changed: %d)' % (
+              host, abs(loss - float(z['loss'])), worst[1], worst[2], worst[3], worst[4], flipped, ef, egm))
+
+
+def test_rank_mismatch_rule_accepts_near_ties_only():
+    """the margin-aware rule itself: a swap of two options whose fp64 scores differ by < 1e-4 is explained, a swap
+    across a real margin is not"""
+    rng = np.random.RandomState(0)
+    ref = rng.randn(6, 100)
+    ref[2, 10], ref[2, 20] = 0.5, 0.5 + 3e-5                       # a near tie in the fp64 scores
+    dev = ref.astype(np.float32).astype(np.float64)
+    dev[2, 10], dev[2, 20] = dev[2, 20], dev[2, 10]                # ... which the fp32 path orders the other way
+    flipped, bad = unexplained_rank_mismatches(dev, ref)
+    assert flipped == 1 and not bad
+    a, b = np.argsort(-ref[4])[:2]
+    dev[4, a], dev[4, b] = ref[4, b], ref[4, a]                    # a swap across a real margin
+    flipped, bad = unexplained_rank_mismatches(dev, ref)
+    assert flipped == 2 and len(bad) == 1 and bad[0][0] == 4

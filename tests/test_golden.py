@@ -8,11 +8,12 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, small_params
+from conftest import ROOT, grad_mismatches, small_params, unexplained_rank_flips
 from oracle import visdial_oracle as vo
 from visdial_amd.opts import derive
 
-FILES = sorted(glob.glob(os.path.join(ROOT, 'tests', 'golden', '*__*.npz')))   # <encoder>__<decoder>.npz
+FILES = sorted(f for f in glob.glob(os.path.join(ROOT, 'tests', 'golden', '*__*.npz'))     # <encoder>__<decoder>.npz
+               if not os.path.basename(f).startswith('full__'))           # (the full-size fixture: test_full_size_golden.py)
 KW = {'lf-ques': dict(dropout=0.5, imgNorm=1, batchSize=2), 'lf-ques-im-hist': dict(dropout=0.5, imgNorm=1, batchSize=2),
       'hre-ques-im-hist': dict(imgNorm=1, batchSize=2), 'mn-att-ques-im-hist': dict(batchSize=2)}
 
@@ -62,10 +63,8 @@ def test_hip_path_matches_golden(path):
     ref = float(z['loss'])
     assert abs(loss - ref) < 1e-4 * max(1.0, abs(ref))
     g = model.get_gradients_dict()
-    scale = max(np.abs(v).max() for v in grads.values())
-    for k, gr in grads.items():
-        err = np.linalg.norm(g[k] - gr) / max(np.linalg.norm(gr), 1e-30)
-        assert err < 1e-4 or np.abs(g[k] - gr).max() < 1e-6 * max(1.0, scale), (k, err)
+    bad = grad_mismatches(g, grads)
+    assert not bad, bad
     if dec == 'disc':
         model.wrapper.evaluate()
         p['useGt'] = False
@@ -73,7 +72,9 @@ def test_hip_path_matches_golden(path):
         dev_scores = model.decoder.output.cpu().numpy()
         assert np.abs(dev_scores - z['eval.scores']).max() < 1e-4
         np.testing.assert_array_equal(ranks, vo.compute_ranks(dev_scores))         # bit-exact on device scores
-        assert (ranks != z['eval.ranks']).mean() < 0.02                           # and equal to golden up to near-ties
+        flipped, unexplained = unexplained_rank_flips(dev_scores, z['eval.scores'])    # and equal to golden up to near ties
+        assert not unexplained, unexplained[:10]
+        assert (np.asarray(ranks) != z['eval.ranks']).sum() <= 2 * flipped
         p['useGt'] = True
         gt = model.retrieveBatch(batch)
         m = utils.processRanks(gt, verbose=False)

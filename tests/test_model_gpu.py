@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import small_params
+from conftest import grad_mismatches, small_params, unexplained_rank_flips
 from oracle import visdial_oracle as vo
 from visdial_amd.dataloader import SyntheticDataloader
 from visdial_amd.opts import derive
@@ -73,8 +73,7 @@ def test_mnatt_disc_step_matches_oracle(gpu, case, train_mode):
     assert abs(loss - ref['loss']) < 1e-4
     g = model.get_gradients_dict()
     # rel-L2 per tensor; 'att.b' feeds a softmax, its true gradient is identically 0 -> absolute bound
-    bad = [(rel(g[k], ref['grads'][k]), k) for k in ref['grads']
-           if rel(g[k], ref['grads'][k]) >= 1e-4 and np.abs(g[k] - ref['grads'][k]).max() >= 1e-6]
+    bad = grad_mismatches(g, ref['grads'])
     assert not bad, bad
     assert rel(model.decoder.output.cpu().numpy(), ref['scores']) < 1e-4
     # clamp + Adam (model.lua:96-99): the update is elementwise, so check the device step against the
@@ -137,8 +136,7 @@ def test_ragged_empty_and_max_length_inputs(gpu, train_mode):
     ref = vo.forward_backward(p['encoder'], p['decoder'], P0, p, batch, drop)
     assert np.isfinite(loss) and abs(loss - ref['loss']) < 1e-4
     g = model.get_gradients_dict()
-    bad = [(rel(g[k], ref['grads'][k]), k) for k in ref['grads']
-           if rel(g[k], ref['grads'][k]) >= 1e-4 and np.abs(g[k] - ref['grads'][k]).max() >= 1e-6]
+    bad = grad_mismatches(g, ref['grads'])
     assert not bad, bad
     assert all(np.isfinite(v).all() for v in g.values())
     assert rel(model.decoder.output.cpu().numpy(), ref['scores']) < 1e-4
@@ -178,8 +176,7 @@ def test_ragged_inputs_gen_decoder(gpu, enc):
     ref = vo.forward_backward(p['encoder'], p['decoder'], P0, p, batch, None)
     assert np.isfinite(loss) and abs(loss - ref['loss']) < 1e-4 * max(1.0, abs(ref['loss']))
     g = model.get_gradients_dict()
-    bad = [(rel(g[k], ref['grads'][k]), k) for k in ref['grads']
-           if rel(g[k], ref['grads'][k]) >= 1e-4 and np.abs(g[k] - ref['grads'][k]).max() >= 1e-6]
+    bad = grad_mismatches(g, ref['grads'])
     assert not bad, bad
 
 
@@ -237,7 +234,10 @@ def test_ranks_and_metrics_match_oracle(gpu):
     # wherever the top-2 margin exceeds the fp32 tolerance
     np.testing.assert_array_equal(gt_ranks, vo.compute_ranks(dev_scores, batch['answer_ind'] - 1))
     ref_ranks = vo.compute_ranks(ref['scores'], batch['answer_ind'] - 1)
-    assert (gt_ranks != ref_ranks).mean() <= 0.02
+    # against the ORACLE's ranks: a difference is accepted only where the fp64 scores are a near tie (< 1e-4)
+    flipped, unexplained = unexplained_rank_flips(dev_scores, ref['scores'])
+    assert not unexplained, unexplained[:10]
+    assert (np.asarray(gt_ranks).reshape(-1) != ref_ranks.reshape(-1)).sum() <= flipped
     m_dev, m_ref = utils.processRanks(gt_ranks, verbose=False), vo.process_ranks(gt_ranks)
     for k in ('r@1', 'r@5', 'r@10', 'medianR', 'meanR', 'meanRR'):
         assert abs(m_dev[k] - m_ref[k]) < 1e-12
@@ -311,8 +311,7 @@ def test_widened_pairs_match_oracle(gpu, enc, dec, case):
     assert abs(loss - ref['loss']) < 1e-4 * max(1.0, abs(ref['loss']))
     g = model.get_gradients_dict()
     gnorm = max(np.abs(v).max() for v in ref['grads'].values())
-    bad = [(rel(g[k], ref['grads'][k]), k) for k in ref['grads']
-           if rel(g[k], ref['grads'][k]) >= 1e-4 and np.abs(g[k] - ref['grads'][k]).max() >= 1e-6 * max(1.0, gnorm)]
+    bad = grad_mismatches(g, ref['grads'])
     assert not bad, bad
     # forward-only (Model:evaluate path, model.lua:128) must give the same loss and leave gradients alone
     before = model.wrapperdW.clone()
@@ -346,7 +345,9 @@ def test_gen_retrieval_matches_oracle(gpu, enc):
     dev = model.scores.cpu().numpy()
     assert np.abs(dev - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
     np.testing.assert_array_equal(gt_ranks, vo.compute_ranks(dev, batch['answer_ind'] - 1))
-    assert (gt_ranks != vo.compute_ranks(ref, batch['answer_ind'] - 1)).mean() <= 0.05
+    flipped, unexplained = unexplained_rank_flips(dev, ref)       # likelihoods are sums of log-probs: scale-aware margin
+    assert not unexplained, unexplained[:10]
+    assert (np.asarray(gt_ranks).reshape(-1) != vo.compute_ranks(ref, batch['answer_ind'] - 1).reshape(-1)).sum() <= flipped
 
 
 @pytest.mark.parametrize("enc", ['lf-ques-im-hist', 'mn-ques-hist'])
@@ -452,10 +453,13 @@ def test_full_size_step_matches_cpp_restatement(gpu):
     G = cs.named(cs.G)
     assert abs(loss - ref_loss) < 1e-4, (loss, ref_loss)
     assert rel(scores, ref_scores) < 1e-4
-    bad = [(rel(g[k], G[k]), k) for k in G if rel(g[k], G[k]) >= 5e-4 and np.abs(g[k] - G[k]).max() >= 1e-6]
+    bad = grad_mismatches(g, G, tol=5e-4)      # two fp32 computations of different summation order
     assert not bad, bad
     gt = batch['answer_ind'].reshape(-1) - 1
-    assert (vo.compute_ranks(scores, gt) == vo.compute_ranks(ref_scores, gt)).mean() >= 0.99
+    # both sides are fp32 here: a rank may differ only where the two score matrices disagree about a near tie
+    flipped, unexplained = unexplained_rank_flips(scores, ref_scores)
+    assert not unexplained, unexplained[:10]
+    assert (vo.compute_ranks(scores, gt) != vo.compute_ranks(ref_scores, gt)).sum() <= flipped
 
 
 def test_weight_gradient_atomics_spread_is_bounded(gpu):

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import small_params
+from conftest import grad_mismatches, small_params, unexplained_rank_flips
 from oracle import visdial_oracle as vo
 from test_model_gpu import ALL_ENC, CASES, WIDE, fuse_masks, make_masks, rel
 from visdial_amd.dataloader import SyntheticDataloader
@@ -39,8 +39,7 @@ def test_native_step_matches_oracle(gpu, case, train_mode):
     ref = vo.forward_backward(p['encoder'], p['decoder'], P0, p, batch, drop)
     assert abs(loss - ref['loss']) < 1e-4
     g = model.get_gradients_dict()
-    bad = [(rel(g[k], ref['grads'][k]), k) for k in ref['grads']
-           if rel(g[k], ref['grads'][k]) >= 1e-4 and np.abs(g[k] - ref['grads'][k]).max() >= 1e-6]
+    bad = grad_mismatches(g, ref['grads'])
     assert not bad, bad
     N, O = batch['options'].shape[0], batch['options'].shape[1]
     assert rel(model.scores(N, O), ref['scores']) < 1e-4
@@ -132,8 +131,7 @@ def test_native_all_pairs_match_oracle(gpu, enc, dec, case):
     assert abs(loss - ref['loss']) < 1e-4 * max(1.0, abs(ref['loss']))
     g = model.get_gradients_dict()
     gnorm = max(np.abs(v).max() for v in ref['grads'].values())
-    bad = [(rel(g[k], ref['grads'][k]), k) for k in ref['grads']
-           if rel(g[k], ref['grads'][k]) >= 1e-4 and np.abs(g[k] - ref['grads'][k]).max() >= 1e-6 * max(1.0, gnorm)]
+    bad = grad_mismatches(g, ref['grads'])
     assert not bad, bad
     # forward-only (Model:evaluate path, model.lua:128): same loss, gradients untouched
     loss2 = model.forwardBackward(batch, onlyForward=True)
@@ -213,10 +211,12 @@ def test_native_full_size_step_matches_cpp_restatement(gpu):
     G = cs.named(cs.G)
     assert abs(loss - ref_loss) < 1e-4, (loss, ref_loss)
     assert rel(scores, ref_scores) < 1e-4
-    bad = [(rel(g[k], G[k]), k) for k in G if rel(g[k], G[k]) >= 5e-4 and np.abs(g[k] - G[k]).max() >= 1e-6]
+    bad = grad_mismatches(g, G, tol=5e-4)      # two fp32 computations of different summation order
     assert not bad, bad
     gt = batch['answer_ind'].reshape(-1) - 1
-    assert (vo.compute_ranks(scores, gt) == vo.compute_ranks(ref_scores, gt)).mean() >= 0.99
+    flipped, unexplained = unexplained_rank_flips(scores, ref_scores)     # both fp32: only near ties may differ
+    assert not unexplained, unexplained[:10]
+    assert (vo.compute_ranks(scores, gt) != vo.compute_ranks(ref_scores, gt)).sum() <= flipped
     # one Adam step on both sides, then the parameters
     model.update()
     cs.step(batch, masks, update=True, lr=p['learningRate'])
@@ -249,8 +249,7 @@ def test_native_ragged_empty_and_max_length_inputs(gpu, train_mode):
     ref = vo.forward_backward(p['encoder'], p['decoder'], P0, p, batch, drop)
     assert np.isfinite(loss) and abs(loss - ref['loss']) < 1e-4
     g = model.get_gradients_dict()
-    bad = [(rel(g[k], ref['grads'][k]), k) for k in ref['grads']
-           if rel(g[k], ref['grads'][k]) >= 1e-4 and np.abs(g[k] - ref['grads'][k]).max() >= 1e-6]
+    bad = grad_mismatches(g, ref['grads'])
     assert not bad, bad
     N, O = batch['options'].shape[0], batch['options'].shape[1]
     dev = model.scores(N, O)
