@@ -120,7 +120,9 @@ end
 function Model:trainIteration(dataloader)
     self:commitW()
     if not self.havePrefetched then
-        self:upload(dataloader:getTrainBatch(self.params)); self.havePrefetched = true
+        -- first call, or evaluate / retrieve / predict replaced the prefetched batch in the library's slot: the batch
+        -- drawn for this step is still on the host (the dataloader's sample stream is not advanced twice)
+        self:upload(self.nextBatch or dataloader:getTrainBatch(self.params)); self.havePrefetched = true
     end
     local numTokens = self.numTokens                                   -- of the batch this step trains on
     vd.call('vd_model_forward_backward', self.h, 0)
@@ -131,7 +133,8 @@ function Model:trainIteration(dataloader)
     vd.call('vd_model_update', self.h, 1.0 / world)                    -- [average] clamp(-5,5) + adam + lr decay (model.lua:96-105)
     vd.call('vd_model_learning_rate', self.h, lr, 0)
     self.optims.learningRate = tonumber(lr[0])
-    self:upload(dataloader:getTrainBatch(self.params))
+    self.nextBatch = dataloader:getTrainBatch(self.params)
+    self:upload(self.nextBatch)                                        -- prefetch into the second slot (copy stream)
     local curLoss = self:loss()
     -- model.lua:73-93: the EMA lives in the GLOBAL `runningLoss` that train.lua:89 initialises and train.lua:113 prints;
     -- gen feeds curLoss / numTokens (the criterion sums over tokens), disc curLoss

@@ -89,7 +89,7 @@ def test_train_evaluate_on_real_format_files(tmp_path):
                         '-saveIter', '1000', '--maxIters', '200', '-saveFormat', 'pt'] + data,
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert 'synthetic' not in r.stdout
+    assert 'using synthetic' not in r.stdout
     loss = [float(l.split('[Loss:')[1].split(']')[0]) for l in r.stdout.splitlines() if '[Loss:' in l]
     assert len(loss) == 2 and loss[1] < loss[0]
     ranks = str(tmp_path / 'logs' / 'ranks.json')

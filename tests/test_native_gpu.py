@@ -211,7 +211,8 @@ def test_native_full_size_step_matches_cpp_restatement(gpu):
     G = cs.named(cs.G)
     assert abs(loss - ref_loss) < 1e-4, (loss, ref_loss)
     assert rel(scores, ref_scores) < 1e-4
-    bad = grad_mismatches(g, G, tol=5e-4)      # two fp32 computations of different summation order
+    bad = grad_mismatches(g, G, tol=5e-4, zero=('att.b',))   # two fp32 computations of different summation order;
+    # 'att.b' shifts every logit of a softmax: its exact gradient is 0 and both sides hold fp32 rounding noise
     assert not bad, bad
     gt = batch['answer_ind'].reshape(-1) - 1
     flipped, unexplained = unexplained_rank_flips(scores, ref_scores)     # both fp32: only near ties may differ

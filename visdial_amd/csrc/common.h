@@ -68,6 +68,28 @@ __device__ __forceinline__ float vd_tanh(float x) {
   return copysignf(t, x);
 }
 
+// Streaming (non-temporal) 16-byte accesses for data that is written once and read much later (saved gates, da):
+// A/B build knob -DVD_EPI_NT=1 (`make variant NAME=nt DEFS=-DVD_EPI_NT=1`), else plain accesses.
+#ifndef VD_EPI_NT
+#define VD_EPI_NT 0
+#endif
+__device__ __forceinline__ void vd_st4_stream(float* p, const float4& v) {
+#if VD_EPI_NT
+  f32x4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ float4 vd_ld4_stream(const float* p) {
+#if VD_EPI_NT
+  const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(t[0], t[1], t[2], t[3]);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
+
 // wave64 all-reduce helpers
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

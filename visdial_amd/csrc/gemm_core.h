@@ -661,10 +661,30 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW)
 gemm_f32_glds_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, int rotate, const float* A, long lda,
                      const float* B, long ldb, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = wg % tiles_n;
-  const int tile_m = (wg / tiles_n) % tiles_m;
-  const int split = wg / (tiles_n * tiles_m);
+  // workgroup -> tile.  bits 8.. of `rotate` select the XCD partition (block b runs on XCD b % 8):
+  //   0  every XCD owns a contiguous range of tiles in n-fastest order (all column tiles of ~tiles_m/8 row tiles)
+  //   1  every XCD owns tiles_n/8 COLUMN tiles for all row tiles: its slice of the B operand (the recurrent weights)
+  //      stays resident in its private L2, the A panels stream through (needs tiles_n % 8 == 0, no split-K)
+  //   2  2 x 4: XCD x owns column group x & 3 (tiles_n/4 tiles) of row half x >> 2 (needs tiles_n % 4 == 0)
+  const int xmap = rotate >> 8;
+  rotate &= 255;
+  int tile_n, tile_m, split = 0;
+  if (xmap == 1) {
+    const int cpx = tiles_n >> 3, xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    tile_n = xcd * cpx + li % cpx;
+    tile_m = li / cpx;
+  } else if (xmap == 2) {
+    const int cpx = tiles_n >> 2, xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int half0 = (tiles_m + 1) >> 1;
+    tile_n = (xcd & 3) * cpx + li % cpx;
+    tile_m = (xcd >> 2) * half0 + li / cpx;
+    if (tile_m >= tiles_m) return;           // the grid is padded to 8 x half0 x cpx
+  } else {
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    tile_n = wg % tiles_n;
+    tile_m = (wg / tiles_n) % tiles_m;
+    split = wg / (tiles_n * tiles_m);
+  }
   const int ks = split * kchunk, ke = min(K, ks + kchunk);
   gemm_block_glds<Cfg, KMAJ>(M, N, ks, ke, tile_m * Cfg::BM, tile_n * Cfg::BN,
                              rotate ? tile_m * 5 + tile_n * 3 + split : -1, A, lda, B, ldb, epi, smem);
@@ -691,11 +711,21 @@ static int launch_gemm_glds(int M, int N, int K, int splits, const float* A, lon
   static bool attr_set = false;
   if (!attr_set) {
     VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               Cfg::LDS_BYTES));
+                               160 * 1024));
     attr_set = true;
   }
-  const int rotate = rotate_in >= 0 ? rotate_in : vd_tune_get("VD_GEMM_ROTATE", 1);
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, M, N, K,
+  int rotate = rotate_in >= 0 ? rotate_in : vd_tune_get("VD_GEMM_ROTATE", 1);
+  // A/B knobs (scripts/microbench.py): XCD partition of the step kernels' tiles, and an LDS request padded beyond
+  // what the kernel uses (occupancy shaping: 41 KB -> 3 workgroups per CU, 70 KB -> 2, 100 KB -> 1)
+  int grid = tiles_m * tiles_n * splits;
+  int xmap = (!KMAJ && splits == 1) ? vd_tune_get("VD_GLDS_XMAP", 0) : 0;
+  if (xmap == 1 && tiles_n % 8 != 0) xmap = 0;
+  if (xmap == 2 && tiles_n % 4 != 0) xmap = 0;
+  if (xmap == 2) grid = 8 * ((tiles_m + 1) / 2) * (tiles_n / 4);
+  rotate |= xmap << 8;
+  int lds = Cfg::LDS_BYTES;
+  if (!KMAJ) lds = max(lds, min(160 * 1024, vd_tune_get("VD_GLDS_LDS_BYTES", 0)));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds, stream, M, N, K,
                      kchunk, tiles_m, tiles_n, rotate, A, lda, B, ldb, e);
   VD_LAUNCH_CHECK();
   return VD_OK;

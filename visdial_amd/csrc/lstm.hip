@@ -174,10 +174,10 @@ struct EpiLstmFwdT {
       const int row = row0 + p * 8 + rl;
       if (row < M) {
         float* gr = gates + (long)row * 4 * H + j;
-        *reinterpret_cast<float4*>(gr) = gi;
-        *reinterpret_cast<float4*>(gr + H) = gf;
-        *reinterpret_cast<float4*>(gr + 2 * H) = go;
-        *reinterpret_cast<float4*>(gr + 3 * H) = gg;
+        vd_st4_stream(gr, gi);           // saved for the backward pass: written once, read ~10 ms later
+        vd_st4_stream(gr + H, gf);
+        vd_st4_stream(gr + 2 * H, go);
+        vd_st4_stream(gr + 3 * H, gg);
         *reinterpret_cast<float4*>(c_out + (long)row * H + j) = c;
         *reinterpret_cast<float4*>(h_out + (long)row * H + j) = h;
       }
@@ -221,10 +221,10 @@ struct EpiLstmBwd {
   __device__ __forceinline__ void load_slot(Slot& L, int rc, int jc) const {
     const long o = (long)rc * H + jc;
     const float* gr = gates + (long)rc * 4 * H + jc;
-    L.g[0] = *reinterpret_cast<const float4*>(gr);
-    L.g[1] = *reinterpret_cast<const float4*>(gr + H);
-    L.g[2] = *reinterpret_cast<const float4*>(gr + 2 * H);
-    L.g[3] = *reinterpret_cast<const float4*>(gr + 3 * H);
+    L.g[0] = vd_ld4_stream(gr);          // saved gates: read exactly once
+    L.g[1] = vd_ld4_stream(gr + H);
+    L.g[2] = vd_ld4_stream(gr + 2 * H);
+    L.g[3] = vd_ld4_stream(gr + 3 * H);
     L.ct = *reinterpret_cast<const float4*>(c_t + o);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     L.cp = c_prev ? *reinterpret_cast<const float4*>(c_prev + o) : z;

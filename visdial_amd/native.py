@@ -78,6 +78,7 @@ class NativeModel(SplitEval):
             self.tensors.append((name.value.decode(), int(off.value), int(r.value), int(c.value)))
         call("vd_model_init_params", h, int(init_seed))
         self._keep = None
+        self._next_batch, self._next_src = None, None
         self.runningLoss = 0.0
         self._W = None
         self.optims = _Optims(self)
@@ -253,11 +254,18 @@ class NativeModel(SplitEval):
         """model.lua:66-106, software-pipelined like Model.trainIteration: enqueue the step, upload the next batch
         (copy stream, second slot) while the device executes, then wait for this step's loss."""
         if self._keep is None or self._keep is not dataloader:
-            self.upload(dataloader.getTrainBatch(self.params))
+            # nothing usable in the library's slot: first call, another dataloader, or evaluate / retrieve / predict
+            # replaced the prefetched batch.  The batch drawn for this step is still on the host: upload it again
+            # (the dataloader's sample stream is not advanced twice).
+            if self._next_batch is not None and self._next_src is dataloader:
+                self.upload(self._next_batch)
+            else:
+                self.upload(dataloader.getTrainBatch(self.params))
         numTokens = self._numTokens                             # of the batch this step trains on
         call("vd_model_forward_backward", self.h, 0)
         self.update()
-        self.upload(dataloader.getTrainBatch(self.params))      # prefetch: the second slot, on the copy stream
+        self._next_batch, self._next_src = dataloader.getTrainBatch(self.params), dataloader
+        self.upload(self._next_batch)                           # prefetch: the second slot, on the copy stream
         self._keep = dataloader                                 # (upload() clears it: set AFTER the prefetch)
         curLoss = self.loss()
         # model.lua:73-93: gen feeds curLoss / numTokens into the EMA (the criterion sums over tokens), disc curLoss
