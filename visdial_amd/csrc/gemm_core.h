@@ -19,6 +19,7 @@
 #pragma once
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -147,6 +148,22 @@ __device__ __forceinline__ void tile_to_rows(const f32x16& a, float* scr, int la
   asm volatile("" ::: "memory");
 }
 
+// Epilogue functors may declare `struct Pre` + `preload(Pre&, row0, lane, M)`: state fetched before the K loop of the
+// LDS-DMA pipeline and handed to operator() as a trailing `const Pre*` (nullptr from the other pipelines).
+struct EpiNoPre {};
+template <class Epi, class = void>
+struct EpiPreOf {
+  static constexpr bool value = false;
+  using type = EpiNoPre;
+};
+#ifndef VD_NO_EPI_PRE   // (A/B build knob: `make variant NAME=nopre DEFS=-DVD_NO_EPI_PRE`)
+template <class Epi>
+struct EpiPreOf<Epi, std::void_t<typename Epi::Pre>> {
+  static constexpr bool value = true;
+  using type = typename Epi::Pre;
+};
+#endif
+
 // XCD-aware bijective remap of the flat workgroup id (guide T1).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7;
@@ -159,12 +176,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // grouped kernels.
 template <class Cfg, class ASrc, class BSrc, class Epi>
 __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row_base, int col_base, int rot_seed,
-                                           const ASrc& asrc, const BSrc& bsrc, const Epi& epi, float* smem) {
+                                           const ASrc& asrc, const BSrc& bsrc, const Epi& epi, float* smem,
+                                           int tid_in = -1) {
   constexpr int WM = Cfg::WM, NT = Cfg::NT, KW = Cfg::KW;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
   constexpr int THREADS = Cfg::THREADS, STR = Cfg::STRIDE;
   constexpr int NA = Cfg::NA, NB = Cfg::NB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // tid_in: callers that loop over tiles pass a laundered thread id so that per-lane address terms are re-derived per
+  // tile instead of being hoisted out of the tile loop (they would stay live across the epilogue)
+  const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wk = wave / WM;
   const int nk = ke > ks ? (ke - ks + BK - 1) / BK : 0;
 
@@ -509,6 +529,11 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+  // epilogues with a dependent first load (row -> token id -> projection row) fetch the ids HERE: the round trip hides
+  // under the whole K loop instead of standing in front of the epilogue's first row loads
+  typename EpiPreOf<Epi>::type pre;
+  if constexpr (EpiPreOf<Epi>::value) epi.preload(pre, row_base + wm * 32, lane, M);
+
   // per-thread source offsets (bytes, first K tile) of this wave's DMA instructions
   unsigned voffa[NIA], voffb[NIB];
 #pragma unroll
@@ -651,7 +676,8 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
     VD_T(2);
     VD_TREAL(9);
   }
-  epi(acc, row_base + wm * 32, col_base, lane, M, N, smem + wm * 1024);
+  if constexpr (EpiPreOf<Epi>::value) epi(acc, row_base + wm * 32, col_base, lane, M, N, smem + wm * 1024, &pre);
+  else epi(acc, row_base + wm * 32, col_base, lane, M, N, smem + wm * 1024);
   VD_T(4);
   VD_TREAL(7);
 }

@@ -100,7 +100,16 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
   // kernel at 1024 blocks (profiles/r02_dwh_sweep.txt; with 1024 blocks the ranking was the opposite in round 1:
   // the 1.33-round tail, not the pipeline, decided).
   const int cfg = vd_tune_get("VD_TN_CFG", 20);
-  const bool kmaj = cfg == 20 && !(flags & VD_FLAG_BF16) && M % 128 == 0 && N % 128 == 0 && K % 16 == 0 && K >= 4096;
+  const bool kmaj = cfg == 20 && !(flags & VD_FLAG_BF16) && M % 128 == 0 && N % 128 == 0 &&
+                    K >= vd_tune_get("VD_TN_KMAJ_MINK", 1024);
+  if (kmaj && K % 16 != 0) {
+    // the k-major pipeline moves whole 16-row K tiles: contract the first floor(K / 16) * 16 rows with it and the last
+    // < 16 rows with the register-staged kernel (one short launch; e.g. the encoder's (T-1)*N = 7 800 rows)
+    const int K1 = K & ~15;
+    if (int rc = vd_gemm_tn_acc(A, lda, B, ldb, C, ldc, M, N, K1, flags, stream)) return rc;
+    SrcK a2{A + (long)K1 * lda, lda}, b2{B + (long)K1 * ldb, ldb};
+    return launch_gemm<GemmCfg<4, 1, 4, 16, 0, 4, 41984>>(M, N, K - K1, 1, a2, b2, e, (hipStream_t)stream);
+  }
   // split-K target: one full round of workgroups for the big k-major shape; the register-staged shapes (encoder weight
   // gradients, K <= 11 323) take fewer, longer slices -- every slice ends in 64 KB of float atomics per tile
   const int target = kmaj ? vd_tune_get("VD_TN_BLOCKS", 768) : vd_tune_get("VD_TN_BLOCKS_SMALL", 768);

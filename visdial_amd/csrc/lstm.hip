@@ -90,8 +90,35 @@ struct EpiLstmFwdT {
       *reinterpret_cast<float4*>(h_out + (long)row * H + j) = h;
     }
   }
+  // token / mask ids of the lane's 4 rows, fetched before the K loop by the LDS-DMA pipeline (gemm_block_glds): the
+  // dependent chain row -> token id -> projection row loses its first round trip (~3 us under load)
+  struct Pre {
+    int tk[4];
+    int keepbits;
+  };
+  __device__ __forceinline__ void preload(Pre& q, int row0, int lane, int M) const {
+    q.keepbits = 15;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = row0 + p * 8 + (lane >> 3);
+      q.tk[p] = row < M ? row : M - 1;
+    }
+    if (tok_gather) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) q.tk[p] = tok_gather[q.tk[p]];
+    }
+    if (tok_mask) {
+      int kb = 0;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = row0 + p * 8 + (lane >> 3);
+        kb |= (tok_mask[row < M ? row : M - 1] != 0) << p;
+      }
+      q.keepbits = kb;
+    }
+  }
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int vcol0, int lane, int M,
-                                             int /*Nv*/, float* scr) const {
+                                             int /*Nv*/, float* scr, const Pre* pre = nullptr) const {
     if constexpr (SEQ == 2) {
       // DIAGNOSTIC build (knob VD_LSTM_FWD_EPI_SEQ=2, scripts/microbench.py): no epilogue loads, no gate math, one
       // 16-byte store per row -- isolates the K loop of the step kernel.  Results are garbage by construction.
@@ -122,13 +149,21 @@ struct EpiLstmFwdT {
     }
     // (one uniform branch per id array with its 4 loads back to back: a per-row `ptr ? ptr[row] : row` select made
     //  the compiler wait for each load before the next)
-    if (tok_gather) {
+    if (pre) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) tk[p] = tok_gather[rowc[p]];
-    }
-    if (tok_mask) {
+      for (int p = 0; p < 4; ++p) {
+        tk[p] = pre->tk[p];
+        keep[p] = (pre->keepbits >> p) & 1;
+      }
+    } else {
+      if (tok_gather) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) keep[p] = tok_mask[rowc[p]];
+        for (int p = 0; p < 4; ++p) tk[p] = tok_gather[rowc[p]];
+      }
+      if (tok_mask) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) keep[p] = tok_mask[rowc[p]];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     float4 a[4][4];  // [gate][p]
@@ -186,6 +221,10 @@ struct EpiLstmFwdT {
 };
 
 using EpiLstmFwd = EpiLstmFwdT<0>;
+#ifndef VD_TICK_EPI_SEQ
+#define VD_TICK_EPI_SEQ 1   // epilogue flavour of the encoder tick kernels: 1 = compiler-scheduled (3 spilled VGPRs in the persistent
+                           // kernel at the 128-register cap), 0 = the hand-scheduled one of the throughput kernels (12 spills)
+#endif
 
 // ---------------------------------------------------------------------------
 // backward epilogue: acc = (da_{t+1} * Wh^T)[row, j]  (zero at the last step)
@@ -327,6 +366,8 @@ using CfgBwdSmallA = GemmCfg<1, 4, 1, 32, 0, 3>;  // 32 x 32 tile, BK = 128, 33.
 using CfgBwdSmallB = GemmCfg<1, 4, 1, 64, 0, 3>;  // BK = 256, 66.6 KB LDS
 using CfgFwdSmallC = GemmCfg<1, 4, 4, 8, 0, 4>;   // as A, <=128 VGPR: fits beside 3 padded throughput workgroups
 using CfgBwdSmallC = GemmCfg<1, 4, 1, 32, 0, 4>;
+using CfgFwdSmallD = GemmCfg<1, 4, 4, 8, 2, 4>;   // as C with two register stages (tiles k+1, k+2 in flight)
+using CfgBwdSmallD = GemmCfg<1, 4, 1, 32, 2, 4>;
 
 static int env_int(const char* name, int dflt) {
   const char* ev = getenv(name);
@@ -665,6 +706,13 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
     const int cfg = cfg0 == 20 ? 11 : cfg0;
     if (use_glds_bwd(N, H) && K > 0) {
       // LDS-DMA pipeline: A = da_{t+1} rows, Bt = Wh rows (both contiguous in k = the 4H gate columns)
+      if (const int nt4 = vd_tune_get("VD_LSTM_BWD_NT4", 0)) {
+        // A/B: 128 x 128 tiles (every da_{t+1} panel is read by 4 column tiles instead of 8: half the L2 -> LDS operand
+        // traffic per FLOP; 628 tiles leave a 2.45-round tail when the kernel runs alone)
+        EpiLstmBwd<4, 1> e4{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
+        if (nt4 == 2) return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 3, 41984>, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e4, s);
+        return launch_gemm_glds<CfgF9, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e4, s);
+      }
       if (vd_tune_get("VD_LSTM_BWD_BATCH2", 0)) {
         EpiLstmBwd<2, 2> e2b{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
         return launch_gemm_glds<CfgB12, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e2b, s);
@@ -730,9 +778,10 @@ struct SrcKSel {
     return *reinterpret_cast<const float4*>(p + (long)k * ld + col);
   }
 };
+using EpiLstmFwdTick = EpiLstmFwdT<VD_TICK_EPI_SEQ>;
 struct EpiTickFwd {
   int kind;  // 0 = LSTM cell update, 1 = plain store (+bias)
-  EpiLstmFwd f;
+  EpiLstmFwdTick f;
   EpiStore<4> s;
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int col0, int lane, int M,
                                              int N, float* scr) const {
@@ -784,6 +833,296 @@ struct vd_lstm2_bwd_t {
 };
 
 #define VD_MAX_STACKS 2
+
+// ---------------------------------------------------------------------------
+// Persistent two-layer recurrences: ALL T+2 ticks of a direction in ONE launch.
+//
+// The per-tick grouped launches above are short dependent kernels.  Inside the training step they share one hardware
+// queue with the option-LSTM step kernels (2 512 workgroups on 768 slots each): a tick's packet is only dispatched
+// once the big kernel in front of it has started its last workgroup, so a tick that takes 34 us alone takes ~150 us
+// there (profiles/r03_kernel_stats_bench.txt) and the 42-tick encoder forward (6.3 ms + prologue) ends AFTER the
+// 7.5 ms option forward: the main stream waits ~0.6 ms for the encoder output before the criterion.
+//
+// Here the tiles of every tick form one work list in tick-major order.  <= one workgroup per CU (the slot a throughput
+// workgroup cannot use: <= 34 KB LDS, <= 128 VGPRs) pulls items from it; an item only waits for the tiles it really
+// depends on -- the same row tile of <= 2 sub-problems of the PREVIOUS tick (forward: L1 <- L1; X2 <- L1; L2 <- X2, L2;
+// backward: L2 <- L2; X <- L2; L1 <- L1, X), one arrival counter per (tick, stack, sub-problem, row tile).  The hand-off
+// is the release / acquire protocol of the option-LSTM persistent kernels (seq_publish / seq_next above); deadlock
+// freedom needs no co-residency: a workgroup only waits for items dequeued earlier from the same list.
+// Sub-problem descriptors are rebuilt on the device from the stack descriptors (kernel arguments: no per-call table
+// upload); the per-step active-row counts travel in the kernel arguments too (T <= VD_L2_MAXT, else per-tick launches).
+// ---------------------------------------------------------------------------
+#define VD_L2_MAXT 128
+#define VD_L2_KINDS 3
+
+struct L2SeqFwdArgs {
+  vd_lstm2_fwd_t st[VD_MAX_STACKS];           // .nact is NOT dereferenced on the device (host pointer)
+  unsigned short nact[VD_MAX_STACKS][VD_L2_MAXT];
+  int nstacks, H, Tmax, row_tiles;            // row_tiles = counters per (tick, stack, kind)
+  unsigned* sync;
+};
+struct L2SeqBwdArgs {
+  vd_lstm2_bwd_t st[VD_MAX_STACKS];
+  unsigned short nact[VD_MAX_STACKS][VD_L2_MAXT];
+  int nstacks, H, Tmax, row_tiles;
+  unsigned* sync;
+};
+
+// step index of sub-problem `kind` of a stack at tick tau (or -1): forward kinds 0 = L1 cell, 1 = L2 cell, 2 = X2
+// projection; backward kinds 0 = L2 cell, 1 = L1 cell, 2 = dh1 projection -- the order the per-tick host loops use
+__device__ __forceinline__ int l2_fwd_step(int kind, int tau, int T) {
+  const int t = kind == 0 ? tau : (kind == 1 ? tau - 2 : tau - 1);
+  return (t >= 0 && t < T) ? t : -1;
+}
+__device__ __forceinline__ int l2_bwd_step(int kind, int tau, int T) {
+  const int t = kind == 0 ? T - 1 - tau : (kind == 1 ? T + 1 - tau : T - tau);
+  return (t >= 0 && t < T) ? t : -1;
+}
+
+__device__ __forceinline__ TickFwdProb l2_fwd_prob(const vd_lstm2_fwd_t& S, int kind, int t, int rows, int H) {
+  const long NH = (long)S.N * H;
+  TickFwdProb P;
+  P.M = rows; P.N = 4 * H; P.tiles_n = (4 * H) / 128;
+  if (kind < 2) {
+    float* gates = kind == 0 ? S.gates1 : S.gates2;
+    float* h = kind == 0 ? S.h1 : S.h2;
+    float* c = kind == 0 ? S.c1 : S.c2;
+    P.K = t ? H : 0;
+    P.a = SrcRow{t ? h + (t - 1) * NH : h, H};
+    P.b = SrcKSel{kind == 0 ? S.Wh1 : S.Wh2, 4L * H, H, 1};
+    P.e.kind = 0;
+    P.e.f.xproj = gates + (long)t * 4 * NH; P.e.f.xld = 4L * H;
+    P.e.f.tok_gather = nullptr;
+    P.e.f.tok_mask = S.tok_mask ? S.tok_mask + (long)t * S.N : nullptr;
+    P.e.f.c_prev = t ? c + (t - 1) * NH : nullptr;
+    P.e.f.gates = gates + (long)t * 4 * NH; P.e.f.c_out = c + t * NH; P.e.f.h_out = h + t * NH; P.e.f.H = H;
+    P.e.s = EpiStore<4>{nullptr, 0, nullptr, 0, 0};
+  } else {
+    P.K = H;
+    P.a = SrcRow{S.h1 + t * NH, H};
+    P.b = SrcKSel{S.Wx2, 4L * H, H, 0};
+    P.e.kind = 1;
+    P.e.s = EpiStore<4>{S.gates2 + (long)t * 4 * NH, 4L * H, S.b2, VD_ACT_NONE, 0};
+    P.e.f = EpiLstmFwdTick{nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, H};
+  }
+  return P;
+}
+
+__device__ __forceinline__ TickBwdProb l2_bwd_prob(const vd_lstm2_bwd_t& S, int kind, int t, int rows, int H) {
+  const long NH = (long)S.N * H;
+  TickBwdProb P;
+  P.M = rows; P.N = H; P.tiles_n = H / 32;
+  if (kind < 2) {
+    const bool l2 = kind == 0;
+    float* gates = l2 ? S.gates2 : S.gates1;
+    const float* c = l2 ? S.c2 : S.c1;
+    const bool last = (t == S.T - 1);
+    P.K = last ? 0 : 4 * H;
+    P.a = SrcRow{last ? gates : gates + (long)(t + 1) * 4 * NH, 4L * H};
+    P.b = SrcRow{l2 ? S.Wh2 : S.Wh1, 4L * H};
+    P.e.kind = 0;
+    P.e.f.dh_a = l2 ? (last ? S.dh_last2 : nullptr) : S.dh1_seq + t * NH;
+    P.e.f.dh_b = nullptr;
+    P.e.f.gates = gates + (long)t * 4 * NH;
+    P.e.f.c_t = c + t * NH;
+    P.e.f.c_prev = t ? c + (t - 1) * NH : nullptr;
+    P.e.f.dc = l2 ? S.dc2 : S.dc1;
+    P.e.f.dc_first = last ? 1 : 0;
+    P.e.f.H = H;
+    P.e.s = EpiStore<1>{nullptr, 0, nullptr, 0, 0};
+  } else {
+    P.K = 4 * H;
+    P.a = SrcRow{S.gates2 + (long)t * 4 * NH, 4L * H};
+    P.b = SrcRow{S.Wx2, 4L * H};
+    P.e.kind = 1;
+    P.e.s = EpiStore<1>{S.dh1_seq + t * NH, H, nullptr, VD_ACT_NONE, 0};
+    P.e.f = EpiLstmBwd<1>{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, H};
+  }
+  return P;
+}
+
+// Setup kernel (one small launch per direction): thread tau builds the <= 6 sub-problem descriptors of its tick into a
+// table in device memory, thread 0 then prefix-sums the tile counts -- the persistent kernel reads descriptors with
+// scalar loads on demand, like the per-tick grouped kernel reads its kernel arguments.
+template <class Cfg, bool FWD, class Args, class Prob>
+__global__ void __launch_bounds__(VD_L2_MAXT + 2) lstm2_seq_setup_kernel(Args a, Prob* tab, int* item_start) {
+  __shared__ int ntiles[VD_L2_MAXT + 2];
+  const int tau = threadIdx.x, nticks = a.Tmax + 2, H = a.H;
+  const int tiles_n = FWD ? (4 * H) / Cfg::BN : H / Cfg::BN;
+  if (tau < nticks) {
+    int n = 0;
+    for (int s = 0; s < VD_MAX_STACKS; ++s)
+      for (int kind = 0; kind < VD_L2_KINDS; ++kind) {
+        Prob P;
+        int rows = 0;
+        if (s < a.nstacks) {
+          const int t = FWD ? l2_fwd_step(kind, tau, a.st[s].T) : l2_bwd_step(kind, tau, a.st[s].T);
+          rows = t < 0 ? 0 : (int)a.nact[s][t];
+          if constexpr (FWD) P = l2_fwd_prob(a.st[s], kind, t < 0 ? 0 : t, rows, H);
+          else P = l2_bwd_prob(a.st[s], kind, t < 0 ? 0 : t, rows, H);
+        } else {
+          if constexpr (FWD) P = l2_fwd_prob(a.st[0], kind, 0, 0, H);
+          else P = l2_bwd_prob(a.st[0], kind, 0, 0, H);
+        }
+        P.M = rows;
+        tab[(tau * VD_MAX_STACKS + s) * VD_L2_KINDS + kind] = P;
+        n += ((rows + Cfg::BM - 1) / Cfg::BM) * tiles_n;
+      }
+    ntiles[tau] = n;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int i = 0; i < nticks; ++i) {
+      item_start[i] = acc;
+      acc += ntiles[i];
+    }
+    item_start[nticks] = acc;
+  }
+}
+
+// FWD = forward direction.  One workgroup = Cfg (the latency shape of the per-tick launches).
+template <class Cfg, bool FWD, class Prob>
+__global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW)
+lstm2_seq_kernel(const Prob* __restrict__ tab, const int* __restrict__ item_start, int nticks, int tiles_n, int RT,
+                 unsigned* sync) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if constexpr (Cfg::WK > 1) __builtin_amdgcn_s_setprio(3);
+  int* const slot = reinterpret_cast<int*>(smem) + Cfg::LDS_BYTES / 4;   // scheduler mailbox behind the GEMM's LDS image
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane0 = (int)threadIdx.x & 63;
+  const int total = item_start[nticks];
+  unsigned* const head = sync;
+  unsigned* const err = sync + VD_SEQ_ERR_WORD;
+  unsigned* const cnt = sync + VD_SEQ_CNT0;
+  auto pidx = [&](int tau, int s, int kind) { return (tau * VD_MAX_STACKS + s) * VD_L2_KINDS + kind; };
+  for (;;) {
+    if (wave == 0) {   // wave-uniform scheduler (see the note on seq_next): dequeue, decode, wait for the producers
+      const int idx = (int)wave_fetch_add(head, 1u, lane0);
+      int tau = -1, pi = 0, r = 0, j = 0;
+      if (idx < total) {
+        tau = 0;
+        while (item_start[tau + 1] <= idx) ++tau;
+        int rem = idx - item_start[tau];
+        pi = pidx(tau, 0, 0);
+        for (int k = 0; k < VD_MAX_STACKS * VD_L2_KINDS; ++k) {
+          const int n = ((tab[pi].M + Cfg::BM - 1) / Cfg::BM) * tiles_n;
+          if (rem < n) break;
+          rem -= n;
+          ++pi;
+        }
+        r = rem / tiles_n;
+        j = rem - r * tiles_n;
+        if (tau > 0) {
+          // producers at tick tau-1 (same stack, same row tile); kinds: fwd 0 = L1, 1 = L2, 2 = X2; bwd 0 = L2, 1 = L1, 2 = X
+          const int sk = pi - pidx(tau, 0, 0), s = sk / VD_L2_KINDS, kind = sk - s * VD_L2_KINDS;
+          int dep0, dep1 = -1;
+          if (FWD) { dep0 = kind == 1 ? 2 : 0; if (kind == 1) dep1 = 1; }
+          else     { dep0 = kind == 1 ? 1 : 0; if (kind == 1) dep1 = 2; }
+          bool waited = false;
+          for (int d = 0; d < 2; ++d) {
+            const int dep = d == 0 ? dep0 : dep1;
+            if (dep < 0) continue;
+            const int pp = pidx(tau - 1, s, dep);
+            if (tab[pp].M <= r * Cfg::BM) continue;   // that row tile did not exist in the producer: state is the pre-filled zero
+            unsigned* const c = cnt + (long)pp * RT + r;
+            if (wave_load(c, lane0) < (unsigned)tiles_n) {
+              const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+              for (;;) {
+                __builtin_amdgcn_s_sleep(2);
+                if (wave_load(c, lane0) >= (unsigned)tiles_n) break;
+                if (wave_load(err, lane0) != 0u) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > VD_SEQ_TIMEOUT_TICKS) {
+                  if (lane0 == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  break;
+                }
+              }
+            }
+            waited = true;
+          }
+          (void)waited;
+        }
+      }
+      if (lane0 == 0) {
+        slot[0] = tau; slot[1] = pi; slot[2] = r; slot[3] = j;
+      }
+    }
+    __syncthreads();
+    const int tau = __builtin_amdgcn_readfirstlane(slot[0]);
+    if (tau < 0) break;
+    const int pi = __builtin_amdgcn_readfirstlane(slot[1]);
+    const int r = __builtin_amdgcn_readfirstlane(slot[2]);
+    const int j = __builtin_amdgcn_readfirstlane(slot[3]);
+    // the tile reads rows other workgroups wrote in this launch: every wave drops its stale L1 lines first
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const Prob& P = tab[pi];
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // per-lane address terms are rebuilt per tile, not kept live across tiles
+    gemm_block<Cfg>(P.M, P.N, 0, P.K, r * Cfg::BM, j * Cfg::BN, -1, P.a, P.b, P.e, smem, tid);
+    // publish: every wave drains its stores, then one wave releases at agent scope and bumps the counter
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane0 == 0) __hip_atomic_fetch_add(cnt + (long)pi * RT + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// host side: shared by both directions.  Returns VD_OK after launching, or 1 when the persistent path does not apply
+// (caller falls back to the per-tick launches).
+template <class Cfg, bool FWD, class Args, class Prob, class Stack>
+static int launch_lstm2_seq(const Stack* st, int nstacks, int H, int Tmax, hipStream_t stream) {
+  if (Tmax > VD_L2_MAXT) return 1;
+  Args a;
+  memset(&a, 0, sizeof(a));
+  int Nmax = 0;
+  long items = 0;
+  for (int s = 0; s < nstacks; ++s) {
+    a.st[s] = st[s];
+    if (st[s].N > 65535) return 1;
+    Nmax = st[s].N > Nmax ? st[s].N : Nmax;
+    for (int t = 0; t < st[s].T; ++t) {
+      const int rows = st[s].nact ? st[s].nact[t] : st[s].N;
+      a.nact[s][t] = (unsigned short)(rows < 0 ? 0 : rows);
+      items += 3L * vd_cdiv(rows, Cfg::BM);
+    }
+    a.st[s].nact = nullptr;
+  }
+  a.nstacks = nstacks; a.H = H; a.Tmax = Tmax;
+  a.row_tiles = vd_cdiv(Nmax, Cfg::BM);
+  a.sync = nullptr;
+  const int tiles_n = FWD ? (4 * H) / Cfg::BN : H / Cfg::BN;
+  items *= tiles_n;
+  if (items <= 0) return VD_OK;
+  const int nprob = (Tmax + 2) * VD_MAX_STACKS * VD_L2_KINDS;
+  const size_t words = (size_t)VD_SEQ_CNT0 + (size_t)nprob * a.row_tiles;
+  const size_t tab_bytes = (size_t)nprob * sizeof(Prob) + (VD_L2_MAXT + 4) * sizeof(int);
+  VdStreamScratch scr;
+  if (int rc = vd_stream_scratch(stream, tab_bytes, words * sizeof(unsigned), &scr)) return rc;
+  Prob* tab = reinterpret_cast<Prob*>(scr.wht);
+  int* item_start = reinterpret_cast<int*>(reinterpret_cast<char*>(scr.wht) + (size_t)nprob * sizeof(Prob));
+  VD_HIP(hipMemsetAsync(scr.sync, 0, words * sizeof(unsigned), stream));
+  hipLaunchKernelGGL((lstm2_seq_setup_kernel<Cfg, FWD, Args, Prob>), dim3(1), dim3(VD_L2_MAXT + 2), 0, stream, a, tab, item_start);
+  VD_LAUNCH_CHECK();
+  auto kern = lstm2_seq_kernel<Cfg, FWD, Prob>;
+  const int lds = Cfg::LDS_BYTES + 64;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  // one workgroup per CU: the slot left beside three throughput workgroups; never more workgroups than items
+  long grid = (long)vd_tune_get("VD_LSTM2_SEQ_WGS_PER_CU", 1) * vd_num_cus();
+  if (const int abs_wgs = vd_tune_get("VD_LSTM2_SEQ_WGS", 0)) grid = abs_wgs;
+  if (grid > items) grid = items;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::THREADS), lds, stream, (const Prob*)tab, (const int*)item_start,
+                     Tmax + 2, tiles_n, a.row_tiles, scr.sync);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
 
 extern "C" {
 
@@ -1057,6 +1396,10 @@ int vd_lstm2_forward(const vd_lstm2_fwd_t* st, int nstacks, int H, void* stream)
                  "vd_lstm2_forward: stack %d has null/empty fields", s);
     Tmax = st[s].T > Tmax ? st[s].T : Tmax;
   }
+  if (vd_tune_get("VD_LSTM2_PERSIST", 0)) {   // one persistent launch for all T + 2 ticks (see lstm2_seq_kernel); opt-in
+    const int rc = launch_lstm2_seq<CfgFwdSmallC, true, L2SeqFwdArgs, TickFwdProb>(st, nstacks, H, Tmax, (hipStream_t)stream);
+    if (rc <= 0) return rc;
+  }
   for (int tau = 0; tau < Tmax + 2; ++tau) {
     GroupArgs<TickFwdProb, 3 * VD_MAX_STACKS> g;
     g.nprob = 0;
@@ -1091,13 +1434,14 @@ int vd_lstm2_forward(const vd_lstm2_fwd_t* st, int nstacks, int H, void* stream)
         P.b = SrcKSel{S.Wx2, 4L * H, H, 0};
         P.e.kind = 1;
         P.e.s = EpiStore<4>{S.gates2 + (long)t * 4 * NH, 4L * H, S.b2, VD_ACT_NONE, 0};
-        P.e.f = EpiLstmFwd{nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, H};
+        P.e.f = EpiLstmFwdTick{nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, H};
       }
     }
     if (g.nprob == 0) continue;
     static const int scfg = env_int("VD_LSTM_FWD_SMALL", 2);
     if (int rc = scfg == 2 ? launch_grouped<CfgFwdSmallC>(g, (hipStream_t)stream)
-                           : launch_grouped<CfgFwdSmallA>(g, (hipStream_t)stream))
+                 : scfg == 3 ? launch_grouped<CfgFwdSmallD>(g, (hipStream_t)stream)
+                             : launch_grouped<CfgFwdSmallA>(g, (hipStream_t)stream))
       return rc;
   }
   return VD_OK;
@@ -1112,6 +1456,10 @@ int vd_lstm2_backward(const vd_lstm2_bwd_t* st, int nstacks, int H, void* stream
                      st[s].gates2 && st[s].c2 && st[s].dh_last2 && st[s].dh1_seq && st[s].dc1 && st[s].dc2,
                  "vd_lstm2_backward: stack %d has null/empty fields", s);
     Tmax = st[s].T > Tmax ? st[s].T : Tmax;
+  }
+  if (vd_tune_get("VD_LSTM2_PERSIST", 0)) {
+    const int rc = launch_lstm2_seq<CfgBwdSmallC, false, L2SeqBwdArgs, TickBwdProb>(st, nstacks, H, Tmax, (hipStream_t)stream);
+    if (rc <= 0) return rc;
   }
   for (int tau = 0; tau < Tmax + 2; ++tau) {
     GroupArgs<TickBwdProb, 3 * VD_MAX_STACKS> g;
@@ -1156,7 +1504,8 @@ int vd_lstm2_backward(const vd_lstm2_bwd_t* st, int nstacks, int H, void* stream
     if (g.nprob == 0) continue;
     static const int scfg = env_int("VD_LSTM_BWD_SMALL", 2);
     if (int rc = scfg == 2 ? launch_grouped<CfgBwdSmallC>(g, (hipStream_t)stream)
-                           : launch_grouped<CfgBwdSmallA>(g, (hipStream_t)stream))
+                 : scfg == 3 ? launch_grouped<CfgBwdSmallD>(g, (hipStream_t)stream)
+                             : launch_grouped<CfgBwdSmallA>(g, (hipStream_t)stream))
       return rc;
   }
   return VD_OK;

@@ -382,7 +382,15 @@ struct SeqLSTM {
     float* dW = Gp(m, name + ".W");
     float* dWh = dW + D * 4 * H;
     const bool by_rows = rows && rows->act && vd_tune_get("VD_SKIP_PAD_WGRAD", 1) != 0;
-    if (by_rows) {
+    // Where the shape fits the k-major LDS-DMA contraction (M, N multiples of 128: the recurrent weights and the
+    // layer-2 input weights at H = 512) the DENSE product over all T*N rows on that kernel beats the index-list
+    // contraction of the non-pad pairs: the pad pairs hold da = 0 (rt_encoders.h zero-fills them), the kernel streams at
+    // the option dWh kernel's rate, and its workgroups live ~0.1 ms instead of ~0.8 ms -- the index-list kernel is a chain
+    // of dependent (row index -> row) loads per K tile whose long-lived workgroups take the third slot of a third of the
+    // CUs away from the option-LSTM backward kernels for most of their run.
+    const int dense_mode = vd_tune_get("VD_WGRAD_DENSE", 1);
+    auto dense_fits = [&](long Mrows, long K) { return dense_mode != 0 && Mrows % 128 == 0 && (4 * H) % 128 == 0 && K >= 1024; };
+    if (by_rows && !(T > 1 && dense_fits(H, (long)(T - 1) * N))) {
       if (rows->n_act1 > 0)
         VD_TRY(vd_gemm_tn_rows_acc(h, H, rows->prev1, gates, 4 * H, rows->act1, dWh, 4 * H, (int)H, (int)(4 * H), rows->n_act1, s));
     } else if (T > 1) {
@@ -393,7 +401,7 @@ struct SeqLSTM {
     if (dxs) dxs->assign(parts.size(), nullptr);
     long roff = 0;
     for (size_t i = 0; i < parts.size(); ++i) {
-      if (by_rows) {
+      if (by_rows && !dense_fits(parts[i], TN)) {
         if (rows->n_act > 0)
           VD_TRY(vd_gemm_tn_rows_acc(xs[i], parts[i], rows->act, gates, 4 * H, rows->act, dW + roff * 4 * H, 4 * H, (int)parts[i],
                                      (int)(4 * H), rows->n_act, s));

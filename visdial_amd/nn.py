@@ -202,7 +202,12 @@ class SeqLSTM(object):
         da = self.gates.view(T * N, 4 * H)
         h2 = self.h.view(T * N, H)
         rows = getattr(self, 'rows', None)          # (act, act1, prev1): contract the non-pad (t, row) pairs only
-        if rows is not None:
+        # ... except where the shape fits the k-major LDS-DMA contraction (M, N multiples of 128): there the DENSE
+        # product over all T*N rows is faster than the index-list kernel (pad pairs hold da = 0) -- same rule as
+        # csrc/rt_core.h SeqLSTM::param_grads
+        dense = os.environ.get('VD_WGRAD_DENSE', '1') != '0'
+        fits = lambda m, kk: dense and m % 128 == 0 and (4 * H) % 128 == 0 and kk >= 1024
+        if rows is not None and not (T > 1 and fits(H, (T - 1) * N)):
             act, act1, prev1 = rows
             if act1.numel():
                 ops.gemm_tn_rows_acc(h2, prev1, da, act1, self.dWh, M=H, N=4 * H)
@@ -215,7 +220,7 @@ class SeqLSTM(object):
         dxs = []
         for i, (xi, wi, dwi, d) in enumerate(zip(self.xs, self._wx_blocks(self.Wx), self._wx_blocks(self.dWx),
                                                 self.part_dims)):
-            if rows is not None:
+            if rows is not None and not fits(d, T * N):
                 ops.gemm_tn_rows_acc(xi, rows[0], da, rows[0], dwi, M=d, N=4 * H)
             else:
                 ops.gemm_tn_acc(xi, da, dwi, M=d, N=4 * H, K=T * N)
