@@ -22,6 +22,11 @@ def main(path, nsteps_back=1):
     step = rows[lo:hi]
     t0 = step[0][2]
     print("step span %.3f ms, %d kernels" % ((step[-1][3] - t0) / 1e6, len(step)))
+    try:    # which hardware (AQL) queue carried each stream's dispatches
+        qs = db.execute("select stream_id, queue_id, count(*) from kernels group by stream_id, queue_id").fetchall()
+        print("stream -> hardware queue (dispatches): " + ", ".join("s%s->q%s (%d)" % q for q in qs))
+    except Exception as exc:
+        print("(no queue ids in this trace: %s)" % exc)
     streams = sorted(set(r[1] for r in step))
     for s in streams:
         ks = [r for r in step if r[1] == s]

@@ -213,6 +213,34 @@ def test_lstm_persistent_equals_per_step_launches(ops, stagger):
             name, int((a != b).sum()))
 
 
+def test_lstm_step_queue_equals_per_step_launches(ops):
+    """VD_LSTM_STEP_QUEUE=1: every step of a throughput recurrence is one round of resident workgroups pulling tiles
+    from per-XCD queues (the persistent kernel with a one-step work list).  Same tile code -> BIT-IDENTICAL outputs."""
+    T, N, H, V = 6, 20000, 64, 50
+    rng = np.random.RandomState(3)
+    Wh = dev((f32(rng, H, 4 * H) / np.sqrt(H)).astype(np.float32))
+    tab = dev(f32(rng, V + 1, 4 * H) * 0.5)
+    tok = dev(rng.randint(0, V + 1, size=(T, N)).astype(np.int32))
+    dh_last = dev(f32(rng, N, H))
+    out = {}
+    for mode in (0, 1):
+        ops.tune_set("VD_LSTM_STEP_QUEUE", mode)
+        gates = torch.empty(T, N, 4 * H, device="cuda")
+        h = torch.empty(T, N, H, device="cuda")
+        c = torch.empty(T, N, H, device="cuda")
+        dc = torch.empty(N, H, device="cuda")
+        ops.lstm_forward(tab, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok)
+        fwd = (gates.clone(), h.clone(), c.clone())
+        ops.lstm_backward(Wh, gates, c, dc, T, N, H, dh_last=dh_last)
+        assert not ops.lstm_seq_status()
+        torch.cuda.synchronize()
+        out[mode] = fwd + (gates.clone(), dc.clone())
+    ops.tune_clear()
+    for a, b, name in zip(out[0], out[1], ("gates", "h", "c", "da", "dc")):
+        assert torch.equal(a, b), "%s differs between per-step launches and tile-queue launches (%d words)" % (
+            name, int((a != b).sum()))
+
+
 def test_embed_gather_scatter(ops):
     rng = np.random.RandomState(1)
     V, E, rows = 40, 300, 1234

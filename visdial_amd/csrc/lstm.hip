@@ -571,6 +571,7 @@ struct LstmSeqFwdArgs {
   const float *h0, *c0;   // [N x H] or null
   float *gates, *h, *c;   // [T x N x 4H], [T x N x H] x 2
   int N, H, rotate;
+  int t_base;             // single-step launches (sc.T == 1): the real step index of item step 0
   SeqSched sc;
 };
 
@@ -580,8 +581,9 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) lstm_seq_fwd_kernel(L
   VD_SEQ_LOOP_HEAD(a)
   const long NH = (long)a.N * a.H;
   for (;;) {
-    VD_SEQ_NEXT_ITEM(a, t, r, j)
-    if (t < 0) break;
+    VD_SEQ_NEXT_ITEM(a, tq, r, j)
+    if (tq < 0) break;
+    const int t = tq + a.t_base;
     const float* hp = t ? a.h + (t - 1) * NH : a.h0;
     EpiLstmFwd e;
     e.xproj = a.xproj + (long)t * a.x_tstride;
@@ -597,7 +599,8 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) lstm_seq_fwd_kernel(L
     asm volatile("" : "+v"(tid));  // per-lane address terms are rebuilt per tile, not kept live across tiles
     gemm_block_glds<Cfg, false>(a.N, 4 * a.H, 0, hp ? a.H : 0, r * Cfg::BM, j * Cfg::BN, a.rotate ? r * 5 + j * 3 : -1, hp,
                                 (long)a.H, a.WhT, (long)a.H, e, smem, tid);
-    seq_publish(a.sc, t, r, wave, lane0);
+    if (a.sc.T > 1) seq_publish(a.sc, tq, r, wave, lane0);
+    else __syncthreads();   // single-step launch: nobody waits for this tile; only the LDS image is reused
   }
 }
 
@@ -610,6 +613,7 @@ struct LstmSeqBwdArgs {
   float* dc;              // [N x H] work (holds dc_last on entry when dc_has_last)
   int dc_has_last;
   int T, N, H, rotate;
+  int s_base;             // single-step launches (sc.T == 1): the real processing-step index of item step 0
   SeqSched sc;
 };
 
@@ -619,8 +623,9 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) lstm_seq_bwd_kernel(L
   VD_SEQ_LOOP_HEAD(a)
   const long NH = (long)a.N * a.H;
   for (;;) {
-    VD_SEQ_NEXT_ITEM(a, s, r, j)
-    if (s < 0) break;
+    VD_SEQ_NEXT_ITEM(a, sq, r, j)
+    if (sq < 0) break;
+    const int s = sq + a.s_base;
     const int t = a.T - 1 - s;
     const bool last = (s == 0);
     const float* da_next = last ? nullptr : a.gates + (long)(t + 1) * 4 * NH;
@@ -637,7 +642,8 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) lstm_seq_bwd_kernel(L
     asm volatile("" : "+v"(tid));
     gemm_block_glds<Cfg, false>(a.N, a.H, 0, last ? 0 : 4 * a.H, r * Cfg::BM, j * Cfg::BN, a.rotate ? r * 5 + j * 3 : -1,
                                 da_next, 4L * a.H, a.Wh, 4L * a.H, e, smem, tid);
-    seq_publish(a.sc, s, r, wave, lane0);
+    if (a.sc.T > 1) seq_publish(a.sc, sq, r, wave, lane0);
+    else __syncthreads();
   }
 }
 
@@ -1221,13 +1227,38 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
     a.tok_gather = tok_gather; a.tok_mask = tok_mask;
     a.WhT = WhT; a.h0 = h0; a.c0 = c0; a.gates = gates; a.h = h; a.c = c;
     a.N = N; a.H = H; a.rotate = vd_tune_get("VD_GEMM_ROTATE", 1);
+    a.t_base = 0;
     a.sc = SeqSched{scr.sync, T, tiles_m, tiles_n, vd_tune_get("VD_LSTM_STAGGER_US", 0) * 100};
     return launch_seq(lstm_seq_fwd_kernel<CfgF9>, a, CfgF9::LDS_BYTES, CfgF9::THREADS, T * tiles_m * tiles_n, s);
+  }
+  // VD_LSTM_STEP_QUEUE=1 (A/B): every step is ONE round of resident workgroups that pull tiles from per-XCD queues
+  // (the persistent kernel with a one-step work list): the launch dispatches at once, so later packets of the shared
+  // hardware queue (the encoder's ticks) are not held back until the step kernel has started its last workgroup
+  const bool step_queue = glds && !bf16 && nchains <= 1 && vd_tune_get("VD_LSTM_STEP_QUEUE", 0) != 0;
+  size_t sq_words = 0;
+  if (step_queue) {
+    const int tiles_m = vd_cdiv(N, CfgF9::BM);
+    sq_words = ((size_t)VD_SEQ_CNT0 + tiles_m + 31) / 32 * 32;
+    if (int rc0 = vd_stream_scratch(s, (size_t)4 * H * H * sizeof(float), sq_words * T * sizeof(unsigned), &scr)) return rc0;
+    VD_HIP(hipMemsetAsync(scr.sync, 0, sq_words * T * sizeof(unsigned), s));
   }
   RowChains rc_;
   int rc = rc_.fork(N, s, nchains);
   if (rc) return rc;
   for (int t = 0; t < T; ++t) {
+    if (step_queue && t > 0) {
+      const int tiles_m = vd_cdiv(N, CfgF9::BM), tiles_n = vd_cdiv(4 * H, CfgF9::BN);
+      LstmSeqFwdArgs a;
+      a.xproj = xproj; a.x_tstride = x_tstride; a.xld = x_ld;
+      a.tok_gather = tok_gather; a.tok_mask = tok_mask;
+      a.WhT = WhT; a.h0 = h0; a.c0 = c0; a.gates = gates; a.h = h; a.c = c;
+      a.N = N; a.H = H; a.rotate = vd_tune_get("VD_GEMM_ROTATE", 1);
+      a.t_base = t;
+      a.sc = SeqSched{scr.sync + sq_words * t, 1, tiles_m, tiles_n, 0};
+      rc = launch_seq(lstm_seq_fwd_kernel<CfgF9>, a, CfgF9::LDS_BYTES, CfgF9::THREADS, tiles_m * tiles_n, s);
+      if (rc) return rc;
+      continue;
+    }
     for (int ch = 0; ch < rc_.n; ++ch) {
       const long r0 = rc_.row0[ch];
       const int nr = rc_.row0[ch + 1] - rc_.row0[ch];
@@ -1319,17 +1350,40 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
     a.Wh = Wh; a.gates = gates; a.c = c; a.c0 = c0; a.dh_seq = dh_seq; a.dh_last = dh_last; a.dc = dc_work;
     a.dc_has_last = dc_last ? 1 : 0;
     a.T = T; a.N = N; a.H = H; a.rotate = vd_tune_get("VD_GEMM_ROTATE", 1);
+    a.s_base = 0;
     a.sc = SeqSched{scr.sync, T, tiles_m, tiles_n, vd_tune_get("VD_LSTM_STAGGER_US", 0) * 100};
     const int rc0 = vd_tune_get("VD_LSTM_BWD_BATCH2", 0)
                         ? launch_seq(lstm_seq_bwd_kernel<CfgB12>, a, CfgB12::LDS_BYTES, CfgB12::THREADS, T * tiles_m * tiles_n, s)
                         : launch_seq(lstm_seq_bwd_kernel<CfgB11>, a, CfgB11::LDS_BYTES, CfgB11::THREADS, T * tiles_m * tiles_n, s);
     if (rc0) return rc0;
   }
+  const bool step_queue = use_glds_bwd(N, H) && !(flags & VD_FLAG_BF16) && T > 1 && nchains <= 1 && !trail && !persist &&
+                          vd_tune_get("VD_LSTM_STEP_QUEUE", 0) != 0;
+  VdStreamScratch sq_scr;
+  size_t sq_words = 0;
+  if (step_queue) {
+    const int tiles_m = vd_cdiv(N, CfgB11::BM);
+    sq_words = ((size_t)VD_SEQ_CNT0 + tiles_m + 31) / 32 * 32;
+    if (int rc0 = vd_stream_scratch(s, 0, sq_words * T * sizeof(unsigned), &sq_scr)) return rc0;
+    VD_HIP(hipMemsetAsync(sq_scr.sync, 0, sq_words * T * sizeof(unsigned), s));
+  }
   RowChains rc_;
   int rc = rc_.fork(N, s, persist ? 1 : nchains);
   if (rc) return rc;
   for (int t = T - 1; t >= 0 && !persist; --t) {
     const bool last = (t == T - 1);
+    if (step_queue && !last) {
+      const int tiles_m = vd_cdiv(N, CfgB11::BM), tiles_n = vd_cdiv(H, CfgB11::BN);
+      LstmSeqBwdArgs a;
+      a.Wh = Wh; a.gates = gates; a.c = c; a.c0 = c0; a.dh_seq = dh_seq; a.dh_last = dh_last; a.dc = dc_work;
+      a.dc_has_last = dc_last ? 1 : 0;
+      a.T = T; a.N = N; a.H = H; a.rotate = vd_tune_get("VD_GEMM_ROTATE", 1);
+      a.s_base = T - 1 - t;
+      a.sc = SeqSched{sq_scr.sync + sq_words * t, 1, tiles_m, tiles_n, 0};
+      rc = launch_seq(lstm_seq_bwd_kernel<CfgB11>, a, CfgB11::LDS_BYTES, CfgB11::THREADS, tiles_m * tiles_n, s);
+      if (rc) return rc;
+      continue;
+    }
     for (int ch = 0; ch < rc_.n; ++ch) {
       const long r0 = rc_.row0[ch];
       const int nr = rc_.row0[ch + 1] - rc_.row0[ch];
@@ -1502,7 +1556,7 @@ int vd_lstm2_backward(const vd_lstm2_bwd_t* st, int nstacks, int H, void* stream
       }
     }
     if (g.nprob == 0) continue;
-    static const int scfg = env_int("VD_LSTM_BWD_SMALL", 2);
+    static const int scfg = env_int("VD_LSTM_BWD_SMALL", 3);   // 3 = two register stages: -0.2 ms per headline step vs 2
     if (int rc = scfg == 2 ? launch_grouped<CfgBwdSmallC>(g, (hipStream_t)stream)
                  : scfg == 3 ? launch_grouped<CfgBwdSmallD>(g, (hipStream_t)stream)
                              : launch_grouped<CfgBwdSmallA>(g, (hipStream_t)stream))

@@ -168,8 +168,17 @@ int vd_model_create(const vd_model_params* p, const char* encoder, const char* d
   int least = 0, greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
   if (hipStreamCreateWithPriority(&m->s_main, hipStreamNonBlocking, least) != hipSuccess) return fail(VD_ERR_HIP);
-  for (hipStream_t* s : {&m->s_enc, &m->s_img, &m->s_tab, &m->s_copy})
+  for (hipStream_t* s : {&m->s_enc, &m->s_img, &m->s_copy})
     if (hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest) != hipSuccess) return fail(VD_ERR_HIP);
+  // A/B knob VD_RT_TAB_MID_PRIO=1: the table-gradient stream at the MIDDLE priority.  HIP gives every priority class its
+  // own hardware queue (rocprofv3 kernel trace, GPU_MAX_HW_QUEUES=1: main -> one queue, all `greatest` streams ->
+  // another); inside a queue packets start in submission order, so the table-gradient chain (segmented row sum, dTable
+  // products -- enqueued behind the encoder backward's ~100 packets) only starts when the encoder backward has drained
+  // and ends ~0.5 ms after the dWh contraction.  On its own queue it starts with dWh instead -- and LOSES 0.5 ms per
+  // step (24.97 / 25.14 vs 24.46 / 24.53 ms): beside the MFMA-bound dWh the HBM-bound row sum takes 2.9 ms instead of
+  // 0.7 and dWh 6.9 instead of 6.1 (profiles/r03_experiments.txt).  Default off.
+  const int tab_prio = (least - greatest >= 2 && vd_tune_get("VD_RT_TAB_MID_PRIO", 0)) ? (least + greatest) / 2 : greatest;
+  if (hipStreamCreateWithPriority(&m->s_tab, hipStreamNonBlocking, tab_prio) != hipSuccess) return fail(VD_ERR_HIP);
   // No encoder uses both side branches, so the history branch of lf-* / hre-* shares the image-branch stream: HIP
   // multiplexes streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, default 4), and a sixth stream put the
   // table-gradient stream on the main stream's queue (measured: +0.75 ms per headline step).  Hosts that own the
