@@ -180,7 +180,8 @@ def test_ragged_inputs_gen_decoder(gpu, enc):
     assert not bad, bad
 
 
-def test_bf16_option_lstm_step(gpu):
+@pytest.mark.parametrize("size", ['h128', 'h512'])
+def test_bf16_option_lstm_step(gpu, size):
     """BASELINE.json configs[4]: the opt-in bf16 recurrence of the option LSTM (bf16 operands, fp32
     accumulation, everything else fp32).  Its own, looser bound -- stated here: |loss diff| < 1e-3, score
     rel-L2 < 1e-2, gradient rel-L2 < 2e-2 per tensor (8-bit mantissa operands through a 20-step recurrence;
@@ -191,6 +192,8 @@ def test_bf16_option_lstm_step(gpu):
     from visdial_amd import utils
     kw = dict(vocabSize=300, embedSize=64, rnnHiddenSize=128, imgFeatureSize=2048, imgSpatialSize=7,
               commonEmbeddingSize=128, maxQuesCount=10, batchSize=3, numOptions=100, maxQuesLen=10, maxAnsLen=20)
+    if size == 'h512':    # the headline widths (E = 300, H = 512) of BASELINE.json configs[4]: same stated bound
+        kw.update(embedSize=300, rnnHiddenSize=512, commonEmbeddingSize=512, maxQuesLen=20, maxHistoryLenPerRound=40)
     out = {}
     for prec in ('fp32', 'bf16'):
         p = derive(small_params(lstmPrecision=prec, **kw))     # N*O = 3000 rows: the throughput kernels run

@@ -241,6 +241,42 @@ def test_lstm_step_queue_equals_per_step_launches(ops):
             name, int((a != b).sum()))
 
 
+def test_bf16_weight_gradient_on_producer_shadows(ops):
+    """BASELINE.json configs[4] (opt-in bf16 option recurrence): the LSTM step kernels of a bf16 pass also write bf16
+    copies of h and da, and the dWh contraction multiplies those copies directly (LDS-DMA + ds_read_b64_tr_b16, no
+    conversion while staging).  Checked against the fp32 product of the SAME h / da the pass produced: the only difference
+    is the bf16 rounding of the operands (rel-L2 < 1e-2), and against the staging kernel (VD_BF16_SHADOW=0), which rounds
+    the same values the same way (rel-L2 < 1e-5: summation order only).  K = 5 x 4160 rows is not a multiple of 32 x 7:
+    the tail rows take the staging kernel."""
+    T, N, H, V = 6, 4168, 128, 40
+    rng = np.random.RandomState(5)
+    Wh = dev((f32(rng, H, 4 * H) / np.sqrt(H)).astype(np.float32))
+    tab = dev(f32(rng, V + 1, 4 * H) * 0.5)
+    tok = dev(rng.randint(0, V + 1, size=(T, N)).astype(np.int32))
+    dh_last = dev(f32(rng, N, H))
+    res = {}
+    for shadow in (1, 0):
+        ops.tune_set("VD_BF16_SHADOW", shadow)
+        gates = torch.empty(T, N, 4 * H, device="cuda")
+        h = torch.empty(T, N, H, device="cuda")
+        c = torch.empty(T, N, H, device="cuda")
+        dc = torch.empty(N, H, device="cuda")
+        ops.lstm_forward(tab, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok, flags=1)
+        ops.lstm_backward(Wh, gates, c, dc, T, N, H, dh_last=dh_last, flags=1)
+        dWh = torch.zeros(H, 4 * H, device="cuda")
+        K = (T - 1) * N
+        ops.gemm_tn_acc(h.view(T * N, H), gates.view(T * N, 4 * H)[N:], dWh, M=H, N=4 * H, K=K, flags=1)
+        torch.cuda.synchronize()
+        ref = h.view(T * N, H)[:K].double().T @ gates.view(T * N, 4 * H)[N:].double()
+        res[shadow] = (dWh.double(), ref)
+    ops.tune_clear()
+    for shadow, (got, ref) in res.items():
+        err = float((got - ref).norm() / ref.norm())
+        assert err < 1e-2, (shadow, err)
+    a, b = res[1][0], res[0][0]
+    assert float((a - b).norm() / b.norm()) < 1e-5     # same rounded operands, different summation order
+
+
 def test_embed_gather_scatter(ops):
     rng = np.random.RandomState(1)
     V, E, rows = 40, 300, 1234

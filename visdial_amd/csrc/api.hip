@@ -68,6 +68,51 @@ int vd_stream_scratch(hipStream_t stream, size_t wht_bytes, size_t sync_bytes, V
   return VD_OK;
 }
 
+// ---- bf16 shadows (common.h) -----------------------------------------------------------------------------
+namespace {
+struct Bf16Shadow {
+  const float* base = nullptr;   // registered fp32 range [base, base + floats)
+  size_t floats = 0;
+  vd_bf16_bits* buf = nullptr;
+  size_t cap = 0;                // elements allocated
+  int dev = -1;
+};
+Bf16Shadow g_shadow[2];
+std::mutex g_shadow_mu;
+}  // namespace
+
+int vd_bf16_shadow_get(int slot, const float* base, size_t floats, vd_bf16_bits** out) {
+  std::lock_guard<std::mutex> lk(g_shadow_mu);
+  Bf16Shadow& s = g_shadow[slot & 1];
+  int dev = 0;
+  VD_HIP(hipGetDevice(&dev));
+  if (s.cap < floats || s.dev != dev) {
+    if (s.buf) VD_HIP(hipFree(s.buf));     // synchronises the device: earlier users are done
+    s.buf = nullptr;
+    s.cap = 0;
+    VD_HIP(hipMalloc((void**)&s.buf, floats * sizeof(vd_bf16_bits)));
+    s.cap = floats;
+    s.dev = dev;
+  }
+  s.base = base;
+  s.floats = floats;
+  *out = s.buf;
+  return VD_OK;
+}
+
+const vd_bf16_bits* vd_bf16_shadow_find(const float* p, size_t floats) {
+  std::lock_guard<std::mutex> lk(g_shadow_mu);
+  for (const Bf16Shadow& s : g_shadow)
+    if (s.base && p >= s.base && p + floats <= s.base + s.floats) return s.buf + (p - s.base);
+  return nullptr;
+}
+
+void vd_bf16_shadow_invalidate(const float* p, size_t floats) {
+  std::lock_guard<std::mutex> lk(g_shadow_mu);
+  for (Bf16Shadow& s : g_shadow)
+    if (s.base && p < s.base + s.floats && s.base < p + floats) s.base = nullptr;
+}
+
 int vd_num_cus() {
   static thread_local int cached_dev = -1, cached = 256;
   int dev = 0;

@@ -52,6 +52,17 @@ struct VdStreamScratch {
 int vd_stream_scratch(hipStream_t stream, size_t wht_bytes, size_t sync_bytes, VdStreamScratch* out);
 int vd_num_cus();  // compute units of the current device (cached)
 
+// bf16 shadows of fp32 activations (opt-in bf16 option recurrence, VD_FLAG_BF16; api.hip).  The producing kernels of a
+// bf16 pass (LSTM forward: h; LSTM backward: da) also write a bf16 copy of what they store, into a library-owned buffer
+// registered against the fp32 tensor's address range; the weight-gradient contraction of the same pass finds the two
+// shadows by address and multiplies them directly (LDS-DMA + transpose reads, no fp32 -> bf16 conversion while staging).
+// slot 0 = hidden states, slot 1 = gate gradients.  A shadow is valid until the next producer call on the same slot, or
+// until an fp32 producer overwrites its range (vd_bf16_shadow_invalidate).
+typedef unsigned short vd_bf16_bits;
+int vd_bf16_shadow_get(int slot, const float* base, size_t floats, vd_bf16_bits** out);
+const vd_bf16_bits* vd_bf16_shadow_find(const float* p, size_t floats);
+void vd_bf16_shadow_invalidate(const float* p, size_t floats);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -88,6 +99,13 @@ __device__ __forceinline__ float4 vd_ld4_stream(const float* p) {
 #else
   return *reinterpret_cast<const float4*>(p);
 #endif
+}
+
+// 4 consecutive fp32 -> 4 bf16 (RNE, v_cvt_pk_bf16_f32), one 8-byte store
+__device__ __forceinline__ void vd_st4_bf16(vd_bf16_bits* p, const float4& v) {
+  typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+  bf4 t = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  *reinterpret_cast<bf4*>(p) = t;
 }
 
 // wave64 all-reduce helpers

@@ -38,6 +38,135 @@ __global__ void colsum_kernel(const float* __restrict__ X, long ld, int M, int N
   unsafeAtomicAdd(out + col, (s0 + s1) + (s2 + s3));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 weight-gradient contraction on bf16 operands (BASELINE.json configs[4]): C[M x N] += A[K x M]^T * B[K x N] with A, B
+// the bf16 shadows the producing kernels wrote (common.h).  Both operands are k-major ([k][m] rows), the MFMA wants 8
+// consecutive k per lane: tiles go global -> LDS by DMA with NO conversion or transposing write, and the fragments are
+// fetched with the gfx950 LDS transpose read (ds_read_b64_tr_b16).
+//   * tile = 32 k x 128 m (8 KB) per operand; LDS image = [8 k-groups][8 m-groups] blocks of [4 k][16 m] bf16 (128 B
+//     contiguous: the 16 lanes of a transpose-read group fetch one block conflict-free).  One DMA instruction moves one
+//     k-group (4 k-rows x 128 m = 1 KB); the block layout is produced on the SOURCE side: LDS position p of an
+//     instruction (16 B, lane-linear) takes row k0 + (p & 7) / 2, columns (p >> 3) * 16 + (p & 1) * 8 .. +7.
+//   * MFMA 32x32x16 bf16: lane l holds row l % 32 and k = 8 * (l / 32) .. +7: two transpose reads (k-groups 2h, 2h + 1
+//     of the step, h = l / 32) of the block (m-group = (l % 32) / 16), lane i = l % 16 of the group receives column i.
+//   * three LDS buffers per operand (48 KB per workgroup, 3 workgroups per CU), one barrier per K tile, counted vmcnt.
+// Bound: operand delivery (L2 -> LDS), not the matrix pipe: 16 KB per 8 MFMAs of 32 cycles.
+// ---------------------------------------------------------------------------------------------------------------
+typedef short vd_s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 vd_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ vd_bf16x8 tr_read8(const char* lds_base, int off) {
+  typedef __attribute__((address_space(3))) vd_s16x4* lds_p;
+  const vd_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_base + off));
+  const vd_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_base + off + 1024));
+  union {
+    vd_s16x4 h[2];
+    vd_bf16x8 v;
+  } u;
+  u.h[0] = lo;
+  u.h[1] = hi;
+  return u.v;
+}
+
+__global__ void __launch_bounds__(256, 3)
+gemm_bf16_tn_tr_kernel(const vd_bf16_bits* __restrict__ A, const vd_bf16_bits* __restrict__ B, float* __restrict__ C, long ldc,
+                       int M, int N, int K, int kchunk, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TILE = 8192;                            // bytes per operand tile; 3 buffers per operand
+  char* const lds = reinterpret_cast<char*>(smem);     // [3][A tile | B tile]
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = wg % tiles_n, tile_m = (wg / tiles_n) % tiles_m, split = wg / (tiles_n * tiles_m);
+  const int ks = split * kchunk, ke = min(K, ks + kchunk);
+  const int nk = ke > ks ? (ke - ks) / 32 : 0;
+  const int lane = threadIdx.x & 63;
+  const int wm = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int m0 = tile_m * 128, n0 = tile_n * 128;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // DMA source offsets (bytes from the tile's first k-row) of this wave's two instructions per operand: k-groups wm, wm + 4
+  const int key = (lane & 7) >> 1, col = (lane >> 3) * 16 + (lane & 1) * 8;
+  unsigned voffa[2], voffb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int krow = (i * 4 + wm) * 4 + key;
+    voffa[i] = (unsigned)(((long)krow * M + m0 + col) * 2);
+    voffb[i] = (unsigned)(((long)krow * N + n0 + col) * 2);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)lds;
+  auto issue = [&](int kt, int buf) {
+    const float* ak = reinterpret_cast<const float*>(A + (long)(ks + kt * 32) * M);
+    const float* bk = reinterpret_cast<const float*>(B + (long)(ks + kt * 32) * N);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(voffb[i], bk, lds0 + buf * 2 * TILE + TILE + (i * 4 + wm) * 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(voffa[i], ak, lds0 + buf * 2 * TILE + (i * 4 + wm) * 1024);
+  };
+  // transpose-read offsets inside a tile: k-group pair by lane half, m-group by lane quarter, 8 bytes per lane
+  const int g = lane >> 4, li = lane & 15;
+  const int frag = ((g >> 1) * 2) * 1024 + (g & 1) * 128 + li * 8;
+
+  if (nk > 0) {
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // tile kt has landed when at most the 4 instructions of tile kt + 1 are still in flight
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");   // everybody's share of tile kt is in LDS; tile kt - 1 is fully consumed
+      if (kt + 2 < nk) issue(kt + 2, buf == 0 ? 2 : buf - 1);   // (kt + 2) % 3 == (kt - 1) % 3
+      const char* ta = lds + buf * 2 * TILE;
+      const char* tb = ta + TILE;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {            // two 16-k MFMA steps per 32-k tile
+        const vd_bf16x8 a8 = tr_read8(ta, frag + st * 4096 + wm * 256);
+        vd_bf16x8 b8[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b8[j] = tr_read8(tb, frag + st * 4096 + j * 256);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8[j], acc[j], 0, 0, 0);
+      }
+      buf = buf == 2 ? 0 : buf + 1;
+    }
+  }
+  // split-K partial sums into the gradient buffer with hardware float atomics
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = n0 + j * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + mfma_row(r, lane);
+      unsafeAtomicAdd(C + (long)row * ldc + c, acc[j][r]);
+    }
+  }
+}
+
+static int launch_gemm_bf16_tn_tr(const vd_bf16_bits* A, const vd_bf16_bits* B, float* C, long ldc, int M, int N, int K,
+                                  hipStream_t stream) {
+  const int tiles_m = M / 128, tiles_n = N / 128;
+  const int target = vd_tune_get("VD_TN_BLOCKS", 768);
+  long splits = vd_cdiv(target, (long)tiles_m * tiles_n);
+  int kchunk = vd_cdiv(vd_cdiv(K, splits), 32) * 32;
+  if (kchunk < 32) kchunk = 32;
+  splits = vd_cdiv(K, kchunk);
+  static bool attr_set = false;
+  const int lds = 3 * 2 * 8192;
+  if (!attr_set) {
+    VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_tn_tr_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_tn_tr_kernel, dim3((unsigned)(tiles_m * tiles_n * splits)), dim3(256), lds, stream, A, B, C,
+                     ldc, M, N, K, kchunk, tiles_m, tiles_n);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
 extern "C" {
 
 // C[M x N] (+)= act(A[M x K] * W[N x K]^T + bias)
@@ -117,8 +246,21 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
   const long max_splits = vd_cdiv(K, vd_tune_get("VD_TN_MIN_KCHUNK", 1024));   // (sweep in the full step: 26.03 -> 25.70 ms vs 1024 blocks / 64-row slices)
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  if (flags & VD_FLAG_BF16)   // opt-in reduced precision: bf16 operands, fp32 accumulation
+  if (flags & VD_FLAG_BF16) {   // opt-in reduced precision: bf16 operands, fp32 accumulation
+    // both operands already exist as bf16 (shadows written by the LSTM step kernels of this pass): multiply them directly
+    if (M % 128 == 0 && N % 128 == 0 && K >= 32 && lda == M && ldb == N && (long)32 * N * 2 + 256 < (1L << 31)) {
+      const vd_bf16_bits* a16 = vd_bf16_shadow_find(A, (size_t)K * M);
+      const vd_bf16_bits* b16 = vd_bf16_shadow_find(B, (size_t)K * N);
+      if (a16 && b16) {
+        const int K1 = K & ~31;     // whole 32-row K tiles; the last < 32 rows go through the staging kernel below
+        if (int rc = launch_gemm_bf16_tn_tr(a16, b16, C, ldc, M, N, K1, (hipStream_t)stream)) return rc;
+        if (K1 == K) return VD_OK;
+        SrcK a2{A + (long)K1 * lda, lda}, b2{B + (long)K1 * ldb, ldb};
+        return launch_gemm<GemmCfg<4, 1, 4, 32, 0, 3, 0, 1>>(M, N, K - K1, 1, a2, b2, e, (hipStream_t)stream);
+      }
+    }
     return launch_gemm<GemmCfg<4, 1, 4, 32, 0, 3, 0, 1>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
+  }
   if (kmaj)
     return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 41984>, true>(M, N, K, (int)splits, A, lda, B, ldb, e,
                                                                       (hipStream_t)stream, vd_tune_get("VD_TN_ROTATE", 0));

@@ -31,6 +31,7 @@ struct EpiLstmFwdT {
   float* c_out;           // [N x H]
   float* h_out;           // [N x H]
   int H;
+  vd_bf16_bits* h16 = nullptr;   // nullable: bf16 copy of h_out (bf16 pass: operand of the weight-gradient contraction)
   // SEQ = 1: compiler-scheduled epilogue of round 1 (A/B build, knob VD_LSTM_FWD_EPI_SEQ)
   // The four accumulator tiles are i,f,o,g of hidden units [j0, j0+32).  Each is staged through the wave's LDS
   // scratch so that a lane ends up with 4 consecutive hidden units of one row: every global access of the cell
@@ -88,6 +89,7 @@ struct EpiLstmFwdT {
       *reinterpret_cast<float4*>(gr + 3 * H) = gg;
       *reinterpret_cast<float4*>(c_out + (long)row * H + j) = c;
       *reinterpret_cast<float4*>(h_out + (long)row * H + j) = h;
+      if (h16) vd_st4_bf16(h16 + (long)row * H + j, h);
     }
   }
   // token / mask ids of the lane's 4 rows, fetched before the K loop by the LDS-DMA pipeline (gemm_block_glds): the
@@ -215,6 +217,7 @@ struct EpiLstmFwdT {
         vd_st4_stream(gr + 3 * H, gg);
         *reinterpret_cast<float4*>(c_out + (long)row * H + j) = c;
         *reinterpret_cast<float4*>(h_out + (long)row * H + j) = h;
+        if (h16) vd_st4_bf16(h16 + (long)row * H + j, h);
       }
     }
   }
@@ -245,6 +248,7 @@ struct EpiLstmBwd {
   float* dc;            // [N x H] in: dc_next (ignored when dc_first), out: dc for step t-1
   int dc_first;
   int H;
+  vd_bf16_bits* da16 = nullptr;   // nullable: bf16 copy of da_t [N x 4H] (bf16 pass)
   // A lane serves NT x 4 (column tile, row) slots of 4 consecutive hidden units.  Each slot reads 7-9 float4 (saved
   // gates, c_t, c_{t-1}, dc, incoming dh) before ~30 flops of math, so the epilogue is pure memory latency.  Left to
   // the compiler the slots ran back to back, each behind its own s_waitcnt vmcnt(0) (plus one more round trip per
@@ -321,6 +325,13 @@ struct EpiLstmBwd {
             *reinterpret_cast<float4*>(gr + 2 * H) = ao;
             *reinterpret_cast<float4*>(gr + 3 * H) = ag;
             *reinterpret_cast<float4*>(dc + o) = dn;
+            if (da16) {
+              vd_bf16_bits* g16 = da16 + (long)row * 4 * H + j;
+              vd_st4_bf16(g16, ai);
+              vd_st4_bf16(g16 + H, af);
+              vd_st4_bf16(g16 + 2 * H, ao);
+              vd_st4_bf16(g16 + 3 * H, ag);
+            }
           }
         }
       }
@@ -700,12 +711,16 @@ static int lstm_step_fwd(const float* h_prev, const float* Wh, int N, int H, int
 
 static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, int K, const float* dh_a,
                          const float* dh_b, float* gates, const float* c_t, const float* c_prev, float* dc,
-                         int dc_first, hipStream_t s, int flags = 0) {
+                         int dc_first, hipStream_t s, int flags = 0, vd_bf16_bits* da16 = nullptr) {
   SrcRow a{da_next, 4L * H};
   SrcRow b{Wh, 4L * H};  // B[k][n] = Wh[n][k]
   if ((flags & VD_FLAG_BF16) && N >= 2048 && K > 0) {
-    EpiLstmBwd<2> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
+    EpiLstmBwd<2> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H, da16};
     return launch_gemm<CfgBbf16>(N, H, K, 1, a, b, e, s);
+  }
+  if (da16 && N >= 2048) {   // bf16 pass, step without a recurrent product (the last one): same shadow, generic kernel
+    EpiLstmBwd<2> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H, da16};
+    return launch_gemm<CfgB11>(N, H, K, 1, a, b, e, s);
   }
   if (N >= 2048) {
     static const int cfg0 = env_int("VD_LSTM_BWD_CFG", 20);
@@ -1242,6 +1257,13 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
     if (int rc0 = vd_stream_scratch(s, (size_t)4 * H * H * sizeof(float), sq_words * T * sizeof(unsigned), &scr)) return rc0;
     VD_HIP(hipMemsetAsync(scr.sync, 0, sq_words * T * sizeof(unsigned), s));
   }
+  // bf16 pass: the step kernels also write a bf16 copy of h (the operand of the dWh contraction of the same pass)
+  vd_bf16_bits* h16 = nullptr;
+  if (bf16 && vd_tune_get("VD_BF16_SHADOW", 1)) {
+    if (int rc0 = vd_bf16_shadow_get(0, h, (size_t)T * NH, &h16)) return rc0;
+  } else {
+    vd_bf16_shadow_invalidate(h, (size_t)T * NH);
+  }
   RowChains rc_;
   int rc = rc_.fork(N, s, nchains);
   if (rc) return rc;
@@ -1274,6 +1296,7 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
       e.c_out = c + t * NH + r0 * H;
       e.h_out = h + t * NH + r0 * H;
       e.H = H;
+      e.h16 = h16 ? h16 + t * NH + r0 * H : nullptr;
       if (bf16 && hp)
         rc = launch_gemm<CfgFbf16>(nr, 4 * H, H, 1, SrcRow{hp, H}, SrcRow{WhT, H}, e, rc_.stream[ch]);
       else if (glds && hp) {
@@ -1328,6 +1351,13 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
   hipStream_t s = (hipStream_t)stream;
   const long NH = (long)N * H;
   if (dc_last) VD_HIP(hipMemcpyAsync(dc_work, dc_last, NH * sizeof(float), hipMemcpyDeviceToDevice, s));
+  // bf16 pass: the step kernels also write a bf16 copy of da (the other operand of the dWh contraction)
+  vd_bf16_bits* da16 = nullptr;
+  if ((flags & VD_FLAG_BF16) && N >= 2048 && H % 32 == 0 && vd_tune_get("VD_BF16_SHADOW", 1)) {
+    if (int rc0 = vd_bf16_shadow_get(1, gates, (size_t)T * 4 * NH, &da16)) return rc0;
+  } else {
+    vd_bf16_shadow_invalidate(gates, (size_t)T * 4 * NH);
+  }
   // Recurrent weight gradient dWh += sum_{t>=1} h_{t-1}^T da_t.  Default: one contraction over all (T-1)*N
   // rows after the recurrence.  VD_LSTM_WGRAD_OVERLAP=1 issues it as one chunk per step on a side stream as
   // soon as step t has produced da_t, so the chunks fill the tails / epilogue phases of the step kernels:
@@ -1392,7 +1422,8 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
       rc = lstm_step_bwd(da_next, Wh, nr, H, last ? 0 : 4 * H, dh_seq ? dh_seq + t * NH + r0 * H : nullptr,
                          (last && dh_last) ? dh_last + r0 * H : nullptr, gates + (long)t * 4 * NH + r0 * 4 * H,
                          c + t * NH + r0 * H, t ? c + (t - 1) * NH + r0 * H : c0r, dc_work + r0 * H,
-                         (last && !dc_last) ? 1 : 0, rc_.stream[ch], flags);
+                         (last && !dc_last) ? 1 : 0, rc_.stream[ch], flags,
+                         da16 ? da16 + (long)t * 4 * NH + r0 * 4 * H : nullptr);
       if (rc) return rc;
     }
     if (trail && t >= 1 && rc_.n == 1) {
