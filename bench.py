@@ -338,7 +338,8 @@ def main():
                        "global_batch_dialogs": world * args.batch, "parallelism": "dp%d" % world,
                        "dropout": "on (device generator)", "loss": round(float(loss), 5), "host": args.host,
                        "GPU_MAX_HW_QUEUES": os.environ.get('GPU_MAX_HW_QUEUES', 'default'),
-                       "collective": collective},
+                       "collective": collective,
+                       "option_rows_executed_of_total": (list(model.option_rows()) if args.host == 'native' else None)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

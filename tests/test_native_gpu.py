@@ -407,3 +407,49 @@ def test_retrieve_between_training_steps_does_not_train_on_the_eval_batch(gpu):
     for k in w1:
         assert np.abs(w1[k] - w2[k]).max() < 2e-5, k
     nat.close()
+
+
+@pytest.mark.parametrize("host", ['native', 'python'])
+def test_duplicate_options_are_encoded_once_and_exactly(gpu, host):
+    """decoders/disc.lua:4-15: an option's encoding depends on its tokens only, and on real VisDial the 100 candidates of
+    a round repeat across the rounds of a batch.  Both hosts encode every DISTINCT candidate row once (forward gather,
+    backward scatter-add of the copies' gradients).  The oracle encodes all N*O rows: loss, scores, every gradient and the
+    post-Adam parameters must still match (duplicates share one forward value; their gradients add)."""
+    p = derive(small_params(**CASES['odd']))
+    batch = SyntheticDataloader(p, seed=17).getTrainBatch(p)
+    B, R = batch['ques_fwd'].shape[:2]
+    O = batch['options'].shape[1]
+    opts = batch['options'].reshape(B, R, O, -1).copy()
+    opts[:, 1:] = opts[:, :1]                        # every round of a dialog offers the same candidates
+    opts[:, :, O - 1] = opts[:, :, 0]                # ... and one candidate appears twice inside a round
+    batch['options'] = opts.reshape(B * R, O, -1)
+    total = B * R * O
+    distinct = len({r.tobytes() for r in batch['options'].reshape(total, -1)})
+    assert distinct <= 0.5 * total
+    if host == 'native':
+        from visdial_amd.native import NativeModel
+        model = NativeModel(p, init_seed=5)
+        model.training(False)
+    else:
+        from visdial_amd.model import Model
+        model = Model(p)
+        model.wrapper.evaluate()
+        model.wrapper.zeroGradParameters()
+    P0 = {k: v.astype(np.float64) for k, v in model.get_parameters_dict().items()}
+    loss = model.forwardBackward(batch)
+    if host == 'native':
+        assert model.option_rows() == (distinct, total)
+        scores = model.scores(B * R, O)
+    else:
+        assert model.decoder.NO == distinct
+        scores = model.decoder.output.cpu().numpy()
+    ref = vo.forward_backward(p['encoder'], p['decoder'], P0, p, batch, None)
+    assert abs(loss - ref['loss']) < 1e-4
+    assert rel(scores, ref['scores']) < 1e-4
+    # identical candidates get identical scores, bit for bit
+    s3 = scores.reshape(B * R, O)
+    np.testing.assert_array_equal(s3[:, O - 1], s3[:, 0])
+    bad = grad_mismatches(model.get_gradients_dict(), ref['grads'])
+    assert not bad, bad
+    if host == 'native':
+        model.close()

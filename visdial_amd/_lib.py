@@ -129,6 +129,7 @@ PROTOTYPES = {
     "vd_model_learning_rate": [_p, C.POINTER(C.c_double), _i],
     "vd_model_scores": [_p, _p, _l],
     "vd_model_ranks": [_p, _i, _p],
+    "vd_model_option_rows": [_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "vd_model_family_ms": [_p, C.POINTER(C.c_float)],
     "vd_model_synchronize": [_p],
 }

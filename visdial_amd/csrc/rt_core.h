@@ -61,6 +61,10 @@ struct BatchSlot {
   int32_t* gt = nullptr;  // [N] 0-based
   std::vector<int32_t> gt_host;
   bool has_gt = false;
+  // option de-duplication (decoder disc): the option LSTM encodes every DISTINCT candidate once (decoders/disc.lua:4-15 --
+  // the encoding depends on the tokens only); opt_uid[n * O + o] = its row among the opt.N unique rows, or null
+  int32_t* opt_uid = nullptr;
+  int opt_total = 0;           // N * O
   hipEvent_t ready = nullptr;  // recorded on the copy stream when the upload has landed
   hipEvent_t done = nullptr;   // recorded on the main stream behind the last reader of this slot
   bool used = false;      // a step has read this slot (done is recorded)

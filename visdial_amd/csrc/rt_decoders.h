@@ -50,7 +50,10 @@ struct Disc : Decoder {
   int forward_backward(vd_model* m, BatchSlot& b, bool only_forward) override {
     VD_CHECK_ARG(b.opt.present, "decoder 'disc' needs batch.options");
     VD_CHECK_ARG(only_forward || b.has_gt, "training decoder 'disc' needs batch.answer_ind");
-    const int N = b.q.N, O = m->p.numOptions, NO = N * O, To = b.opt.T;
+    // NO = rows the option LSTM executes: N * O, or the number of DISTINCT candidates when the upload de-duplicated them
+    const int N = b.q.N, O = m->p.numOptions, NOfull = N * O, NO = b.opt.N, To = b.opt.T;
+    const bool dedup = b.opt_uid != nullptr;
+    VD_CHECK_ARG(dedup ? NO <= NOfull : NO == NOfull, "decoder 'disc': %d option rows for %d x %d candidates", NO, N, O);
     const long H = m->p.rnnHiddenSize, E = m->p.embedSize, V = m->p.vocabSize;
     hipStream_t s = m->s_main;
     hipStream_t se = side_stream(m, m->s_enc, s);
@@ -76,12 +79,23 @@ struct Disc : Decoder {
     VD_TRY(join_stream(m, se, s));
     // criterion (+ nn.MM backward) in one kernel (model.lua:330-335)
     const float* optH = h + (long)(To - 1) * NO * H;
-    float *d_optH = nullptr, *d_enc = nullptr;
+    float *d_optH = nullptr, *d_enc = nullptr, *d_optH_full = nullptr;
+    if (dedup) {   // candidate (n, o) reads the state of its distinct row
+      float* full;
+      VD_TRY(ws_get(m, "opt.h_full", (size_t)NOfull * H, &full));
+      VD_TRY(vd_embed_gather(optH, b.opt_uid, nullptr, full, NOfull, (int)H, 1.f, s));
+      optH = full;
+    }
     if (!only_forward) {
       VD_TRY(ws_get(m, "crit.d_optH", (size_t)NO * H, &d_optH));
       VD_TRY(ws_get(m, "crit.d_enc", (size_t)N * H, &d_enc));
+      if (dedup) VD_TRY(ws_get(m, "crit.d_optH_full", (size_t)NOfull * H, &d_optH_full));
     }
-    VD_TRY(vd_score_ce(optH, enc_out, b.gt, scores, loss_rows, d_optH, d_enc, N, O, (int)H, 1.0f / N, s));
+    VD_TRY(vd_score_ce(optH, enc_out, b.gt, scores, loss_rows, dedup ? d_optH_full : d_optH, d_enc, N, O, (int)H, 1.0f / N, s));
+    if (dedup && !only_forward) {   // the gradients of the copies of a distinct row add up
+      VD_TRY(vd_memset(d_optH, 0, (long)NO * H * 4, s));
+      VD_TRY(vd_embed_scatter_acc(d_optH, b.opt_uid, nullptr, d_optH_full, NOfull, (int)H, 1.f, s));
+    }
     VD_TRY(stage_loss(m, loss_rows, N, false, s));
     m->scores = scores;
     m->prof_valid = !only_forward;

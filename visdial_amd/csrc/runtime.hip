@@ -383,7 +383,53 @@ int vd_model_upload_batch(vd_model* m, const vd_batch* hb) {
     VD_TRY(dev_get(sl.bufs, "img", img_n * sizeof(float), (void**)&sl.img));
     VD_HIP(hipMemcpyAsync(sl.img, ip, img_n * sizeof(float), hipMemcpyHostToDevice, s));
   }
-  if (disc) VD_TRY(upload_tokens(sl, sl.opt, "opt", hb->options, (int)NO, hb->To, false, s));   // [N x O x To] -> [To x N*O]
+  if (disc) {
+    // Candidate answers repeat inside a batch on real VisDial (every round's 100 options draw from one answer pool: the
+    // popular answers appear in most rounds), and the option encoding depends on the tokens alone (decoders/disc.lua:4-15):
+    // encode each DISTINCT row once and address it through opt_uid (first-occurrence order; exact -- duplicates share
+    // one forward value and their gradients add).  Synthetic batches have no repeats: the plain path, no extra kernels.
+    sl.opt_uid = nullptr;
+    sl.opt_total = (int)NO;
+    const int To = hb->To;
+    bool dedup = false;
+    if (vd_tune_get("VD_DISC_DEDUP", 1) && NO > 1) {
+      std::vector<int32_t> uid((size_t)NO), uniq;
+      uniq.reserve((size_t)NO * To);
+      const size_t cap = (size_t)1 << (64 - __builtin_clzll((unsigned long long)(2 * NO)));   // power of two >= 2 NO
+      std::vector<int32_t> table(cap, -1);
+      int U = 0;
+      for (long r = 0; r < NO; ++r) {
+        const int32_t* row = hb->options + (size_t)r * To;
+        uint64_t h = 1469598103934665603ull;
+        for (int t = 0; t < To; ++t) h = (h ^ (uint32_t)row[t]) * 1099511628211ull;
+        size_t pos = (size_t)(h ^ (h >> 29)) & (cap - 1);
+        for (;;) {
+          const int32_t u = table[pos];
+          if (u < 0) {
+            table[pos] = U;
+            uid[r] = U++;
+            uniq.insert(uniq.end(), row, row + To);
+            break;
+          }
+          if (memcmp(uniq.data() + (size_t)u * To, row, (size_t)To * sizeof(int32_t)) == 0) {
+            uid[r] = u;
+            break;
+          }
+          pos = (pos + 1) & (cap - 1);
+        }
+      }
+      if ((double)U <= 0.95 * (double)NO) {     // worth two extra [N*O x H] passes (gather / scatter-add)
+        dedup = true;
+        VD_TRY(upload_tokens(sl, sl.opt, "opt", uniq.data(), U, To, false, s));
+        int32_t* up = nullptr;
+        VD_TRY(pin_get(sl.pinned, "opt.uid.stage", (size_t)NO * sizeof(int32_t), (void**)&up));
+        memcpy(up, uid.data(), (size_t)NO * sizeof(int32_t));
+        VD_TRY(dev_get(sl.bufs, "opt.uid", (size_t)NO * sizeof(int32_t), (void**)&sl.opt_uid));
+        VD_HIP(hipMemcpyAsync(sl.opt_uid, up, (size_t)NO * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      }
+    }
+    if (!dedup) VD_TRY(upload_tokens(sl, sl.opt, "opt", hb->options, (int)NO, hb->To, false, s));   // [N x O x To] -> [To x N*O]
+  }
   if (!disc && hb->answer_in && hb->answer_out) {
     VD_TRY(upload_tokens(sl, sl.ain, "ain", hb->answer_in, N, hb->Ta, false, s));
     VD_TRY(upload_tokens(sl, sl.aout, "aout", hb->answer_out, N, hb->Ta, false, s));
@@ -541,6 +587,15 @@ int vd_model_family_ms(vd_model* m, float* ms3) {
   VD_HIP(hipEventElapsedTime(&ms3[0], m->ev_prof[0], m->ev_prof[1]));
   VD_HIP(hipEventElapsedTime(&ms3[1], m->ev_prof[2], m->ev_prof[3]));
   VD_HIP(hipEventElapsedTime(&ms3[2], m->ev_prof[4], m->ev_prof[5]));
+  return VD_OK;
+}
+
+// rows the option LSTM of the last uploaded batch executes vs the N * O candidates it stands for (decoder disc)
+int vd_model_option_rows(vd_model* m, int64_t* executed, int64_t* total) {
+  VD_CHECK_ARG(m && executed && total && m->uploaded >= 0, "vd_model_option_rows: no batch uploaded");
+  const BatchSlot& b = m->slot[m->cur >= 0 ? m->cur : m->uploaded];
+  *executed = b.opt.present ? b.opt.N : 0;
+  *total = b.opt.present ? (b.opt_total ? b.opt_total : b.opt.N) : 0;
   return VD_OK;
 }
 

@@ -36,9 +36,10 @@ class Decoder(object):
         """inputs = {options [To x N*O] int32 time-major, encOut [N x H]} -> scores [N x O]"""
         otok, enc_out = inputs
         ws, H, V = self.ws, self.H, self.V
-        To, NO = otok.shape
+        To, NO = otok.shape            # NO = rows the option LSTM executes: N*O, or the DISTINCT candidates (vd_uid set)
         N = enc_out.shape[0]
-        O = NO // N
+        self.uid = getattr(otok, 'vd_uid', None)
+        O = (otok.vd_total if self.uid is not None else NO) // N
         self.To, self.NO, self.N, self.O = To, NO, N, O
         self.table = ws.get('opt.table', (V + 1, 4 * H))
         ops.gemm_nn(self.emb, self.Wx, self.table, bias=self.b, M=V + 1, N=4 * H, K=self.E)
@@ -50,6 +51,10 @@ class Decoder(object):
                          flags=self.flags)
         ops.prof_end('opt_lstm_fwd', t0, 1)      # one persistent launch for all To steps
         self.optH = self.h[To - 1]
+        if self.uid is not None:       # candidate (n, o) reads the state of its distinct row
+            full = ws.get('opt.h_full', (N * O, H))
+            ops.embed_gather(self.optH, self.uid, full)
+            self.optH = full
         self.output = ws.get('opt.scores', (N, O))   # filled by the criterion call (scores + loss are one kernel)
         return DiscDecoderOutput(self.optH, enc_out, self.output, N, O, H)
 
@@ -62,6 +67,11 @@ class Decoder(object):
         otok, enc_out = inputs
         d_optH, d_enc = gradOutput
         ws, H, V, To, NO = self.ws, self.H, self.V, self.To, self.NO
+        if self.uid is not None:       # the gradients of the copies of a distinct row add up
+            d_u = ws.get('opt.d_optH_u', (NO, H))
+            ops.zero(d_u)
+            ops.embed_scatter_acc(d_u, self.uid, d_optH)
+            d_optH = d_u
         dc = ws.get('opt.dc', (NO, H))
         # the token counting sort and the zero-fill of the table gradient depend on the inputs only:
         # they run on a side stream underneath the backward recurrence

@@ -147,7 +147,17 @@ class Model(SplitEval):
             dec_in['gt'] = self._dev(np.asarray(batch['answer_ind']).reshape(-1) - 1, np.int32)       # 0-based
         if p['decoder'] == 'disc':
             o = batch['options']
-            dec_in['options'] = self._dev(o.reshape(-1, o.shape[2]).T, np.int32)     # [To x N*O]
+            rows = np.ascontiguousarray(o.reshape(-1, o.shape[2]), dtype=np.int32)   # [N*O x To]
+            uid = None
+            if os.environ.get('VD_DISC_DEDUP', '1') != '0' and rows.shape[0] > 1:
+                # encode every DISTINCT candidate once (decoders/disc.lua:4-15: the encoding depends on the tokens only);
+                # same rule as the native runtime (csrc/runtime.hip: vd_model_upload_batch)
+                uniq, inv = np.unique(rows, axis=0, return_inverse=True)
+                if uniq.shape[0] <= 0.95 * rows.shape[0]:
+                    uid, total, rows = self._dev(inv.reshape(-1), np.int32), rows.shape[0], uniq
+            dec_in['options'] = self._dev(rows.T, np.int32)                          # [To x rows]
+            if uid is not None:
+                dec_in['options'].vd_uid, dec_in['options'].vd_total = uid, total
         else:
             for k in ('answer_in', 'answer_out'):
                 if k in batch:

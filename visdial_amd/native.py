@@ -314,6 +314,12 @@ class NativeModel(SplitEval):
         s_ = np.ascontiguousarray(src, dtype=np.int32)
         call("vd_model_decode_select", self.h, s_.ctypes.data, int(n_keep))
 
+    def option_rows(self):
+        """(rows the option LSTM executes, N * O candidates) of the current batch: the upload de-duplicates candidates"""
+        a, b = C.c_int64(), C.c_int64()
+        call("vd_model_option_rows", self.h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
     def family_ms(self):
         a = (C.c_float * 3)()
         call("vd_model_family_ms", self.h, a)
