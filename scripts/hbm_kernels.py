@@ -57,7 +57,8 @@ def main():
     def add(name, kernel_substr, alg_bytes, fn, iters=20, note=''):
         us = timeit(fn, iters=iters)
         gbs = alg_bytes / us / 1e3
-        ins = [(k, v) for k, v in stats.items() if kernel_substr and kernel_substr in k]
+        subs = kernel_substr if isinstance(kernel_substr, (tuple, list)) else (kernel_substr,)
+        ins = [(k, v) for k, v in stats.items() if any(x and x in k for x in subs)]
         ins_txt = ' | '.join('%s x%d avg %.1f us' % (k.split('(')[0][:40], v[0], v[1]) for k, v in ins) or '-'
         rows.append((name, alg_bytes / 1e6, us, gbs, gbs / PEAK, ins_txt, note))
 
@@ -100,12 +101,12 @@ def main():
     wa, ba, u0 = rnd(K) * 0.05, rnd(1), rnd(N, H)
     patt, u1 = torch.empty(N, S2, device=dev), torch.empty(N, H, device=dev)
     fwd_bytes = N * S2 * K * 4 + B * S2 * H * 4 + N * S2 * H + N * H * 8 + N * S2 * 4
-    add('img_att forward (score + softmax + weighted sum)', 'img_att_', fwd_bytes,
+    add('img_att forward (score + softmax + weighted sum)', ('img_att_score', 'img_att_wsum'), fwd_bytes,
         lambda: ops.img_att_forward(iqc, wa, ba, pre, m1, u0, patt, u1, N, R, S2, H, K, 2.0))
     datt, dwa, dba = rnd(N, H), torch.zeros(K, device=dev), torch.zeros(1, device=dev)
     dqc, wk = torch.empty(N, K, device=dev), torch.empty(N, S2, device=dev)
     bwd_bytes = N * S2 * K * 4 * 2 + B * S2 * H * 4 + N * S2 * (H + K) + N * H * 4 + N * K * 4 + N * S2 * 8
-    add('img_att backward (dscore + dz in place)', 'img_att_d', bwd_bytes,
+    add('img_att backward (dscore + dz in place)', ('img_att_dscore', 'img_att_dz'), bwd_bytes,
         lambda: ops.img_att_backward(iqc, wa, pre, m1, m2, patt, datt, dwa, dba, dqc, wk, N, R, S2, H, K, 2.0))
     # --- option scoring + CrossEntropy (forward + backward in one kernel)
     optH, enc = rnd(NO, H), rnd(N, H)

@@ -1350,7 +1350,7 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
   VD_CHECK_ARG((h_seq == nullptr) == (dWh_acc == nullptr), "vd_lstm_backward: h_seq and dWh_acc go together");
   hipStream_t s = (hipStream_t)stream;
   const long NH = (long)N * H;
-  if (dc_last) VD_HIP(hipMemcpyAsync(dc_work, dc_last, NH * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (dc_last && dc_last != dc_work) VD_HIP(hipMemcpyAsync(dc_work, dc_last, NH * sizeof(float), hipMemcpyDeviceToDevice, s));
   // bf16 pass: the step kernels also write a bf16 copy of da (the other operand of the dWh contraction)
   vd_bf16_bits* da16 = nullptr;
   if ((flags & VD_FLAG_BF16) && N >= 2048 && H % 32 == 0 && vd_tune_get("VD_BF16_SHADOW", 1)) {

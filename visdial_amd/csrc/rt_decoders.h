@@ -113,9 +113,6 @@ struct Disc : Decoder {
     VD_TRY(vd_token_sort(b.opt.tok, (long)To * NO, (int)V + 1, offset, work, perm, st));
     VD_TRY(vd_memset(dtab, 0, (V + 1) * 4 * H * 4, st));
     VD_HIP(hipEventRecord(m->ev_prof[2], s));
-    VD_TRY(vd_lstm_backward(Wopt + E * 4 * H, gates, c, nullptr, nullptr, d_optH, nullptr, dc, nullptr, nullptr, nullptr, To, NO, (int)H, flags,
-                            s));
-    VD_HIP(hipEventRecord(m->ev_prof[3], s));
     const bool dwh_first = vd_tune_get("VD_RT_DWH_FIRST", 0) != 0;   // host enqueue order (matters when streams share a hardware queue)
     auto enc_bwd = [&]() -> int {
       VD_TRY(m->enc->backward(m, se, b, d_enc));
@@ -123,7 +120,28 @@ struct Disc : Decoder {
       m->enc_grads_recorded = true;
       return VD_OK;
     };
-    if (!dwh_first) VD_TRY(enc_bwd());
+    // A/B knob VD_RT_ENC_BWD_SPLIT = k (0 = off): the option-LSTM backward runs steps To-1 .. k ALONE, and the encoder
+    // backward only starts beside steps k-1 .. 0 and the dWh contraction (the backward step kernels lose 30 % beside the
+    // encoder, the one-round dWh kernel 7 %).  Two calls of the recurrence: the hand-off is the library's own
+    // (dh0, dc) of the first slice = (dh_last, dc_last) of the second.
+    const int split_k = (!flags && To > 2) ? vd_tune_get("VD_RT_ENC_BWD_SPLIT", 0) : 0;
+    bool enc_started = false;
+    if (split_k > 0 && split_k < To) {
+      const long NH = (long)NO * H;
+      float* dh_mid;
+      VD_TRY(ws_get(m, "opt.dh_mid", (size_t)NO * H, &dh_mid));
+      VD_TRY(vd_lstm_backward(Wopt + E * 4 * H, gates + (long)split_k * 4 * NH, c + (long)split_k * NH, c + (long)(split_k - 1) * NH, nullptr,
+                              d_optH, nullptr, dc, dh_mid, nullptr, nullptr, To - split_k, NO, (int)H, flags, s));
+      VD_TRY(fork_stream(m, s, se));      // the encoder backward may start now
+      if (!dwh_first) { VD_TRY(enc_bwd()); enc_started = true; }
+      VD_TRY(vd_lstm_backward(Wopt + E * 4 * H, gates, c, nullptr, nullptr, dh_mid, dc, dc, nullptr, nullptr, nullptr, split_k, NO, (int)H,
+                              flags, s));
+    } else {
+      VD_TRY(vd_lstm_backward(Wopt + E * 4 * H, gates, c, nullptr, nullptr, d_optH, nullptr, dc, nullptr, nullptr, nullptr, To, NO, (int)H, flags,
+                              s));
+    }
+    VD_HIP(hipEventRecord(m->ev_prof[3], s));
+    if (!dwh_first && !enc_started) VD_TRY(enc_bwd());
     // table gradient + its consumers beside the dWh contraction
     VD_TRY(fork_stream(m, s, st));
     VD_TRY(vd_segment_rowsum_acc(gates, 4 * H, b.opt.tok, perm, (long)To * NO, (int)(4 * H), dtab, 4 * H, st));
