@@ -62,6 +62,9 @@ int vd_stream_scratch(hipStream_t stream, size_t wht_bytes, size_t sync_bytes, V
     s.sync = nullptr;
     s.sync_bytes = 0;
     VD_HIP(hipMalloc((void**)&s.sync, sync_bytes));
+    // a fresh buffer reads as "no time-out recorded": vd_lstm_seq_status looks at its sticky word even when no persistent
+    // launch has initialised the buffer yet (paths that only borrow the scratch for the transposed weights)
+    VD_HIP(hipMemset(s.sync, 0, sync_bytes));
     s.sync_bytes = sync_bytes;
   }
   *out = s;
