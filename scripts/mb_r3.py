@@ -44,9 +44,20 @@ def main():
     bwd = lambda: ops.lstm_backward(Wh, gates, c, dcw, T, N, H, dh_last=dh_last)
     print("library: %s" % os.environ.get("VD_LIB_PATH", "default"))
     variants = [("baseline (3 WG/CU)", {})]
+    if os.environ.get("MB_FULL", "1") == "2":
+        variants += [("K loop only (3 WG/CU)", dict(VD_LSTM_FWD_EPI_SEQ=2)),
+                     ("K loop + epilogue-sized traffic spread over it", dict(VD_LSTM_FWD_EPI_SEQ=3)),
+                     ("K loop + fire-and-forget traffic (DMA gather + store)", dict(VD_LSTM_FWD_EPI_SEQ=4)),
+                     ("256 x 128 tiles, 8 waves, 64 KB LDS (3 A + 2 B buffers), 2 WG/CU", dict(VD_LSTM_FWD_BM256=1)),
+                     ("256 x 128 tiles, 48 KB LDS (2 + 2 buffers)", dict(VD_LSTM_FWD_BM256=2)),
+                     ("K loop + fire-and-forget DMA gathers only", dict(VD_LSTM_FWD_EPI_SEQ=5)),
+                     ("K loop + fire-and-forget stores only", dict(VD_LSTM_FWD_EPI_SEQ=6)),
+                     ("baseline (repeat)", {})]
     if os.environ.get("MB_FULL", "1") == "1":
         variants += [
             ("K loop only (3 WG/CU)", dict(VD_LSTM_FWD_EPI_SEQ=2)),
+            ("K loop + epilogue-sized traffic spread over it", dict(VD_LSTM_FWD_EPI_SEQ=3)),
+            ("the same, 2 WG/CU", dict(VD_LSTM_FWD_EPI_SEQ=3, VD_GLDS_LDS_BYTES=70 * 1024)),
             ("2 WG/CU", dict(VD_GLDS_LDS_BYTES=70 * 1024)),
             ("2 WG/CU, K loop only", dict(VD_GLDS_LDS_BYTES=70 * 1024, VD_LSTM_FWD_EPI_SEQ=2)),
             ("1 WG/CU", dict(VD_GLDS_LDS_BYTES=100 * 1024)),

@@ -164,6 +164,22 @@ struct EpiPreOf<Epi, std::void_t<typename Epi::Pre>> {
 };
 #endif
 
+// Epilogue functors may declare `struct KHook` + khook_init / khook(state, kt, nk, ...) / khook_finish: work issued from
+// INSIDE the K loop of the LDS-DMA pipeline, once per K tile between the barrier and the second half of the MFMA burst
+// (diagnostic: memory traffic of the epilogue's volume spread over the K loop, lstm.hip EpiLstmFwdT<3>).
+template <class Epi, class = void>
+struct EpiKHookOf {
+  static constexpr bool value = false;
+  static constexpr int vm_ops = 0;
+  using type = EpiNoPre;
+};
+template <class Epi>
+struct EpiKHookOf<Epi, std::void_t<typename Epi::KHook>> {
+  static constexpr bool value = true;
+  static constexpr int vm_ops = Epi::KHOOK_VM_OPS;   // fire-and-forget VM operations per hook call
+  using type = typename Epi::KHook;
+};
+
 // XCD-aware bijective remap of the flat workgroup id (guide T1).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7;
@@ -628,6 +644,8 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
     }
   };
 
+  typename EpiKHookOf<Epi>::type hook_state;
+  if constexpr (EpiKHookOf<Epi>::value) epi.khook_init(hook_state);
   if (nk > 0) {
     Frag f0, f1;
     // request order inside every group is B first, then A: the operand with fewer buffers is always the
@@ -654,7 +672,9 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
       // the barrier and expose the fragment-read latency in front of it)
       __builtin_amdgcn_sched_barrier(0);
       if (kt + NBA <= nk) {  // steady state: constant allowance, one immediate
-        constexpr int STEADY = NIA * (NBA - 2) + NIB * (NBB - 2);
+        // (+ the VM operations a K-loop hook issues per iteration without ever waiting for them: they sit between the
+        //  tiles' requests in the in-order queue and must not be mistaken for a tile)
+        constexpr int STEADY = NIA * (NBA - 2) + NIB * (NBB - 2) + EpiKHookOf<Epi>::vm_ops;
         if constexpr (STEADY == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if constexpr (STEADY == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else if constexpr (STEADY == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -669,6 +689,8 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
       if (kt + NBB < nk) issue_b(kt + NBB, cb);
       if (kt + NBA < nk) issue_a(kt + NBA, ca);
       if (kt + 1 < nk) read_frags(na, nb, 0, f0);
+      if constexpr (EpiKHookOf<Epi>::value)
+        epi.khook(hook_state, kt, nk, row_base + wm * 32, col_base, lane, M, ldsA + (NBA * ABUF + NBB * BBUF) * 4);
       mfma16(f1);
       ca = na;
       cb = nb;
@@ -676,6 +698,7 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
     VD_T(2);
     VD_TREAL(9);
   }
+  if constexpr (EpiKHookOf<Epi>::value) epi.khook_finish(hook_state, row_base + wm * 32, col_base, lane, M);
   if constexpr (EpiPreOf<Epi>::value) epi(acc, row_base + wm * 32, col_base, lane, M, N, smem + wm * 1024, &pre);
   else epi(acc, row_base + wm * 32, col_base, lane, M, N, smem + wm * 1024);
   VD_T(4);

@@ -224,6 +224,101 @@ struct EpiLstmFwdT {
 };
 
 using EpiLstmFwd = EpiLstmFwdT<0>;
+
+struct EpiLstmFwdSpread;
+// DIAGNOSTIC (knob VD_LSTM_FWD_EPI_SEQ=4): as EpiLstmFwdSpread below, but the traffic is FIRE-AND-FORGET -- the gather goes
+// global -> LDS by DMA into 1 KB of spare LDS (no register, no consumer, hence no wait), the store writes a constant -- so the
+// only thing measured is whether epilogue-sized traffic issued smoothly from inside the K loop slows the K loop.
+template <int MODE>   // 1 = the DMA gathers only, 2 = the stores only, 3 = both
+struct EpiLstmFwdSpreadNoWaitT {
+  const float* xproj;
+  long xld;
+  const int* tok_gather;
+  float* gates;
+  float* h_out;
+  int H;
+  static constexpr int KHOOK_VM_OPS = MODE == 3 ? 2 : 1;
+  struct KHook {
+    int tk[4];
+  };
+  __device__ __forceinline__ void khook_init(KHook& s) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.tk[i] = 0;
+  }
+  __device__ __forceinline__ void khook(KHook& s, int kt, int nk, int row0, int vcol0, int lane, int M, unsigned lds_spare) const {
+    const int j = (vcol0 >> 7) * 32 + (lane & 7) * 4;
+    const int row = min(row0 + (kt & 3) * 8 + (lane >> 3), M - 1);
+    const int g = (kt >> 2) & 3;
+    if (kt < 4) s.tk[kt & 3] = tok_gather ? tok_gather[row] : row;      // 4 id loads per tile, like the real epilogue
+    const unsigned voff = (unsigned)(((long)s.tk[kt & 3] * xld + g * H + j) * 4);
+    if constexpr (MODE & 1) glds16(voff, xproj, lds_spare);
+    if constexpr (MODE & 2) *reinterpret_cast<float4*>(gates + (long)row * 4 * H + g * H + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __device__ __forceinline__ void khook_finish(KHook&, int, int, int, int) const {}
+  __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int vcol0, int lane, int M, int /*Nv*/,
+                                             float* scr) const {
+    float4 a0[4];
+    const f32x16 sum = acc[0] + acc[1] + acc[2] + acc[3];
+    tile_to_rows(sum, scr, lane, a0);
+    const int j0 = (vcol0 >> 7) * 32 + (lane & 7) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = row0 + p * 8 + (lane >> 3);
+      if (row < M) *reinterpret_cast<float4*>(h_out + (long)row * H + j0) = a0[p];
+    }
+  }
+};
+
+// DIAGNOSTIC (knob VD_LSTM_FWD_EPI_SEQ=3, scripts/mb_r3.py): the K loop of the forward step kernel with memory traffic of the
+// real epilogue's volume and kind ISSUED FROM INSIDE the K loop -- per K tile and lane one 16-byte gather from the projection
+// table (a pseudo-random row) and one 16-byte store into the gates buffer, the loaded value consumed 4 K tiles later -- and the
+// minimal tail of the K-loop-only build.  Answers one question: does epilogue traffic that is spread over the K loop cost the
+// matrix pipe what the epilogue after the K loop costs?  Results are garbage by construction.
+struct EpiLstmFwdSpread {
+  const float* xproj;
+  long xld;
+  const int* tok_gather;
+  float* gates;
+  float* h_out;
+  int H;
+  static constexpr int KHOOK_VM_OPS = 0;   // its loads are consumed (compiler-managed waits): nothing fire-and-forget
+  struct KHook {
+    float4 ring[4];
+    float4 sum;
+  };
+  __device__ __forceinline__ void khook_init(KHook& s) const {
+    s.sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.ring[i] = s.sum;
+  }
+  __device__ __forceinline__ void khook(KHook& s, int kt, int nk, int row0, int vcol0, int lane, int M, unsigned /*lds_spare*/) const {
+    const int j = (vcol0 >> 7) * 32 + (lane & 7) * 4;
+    const int row = min(row0 + (kt & 3) * 8 + (lane >> 3), M - 1);
+    const int g = (kt >> 2) & 3;
+    // consume the load of 4 K tiles ago, then reuse its slot
+    const float4 old = s.ring[kt & 3];
+    s.sum.x += old.x; s.sum.y += old.y; s.sum.z += old.z; s.sum.w += old.w;
+    const long trow = tok_gather ? (long)tok_gather[row] : (long)row;
+    s.ring[kt & 3] = *reinterpret_cast<const float4*>(xproj + trow * xld + g * H + j);
+    *reinterpret_cast<float4*>(gates + (long)row * 4 * H + g * H + j) = s.sum;
+  }
+  __device__ __forceinline__ void khook_finish(KHook& s, int row0, int vcol0, int lane, int M) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s.sum.x += s.ring[i].x; s.sum.y += s.ring[i].y; s.sum.z += s.ring[i].z; s.sum.w += s.ring[i].w; }
+  }
+  __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int vcol0, int lane, int M, int /*Nv*/,
+                                             float* scr) const {
+    float4 a0[4];
+    const f32x16 sum = acc[0] + acc[1] + acc[2] + acc[3];
+    tile_to_rows(sum, scr, lane, a0);
+    const int j0 = (vcol0 >> 7) * 32 + (lane & 7) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = row0 + p * 8 + (lane >> 3);
+      if (row < M) *reinterpret_cast<float4*>(h_out + (long)row * H + j0) = a0[p];
+    }
+  }
+};
 #ifndef VD_TICK_EPI_SEQ
 #define VD_TICK_EPI_SEQ 1   // epilogue flavour of the encoder tick kernels: 1 = compiler-scheduled (3 spilled VGPRs in the persistent
                            // kernel at the 128-register cap), 0 = the hand-scheduled one of the throughput kernels (12 spills)
@@ -1301,9 +1396,26 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
         rc = launch_gemm<CfgFbf16>(nr, 4 * H, H, 1, SrcRow{hp, H}, SrcRow{WhT, H}, e, rc_.stream[ch]);
       else if (glds && hp) {
         const int epi = vd_tune_get("VD_LSTM_FWD_EPI_SEQ", 0);
-        if (epi == 1) {
+        if (const int big = vd_tune_get("VD_LSTM_FWD_BM256", 0)) {
+          // A/B: 256 x 128 workgroup tiles (8 waves): 25 % less operand traffic per FLOP than 128 x 128 -- the step kernels
+          // pay ~6.5 % per extra 25 % of memory traffic through the CU (profiles/r03_experiments.txt section 13)
+          if (big == 2) rc = launch_gemm_glds<GemmCfg<8, 1, 4, 16, 0, 2, 49152>, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e, rc_.stream[ch]);
+          else rc = launch_gemm_glds<GemmCfg<8, 1, 4, 16, 0, 2, 65536>, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e, rc_.stream[ch]);
+        } else if (epi == 1) {
           EpiLstmFwdT<1> e1{e.xproj, e.xld, e.tok_gather, e.tok_mask, e.c_prev, e.gates, e.c_out, e.h_out, e.H};
           rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e1, rc_.stream[ch]);
+        } else if (epi == 4) {
+          EpiLstmFwdSpreadNoWaitT<3> e4{e.xproj, e.xld, e.tok_gather, e.gates, e.h_out, e.H};
+          rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e4, rc_.stream[ch]);
+        } else if (epi == 5) {
+          EpiLstmFwdSpreadNoWaitT<1> e5{e.xproj, e.xld, e.tok_gather, e.gates, e.h_out, e.H};
+          rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e5, rc_.stream[ch]);
+        } else if (epi == 6) {
+          EpiLstmFwdSpreadNoWaitT<2> e6{e.xproj, e.xld, e.tok_gather, e.gates, e.h_out, e.H};
+          rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e6, rc_.stream[ch]);
+        } else if (epi == 3) {
+          EpiLstmFwdSpread e3{e.xproj, e.xld, e.tok_gather, e.gates, e.h_out, e.H};
+          rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e3, rc_.stream[ch]);
         } else if (epi == 2) {
           EpiLstmFwdT<2> e2{e.xproj, e.xld, e.tok_gather, e.tok_mask, e.c_prev, e.gates, e.c_out, e.h_out, e.H};
           rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e2, rc_.stream[ch]);
