@@ -1,0 +1,81 @@
+-- model_ops.lua -- class ModelOps: the reference's Model (model.lua:8-106, 249-342) over plug-in files that are composed IN LUA from
+-- module objects (lua/vdnn.lua, operator-level C ABI) -- lua/encoders/lf-ques.lua + lua/decoders/disc.lua today.  Same control flow
+-- as the reference, call for call: encoder:forward(inputs) -> forwardConnect -> decoder:forward({options, encOut}) ->
+-- criterion:forward / :backward -> decoder:backward -> encoder:backward(inputs, t[2]) (model.lua:297-337), wrapperW / wrapperdW from
+-- getParameters() (model.lua:55), clamp(-5, 5) + adam + learning-rate decay (model.lua:96-105).  lua/model.lua is the other host:
+-- the whole step behind the model-level ABI, any of the 11 x 2 pairs.
+-- UNTESTED HERE (no Lua interpreter); transliteration of examples/host_c_plugin_lf_ques.c, which is built and checked on the GPU.
+local vdnn = dofile('vdnn.lua')
+local vd = vdnn.vd
+
+local ModelOps = torch.class('ModelOps')
+
+function ModelOps:__init(params)
+    self.params = params
+    local encoder = dofile(string.format('encoders/%s.lua', params.encoder))
+    local decoder = dofile(string.format('decoders/%s.lua', params.decoder))
+    self.encoder = encoder.model(params)
+    self.decoder = decoder.model(params, self.encoder)
+    assert(self.encoder.build and self.decoder.build, 'this plug-in pair has no operator-level implementation in Lua: use lua/model.lua')
+    self.forwardConnect, self.backwardConnect = decoder.forwardConnect, decoder.backwardConnect
+    vd.call('vd_set_device', tonumber(os.getenv('VD_DEVICE') or '') or ((params.gpuid or -1) >= 0 and params.gpuid or 0))
+    -- wrapper:getParameters(): embed | encoder tensors | decoder tensors
+    local spec = {{'embed', (params.vocabSize + 1) * params.embedSize}}
+    self.encoder:declare(spec); self.decoder:declare(spec)
+    self.fp = vdnn.FlatParams(spec)
+    self.wrapperW, self.wrapperdW = self.fp.W, self.fp.dW
+    local wordEmbed = vdnn.LookupTableMaskZero(self.fp, 'embed', params.vocabSize, params.embedSize)
+    self.encoder:build(vdnn, self.fp, wordEmbed); self.decoder:build(vdnn, self.fp, wordEmbed)
+    self.wordEmbed = wordEmbed
+    self.optims = {learningRate = params.learningRate, t = 0}
+end
+
+-- [B x R x T] (or [N x O x T]) token tensor -> device int32 [T x rows] time-major (model.lua:255-257: view(-1, T):t())
+local function timeMajor(t)
+    local T = t:size(t:dim())
+    local tm = t:int():view(-1, T):t():contiguous()
+    return {tok = vdnn.devInts(tm), T = T, N = tm:size(2)}
+end
+
+function ModelOps:forwardBackward(batch, onlyForward)
+    local p = self.params
+    local inputs = {timeMajor(batch['ques_fwd'])}
+    local N, H = inputs[1].N, p.rnnHiddenSize
+    self.wordEmbed:zeroPad()
+    local encOut = self.encoder:forward(inputs)                                        -- model.lua:297
+    self.forwardConnect(self.encoder, self.decoder, encOut, inputs[1].T)                -- model.lua:300
+    assert(p.decoder == 'disc', 'ModelOps: the Lua-composed decoders are disc only')
+    local options = timeMajor(batch['options'])
+    local O = options.N / N
+    local gt = vdnn.devInts(batch['answer_ind']:int():view(-1):add(-1):contiguous())    -- 0-based targets
+    local decOut = self.decoder:forward({options, encOut})                              -- model.lua:329
+    -- criterion:forward(decOut, answerInd) + :backward (model.lua:330,334): nn.MM + CrossEntropyCriterion and both gradients, one kernel
+    local scores, lossRows = vdnn.devFloats(N * O), vdnn.devFloats(N)
+    local dOptH, dEnc = vdnn.devFloats(options.N * H), vdnn.devFloats(N * H)
+    if onlyForward then dOptH, dEnc = nil, nil end
+    vd.call('vd_score_ce', decOut, encOut, gt, scores, lossRows, dOptH, dEnc, N, O, H, 1.0 / N, nil)
+    if not onlyForward then
+        local t = self.decoder:backward({options, encOut}, {dOptH, dEnc})              -- model.lua:335
+        self.encoder:backward(inputs, t[2])                                            -- model.lua:337
+    end
+    local host = torch.FloatTensor(N)
+    vd.call('vd_stream_synchronize', nil)
+    vd.call('vd_memcpy_d2h', host:data(), lossRows, N * 4, nil)
+    return host:mean()
+end
+
+function ModelOps:trainIteration(dataloader)
+    self.fp:zeroGrad()                                                                  -- model.lua:68
+    local batch = dataloader:getTrainBatch(self.params)
+    local curLoss = self:forwardBackward(batch)
+    if (runningLoss or 0) > 0 then runningLoss = 0.95 * runningLoss + 0.05 * curLoss else runningLoss = curLoss end   -- model.lua:88-92
+    -- wrapperdW:clamp(-5, 5); adam(wrapperW, wrapperdW, optims)  (model.lua:96-99; optim_updates.lua:62-91)
+    local o = self.optims
+    o.t = o.t + 1
+    local step = o.learningRate * math.sqrt(1 - 0.999 ^ o.t) / (1 - 0.9 ^ o.t)
+    vd.call('vd_clamp_adam', self.fp.W, self.fp.dW, self.fp.m, self.fp.v, self.fp.numel, 1.0, 5.0, 0.9, 0.999, 1e-8, step, nil)
+    if o.learningRate > self.params.minLRate then o.learningRate = o.learningRate * self.params.lrDecayRate end   -- model.lua:102-105
+    return curLoss
+end
+
+return ModelOps

@@ -1,0 +1,165 @@
+-- vdnn.lua -- module objects over the OPERATOR-LEVEL C ABI (include/visdial_hip.h): what `nn` / `rnn` are to the reference's
+-- plug-in files (encoders/*.lua, decoders/*.lua build nn.LookupTableMaskZero, nn.SeqLSTM, nn.Linear, ... and model.lua calls
+-- :forward / :backward on them), for a host whose arithmetic lives in libvisdial_hip.so.  Every method is a handful of ABI
+-- calls; there is no arithmetic in Lua.  A plug-in file written with these modules is lua/encoders/lf-ques.lua (with
+-- lua/decoders/disc.lua and lua/model_ops.lua = the operator-level Model).
+--
+-- UNTESTED HERE (no Lua/LuaJIT/Torch7 in the build container or on the GPU box).  This file is a transliteration of
+-- examples/host_c_plugin_lf_ques.c -- the same module objects and the same ABI calls in the same order, in C -- which IS built
+-- and checked on the GPU against the library's own model-level implementation (tests/test_abi_c_host.py);
+-- tests/test_lua_surface_cpu.py pins that both files use the same entry points.
+local ffi = require 'ffi'
+local vd = dofile('visdial_ffi.lua')
+
+local M = {}
+
+-- ---- device memory (the host has no CUDA tensor type: vd_malloc, vd_memcpy_*) -------------------------------------------------
+function M.devFloats(n)                                   -- torch.CudaTensor(n):zero()
+    local p = ffi.new('void*[1]')
+    local bytes = math.max(n, 4) * 4
+    vd.call('vd_malloc', p, bytes)
+    vd.call('vd_memset', p[0], 0, bytes, nil)
+    return ffi.cast('float*', p[0])
+end
+
+function M.devInts(intTensor)                             -- IntTensor (host, contiguous) -> device int32
+    local n = intTensor:nElement()
+    local p = ffi.new('void*[1]')
+    vd.call('vd_malloc', p, n * 4)
+    vd.call('vd_memcpy_h2d', p[0], intTensor:data(), n * 4, nil)
+    return ffi.cast('int32_t*', p[0])
+end
+
+local function align4(n) return math.floor((n + 3) / 4) * 4 end
+
+-- ---- wrapper:getParameters() (model.lua:55): flat W / dW (+ Adam m, v), every tensor 16-byte aligned ---------------------------
+-- spec = { {name, numel}, ... } in module order; returns an object with .W .dW .m .v (float*), .numel, :view(name) -> W, dW
+local FlatParams = {}
+FlatParams.__index = FlatParams
+
+function M.FlatParams(spec)
+    local self = setmetatable({off = {}, size = {}, order = {}}, FlatParams)
+    local o = 0
+    for _, e in ipairs(spec) do
+        self.off[e[1]] = o; self.size[e[1]] = e[2]; table.insert(self.order, e[1])
+        o = o + align4(e[2])
+    end
+    self.numel = o
+    self.W = M.devFloats(o); self.dW = M.devFloats(o); self.m = M.devFloats(o); self.v = M.devFloats(o)
+    return self
+end
+
+function FlatParams:view(name) return self.W + self.off[name], self.dW + self.off[name] end
+
+function FlatParams:zeroGrad() vd.call('vd_memset', self.dW, 0, self.numel * 4, nil) end       -- wrapper:zeroGradParameters()
+
+-- wrapperW:copy(flat FloatTensor in getParameters() order, tensors back to back) / wrapperW:float()
+function FlatParams:copyFrom(flat)
+    flat = flat:float():contiguous()
+    local src = 0
+    for _, name in ipairs(self.order) do
+        vd.call('vd_memcpy_h2d', self.W + self.off[name], flat:data() + src, self.size[name] * 4, nil)
+        src = src + self.size[name]
+    end
+end
+
+function FlatParams:toFloat(which)
+    local total = 0
+    for _, name in ipairs(self.order) do total = total + self.size[name] end
+    local flat, dst = torch.FloatTensor(total), 0
+    vd.call('vd_stream_synchronize', nil)
+    for _, name in ipairs(self.order) do
+        vd.call('vd_memcpy_d2h', flat:data() + dst, (which == 'dW' and self.dW or self.W) + self.off[name], self.size[name] * 4, nil)
+        dst = dst + self.size[name]
+    end
+    return flat
+end
+
+-- ---- nn.LookupTableMaskZero(V, E) (encoders/lf-ques.lua:12): table [(V+1) x E], row 0 = pad ------------------------------------
+local Lookup = {}
+Lookup.__index = Lookup
+
+function M.LookupTableMaskZero(fp, name, V, E)
+    local W, dW = fp:view(name)
+    return setmetatable({weight = W, gradWeight = dW, V = V, E = E}, Lookup)
+end
+
+function Lookup:zeroPad() vd.call('vd_memset', self.weight, 0, self.E * 4, nil) end         -- the pad row is re-zeroed on every forward
+
+function Lookup:forward(tok, rows)                          -- tok: device int32 [rows]; returns [rows x E]
+    local out = M.devFloats(rows * self.E)
+    vd.call('vd_embed_gather', self.weight, tok, nil, out, rows, self.E, 1.0, nil)
+    return out
+end
+
+function Lookup:backward(tok, rows, dx) vd.call('vd_embed_scatter_acc', self.gradWeight, tok, nil, dx, rows, self.E, 1.0, nil) end
+
+-- ---- nn.SeqLSTM(D, H):maskZero() (encoders/lf-ques.lua:18-24, decoders/disc.lua:4): W = [Wx ; Wh] [(D+H) x 4H], gates i,f,o,g --
+local SeqLSTM = {}
+SeqLSTM.__index = SeqLSTM
+
+function M.SeqLSTM(fp, name, D, H)
+    local W, dW = fp:view(name .. '.W')
+    local b, db = fp:view(name .. '.b')
+    return setmetatable({D = D, H = H, W = W, b = b, dW = dW, db = db}, SeqLSTM)
+end
+
+function SeqLSTM:Wh() return self.W + self.D * 4 * self.H end
+
+-- x: [T*N x D] rows (time-major); tokMask: device int32 [T x N] or nil (maskZero); .output = h [T x N x H], .cell = c
+function SeqLSTM:forward(x, T, N, tokMask)
+    local H = self.H
+    self.x, self.T, self.N = x, T, N
+    self.gates = M.devFloats(T * N * 4 * H); self.output = M.devFloats(T * N * H); self.cell = M.devFloats(T * N * H)
+    -- hoisted input projection x*Wx + b straight into the gates buffer, then the recurrence in place
+    vd.call('vd_gemm_nn', x, self.D, self.W, 4 * H, self.b, self.gates, 4 * H, T * N, 4 * H, self.D, 0, nil)
+    vd.call('vd_lstm_forward', self.gates, N * 4 * H, 4 * H, nil, tokMask, self:Wh(), nil, nil, self.gates, self.output, self.cell,
+            T, N, H, 0, nil)
+    return self.output
+end
+
+-- dhSeq [T x N x H] or nil, dhLast [N x H] or nil; accumulates gradWeight / gradBias; returns dx [T*N x D] (or nil)
+function SeqLSTM:backward(dhSeq, dhLast, needDx)
+    local H, T, N = self.H, self.T, self.N
+    local dc = M.devFloats(N * H)
+    vd.call('vd_lstm_backward', self:Wh(), self.gates, self.cell, nil, dhSeq, dhLast, nil, dc, nil, nil, nil, T, N, H, 0, nil)
+    local dWh = self.dW + self.D * 4 * H                                   -- da now lives in self.gates
+    if T > 1 then vd.call('vd_gemm_tn_acc', self.output, H, self.gates + N * 4 * H, 4 * H, dWh, 4 * H, H, 4 * H, (T - 1) * N, 0, nil) end
+    vd.call('vd_colsum_acc', self.gates, 4 * H, T * N, 4 * H, self.db, nil)
+    vd.call('vd_gemm_tn_acc', self.x, self.D, self.gates, 4 * H, self.dW, 4 * H, self.D, 4 * H, T * N, 0, nil)
+    if not needDx then return nil end
+    local dx = M.devFloats(T * N * self.D)
+    vd.call('vd_gemm_nt', self.gates, 4 * H, self.W, 4 * H, nil, dx, self.D, T * N, self.D, 4 * H, vd.C.VD_ACT_NONE, 0, nil)   -- da * Wx^T
+    return dx
+end
+
+-- ---- nn.Linear(nIn, nOut) + nn.Tanh (encoders/lf-ques.lua:29-31) ----------------------------------------------------------------
+local LinearTanh = {}
+LinearTanh.__index = LinearTanh
+
+function M.LinearTanh(fp, name, nIn, nOut)
+    local W, dW = fp:view(name .. '.W')
+    local b, db = fp:view(name .. '.b')
+    return setmetatable({nIn = nIn, nOut = nOut, W = W, b = b, dW = dW, db = db}, LinearTanh)
+end
+
+function LinearTanh:forward(x, rows)
+    self.x, self.rows = x, rows
+    self.output = M.devFloats(rows * self.nOut)
+    vd.call('vd_gemm_nt', x, self.nIn, self.W, self.nIn, self.b, self.output, self.nOut, rows, self.nOut, self.nIn, vd.C.VD_ACT_TANH, 0, nil)
+    return self.output
+end
+
+function LinearTanh:backward(dy)
+    local rows = self.rows
+    local dpre = M.devFloats(rows * self.nOut)
+    vd.call('vd_tanh_backward', dy, self.output, dpre, rows * self.nOut, nil)
+    vd.call('vd_gemm_tn_acc', dpre, self.nOut, self.x, self.nIn, self.dW, self.nIn, self.nOut, self.nIn, rows, 0, nil)
+    vd.call('vd_colsum_acc', dpre, self.nOut, rows, self.nOut, self.db, nil)
+    local dx = M.devFloats(rows * self.nIn)
+    vd.call('vd_gemm_nn', dpre, self.nOut, self.W, self.nIn, nil, dx, self.nIn, rows, self.nIn, self.nOut, 0, nil)
+    return dx
+end
+
+M.vd = vd
+return M

@@ -14,17 +14,19 @@ from conftest import ROOT, small_params
 from visdial_amd.opts import derive
 
 SRC = os.path.join(ROOT, 'examples', 'host_c_train.c')
+SRC_PLUGIN = os.path.join(ROOT, 'examples', 'host_c_plugin_lf_ques.c')
 
 
-def build(tmp_path):
-    exe = str(tmp_path / 'host_c_train')
-    r = subprocess.run(['gcc', '-O2', '-Wall', '-Werror', '-std=c99', '-D_DEFAULT_SOURCE', '-I', os.path.join(ROOT, 'include'), SRC, '-ldl', '-o', exe],
-                       capture_output=True, text=True)
+def build(tmp_path, src=SRC):
+    exe = str(tmp_path / os.path.basename(src)[:-2])
+    r = subprocess.run(['gcc', '-O2', '-Wall', '-Werror', '-std=c99', '-D_DEFAULT_SOURCE', '-I', os.path.join(ROOT, 'include'), src, '-ldl', '-lm',
+                        '-o', exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe
 
 
 def test_header_is_valid_c_and_the_c_host_builds(tmp_path):
+    build(tmp_path, SRC_PLUGIN)
     exe = build(tmp_path)
     # without a library the host fails loudly at dlopen -- no fallback of any kind
     r = subprocess.run([exe, '/nonexistent/libvisdial_hip.so', '/dev/null', '1', '0'], capture_output=True, text=True)
@@ -84,4 +86,58 @@ def test_c_host_equals_python_host(tmp_path, use_comm):
     assert np.allclose(c_loss, py_loss, rtol=1e-4, atol=0), (c_loss, py_loss)
     assert abs(c_lr - m.optims['learningRate']) < 1e-12
     assert c_loss[-1] < c_loss[0]          # and it trains
+    m.close()
+
+
+@pytest.mark.gpu
+def test_c_plugin_pair_on_the_operator_level_abi_equals_the_library(tmp_path):
+    """examples/host_c_plugin_lf_ques.c composes encoders/lf-ques.lua + decoders/disc.lua + criterion + clamp/adam from
+    OPERATOR-LEVEL entry points (module objects with forward / backward, flat parameter vectors) -- what a Lua plug-in file would
+    do through ffi.  Its loss, every gradient tensor and the post-Adam parameters must equal the library's own model-level
+    implementation of the same pair (NativeModel) on the same parameters and batch."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from visdial_amd import _lib
+    from visdial_amd.dataloader import SyntheticDataloader
+    from visdial_amd.native import NativeModel
+    p = derive(small_params(encoder='lf-ques', decoder='disc'))
+    batch = SyntheticDataloader(p, seed=8).getTrainBatch(p)
+    m = NativeModel(dict(p), init_seed=3)
+    m.training(False)
+    P = m.get_parameters_dict()
+    names = [t[0] for t in m.tensors]
+    assert names == ['embed', 'ques1.W', 'ques1.b', 'ques2.W', 'ques2.b', 'fuse.W', 'fuse.b', 'opt.W', 'opt.b']
+    B, R, Tq = batch['ques_fwd'].shape
+    O, To = batch['options'].shape[1], batch['options'].shape[2]
+    inp, outp = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
+    with open(inp, 'wb') as f:
+        f.write(struct.pack('<8i', p['vocabSize'], p['embedSize'], p['rnnHiddenSize'], B, R, O, Tq, To))
+        for k in names:
+            f.write(np.ascontiguousarray(P[k], np.float32).tobytes())
+        for k in ('ques_fwd', 'options', 'answer_ind'):
+            f.write(np.ascontiguousarray(batch[k], np.int32).tobytes())
+    exe = build(tmp_path, SRC_PLUGIN)
+    r = subprocess.run([exe, _lib.LIB_PATH, inp, outp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    raw = np.fromfile(outp, np.float32)
+    n = sum(P[k].size for k in names)
+    assert raw.size == 1 + 2 * n
+    loss = m.forwardBackward(batch)
+    G = m.get_gradients_dict()
+    m.update()
+    W1 = m.get_parameters_dict()
+    assert abs(float(raw[0]) - loss) < 1e-6 * max(1.0, abs(loss))
+    o = 1
+    for k in names:
+        g = raw[o:o + P[k].size].reshape(P[k].shape)
+        ref = G[k]
+        den = max(float(np.linalg.norm(ref)), 1e-12)
+        assert float(np.linalg.norm(g - ref)) / den < 1e-5, k          # same kernels; float-atomic sums differ in the last bits
+        o += P[k].size
+    for k in names:
+        w = raw[o:o + P[k].size].reshape(P[k].shape)
+        settled = np.abs(G[k]) > 1e-6                                  # Adam's first step is ~lr * sign(g)
+        assert np.abs(w - W1[k])[settled].max() < 1e-6 if settled.any() else True, k
+        o += P[k].size
     m.close()

@@ -86,3 +86,109 @@ def test_model_lua_keeps_the_reference_script_contract():
     # the three scripts need no edit: INTEGRATION.md must not tell the user to edit them any more
     integ = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
     assert 'setFlatParameters(savedModel.modelW)' not in integ
+
+
+def _calls(text):
+    """ordered vd_* entry points named in a piece of source (C: p_<name>( calls; Lua: vd.call('vd_<name>', ...))"""
+    return re.findall(r"vd\.call\('(vd_[a-z0-9_]+)'", text) or ['vd_' + x for x in re.findall(r'\bp_([a-z0-9_]+)\(', text)]
+
+
+C_NAMES = {'h2d': 'memcpy_h2d', 'd2h': 'memcpy_d2h', 'sync': 'stream_synchronize', 'malloc': 'malloc', 'memset': 'memset',
+           'set_device': 'set_device'}
+
+
+def _c_calls(text):
+    out = []
+    for x in re.findall(r'\bp_([a-z0-9_]+)\(', text):
+        if x == 'last_error':
+            continue
+        out.append('vd_' + C_NAMES.get(x, x))
+    return out
+
+
+def _body(src, start, end):
+    a = src.index(start)
+    return src[a:src.index(end, a + len(start))]
+
+
+def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
+    """lua/vdnn.lua + lua/encoders/lf-ques.lua + lua/decoders/disc.lua + lua/model_ops.lua (an encoder / decoder pair composed in Lua
+    from module objects over the operator-level ABI) cannot be executed here; examples/host_c_plugin_lf_ques.c is the same code in C
+    and IS checked on the GPU (tests/test_abi_c_host.py).  Pin the correspondence: every module method makes the same ABI calls in
+    the same order as its C twin, the Lua files use exactly the entry points the C host loads, and all of them are exported."""
+    funcs, _ = header_symbols()
+    c = open(os.path.join(ROOT, 'examples', 'host_c_plugin_lf_ques.c')).read()
+    lua = {n: open(os.path.join(ROOT, 'lua', n)).read() for n in ('vdnn.lua', 'encoders/lf-ques.lua', 'decoders/disc.lua', 'model_ops.lua')}
+    strip = lambda s: '\n'.join(l.split('--')[0] for l in s.splitlines())
+    lua = {k: strip(v) for k, v in lua.items()}
+    pairs = [
+        (_body(c, 'static void lstm_forward(', '\n}\n'), _body(lua['vdnn.lua'], 'function SeqLSTM:forward(', '\nend\n')),
+        (_body(c, 'static float* lstm_backward(', '\n}\n'), _body(lua['vdnn.lua'], 'function SeqLSTM:backward(', '\nend\n')),
+        (_body(c, 'static float* linear_forward(', '\n}\n'), _body(lua['vdnn.lua'], 'function LinearTanh:forward(', '\nend\n')),
+        (_body(c, 'static float* linear_backward(', '\n}\n'), _body(lua['vdnn.lua'], 'function LinearTanh:backward(', '\nend\n')),
+        (_body(c, '/* decoder:backward (model.lua:335) */', '/* encoder:backward'), _body(lua['decoders/disc.lua'], 'function dec:backward(', '\n    end\n')),
+    ]
+    drop = {'vd_malloc', 'vd_memset'}          # buffer allocation is interleaved differently (dev_floats / devFloats helpers)
+    for c_body, l_body in pairs:
+        a = [x for x in _c_calls(c_body) if x not in drop]
+        b = [x for x in _calls(l_body) if x not in drop]
+        assert a == b and a, (a, b)
+    used_lua = set()
+    for v in lua.values():
+        used_lua |= set(re.findall(r"vd\.call\('(vd_[a-z0-9_]+)'", v))
+    used_c = set('vd_' + x for x in re.findall(r'LOAD\(p_[a-z0-9_]+, "vd_([a-z0-9_]+)"\)', c)) - {'vd_last_error'}
+    assert used_lua == used_c, (used_lua ^ used_c)
+    assert used_lua <= funcs
+    # the plug-in files keep the reference's contract AND carry a Lua-side implementation
+    assert 'function enc:forward(inputs)' in lua['encoders/lf-ques.lua'] and 'function enc:backward(inputs, gradOutput)' in lua['encoders/lf-ques.lua']
+    assert 'function dec:forward(input)' in lua['decoders/disc.lua'] and 'return {nil, gradOutput[2]}' in lua['decoders/disc.lua']
+    for call in ('self.encoder:forward(inputs)', 'self.decoder:forward({options, encOut})', 'self.decoder:backward({options, encOut}, {dOptH, dEnc})',
+                 'self.encoder:backward(inputs, t[2])'):
+        assert call in lua['model_ops.lua'], call
+
+
+def _lua_tokens(src):
+    """identifiers / keywords of Lua source with comments and string literals removed"""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        ch = src[i]
+        if src.startswith('--[[', i):
+            i = src.index(']]', i) + 2
+        elif src.startswith('--', i):
+            j = src.find('\n', i)
+            i = n if j < 0 else j
+        elif src.startswith('[[', i):
+            i = src.index(']]', i) + 2
+        elif ch in '"\'':
+            j = i + 1
+            while src[j] != ch:
+                j += 2 if src[j] == '\\' else 1
+            i = j + 1
+        elif ch.isalpha() or ch == '_':
+            j = i
+            while j < n and (src[j].isalnum() or src[j] == '_'):
+                j += 1
+            out.append(src[i:j])
+            i = j
+        else:
+            if ch in '(){}':
+                out.append(ch)
+            i += 1
+    return out
+
+
+def test_lua_files_are_block_balanced():
+    """no Lua interpreter exists here: at least every hand-written Lua file must have balanced blocks and brackets
+    (function / do / if / repeat ... end / until), the commonest slip in code that cannot be run"""
+    files = ['model.lua', 'model_ops.lua', 'vdnn.lua', 'visdial_ffi.lua'] + ['encoders/%s.lua' % e for e in REF_ENCODERS] + ['decoders/disc.lua', 'decoders/gen.lua']
+    for name in files:
+        toks = _lua_tokens(open(os.path.join(ROOT, 'lua', name)).read())
+        depth = 0
+        for t in toks:
+            if t in ('function', 'do', 'if', 'repeat'):
+                depth += 1
+            elif t in ('end', 'until'):
+                depth -= 1
+            assert depth >= 0, name
+        assert depth == 0, (name, depth)
+        assert toks.count('(') == toks.count(')') and toks.count('{') == toks.count('}'), name
