@@ -312,7 +312,9 @@ def main():
                     "note": "achieved = EXECUTED FLOPs of the dominant kernel per launch (the recurrent h*Wh / da*Wh^T "
                             "products actually issued on the matrix pipe) / its HIP-event launch time measured inside "
                             "the overlapped step; achieved_nominal also counts the x*Wx product of the reference graph "
-                            "that this build replaces by an exact table gather (SURVEY 8d)",
+                            "that this build replaces by an exact table gather (SURVEY 8d); traffic = HBM-side bytes per launch of the "
+                            "same kernel on the same shapes from the committed rocprofv3 PMC passes (profiles/pmc_summary.json: 2 x "
+                            "FETCH_SIZE + WRITE_SIZE), a stored measurement, not a live counter",
                     "step_tflops_nominal": round(STEP_GFLOP_PER_ROUND * value / 1e3, 2),
                     "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
         if roof and roof.get("bound") == "mfma" and world == 1:
