@@ -474,6 +474,9 @@ using CfgFwdSmallC = GemmCfg<1, 4, 4, 8, 0, 4>;   // as A, <=128 VGPR: fits besi
 using CfgBwdSmallC = GemmCfg<1, 4, 1, 32, 0, 4>;
 using CfgFwdSmallD = GemmCfg<1, 4, 4, 8, 2, 4>;   // as C with two register stages (tiles k+1, k+2 in flight)
 using CfgBwdSmallD = GemmCfg<1, 4, 1, 32, 2, 4>;
+using CfgBwdSmallE = GemmCfg<1, 4, 2, 16, 0, 4>;   // 32 x 64 tiles (NT = 2), BK = 64: the A panel is re-read by 8 column tiles, not 16
+using CfgBwdSmallF = GemmCfg<2, 2, 2, 32, 0, 4>;   // 64 x 64 tiles, 2-way intra-block split-K, BK = 64: -43 % operand traffic
+using CfgBwdSmallG = GemmCfg<1, 4, 2, 16, 2, 4>;   // E with two register stages
 
 static int env_int(const char* name, int dflt) {
   const char* ev = getenv(name);
@@ -911,22 +914,26 @@ struct TickFwdProb {
   SrcKSel b;
   EpiTickFwd e;
 };
-struct EpiTickBwd {
+template <int NT>   // column tiles per wave: 1 = 32 x 32 tiles, 2 = 32 (or 64) x 64 tiles (less operand traffic per FLOP)
+struct EpiTickBwdT {
   int kind;
-  EpiLstmBwd<1> f;
-  EpiStore<1> s;
-  __device__ __forceinline__ void operator()(const f32x16 (&acc)[1], int row0, int col0, int lane, int M,
+  EpiLstmBwd<NT> f;      // (default BATCH: 2 slots in flight for NT = 1, 1 for NT >= 2)
+  EpiStore<NT> s;
+  __device__ __forceinline__ void operator()(const f32x16 (&acc)[NT], int row0, int col0, int lane, int M,
                                              int N, float* scr) const {
     if (kind == 0) f(acc, row0, col0, lane, M, N, scr);
     else s(acc, row0, col0, lane, M, N);
   }
 };
-struct TickBwdProb {
+template <int NT>
+struct TickBwdProbT {
   int M, N, K, tiles_n;
   SrcRow a;
   SrcRow b;
-  EpiTickBwd e;
+  EpiTickBwdT<NT> e;
 };
+using EpiTickBwd = EpiTickBwdT<1>;
+using TickBwdProb = TickBwdProbT<1>;
 
 struct vd_lstm2_fwd_t {
   int T, N;
@@ -1237,6 +1244,55 @@ static int launch_lstm2_seq(const Stack* st, int nstacks, int H, int Tmax, hipSt
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::THREADS), lds, stream, (const Prob*)tab, (const int*)item_start,
                      Tmax + 2, tiles_n, a.row_tiles, scr.sync);
   VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+// the per-tick grouped launches of the backward direction, for one tile configuration (NT = column tiles per wave)
+template <class Cfg, int NT>
+static int lstm2_backward_ticks(const vd_lstm2_bwd_t* st, int nstacks, int H, int Tmax, hipStream_t stream) {
+  for (int tau = 0; tau < Tmax + 2; ++tau) {
+    GroupArgs<TickBwdProbT<NT>, 3 * VD_MAX_STACKS> g;
+    g.nprob = 0;
+    for (int s = 0; s < nstacks; ++s) {
+      const vd_lstm2_bwd_t& S = st[s];
+      const long NH = (long)S.N * H;
+      for (int layer = 2; layer >= 1; --layer) {  // cell backward: L2 at t = T-1-tau, L1 at t = T+1-tau
+        const int t = layer == 2 ? S.T - 1 - tau : S.T + 1 - tau;
+        if (t < 0 || t >= S.T) continue;
+        float* gates = layer == 2 ? S.gates2 : S.gates1;
+        const float* c = layer == 2 ? S.c2 : S.c1;
+        const bool last = (t == S.T - 1);
+        const int rows = S.nact ? S.nact[t] : S.N;
+        if (rows <= 0) continue;
+        TickBwdProbT<NT>& P = g.p[g.nprob++];
+        P.M = rows; P.N = H; P.K = last ? 0 : 4 * H;
+        P.a = SrcRow{last ? gates : gates + (long)(t + 1) * 4 * NH, 4L * H};
+        P.b = SrcRow{layer == 2 ? S.Wh2 : S.Wh1, 4L * H};
+        P.e.kind = 0;
+        P.e.f.dh_a = layer == 2 ? (last ? S.dh_last2 : nullptr) : S.dh1_seq + t * NH;
+        P.e.f.dh_b = nullptr;
+        P.e.f.gates = gates + (long)t * 4 * NH;
+        P.e.f.c_t = c + t * NH;
+        P.e.f.c_prev = t ? c + (t - 1) * NH : nullptr;
+        P.e.f.dc = layer == 2 ? S.dc2 : S.dc1;
+        P.e.f.dc_first = last ? 1 : 0;
+        P.e.f.H = H;
+        P.e.s = EpiStore<NT>{nullptr, 0, nullptr, 0, 0};
+      }
+      const int t = S.T - tau;  // dh1[t] = da2[t] * Wx2^T
+      if (t >= 0 && t < S.T && (S.nact ? S.nact[t] : S.N) > 0) {
+        TickBwdProbT<NT>& P = g.p[g.nprob++];
+        P.M = S.nact ? S.nact[t] : S.N; P.N = H; P.K = 4 * H;
+        P.a = SrcRow{S.gates2 + (long)t * 4 * NH, 4L * H};
+        P.b = SrcRow{S.Wx2, 4L * H};
+        P.e.kind = 1;
+        P.e.s = EpiStore<NT>{S.dh1_seq + t * NH, H, nullptr, VD_ACT_NONE, 0};
+        P.e.f = EpiLstmBwd<NT>{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, H};
+      }
+    }
+    if (g.nprob == 0) continue;
+    if (int rc = launch_grouped<Cfg>(g, stream)) return rc;
+  }
   return VD_OK;
 }
 
@@ -1658,54 +1714,15 @@ int vd_lstm2_backward(const vd_lstm2_bwd_t* st, int nstacks, int H, void* stream
     const int rc = launch_lstm2_seq<CfgBwdSmallC, false, L2SeqBwdArgs, TickBwdProb>(st, nstacks, H, Tmax, (hipStream_t)stream);
     if (rc <= 0) return rc;
   }
-  for (int tau = 0; tau < Tmax + 2; ++tau) {
-    GroupArgs<TickBwdProb, 3 * VD_MAX_STACKS> g;
-    g.nprob = 0;
-    for (int s = 0; s < nstacks; ++s) {
-      const vd_lstm2_bwd_t& S = st[s];
-      const long NH = (long)S.N * H;
-      for (int layer = 2; layer >= 1; --layer) {  // cell backward: L2 at t = T-1-tau, L1 at t = T+1-tau
-        const int t = layer == 2 ? S.T - 1 - tau : S.T + 1 - tau;
-        if (t < 0 || t >= S.T) continue;
-        float* gates = layer == 2 ? S.gates2 : S.gates1;
-        const float* c = layer == 2 ? S.c2 : S.c1;
-        const bool last = (t == S.T - 1);
-        const int rows = S.nact ? S.nact[t] : S.N;
-        if (rows <= 0) continue;
-        TickBwdProb& P = g.p[g.nprob++];
-        P.M = rows; P.N = H; P.K = last ? 0 : 4 * H;
-        P.a = SrcRow{last ? gates : gates + (long)(t + 1) * 4 * NH, 4L * H};
-        P.b = SrcRow{layer == 2 ? S.Wh2 : S.Wh1, 4L * H};
-        P.e.kind = 0;
-        P.e.f.dh_a = layer == 2 ? (last ? S.dh_last2 : nullptr) : S.dh1_seq + t * NH;
-        P.e.f.dh_b = nullptr;
-        P.e.f.gates = gates + (long)t * 4 * NH;
-        P.e.f.c_t = c + t * NH;
-        P.e.f.c_prev = t ? c + (t - 1) * NH : nullptr;
-        P.e.f.dc = layer == 2 ? S.dc2 : S.dc1;
-        P.e.f.dc_first = last ? 1 : 0;
-        P.e.f.H = H;
-        P.e.s = EpiStore<1>{nullptr, 0, nullptr, 0, 0};
-      }
-      const int t = S.T - tau;  // dh1[t] = da2[t] * Wx2^T
-      if (t >= 0 && t < S.T && (S.nact ? S.nact[t] : S.N) > 0) {
-        TickBwdProb& P = g.p[g.nprob++];
-        P.M = S.nact ? S.nact[t] : S.N; P.N = H; P.K = 4 * H;
-        P.a = SrcRow{S.gates2 + (long)t * 4 * NH, 4L * H};
-        P.b = SrcRow{S.Wx2, 4L * H};
-        P.e.kind = 1;
-        P.e.s = EpiStore<1>{S.dh1_seq + t * NH, H, nullptr, VD_ACT_NONE, 0};
-        P.e.f = EpiLstmBwd<1>{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, H};
-      }
-    }
-    if (g.nprob == 0) continue;
-    static const int scfg = env_int("VD_LSTM_BWD_SMALL", 3);   // 3 = two register stages: -0.2 ms per headline step vs 2
-    if (int rc = scfg == 2 ? launch_grouped<CfgBwdSmallC>(g, (hipStream_t)stream)
-                 : scfg == 3 ? launch_grouped<CfgBwdSmallD>(g, (hipStream_t)stream)
-                             : launch_grouped<CfgBwdSmallA>(g, (hipStream_t)stream))
-      return rc;
+  static const int scfg = env_int("VD_LSTM_BWD_SMALL", 3);   // 3 = two register stages: -0.2 ms per headline step vs 2
+  switch (scfg) {
+    case 2: return lstm2_backward_ticks<CfgBwdSmallC, 1>(st, nstacks, H, Tmax, (hipStream_t)stream);
+    case 3: return lstm2_backward_ticks<CfgBwdSmallD, 1>(st, nstacks, H, Tmax, (hipStream_t)stream);
+    case 4: return lstm2_backward_ticks<CfgBwdSmallE, 2>(st, nstacks, H, Tmax, (hipStream_t)stream);   // 32 x 64 tiles
+    case 5: return lstm2_backward_ticks<CfgBwdSmallF, 2>(st, nstacks, H, Tmax, (hipStream_t)stream);   // 64 x 64 tiles
+    case 6: return lstm2_backward_ticks<CfgBwdSmallG, 2>(st, nstacks, H, Tmax, (hipStream_t)stream);   // 32 x 64, two register stages
+    default: return lstm2_backward_ticks<CfgBwdSmallA, 1>(st, nstacks, H, Tmax, (hipStream_t)stream);
   }
-  return VD_OK;
 }
 
 }  // extern "C"
