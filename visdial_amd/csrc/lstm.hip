@@ -473,6 +473,9 @@ using CfgBwdSmallB = GemmCfg<1, 4, 1, 64, 0, 3>;  // BK = 256, 66.6 KB LDS
 using CfgFwdSmallC = GemmCfg<1, 4, 4, 8, 0, 4>;   // as A, <=128 VGPR: fits beside 3 padded throughput workgroups
 using CfgBwdSmallC = GemmCfg<1, 4, 1, 32, 0, 4>;
 using CfgFwdSmallD = GemmCfg<1, 4, 4, 8, 2, 4>;   // as C with two register stages (tiles k+1, k+2 in flight)
+using CfgFwdSmallE = GemmCfg<2, 2, 4, 8, 0, 4>;   // 64 x 128 tiles, 2-way split-K, BK = 16: 40 % fewer operand bytes per output than 32 x 128
+using CfgFwdSmallF = GemmCfg<2, 2, 4, 8, 2, 4>;   // E with two register stages
+using CfgFwdSmallG = GemmCfg<2, 2, 4, 16, 0, 4>;  // E with BK = 32
 using CfgBwdSmallD = GemmCfg<1, 4, 1, 32, 2, 4>;
 using CfgBwdSmallE = GemmCfg<1, 4, 2, 16, 0, 4>;   // 32 x 64 tiles (NT = 2), BK = 64: the A panel is re-read by 8 column tiles, not 16
 using CfgBwdSmallF = GemmCfg<2, 2, 2, 32, 0, 4>;   // 64 x 64 tiles, 2-way intra-block split-K, BK = 64: -43 % operand traffic
@@ -1694,6 +1697,9 @@ int vd_lstm2_forward(const vd_lstm2_fwd_t* st, int nstacks, int H, void* stream)
     static const int scfg = env_int("VD_LSTM_FWD_SMALL", 2);
     if (int rc = scfg == 2 ? launch_grouped<CfgFwdSmallC>(g, (hipStream_t)stream)
                  : scfg == 3 ? launch_grouped<CfgFwdSmallD>(g, (hipStream_t)stream)
+                 : scfg == 4 ? launch_grouped<CfgFwdSmallE>(g, (hipStream_t)stream)
+                 : scfg == 5 ? launch_grouped<CfgFwdSmallF>(g, (hipStream_t)stream)
+                 : scfg == 6 ? launch_grouped<CfgFwdSmallG>(g, (hipStream_t)stream)
                              : launch_grouped<CfgFwdSmallA>(g, (hipStream_t)stream))
       return rc;
   }
