@@ -70,6 +70,11 @@ def main():
             ("no K rotation", dict(VD_GEMM_ROTATE=0)),
             ("baseline (repeat)", {}),
         ]
+    if os.environ.get("MB_FULL", "1") == "3":
+        variants += [("128 x 256 tiles, 4 waves x (32 x 256), 72 KB, 2 WG/CU", dict(VD_LSTM_FWD_NT8=1)),
+                     ("128 x 256 tiles, 3 A + 2 B buffers (56 KB)", dict(VD_LSTM_FWD_NT8=2)),
+                     ("128 x 256 tiles, K loop only", dict(VD_LSTM_FWD_NT8=1, VD_LSTM_FWD_EPI_SEQ=2)),
+                     ("baseline (repeat)", {})]
     for name, knobs in variants:
         ops.tune_clear()
         for k, v in knobs.items():

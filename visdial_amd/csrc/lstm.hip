@@ -490,12 +490,13 @@ static int env_int(const char* name, int dflt) {
 // in the gate-interleaved column order of the forward step, so that both operands of the LDS-DMA pipeline
 // are plain row-major.  4 MB, rebuilt once per forward pass (the weights change every update).
 __global__ void __launch_bounds__(256) wh_gate_transpose_kernel(const float* __restrict__ Wh,
-                                                                float* __restrict__ WhT, int H) {
+                                                                float* __restrict__ WhT, int H, int plain = 0) {
   __shared__ float tile[32][33];
   const int vt = blockIdx.x, kt = blockIdx.y;
   const int jb = vt >> 2, g = vt & 3;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const long src_col = (long)g * H + jb * 32;
+  // plain: WhT[c][k] = Wh[k][c] (column order kept: the layer-2 input projection of the encoder ticks)
+  const long src_col = plain ? (long)vt * 32 : (long)g * H + jb * 32;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int k = kt * 32 + ty + i * 8;
@@ -915,6 +916,14 @@ struct TickFwdProb {
   int M, N, K, tiles_n;
   SrcRow a;
   SrcKSel b;
+  EpiTickFwd e;
+};
+struct TickFwdProbT {      // forward tick sub-problem for gemm_block_glds_wk: B given as its transpose (k-contiguous rows)
+  int M, N, K, tiles_n;
+  const float* a;
+  long lda;
+  const float* bt;
+  long ldb;
   EpiTickFwd e;
 };
 template <int NT>   // column tiles per wave: 1 = 32 x 32 tiles, 2 = 32 (or 64) x 64 tiles (less operand traffic per FLOP)
@@ -1455,7 +1464,16 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
         rc = launch_gemm<CfgFbf16>(nr, 4 * H, H, 1, SrcRow{hp, H}, SrcRow{WhT, H}, e, rc_.stream[ch]);
       else if (glds && hp) {
         const int epi = vd_tune_get("VD_LSTM_FWD_EPI_SEQ", 0);
-        if (const int big = vd_tune_get("VD_LSTM_FWD_BM256", 0)) {
+        if (const int wide = vd_tune_get("VD_LSTM_FWD_NT8", 0)) {
+          // A/B: 128 x 256 workgroup tiles, FOUR waves of 32 x 256 (two gate groups per wave, 128 accumulator registers,
+          // 2 workgroups per CU = 2 waves per SIMD): the 25 % operand-traffic cut of the 256 x 128 variant below without
+          // its 4 waves per SIMD, and twice the MFMA burst per barrier.  wide = 2: two A buffers (56 KB request)
+          if (epi == 2) {
+            EpiLstmFwdT<2> e2{e.xproj, e.xld, e.tok_gather, e.tok_mask, e.c_prev, e.gates, e.c_out, e.h_out, e.H};
+            rc = launch_gemm_glds<GemmCfg<4, 1, 8, 16, 0, 2, 73728>, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e2, rc_.stream[ch]);
+          } else if (wide == 2) rc = launch_gemm_glds<GemmCfg<4, 1, 8, 16, 0, 2, 57344>, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e, rc_.stream[ch]);
+          else rc = launch_gemm_glds<GemmCfg<4, 1, 8, 16, 0, 2, 73728>, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e, rc_.stream[ch]);
+        } else if (const int big = vd_tune_get("VD_LSTM_FWD_BM256", 0)) {
           // A/B: 256 x 128 workgroup tiles (8 waves): 25 % less operand traffic per FLOP than 128 x 128 -- the step kernels
           // pay ~6.5 % per extra 25 % of memory traffic through the CU (profiles/r03_experiments.txt section 13)
           if (big == 2) rc = launch_gemm_glds<GemmCfg<8, 1, 4, 16, 0, 2, 49152>, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e, rc_.stream[ch]);
@@ -1655,6 +1673,63 @@ int vd_lstm2_forward(const vd_lstm2_fwd_t* st, int nstacks, int H, void* stream)
   if (vd_tune_get("VD_LSTM2_PERSIST", 0)) {   // one persistent launch for all T + 2 ticks (see lstm2_seq_kernel); opt-in
     const int rc = launch_lstm2_seq<CfgFwdSmallC, true, L2SeqFwdArgs, TickFwdProb>(st, nstacks, H, Tmax, (hipStream_t)stream);
     if (rc <= 0) return rc;
+  }
+  static const int scfg_fwd = env_int("VD_LSTM_FWD_SMALL", 2);
+  if (scfg_fwd == 7 && H % 32 == 0) {
+    // LDS-DMA ticks (gemm_block_glds_wk): the three weight matrices of every stack as k-contiguous rows -- Wh1 / Wh2
+    // gate-interleaved (the cell-update epilogue wants i,f,o,g of a hidden unit in one wave), Wx2 plain -- rebuilt per call
+    const size_t mat = (size_t)4 * H * H;
+    VdStreamScratch scr;
+    if (int rc = vd_stream_scratch((hipStream_t)stream, 3 * VD_MAX_STACKS * mat * sizeof(float), 0, &scr)) return rc;
+    for (int s = 0; s < nstacks; ++s) {
+      const float* src[3] = {st[s].Wh1, st[s].Wh2, st[s].Wx2};
+      for (int i = 0; i < 3; ++i) {
+        hipLaunchKernelGGL(wh_gate_transpose_kernel, dim3(4 * H / 32, H / 32), dim3(256), 0, (hipStream_t)stream, src[i],
+                           scr.wht + (3 * s + i) * mat, H, i == 2 ? 1 : 0);
+        VD_LAUNCH_CHECK();
+      }
+    }
+    for (int tau = 0; tau < Tmax + 2; ++tau) {
+      GroupArgs<TickFwdProbT, 3 * VD_MAX_STACKS> g;
+      g.nprob = 0;
+      for (int s = 0; s < nstacks; ++s) {
+        const vd_lstm2_fwd_t& S = st[s];
+        const long NH = (long)S.N * H;
+        for (int layer = 1; layer <= 2; ++layer) {
+          const int t = layer == 1 ? tau : tau - 2;
+          if (t < 0 || t >= S.T) continue;
+          float* gates = layer == 1 ? S.gates1 : S.gates2;
+          float* h = layer == 1 ? S.h1 : S.h2;
+          float* c = layer == 1 ? S.c1 : S.c2;
+          const int rows = S.nact ? S.nact[t] : S.N;
+          if (rows <= 0) continue;
+          TickFwdProbT& P = g.p[g.nprob++];
+          P.M = rows; P.N = 4 * H; P.K = t ? H : 0;
+          P.a = t ? h + (t - 1) * NH : h; P.lda = H;
+          P.bt = scr.wht + (3 * s + (layer == 1 ? 0 : 1)) * mat; P.ldb = H;
+          P.e.kind = 0;
+          P.e.f.xproj = gates + (long)t * 4 * NH; P.e.f.xld = 4L * H;
+          P.e.f.tok_gather = nullptr;
+          P.e.f.tok_mask = S.tok_mask ? S.tok_mask + (long)t * S.N : nullptr;
+          P.e.f.c_prev = t ? c + (t - 1) * NH : nullptr;
+          P.e.f.gates = gates + (long)t * 4 * NH; P.e.f.c_out = c + t * NH; P.e.f.h_out = h + t * NH; P.e.f.H = H;
+          P.e.s = EpiStore<4>{nullptr, 0, nullptr, 0, 0};
+        }
+        const int t = tau - 1;
+        if (t >= 0 && t < S.T && (S.nact ? S.nact[t] : S.N) > 0) {
+          TickFwdProbT& P = g.p[g.nprob++];
+          P.M = S.nact ? S.nact[t] : S.N; P.N = 4 * H; P.K = H;
+          P.a = S.h1 + t * NH; P.lda = H;
+          P.bt = scr.wht + (3 * s + 2) * mat; P.ldb = H;
+          P.e.kind = 1;
+          P.e.s = EpiStore<4>{S.gates2 + (long)t * 4 * NH, 4L * H, S.b2, VD_ACT_NONE, 0};
+          P.e.f = EpiLstmFwdTick{nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, H};
+        }
+      }
+      if (g.nprob == 0) continue;
+      if (int rc = launch_grouped_glds_wk<4>(g, (hipStream_t)stream)) return rc;
+    }
+    return VD_OK;
   }
   for (int tau = 0; tau < Tmax + 2; ++tau) {
     GroupArgs<TickFwdProb, 3 * VD_MAX_STACKS> g;
