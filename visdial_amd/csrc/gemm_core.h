@@ -531,6 +531,7 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
   static_assert((BM / 16) % WM == 0 && (BN / 16) % WM == 0, "16-row DMA groups must split evenly over the waves");
   static_assert((NBA * ABUF + NBB * BBUF) * 4 <= Cfg::LDS_BYTES, "DMA buffers must fit the LDS request");
   static_assert(!KMAJ || (BM == 128 && BN == 128), "k-major tiles: one DMA instruction = two 128-float k rows");
+  static_assert(!KMAJ || Cfg::BF16 == 0, "bf16 operands: row-major (k-contiguous) tiles only");
   // tid_in: callers that loop over tiles pass a laundered thread id so per-lane address terms are re-derived
   // per tile instead of being hoisted out of the tile loop (they would stay live across the epilogue)
   const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63;
@@ -623,10 +624,25 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
     }
   };
   auto mfma16 = [&](const Frag& f) {
+    if constexpr (Cfg::BF16 != 0) {
+      // bf16 operands (A, B point at bf16 rows; all K arguments count 4-byte units = bf16 PAIRS): a 16-byte chunk is 8
+      // consecutive k = one operand of v_mfma_f32_32x32x16_bf16 (lanes 0-31: k .. k+7, lanes 32-63: k+8 .. k+15), so the
+      // same tiles, the same swizzle and the same reads feed ONE instruction per column tile and half tile
+      typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+      typedef float f32x4_t __attribute__((ext_vector_type(4)));
+      const f32x4_t af = {f.a[0], f.a[1], f.a[2], f.a[3]};
+      const bf16x8_t a8 = __builtin_bit_cast(bf16x8_t, af);
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
+      for (int j = 0; j < NT; ++j) {
+        const f32x4_t bf = {f.b[j][0], f.b[j][1], f.b[j][2], f.b[j][3]};
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(bf16x8_t, bf), acc[j], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s4], f.b[j][s4], acc[j], 0, 0, 0);
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s4], f.b[j][s4], acc[j], 0, 0, 0);
+    }
   };
   // s_waitcnt needs an immediate.  n = DMA instructions of this wave allowed to stay in flight.
   auto wait_vm = [&](int n) {

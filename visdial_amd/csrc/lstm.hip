@@ -466,6 +466,9 @@ using CfgB12 = GemmCfg<4, 1, 2, 16, 0, 3, 41984>;  // <=168 VGPR build of B11 fo
 // concurrently on other streams).
 using CfgFbf16 = GemmCfg<4, 1, 4, 32, 0, 3, 0, 1>;  // bf16 operands (opt-in), BK = 32 = two 32x32x16 MFMAs per tile
 using CfgBbf16 = GemmCfg<4, 1, 2, 32, 0, 3, 0, 1>;
+// bf16 pass with shadows: the LDS-DMA pipeline of the fp32 step kernels over bf16 rows (h / da shadows, bf16 weight copies)
+using CfgF9bf16 = GemmCfg<4, 1, 4, 16, 0, 4, 41984, 1>;
+using CfgB11bf16 = GemmCfg<4, 1, 2, 16, 0, 4, 41984, 1>;
 using CfgFwdSmallA = GemmCfg<1, 4, 4, 8, 0, 3>;   // 32 x (32 j x 4 gates), BK = 32, 23 KB LDS
 using CfgFwdSmallB = GemmCfg<1, 4, 4, 16, 0, 3>;  // BK = 64, 43.5 KB LDS, half the dependent K iterations
 using CfgBwdSmallA = GemmCfg<1, 4, 1, 32, 0, 3>;  // 32 x 32 tile, BK = 128, 33.8 KB LDS
@@ -508,6 +511,18 @@ __global__ void __launch_bounds__(256) wh_gate_transpose_kernel(const float* __r
     const int vc = vt * 32 + ty + i * 8;
     WhT[(long)vc * H + kt * 32 + tx] = tile[tx][ty + i * 8];
   }
+}
+
+// fp32 -> bf16 copy of a weight matrix (bf16 pass of the option recurrence: the LDS-DMA step kernels multiply bf16 rows
+// as they lie in memory; same rounding as the activations' shadows, vd_st4_bf16)
+__global__ void __launch_bounds__(256) f32_to_bf16_kernel(const float* __restrict__ src, vd_bf16_bits* __restrict__ dst, long n4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) vd_st4_bf16(dst + i * 4, reinterpret_cast<const float4*>(src)[i]);
+}
+static int weights_to_bf16(const float* src, vd_bf16_bits* dst, long n, hipStream_t s) {
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, src, dst, n / 4);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
 }
 
 // LDS-DMA pipeline eligibility: throughput shape, K % 16 == 0, 32-bit row byte offsets
@@ -813,11 +828,17 @@ static int lstm_step_fwd(const float* h_prev, const float* Wh, int N, int H, int
 
 static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, int K, const float* dh_a,
                          const float* dh_b, float* gates, const float* c_t, const float* c_prev, float* dc,
-                         int dc_first, hipStream_t s, int flags = 0, vd_bf16_bits* da16 = nullptr) {
+                         int dc_first, hipStream_t s, int flags = 0, vd_bf16_bits* da16 = nullptr,
+                         const vd_bf16_bits* da16_next = nullptr, const vd_bf16_bits* Wh16 = nullptr) {
   SrcRow a{da_next, 4L * H};
   SrcRow b{Wh, 4L * H};  // B[k][n] = Wh[n][k]
   if ((flags & VD_FLAG_BF16) && N >= 2048 && K > 0) {
     EpiLstmBwd<2> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H, da16};
+    // shadows on: da_{t+1} and Wh are read as the bf16 rows their producers wrote (half the operand bytes, no conversion
+    // while staging, LDS-DMA pipeline); K counts bf16 pairs
+    if (da16_next && Wh16 && K % 32 == 0)
+      return launch_gemm_glds<CfgB11bf16, false>(N, H, K / 2, 1, reinterpret_cast<const float*>(da16_next), 2L * H,
+                                                 reinterpret_cast<const float*>(Wh16), 2L * H, e, s);
     return launch_gemm<CfgBbf16>(N, H, K, 1, a, b, e, s);
   }
   if (da16 && N >= 2048) {   // bf16 pass, step without a recurrent product (the last one): same shadow, generic kernel
@@ -1391,7 +1412,7 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
   VdStreamScratch scr;
   if (glds) {
     const int tiles_m = vd_cdiv(N, CfgF9::BM);
-    if (int rc0 = vd_stream_scratch(s, (size_t)4 * H * H * sizeof(float), seq_sync_bytes(T, tiles_m), &scr)) return rc0;
+    if (int rc0 = vd_stream_scratch(s, (size_t)4 * H * H * (bf16 ? 6 : 4), seq_sync_bytes(T, tiles_m), &scr)) return rc0;
     WhT = scr.wht;
     hipLaunchKernelGGL(wh_gate_transpose_kernel, dim3(4 * H / 32, H / 32), dim3(256), 0, s, Wh, WhT, H);
     VD_LAUNCH_CHECK();
@@ -1427,6 +1448,12 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
   } else {
     vd_bf16_shadow_invalidate(h, (size_t)T * NH);
   }
+  // ... and READ the shadow of h_{t-1} and a bf16 copy of the transposed weights through the LDS-DMA pipeline (VD_BF16_GLDS)
+  vd_bf16_bits* WhT16 = nullptr;
+  if (h16 && glds && vd_tune_get("VD_BF16_GLDS", 1)) {
+    WhT16 = reinterpret_cast<vd_bf16_bits*>(scr.wht + (size_t)4 * H * H);
+    if (int rc0 = weights_to_bf16(WhT, WhT16, 4L * H * H, s)) return rc0;
+  }
   RowChains rc_;
   int rc = rc_.fork(N, s, nchains);
   if (rc) return rc;
@@ -1460,7 +1487,10 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
       e.h_out = h + t * NH + r0 * H;
       e.H = H;
       e.h16 = h16 ? h16 + t * NH + r0 * H : nullptr;
-      if (bf16 && hp)
+      if (bf16 && hp && WhT16 && t > 0)
+        rc = launch_gemm_glds<CfgF9bf16, false>(nr, 4 * H, H / 2, 1, reinterpret_cast<const float*>(h16 + (t - 1) * NH + r0 * H),
+                                                (long)H / 2, reinterpret_cast<const float*>(WhT16), (long)H / 2, e, rc_.stream[ch]);
+      else if (bf16 && hp)
         rc = launch_gemm<CfgFbf16>(nr, 4 * H, H, 1, SrcRow{hp, H}, SrcRow{WhT, H}, e, rc_.stream[ch]);
       else if (glds && hp) {
         const int epi = vd_tune_get("VD_LSTM_FWD_EPI_SEQ", 0);
@@ -1542,8 +1572,15 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
   if (dc_last && dc_last != dc_work) VD_HIP(hipMemcpyAsync(dc_work, dc_last, NH * sizeof(float), hipMemcpyDeviceToDevice, s));
   // bf16 pass: the step kernels also write a bf16 copy of da (the other operand of the dWh contraction)
   vd_bf16_bits* da16 = nullptr;
+  vd_bf16_bits* Wh16 = nullptr;
   if ((flags & VD_FLAG_BF16) && N >= 2048 && H % 32 == 0 && vd_tune_get("VD_BF16_SHADOW", 1)) {
     if (int rc0 = vd_bf16_shadow_get(1, gates, (size_t)T * 4 * NH, &da16)) return rc0;
+    if (T > 1 && vd_tune_get("VD_BF16_GLDS", 1)) {
+      VdStreamScratch wscr;
+      if (int rc0 = vd_stream_scratch(s, (size_t)4 * H * H * 6, 0, &wscr)) return rc0;
+      Wh16 = reinterpret_cast<vd_bf16_bits*>(wscr.wht + (size_t)4 * H * H);
+      if (int rc0 = weights_to_bf16(Wh, Wh16, 4L * H * H, s)) return rc0;
+    }
   } else {
     vd_bf16_shadow_invalidate(gates, (size_t)T * 4 * NH);
   }
@@ -1612,7 +1649,8 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
                          (last && dh_last) ? dh_last + r0 * H : nullptr, gates + (long)t * 4 * NH + r0 * 4 * H,
                          c + t * NH + r0 * H, t ? c + (t - 1) * NH + r0 * H : c0r, dc_work + r0 * H,
                          (last && !dc_last) ? 1 : 0, rc_.stream[ch], flags,
-                         da16 ? da16 + (long)t * 4 * NH + r0 * 4 * H : nullptr);
+                         da16 ? da16 + (long)t * 4 * NH + r0 * 4 * H : nullptr,
+                         (da16 && !last) ? da16 + (long)(t + 1) * 4 * NH + r0 * 4 * H : nullptr, Wh16);
       if (rc) return rc;
     }
     if (trail && t >= 1 && rc_.n == 1) {
