@@ -15,11 +15,13 @@ from visdial_amd.opts import derive
 
 SRC = os.path.join(ROOT, 'examples', 'host_c_train.c')
 SRC_PLUGIN = os.path.join(ROOT, 'examples', 'host_c_plugin_lf_ques.c')
+SRC_PLUGIN_MN = os.path.join(ROOT, 'examples', 'host_c_plugin_mn_att.c')
 
 
 def build(tmp_path, src=SRC):
     exe = str(tmp_path / os.path.basename(src)[:-2])
-    r = subprocess.run(['gcc', '-O2', '-Wall', '-Werror', '-std=c99', '-D_DEFAULT_SOURCE', '-I', os.path.join(ROOT, 'include'), src, '-ldl', '-lm',
+    r = subprocess.run(['gcc', '-O2', '-Wall', '-Werror', '-std=c99', '-D_DEFAULT_SOURCE', '-I', os.path.join(ROOT, 'include'), '-I', os.path.join(ROOT, 'examples'), src,
+                        '-ldl', '-lm',
                         '-o', exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe
@@ -27,6 +29,7 @@ def build(tmp_path, src=SRC):
 
 def test_header_is_valid_c_and_the_c_host_builds(tmp_path):
     build(tmp_path, SRC_PLUGIN)
+    build(tmp_path, SRC_PLUGIN_MN)
     exe = build(tmp_path)
     # without a library the host fails loudly at dlopen -- no fallback of any kind
     r = subprocess.run([exe, '/nonexistent/libvisdial_hip.so', '/dev/null', '1', '0'], capture_output=True, text=True)
@@ -141,3 +144,71 @@ def test_c_plugin_pair_on_the_operator_level_abi_equals_the_library(tmp_path):
         assert np.abs(w - W1[k])[settled].max() < 1e-6 if settled.any() else True, k
         o += P[k].size
     m.close()
+
+
+@pytest.mark.gpu
+def test_c_plugin_flagship_pair_on_the_operator_level_abi_equals_the_library(tmp_path):
+    """examples/host_c_plugin_mn_att.c composes encoders/mn-att-ques-im-hist.lua (text branches, memory attention, stacked image
+    attention, output layer) + decoders/disc.lua from OPERATOR-LEVEL entry points, module object by module object -- the flagship
+    pair as a plug-in author would write it (lua/encoders/mn-att-ques-im-hist.lua is the same file in Lua).  Loss, every gradient
+    tensor and the post-Adam parameters must equal the library's own model-level implementation on the same parameters and batch;
+    the training-mode run (seven Dropout nodes drawing masks) must produce a finite, different loss and finite gradients."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from visdial_amd import _lib
+    from visdial_amd.dataloader import SyntheticDataloader
+    from visdial_amd.native import NativeModel
+    p = derive(small_params(encoder='mn-att-ques-im-hist', decoder='disc'))
+    batch = SyntheticDataloader(p, seed=8).getTrainBatch(p)
+    m = NativeModel(dict(p), init_seed=3)
+    m.training(False)
+    P = m.get_parameters_dict()
+    names = [t[0] for t in m.tensors]
+    assert names == ['embed', 'hist1.W', 'hist1.b', 'hist2.W', 'hist2.b', 'ques1.W', 'ques1.b', 'ques2.W', 'ques2.b', 'mn1.W', 'mn1.b',
+                     'mn2.W', 'mn2.b', 'img_proj.W', 'img_proj.b', 'img_common.W', 'img_common.b', 'ques_common.W', 'ques_common.b',
+                     'att.W', 'att.b', 'out.W', 'out.b', 'opt.W', 'opt.b']
+    B, R, Tq = batch['ques_fwd'].shape
+    Th, O, To = batch['hist'].shape[2], batch['options'].shape[1], batch['options'].shape[2]
+    inp, outp = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
+    with open(inp, 'wb') as f:
+        f.write(struct.pack('<12i', p['vocabSize'], p['embedSize'], p['rnnHiddenSize'], p['imgFeatureSize'], p['imgSpatialSize'],
+                            p['commonEmbeddingSize'], B, R, O, Tq, Th, To))
+        for k in names:
+            f.write(np.ascontiguousarray(P[k], np.float32).tobytes())
+        for k, dt in (('ques_fwd', np.int32), ('hist', np.int32), ('img_feat', np.float32), ('options', np.int32), ('answer_ind', np.int32)):
+            f.write(np.ascontiguousarray(batch[k], dt).tobytes())
+    exe = build(tmp_path, SRC_PLUGIN_MN)
+    r = subprocess.run([exe, _lib.LIB_PATH, inp, outp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    raw = np.fromfile(outp, np.float32)
+    n = sum(P[k].size for k in names)
+    assert raw.size == 1 + 2 * n
+    loss = m.forwardBackward(batch)
+    G = m.get_gradients_dict()
+    m.update()
+    W1 = m.get_parameters_dict()
+    assert abs(float(raw[0]) - loss) < 1e-6 * max(1.0, abs(loss))
+    o = 1
+    for k in names:
+        g = raw[o:o + P[k].size].reshape(P[k].shape)
+        ref = G[k]
+        den = float(np.linalg.norm(ref))
+        if k == 'att.b':                                               # the softmax is shift-invariant: the true gradient is 0,
+            assert float(np.abs(g).max()) < 1e-6 and float(np.abs(ref).max()) < 1e-6, k      # both sides hold fp32 rounding noise
+        else:
+            assert float(np.linalg.norm(g - ref)) / den < 1e-5, k      # same kernels; float-atomic sums differ in the last bits
+        o += P[k].size
+    for k in names:
+        w = raw[o:o + P[k].size].reshape(P[k].shape)
+        settled = np.abs(G[k]) > 1e-6                                  # Adam's first step is ~lr * sign(g)
+        assert np.abs(w - W1[k])[settled].max() < 1e-6 if settled.any() else True, k
+        o += P[k].size
+    m.close()
+    # training mode: the Dropout masks go through the fused gather / attention kernels
+    out2 = str(tmp_path / 'out_train.bin')
+    r = subprocess.run([exe, _lib.LIB_PATH, inp, out2, 'train'], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    raw2 = np.fromfile(out2, np.float32)
+    assert raw2.size == raw.size and np.isfinite(raw2).all()
+    assert abs(float(raw2[0]) - float(raw[0])) > 1e-6 and float(np.abs(raw2[1:1 + n]).max()) > 0

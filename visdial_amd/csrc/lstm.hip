@@ -836,6 +836,9 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
     EpiLstmBwd<2> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H, da16};
     // shadows on: da_{t+1} and Wh are read as the bf16 rows their producers wrote (half the operand bytes, no conversion
     // while staging, LDS-DMA pipeline); K counts bf16 pairs
+    if (da16_next && Wh16 && K % 32 == 0 && vd_tune_get("VD_BF16_OCC4", 0))   // A/B: 36 KB request = 4 workgroups per CU
+      return launch_gemm_glds<GemmCfg<4, 1, 2, 16, 0, 4, 36864, 1>, false>(N, H, K / 2, 1, reinterpret_cast<const float*>(da16_next), 2L * H,
+                                                                       reinterpret_cast<const float*>(Wh16), 2L * H, e, s);
     if (da16_next && Wh16 && K % 32 == 0)
       return launch_gemm_glds<CfgB11bf16, false>(N, H, K / 2, 1, reinterpret_cast<const float*>(da16_next), 2L * H,
                                                  reinterpret_cast<const float*>(Wh16), 2L * H, e, s);
@@ -1487,7 +1490,10 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
       e.h_out = h + t * NH + r0 * H;
       e.H = H;
       e.h16 = h16 ? h16 + t * NH + r0 * H : nullptr;
-      if (bf16 && hp && WhT16 && t > 0)
+      if (bf16 && hp && WhT16 && t > 0 && vd_tune_get("VD_BF16_OCC4", 0))
+        rc = launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 40960, 1>, false>(nr, 4 * H, H / 2, 1, reinterpret_cast<const float*>(h16 + (t - 1) * NH + r0 * H),
+                                                (long)H / 2, reinterpret_cast<const float*>(WhT16), (long)H / 2, e, rc_.stream[ch]);
+      else if (bf16 && hp && WhT16 && t > 0)
         rc = launch_gemm_glds<CfgF9bf16, false>(nr, 4 * H, H / 2, 1, reinterpret_cast<const float*>(h16 + (t - 1) * NH + r0 * H),
                                                 (long)H / 2, reinterpret_cast<const float*>(WhT16), (long)H / 2, e, rc_.stream[ch]);
       else if (bf16 && hp)
