@@ -160,8 +160,10 @@ int main(int argc, char** argv) {
   CHECK(p_mn_attention_backward(q3, h3, prob, dhatt, dq_att, dh3, B, R, H, NULL));
   CHECK(p_axpby(dq_att, ds2, dq3, (int64_t)N * H, 1.f, 1.f, NULL));
   /* text branches: the gradient arrives at the last step of the top layers only */
-  float* dhx = lstm_backward(&hist1, lstm_backward(&hist2, NULL, dh3, 1), NULL, 1);
-  float* dqx = lstm_backward(&ques1, lstm_backward(&ques2, NULL, dq3, 1), NULL, 1);
+  float* dh1_seq = lstm_backward(&hist2, NULL, dh3, 1);
+  float* dhx = lstm_backward(&hist1, dh1_seq, NULL, 1);
+  float* dq1_seq = lstm_backward(&ques2, NULL, dq3, 1);
+  float* dqx = lstm_backward(&ques1, dq1_seq, NULL, 1);
   CHECK(p_embed_scatter_acc(demb, hist, m_h, dhx, (int64_t)Th * N, E, m_h ? S5 : 1.f, NULL));
   CHECK(p_embed_scatter_acc(demb, ques, m_q, dqx, (int64_t)Tq * N, E, m_q ? S5 : 1.f, NULL));
 

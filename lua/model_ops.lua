@@ -1,10 +1,12 @@
 -- model_ops.lua -- class ModelOps: the reference's Model (model.lua:8-106, 249-342) over plug-in files that are composed IN LUA from
--- module objects (lua/vdnn.lua, operator-level C ABI) -- lua/encoders/lf-ques.lua + lua/decoders/disc.lua today.  Same control flow
+-- module objects (lua/vdnn.lua, operator-level C ABI) -- lua/encoders/lf-ques.lua, lua/encoders/mn-att-ques-im-hist.lua (the
+-- flagship) + lua/decoders/disc.lua today.  Same control flow
 -- as the reference, call for call: encoder:forward(inputs) -> forwardConnect -> decoder:forward({options, encOut}) ->
 -- criterion:forward / :backward -> decoder:backward -> encoder:backward(inputs, t[2]) (model.lua:297-337), wrapperW / wrapperdW from
 -- getParameters() (model.lua:55), clamp(-5, 5) + adam + learning-rate decay (model.lua:96-105).  lua/model.lua is the other host:
 -- the whole step behind the model-level ABI, any of the 11 x 2 pairs.
--- UNTESTED HERE (no Lua interpreter); transliteration of examples/host_c_plugin_lf_ques.c, which is built and checked on the GPU.
+-- UNTESTED HERE (no Lua interpreter); transliteration of examples/host_c_plugin_lf_ques.c / host_c_plugin_mn_att.c, which are built
+-- and checked on the GPU.
 local vdnn = dofile('vdnn.lua')
 local vd = vdnn.vd
 
@@ -37,9 +39,31 @@ local function timeMajor(t)
     return {tok = vdnn.devInts(tm), T = T, N = tm:size(2)}
 end
 
+-- wrapper:training() / wrapper:evaluate() (model.lua:57,111,144): the Dropout nodes of the Lua-composed modules
+function ModelOps:training() vdnn.training = true end
+function ModelOps:evaluate() vdnn.training = false end
+
 function ModelOps:forwardBackward(batch, onlyForward)
     local p = self.params
+    -- the reference's input table, in its order (model.lua:252-294): ques [, img] [, hist] [, mask]
     local inputs = {timeMajor(batch['ques_fwd'])}
+    if p.useIm == true then
+        -- ONE feature map per image on the device: the reference's repeatTensor over the 10 rounds (model.lua:262-270) is an index
+        -- computation inside the attention kernels' loaders
+        local f = batch['img_feat']:float():contiguous()
+        local d = vdnn.devFloats(f:nElement())
+        vd.call('vd_memcpy_h2d', d, f:data(), f:nElement() * 4, nil)
+        table.insert(inputs, {data = d, B = f:size(1)})
+    end
+    if p.useHistory == true then table.insert(inputs, timeMajor(batch['hist'])) end
+    if string.match(p.encoder, 'mn') then
+        -- model.lua:280-294: round i attends to facts j <= i; 1 = hidden; repeated over the dialogs of the batch
+        local R = p.maxQuesCount
+        local mask = torch.ones(R, R):byte()
+        for i = 1, R do for j = 1, R do if j <= i then mask[i][j] = 0 end end end
+        local maskRepeat = torch.repeatTensor(mask, batch['hist']:size(1), 1):contiguous()
+        table.insert(inputs, vdnn.devBytesFrom(maskRepeat))
+    end
     local N, H = inputs[1].N, p.rnnHiddenSize
     self.wordEmbed:zeroPad()
     local encOut = self.encoder:forward(inputs)                                        -- model.lua:297

@@ -5,8 +5,9 @@
 -- lua/decoders/disc.lua and lua/model_ops.lua = the operator-level Model).
 --
 -- UNTESTED HERE (no Lua/LuaJIT/Torch7 in the build container or on the GPU box).  This file is a transliteration of
--- examples/host_c_plugin_lf_ques.c -- the same module objects and the same ABI calls in the same order, in C -- which IS built
--- and checked on the GPU against the library's own model-level implementation (tests/test_abi_c_host.py);
+-- examples/host_c_modules.h (+ host_c_plugin_lf_ques.c, host_c_plugin_mn_att.c) -- the same module objects and the same ABI calls
+-- in the same order, in C -- which ARE built and checked on the GPU against the library's own model-level implementation
+-- (tests/test_abi_c_host.py);
 -- tests/test_lua_surface_cpu.py pins that both files use the same entry points.
 local ffi = require 'ffi'
 local vd = dofile('visdial_ffi.lua')
@@ -28,6 +29,44 @@ function M.devInts(intTensor)                             -- IntTensor (host, co
     vd.call('vd_malloc', p, n * 4)
     vd.call('vd_memcpy_h2d', p[0], intTensor:data(), n * 4, nil)
     return ffi.cast('int32_t*', p[0])
+end
+
+function M.devBytes(n)                                    -- raw device bytes (byte masks, sort scratch)
+    local p = ffi.new('void*[1]')
+    vd.call('vd_malloc', p, math.max(n, 4))
+    return p[0]
+end
+
+function M.devBytesFrom(byteTensor)                       -- ByteTensor (host, contiguous) -> device uint8
+    local n = byteTensor:nElement()
+    local p = M.devBytes(n)
+    vd.call('vd_memcpy_h2d', p, byteTensor:data(), n, nil)
+    return ffi.cast('uint8_t*', p)
+end
+
+-- ---- nn.Dropout(p): wrapper:training() / :evaluate() flip M.training (model.lua:57,111,144) -------------------------------------
+-- :mask(n) draws this forward's noise (nil = identity: evaluate); :apply(x, mask, n) is the forward AND the backward of the node.
+-- The fused kernels (embedding gather / scatter, image attention) take the mask pointer + the 1/(1-p) scale instead.
+M.training = true
+local Dropout = {}
+Dropout.__index = Dropout
+local dropSeed = 1234
+
+function M.Dropout(p) return setmetatable({p = p, scale = 1.0 / (1.0 - p)}, Dropout) end
+
+function Dropout:mask(n)
+    if not M.training then return nil end
+    local m = ffi.cast('uint8_t*', M.devBytes(n))
+    vd.call('vd_dropout_mask', m, n, dropSeed, self.p, nil)
+    dropSeed = dropSeed + 1
+    return m
+end
+
+function Dropout:apply(x, mask, n)
+    if mask == nil then return x end
+    local y = M.devFloats(n)
+    vd.call('vd_dropout_apply', x, mask, y, n, self.scale, nil)
+    return y
 end
 
 local function align4(n) return math.floor((n + 3) / 4) * 4 end
@@ -86,13 +125,17 @@ end
 
 function Lookup:zeroPad() vd.call('vd_memset', self.weight, 0, self.E * 4, nil) end         -- the pad row is re-zeroed on every forward
 
-function Lookup:forward(tok, rows)                          -- tok: device int32 [rows]; returns [rows x E]
+-- tok: device int32 [rows]; returns [rows x E].  mask / scale: the nn.Dropout that follows the table in the nngraph encoders
+-- (mn-att:24-25), fused into the gather (nil = none)
+function Lookup:forward(tok, rows, mask, scale)
     local out = M.devFloats(rows * self.E)
-    vd.call('vd_embed_gather', self.weight, tok, nil, out, rows, self.E, 1.0, nil)
+    vd.call('vd_embed_gather', self.weight, tok, mask, out, rows, self.E, mask ~= nil and scale or 1.0, nil)
     return out
 end
 
-function Lookup:backward(tok, rows, dx) vd.call('vd_embed_scatter_acc', self.gradWeight, tok, nil, dx, rows, self.E, 1.0, nil) end
+function Lookup:backward(tok, rows, dx, mask, scale)
+    vd.call('vd_embed_scatter_acc', self.gradWeight, tok, mask, dx, rows, self.E, mask ~= nil and scale or 1.0, nil)
+end
 
 -- ---- nn.SeqLSTM(D, H):maskZero() (encoders/lf-ques.lua:18-24, decoders/disc.lua:4): W = [Wx ; Wh] [(D+H) x 4H], gates i,f,o,g --
 local SeqLSTM = {}
@@ -133,29 +176,37 @@ function SeqLSTM:backward(dhSeq, dhLast, needDx)
     return dx
 end
 
--- ---- nn.Linear(nIn, nOut) + nn.Tanh (encoders/lf-ques.lua:29-31) ----------------------------------------------------------------
+-- ---- nn.Linear(nIn, nOut) [+ nn.Tanh] (encoders/lf-ques.lua:29-31; mn-att:64-65,77,88,106) -------------------------------------
 local LinearTanh = {}
 LinearTanh.__index = LinearTanh
 
-function M.LinearTanh(fp, name, nIn, nOut)
+function M.LinearTanh(fp, name, nIn, nOut, noTanh)          -- noTanh = true: plain nn.Linear (mn-att:88 ques_common)
     local W, dW = fp:view(name .. '.W')
     local b, db = fp:view(name .. '.b')
-    return setmetatable({nIn = nIn, nOut = nOut, W = W, b = b, dW = dW, db = db}, LinearTanh)
+    return setmetatable({nIn = nIn, nOut = nOut, W = W, b = b, dW = dW, db = db, noTanh = noTanh or false}, LinearTanh)
 end
+
+function M.Linear(fp, name, nIn, nOut) return M.LinearTanh(fp, name, nIn, nOut, true) end
 
 function LinearTanh:forward(x, rows)
     self.x, self.rows = x, rows
     self.output = M.devFloats(rows * self.nOut)
-    vd.call('vd_gemm_nt', x, self.nIn, self.W, self.nIn, self.b, self.output, self.nOut, rows, self.nOut, self.nIn, vd.C.VD_ACT_TANH, 0, nil)
+    vd.call('vd_gemm_nt', x, self.nIn, self.W, self.nIn, self.b, self.output, self.nOut, rows, self.nOut, self.nIn,
+            self.noTanh and vd.C.VD_ACT_NONE or vd.C.VD_ACT_TANH, 0, nil)
     return self.output
 end
 
-function LinearTanh:backward(dy)
+-- returns dx [rows x nIn] (nil when needDx == false); accumulates gradWeight / gradBias
+function LinearTanh:backward(dy, needDx)
     local rows = self.rows
-    local dpre = M.devFloats(rows * self.nOut)
-    vd.call('vd_tanh_backward', dy, self.output, dpre, rows * self.nOut, nil)
+    local dpre = dy
+    if not self.noTanh then
+        dpre = M.devFloats(rows * self.nOut)
+        vd.call('vd_tanh_backward', dy, self.output, dpre, rows * self.nOut, nil)
+    end
     vd.call('vd_gemm_tn_acc', dpre, self.nOut, self.x, self.nIn, self.dW, self.nIn, self.nOut, self.nIn, rows, 0, nil)
     vd.call('vd_colsum_acc', dpre, self.nOut, rows, self.nOut, self.db, nil)
+    if needDx == false then return nil end
     local dx = M.devFloats(rows * self.nIn)
     vd.call('vd_gemm_nn', dpre, self.nOut, self.W, self.nIn, nil, dx, self.nIn, rows, self.nIn, self.nOut, 0, nil)
     return dx

@@ -112,39 +112,72 @@ def _body(src, start, end):
 
 
 def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
-    """lua/vdnn.lua + lua/encoders/lf-ques.lua + lua/decoders/disc.lua + lua/model_ops.lua (an encoder / decoder pair composed in Lua
-    from module objects over the operator-level ABI) cannot be executed here; examples/host_c_plugin_lf_ques.c is the same code in C
-    and IS checked on the GPU (tests/test_abi_c_host.py).  Pin the correspondence: every module method makes the same ABI calls in
-    the same order as its C twin, the Lua files use exactly the entry points the C host loads, and all of them are exported."""
+    """lua/vdnn.lua + lua/encoders/{lf-ques, mn-att-ques-im-hist}.lua + lua/decoders/disc.lua + lua/model_ops.lua (encoder / decoder
+    pairs composed in Lua from module objects over the operator-level ABI) cannot be executed here; examples/host_c_modules.h +
+    host_c_plugin_lf_ques.c + host_c_plugin_mn_att.c are the same code in C and ARE checked on the GPU (tests/test_abi_c_host.py).
+    Pin the correspondence: every module method makes the same ABI calls in the same order as its C twin, the flagship encoder's
+    forward / backward drive the same module objects and entry points in the same order, the Lua files use exactly the entry points
+    the C hosts load, and all of them are exported."""
     funcs, _ = header_symbols()
-    c = open(os.path.join(ROOT, 'examples', 'host_c_plugin_lf_ques.c')).read()
-    lua = {n: open(os.path.join(ROOT, 'lua', n)).read() for n in ('vdnn.lua', 'encoders/lf-ques.lua', 'decoders/disc.lua', 'model_ops.lua')}
+    rd = lambda *a: open(os.path.join(ROOT, *a)).read()
+    hdr, c_lf, c_mn = rd('examples', 'host_c_modules.h'), rd('examples', 'host_c_plugin_lf_ques.c'), rd('examples', 'host_c_plugin_mn_att.c')
+    names = ('vdnn.lua', 'encoders/lf-ques.lua', 'encoders/mn-att-ques-im-hist.lua', 'decoders/disc.lua', 'model_ops.lua')
     strip = lambda s: '\n'.join(l.split('--')[0] for l in s.splitlines())
-    lua = {k: strip(v) for k, v in lua.items()}
+    lua = {n: strip(rd('lua', n)) for n in names}
+    mn = lua['encoders/mn-att-ques-im-hist.lua']
     pairs = [
-        (_body(c, 'static void lstm_forward(', '\n}\n'), _body(lua['vdnn.lua'], 'function SeqLSTM:forward(', '\nend\n')),
-        (_body(c, 'static float* lstm_backward(', '\n}\n'), _body(lua['vdnn.lua'], 'function SeqLSTM:backward(', '\nend\n')),
-        (_body(c, 'static float* linear_forward(', '\n}\n'), _body(lua['vdnn.lua'], 'function LinearTanh:forward(', '\nend\n')),
-        (_body(c, 'static float* linear_backward(', '\n}\n'), _body(lua['vdnn.lua'], 'function LinearTanh:backward(', '\nend\n')),
-        (_body(c, '/* decoder:backward (model.lua:335) */', '/* encoder:backward'), _body(lua['decoders/disc.lua'], 'function dec:backward(', '\n    end\n')),
+        (_body(hdr, 'static void lstm_forward(', '\n}\n'), _body(lua['vdnn.lua'], 'function SeqLSTM:forward(', '\nend\n')),
+        (_body(hdr, 'static float* lstm_backward(', '\n}\n'), _body(lua['vdnn.lua'], 'function SeqLSTM:backward(', '\nend\n')),
+        (_body(hdr, 'static float* linear_forward(', '\n}\n'), _body(lua['vdnn.lua'], 'function LinearTanh:forward(', '\nend\n')),
+        (_body(hdr, 'static float* linear_backward_ex(', '\n}\n'), _body(lua['vdnn.lua'], 'function LinearTanh:backward(', '\nend\n')),
+        (_body(hdr, 'static const float* disc_forward(', '\n}\n'), _body(lua['decoders/disc.lua'], 'function dec:forward(', '\n    end\n')),
+        (_body(hdr, 'static void disc_backward(', '\n}\n'), _body(lua['decoders/disc.lua'], 'function dec:backward(', '\n    end\n')),
+        (_body(c_mn, '/* ================= encoder:forward', '/* ================= decoder:forward'), _body(mn, 'function enc:forward(', '\n    end\n')),
+        (_body(c_mn, '/* ================= encoder:backward', '/* curLoss'), _body(mn, 'function enc:backward(', '\n    end\n')),
     ]
     drop = {'vd_malloc', 'vd_memset'}          # buffer allocation is interleaved differently (dev_floats / devFloats helpers)
-    for c_body, l_body in pairs:
-        a = [x for x in _c_calls(c_body) if x not in drop]
-        b = [x for x in _calls(l_body) if x not in drop]
+    for k, (c_body, l_body) in enumerate(pairs):
+        # (the flagship's embedding gathers / scatters are direct calls in C and self.wordEmbed methods in Lua: pinned just below)
+        skip = drop | ({'vd_embed_gather', 'vd_embed_scatter_acc'} if k >= len(pairs) - 2 else set())
+        a = [x for x in _c_calls(c_body) if x not in skip]
+        b = [x for x in _calls(l_body) if x not in skip]
         assert a == b and a, (a, b)
+    # the flagship encoder drives the same module objects in the same order: C `lstm_forward(&hist1` == Lua `self.hist1:forward(`,
+    # embedding gathers / scatters (direct calls in C, self.wordEmbed methods in Lua) and the Dropout helper included
+    def c_seq(body):
+        out = []
+        for m in re.finditer(r'\b(?:lstm|linear)_(forward|backward)(?:_ex)?\(&(\w+)|\bp_embed_(gather|scatter_acc)\(|\bdrop_(mask|apply)\(', body):
+            out.append((m.group(2), m.group(1)) if m.group(2) else ('wordEmbed', 'forward' if m.group(3) == 'gather' else 'backward') if m.group(3)
+                       else ('drop', m.group(4)))
+        return out
+    def lua_seq(body):
+        return [(m.group(1), m.group(2)) for m in re.finditer(r'\b(?:self\.)?(\w+):(forward|backward|mask|apply)\(', body) if m.group(1) != 'enc']
+    for c_body, l_body in pairs[-2:]:
+        a, b = c_seq(c_body), lua_seq(l_body)
+        # (evaluation order inside one statement: C writes linear_forward(&mn1, drop_apply(...)), Lua self.mn1:forward(drop:apply(...)) --
+        #  the same nesting, so the textual order agrees too)
+        assert a == b and len(a) >= 13, (a, b)
     used_lua = set()
     for v in lua.values():
         used_lua |= set(re.findall(r"vd\.call\('(vd_[a-z0-9_]+)'", v))
-    used_c = set('vd_' + x for x in re.findall(r'LOAD\(p_[a-z0-9_]+, "vd_([a-z0-9_]+)"\)', c)) - {'vd_last_error'}
+    used_c = set('vd_' + x for x in re.findall(r'LOAD\(p_[a-z0-9_]+, "vd_([a-z0-9_]+)"\)', hdr)) - {'vd_last_error'}
     assert used_lua == used_c, (used_lua ^ used_c)
     assert used_lua <= funcs
+    # both C hosts use nothing the shared header does not load
+    for c in (c_lf, c_mn):
+        assert set(_c_calls(c)) <= used_c | {'vd_last_error'}, set(_c_calls(c)) - used_c
     # the plug-in files keep the reference's contract AND carry a Lua-side implementation
-    assert 'function enc:forward(inputs)' in lua['encoders/lf-ques.lua'] and 'function enc:backward(inputs, gradOutput)' in lua['encoders/lf-ques.lua']
+    for e in ('encoders/lf-ques.lua', 'encoders/mn-att-ques-im-hist.lua'):
+        assert 'function enc:forward(inputs)' in lua[e] and 'function enc:backward(inputs, gradOutput)' in lua[e], e
+        assert 'function enc:declare(spec)' in lua[e] and 'function enc:build(vdnn, fp, wordEmbed)' in lua[e], e
     assert 'function dec:forward(input)' in lua['decoders/disc.lua'] and 'return {nil, gradOutput[2]}' in lua['decoders/disc.lua']
     for call in ('self.encoder:forward(inputs)', 'self.decoder:forward({options, encOut})', 'self.decoder:backward({options, encOut}, {dOptH, dEnc})',
                  'self.encoder:backward(inputs, t[2])'):
         assert call in lua['model_ops.lua'], call
+    # the flagship's parameter list is the library's (visdial_amd ParamSpec order = getParameters() order of the C host's in.bin)
+    declared = re.findall(r"table\.insert\(spec, \{(?:name \.\. )?'([A-Za-z_0-9.]+)'", _body(mn, 'function enc:declare(', '\n    end\n'))
+    assert declared == ['1.W', '1.b', '2.W', '2.b', 'mn1.W', 'mn1.b', 'mn2.W', 'mn2.b', 'img_proj.W', 'img_proj.b', 'img_common.W', 'img_common.b',
+                        'ques_common.W', 'ques_common.b', 'att.W', 'att.b', 'out.W', 'out.b'], declared
 
 
 def _lua_tokens(src):
