@@ -114,6 +114,9 @@ struct Disc : Decoder {
     VD_TRY(vd_memset(dtab, 0, (V + 1) * 4 * H * 4, st));
     VD_HIP(hipEventRecord(m->ev_prof[2], s));
     const bool dwh_first = vd_tune_get("VD_RT_DWH_FIRST", 0) != 0;   // host enqueue order (matters when streams share a hardware queue)
+    // the encoder backward's ~110 launches enqueued BEFORE the option recurrence's (A/B knob): whichever chain is the critical path
+    // of the step should not wait for the host to finish enqueueing the other one
+    const bool enc_bwd_first = !dwh_first && vd_tune_get("VD_RT_ENC_BWD_FIRST", 0) != 0;
     auto enc_bwd = [&]() -> int {
       VD_TRY(m->enc->backward(m, se, b, d_enc));
       VD_HIP(hipEventRecord(m->ev_enc_grads, se));                                  // encoder tensors final (data-parallel bucket 1)
@@ -124,8 +127,9 @@ struct Disc : Decoder {
     // backward only starts beside steps k-1 .. 0 and the dWh contraction (the backward step kernels lose 30 % beside the
     // encoder, the one-round dWh kernel 7 %).  Two calls of the recurrence: the hand-off is the library's own
     // (dh0, dc) of the first slice = (dh_last, dc_last) of the second.
-    const int split_k = (!flags && To > 2) ? vd_tune_get("VD_RT_ENC_BWD_SPLIT", 0) : 0;
+    const int split_k = (!flags && To > 2 && !enc_bwd_first) ? vd_tune_get("VD_RT_ENC_BWD_SPLIT", 0) : 0;
     bool enc_started = false;
+    if (enc_bwd_first) { VD_TRY(enc_bwd()); enc_started = true; }
     if (split_k > 0 && split_k < To) {
       const long NH = (long)NO * H;
       float* dh_mid;
