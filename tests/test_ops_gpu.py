@@ -53,6 +53,26 @@ def test_gemm_nt(ops, M, N, K, act):
     assert relerr(Cd, C0 + A.astype(np.float64) @ W.astype(np.float64).T) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(11323, 300, 2048), (1500, 512, 304), (1100, 130, 4096)])
+def test_gemm_nt_atomic_accumulate_splits_k(ops, M, N, K):
+    """accumulate = 2 (hardware float atomics; dEmb += dTable * Wx^T beside the encoder's scatters): throughput shapes split K over
+    several workgroups per tile (VD_NT_SPLITK) so the launch fills the chip -- same sum, ragged last K slice included"""
+    rng = np.random.RandomState(M + N + K + 7)
+    A, W = f32(rng, M, K), f32(rng, N, K) * 0.1
+    C0 = f32(rng, M, N)
+    Cd = dev(C0)
+    ref = C0 + A.astype(np.float64) @ W.astype(np.float64).T
+    ops.tune_set("VD_NT_SPLITK", 1)                      # opt-in (neutral in the training step: profiles/r03_experiments.txt section 19)
+    try:
+        ops.gemm_nt(dev(A), dev(W), Cd, bias=None, act=0, accumulate=2)
+    finally:
+        ops.tune_clear()
+    assert relerr(Cd, ref) < 1e-5
+    Ce = dev(C0)
+    ops.gemm_nt(dev(A), dev(W), Ce, bias=None, act=0, accumulate=2)
+    assert relerr(Ce, ref) < 1e-5 and relerr(Cd, Ce.cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(8000, 2048, 300), (200, 2048, 512), (130, 300, 2048), (51, 2048, 12), (4000, 512, 512)])
 def test_gemm_nn(ops, M, N, K):
     rng = np.random.RandomState(M + N + K + 1)

@@ -769,17 +769,18 @@ gemm_f32_glds_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, 
 
 // KMAJ == false: C[M x N] = epi(A[M x K] * Bt[N x K]^T), K % 16 == 0, row byte offsets below 4 GB.
 // KMAJ == true : C[M x N] (+)= epi over `splits` K ranges of A[K x M]^T * B[K x N]; M, N % 128 == 0, K % 16 == 0.
+// (row-major operands take splits > 1 only with `atomic_epi`: the caller vouches that the epilogue ACCUMULATES atomically)
 template <class Cfg, bool KMAJ, class Epi>
 static int launch_gemm_glds(int M, int N, int K, int splits, const float* A, long lda, const float* B, long ldb,
-                            const Epi& e, hipStream_t stream, int rotate_in = -1) {
+                            const Epi& e, hipStream_t stream, int rotate_in = -1, bool atomic_epi = false) {
   if (M <= 0 || N <= 0) return VD_OK;
   VD_CHECK_ARG(K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && splits >= 1,
                "launch_gemm_glds: unsupported shape M=%d N=%d K=%d", M, N, K);
   if (KMAJ)
     VD_CHECK_ARG(M % Cfg::BM == 0 && N % Cfg::BN == 0, "launch_gemm_glds: k-major tiles need M, N %% 128 == 0");
   else
-    VD_CHECK_ARG((long)M * lda * 4 < (1L << 32) && (long)N * ldb * 4 < (1L << 32) && splits == 1,
-                 "launch_gemm_glds: row offsets beyond 32 bits");
+    VD_CHECK_ARG((long)M * lda * 4 < (1L << 32) && (long)N * ldb * 4 < (1L << 32) && (splits == 1 || atomic_epi),
+                 "launch_gemm_glds: row offsets beyond 32 bits, or split-K without an accumulating epilogue");
   const int tiles_m = vd_cdiv(M, Cfg::BM), tiles_n = vd_cdiv(N, Cfg::BN);
   int kchunk = vd_cdiv(vd_cdiv(K, splits), 16) * 16;
   if (kchunk < 16) kchunk = 16;

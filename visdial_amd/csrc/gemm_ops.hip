@@ -185,8 +185,16 @@ int vd_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const f
   EpiStore<4> e{C, ldc, bias, act, accumulate};
   // both operands are k-contiguous rows: throughput shapes take the LDS-DMA pipeline (gemm_core.h)
   static const int nt_glds = getenv("VD_NT_GLDS") ? atoi(getenv("VD_NT_GLDS")) : 1;
-  if (nt_glds && M >= 1024 && K >= 64 && K % 16 == 0 && (long)M * lda * 4 < (1L << 32) && (long)N * ldw * 4 < (1L << 32))
-    return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 41984>, false>(M, N, K, 1, A, lda, W, ldw, e, s);
+  if (nt_glds && M >= 1024 && K >= 64 && K % 16 == 0 && (long)M * lda * 4 < (1L << 32) && (long)N * ldw * 4 < (1L << 32)) {
+    // atomic accumulation (accumulate == 2, no bias / activation: the shared embedding gradient dEmb += dTable * Wx^T, 267 tiles
+    // of K = 2048 -- one latency-bound wave of workgroups at the very end of the step): split K so the launch fills the chip
+    int splits = 1;
+    if (accumulate == 2 && !bias && act == VD_ACT_NONE && vd_tune_get("VD_NT_SPLITK", 0)) {
+      const long tiles = (long)vd_cdiv(M, 128) * vd_cdiv(N, 128);
+      splits = (int)std::max(1L, std::min((long)K / 256, 768 / tiles));
+    }
+    return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 41984>, false>(M, N, K, splits, A, lda, W, ldw, e, s, -1, splits > 1);
+  }
   return launch_gemm<CfgBig>(M, N, K, 1, a, b, e, s);
 }
 
