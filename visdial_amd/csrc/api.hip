@@ -116,6 +116,29 @@ void vd_bf16_shadow_invalidate(const float* p, size_t floats) {
     if (s.base && p < s.base + s.floats && s.base < p + floats) s.base = nullptr;
 }
 
+// ---- side streams (common.h) ---------------------------------------------------------------------------------------
+namespace {
+std::mutex g_side_mu;
+hipStream_t g_side[16];
+int g_side_n = 0;
+}  // namespace
+void vd_stream_mark_side(hipStream_t stream, bool on) {
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  for (int i = 0; i < g_side_n; ++i)
+    if (g_side[i] == stream) {
+      if (!on) g_side[i] = g_side[--g_side_n];
+      return;
+    }
+  if (on && stream && g_side_n < 16) g_side[g_side_n++] = stream;
+}
+bool vd_stream_is_side(hipStream_t stream) {
+  if (!stream) return false;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  for (int i = 0; i < g_side_n; ++i)
+    if (g_side[i] == stream) return true;
+  return false;
+}
+
 int vd_num_cus() {
   static thread_local int cached_dev = -1, cached = 256;
   int dev = 0;

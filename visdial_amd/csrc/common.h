@@ -52,6 +52,16 @@ struct VdStreamScratch {
 int vd_stream_scratch(hipStream_t stream, size_t wht_bytes, size_t sync_bytes, VdStreamScratch* out);
 int vd_num_cus();  // compute units of the current device (cached)
 
+// Streams that run BESIDE the throughput kernels of another stream (the step runtime's encoder / image / table-gradient
+// streams; A/B knob VD_SIDE_SMALL_LDS, default OFF).  The contraction entry points give a launch on a marked stream an LDS
+// request that fits the space three 41 KB throughput workgroups leave on a CU (20 / 32 KB), so it co-resides as a FOURTH
+// workgroup instead of waiting for one of the three to retire -- beside the one-round dWh contraction, whose workgroups
+// live for the whole kernel, the 41 KB requests of the encoder's weight gradients wait for milliseconds.  Measured: the
+// side kernels then run at their stand-alone speed, and dWh loses exactly their matrix-pipe time (the step is
+// work-conserving on the MFMA pipe): 24.47 / 24.72 vs 24.36 / 24.50 ms (profiles/r03_experiments.txt section 20).
+void vd_stream_mark_side(hipStream_t stream, bool on);
+bool vd_stream_is_side(hipStream_t stream);
+
 // bf16 shadows of fp32 activations (opt-in bf16 option recurrence, VD_FLAG_BF16; api.hip).  The producing kernels of a
 // bf16 pass (LSTM forward: h; LSTM backward: da) also write a bf16 copy of what they store, into a library-owned buffer
 // registered against the fp32 tensor's address range; the weight-gradient contraction of the same pass finds the two

@@ -170,6 +170,11 @@ static int launch_gemm_bf16_tn_tr(const vd_bf16_bits* A, const vd_bf16_bits* B, 
 extern "C" {
 
 // C[M x N] (+)= act(A[M x K] * W[N x K]^T + bias)
+// Launches on a SIDE stream (common.h: beside another stream's throughput kernels) take these: the same kernels with
+// an LDS request that fits beside three 41 KB workgroups -- 20 KB register-staged, 32 KB LDS-DMA (2 + 2 buffers).
+using CfgSideStaged = GemmCfg<4, 1, 4, 16, 0, 4, 0>;
+using CfgSideDma = GemmCfg<4, 1, 4, 16, 0, 4, 32768>;
+
 int vd_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C,
                int64_t ldc, int M, int N, int K, int act, int accumulate, void* stream) {
   VD_CHECK_ARG(A && W && C && M >= 0 && N >= 0 && K >= 0 && K % 4 == 0, "vd_gemm_nt: bad args M=%d N=%d K=%d", M,
@@ -193,6 +198,7 @@ int vd_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const f
       const long tiles = (long)vd_cdiv(M, 128) * vd_cdiv(N, 128);
       splits = (int)std::max(1L, std::min((long)K / 256, 768 / tiles));
     }
+    if (vd_stream_is_side(s)) return launch_gemm_glds<CfgSideDma, false>(M, N, K, splits, A, lda, W, ldw, e, s, -1, splits > 1);
     return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 41984>, false>(M, N, K, splits, A, lda, W, ldw, e, s, -1, splits > 1);
   }
   return launch_gemm<CfgBig>(M, N, K, 1, a, b, e, s);
@@ -245,6 +251,7 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
     const int K1 = K & ~15;
     if (int rc = vd_gemm_tn_acc(A, lda, B, ldb, C, ldc, M, N, K1, flags, stream)) return rc;
     SrcK a2{A + (long)K1 * lda, lda}, b2{B + (long)K1 * ldb, ldb};
+    if (vd_stream_is_side((hipStream_t)stream)) return launch_gemm<CfgSideStaged>(M, N, K - K1, 1, a2, b2, e, (hipStream_t)stream);
     return launch_gemm<GemmCfg<4, 1, 4, 16, 0, 4, 41984>>(M, N, K - K1, 1, a2, b2, e, (hipStream_t)stream);
   }
   // split-K target: one full round of workgroups for the big k-major shape; the register-staged shapes (encoder weight
@@ -269,9 +276,14 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
     }
     return launch_gemm<GemmCfg<4, 1, 4, 32, 0, 3, 0, 1>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
   }
+  const bool side = vd_stream_is_side((hipStream_t)stream);
+  if (kmaj && side)
+    return launch_gemm_glds<CfgSideDma, true>(M, N, K, (int)splits, A, lda, B, ldb, e, (hipStream_t)stream,
+                                              vd_tune_get("VD_TN_ROTATE", 0));
   if (kmaj)
     return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 41984>, true>(M, N, K, (int)splits, A, lda, B, ldb, e,
                                                                       (hipStream_t)stream, vd_tune_get("VD_TN_ROTATE", 0));
+  if ((cfg == 20 || cfg == 5) && side) return launch_gemm<CfgSideStaged>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
   if (cfg == 20 || cfg == 5)   // (cfg 20 on a shape the k-major pipeline does not take: the register-staged default)
     return launch_gemm<GemmCfg<4, 1, 4, 16, 0, 4, 41984>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
   if (cfg == 1) return launch_gemm<CfgBig>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
@@ -299,6 +311,7 @@ int vd_gemm_tn_rows_acc(const float* A, int64_t lda, const int32_t* a_rows, cons
   const long max_splits = vd_cdiv(K, vd_tune_get("VD_TN_MIN_KCHUNK", 1024));
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
+  if (vd_stream_is_side((hipStream_t)stream)) return launch_gemm<CfgSideStaged>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
   return launch_gemm<Cfg>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
 }
 

@@ -186,6 +186,8 @@ int vd_model_create(const vd_model_params* p, const char* encoder, const char* d
   // of the step multiplexed onto ONE hardware queue the cross-stream event waits resolve inside the command processor
   // and the headline step is 0.75-1.0 ms (3-4 %) faster (profiles/r02_hw_queues.txt).
   m->s_hist = m->s_img;
+  if (vd_tune_get("VD_SIDE_SMALL_LDS", 0))   // A/B knob, default off: see common.h
+    for (hipStream_t s : {m->s_enc, m->s_img, m->s_tab}) vd_stream_mark_side(s, true);
   m->ev_pool.resize(64);
   for (auto& e : m->ev_pool)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(VD_ERR_HIP);
@@ -226,7 +228,10 @@ void vd_model_destroy(vd_model* m) {
   for (auto& e : m->ev_prof)
     if (e) (void)hipEventDestroy(e);
   for (hipStream_t s : {m->s_main, m->s_enc, m->s_img, m->s_tab, m->s_copy})
-    if (s) (void)hipStreamDestroy(s);
+    if (s) {
+      vd_stream_mark_side(s, false);
+      (void)hipStreamDestroy(s);
+    }
   delete m;
 }
 
