@@ -70,6 +70,10 @@ def main():
             ("no K rotation", dict(VD_GEMM_ROTATE=0)),
             ("baseline (repeat)", {}),
         ]
+    if os.environ.get("MB_FULL", "1") == "4":
+        variants += [("3 + 3 LDS buffers (48 KB, 3 WG/CU)", dict(VD_LSTM_FWD_DEEP=1)),
+                     ("baseline (repeat)", {}),
+                     ("3 + 3 LDS buffers (repeat)", dict(VD_LSTM_FWD_DEEP=1))]
     if os.environ.get("MB_FULL", "1") == "3":
         variants += [("128 x 256 tiles, 4 waves x (32 x 256), 72 KB, 2 WG/CU", dict(VD_LSTM_FWD_NT8=1)),
                      ("128 x 256 tiles, 3 A + 2 B buffers (56 KB)", dict(VD_LSTM_FWD_NT8=2)),

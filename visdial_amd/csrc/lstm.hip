@@ -1500,7 +1500,11 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
         rc = launch_gemm<CfgFbf16>(nr, 4 * H, H, 1, SrcRow{hp, H}, SrcRow{WhT, H}, e, rc_.stream[ch]);
       else if (glds && hp) {
         const int epi = vd_tune_get("VD_LSTM_FWD_EPI_SEQ", 0);
-        if (const int wide = vd_tune_get("VD_LSTM_FWD_NT8", 0)) {
+        if (vd_tune_get("VD_LSTM_FWD_DEEP", 0)) {
+          // A/B: three LDS buffers for BOTH operands (48 KB request, still 3 workgroups per CU but no room for a latency
+          // workgroup beside them): is the epilogue's cost the extra latency its traffic puts on the K loops' DMA?
+          rc = launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 49152>, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e, rc_.stream[ch]);
+        } else if (const int wide = vd_tune_get("VD_LSTM_FWD_NT8", 0)) {
           // A/B: 128 x 256 workgroup tiles, FOUR waves of 32 x 256 (two gate groups per wave, 128 accumulator registers,
           // 2 workgroups per CU = 2 waves per SIMD): the 25 % operand-traffic cut of the 256 x 128 variant below without
           // its 4 waves per SIMD, and twice the MFMA burst per barrier.  wide = 2: two A buffers (56 KB request)
