@@ -70,6 +70,12 @@ def main():
             ("no K rotation", dict(VD_GEMM_ROTATE=0)),
             ("baseline (repeat)", {}),
         ]
+    if os.environ.get("MB_FULL", "1") == "5":
+        variants += [("K loop only", dict(VD_LSTM_FWD_EPI_SEQ=2)),
+                     ("K loop + VALU lump after it (160 exp + 160 rcp + 640 fma)", dict(VD_LSTM_FWD_EPI_SEQ=7)),
+                     ("K loop + the same VALU spread over it", dict(VD_LSTM_FWD_EPI_SEQ=8)),
+                     ("K loop only (repeat)", dict(VD_LSTM_FWD_EPI_SEQ=2)),
+                     ("baseline (repeat)", {})]
     if os.environ.get("MB_FULL", "1") == "4":
         variants += [("3 + 3 LDS buffers (48 KB, 3 WG/CU)", dict(VD_LSTM_FWD_DEEP=1)),
                      ("baseline (repeat)", {}),

@@ -319,6 +319,61 @@ struct EpiLstmFwdSpread {
     }
   }
 };
+// DIAGNOSTIC (knob VD_LSTM_FWD_EPI_SEQ=7 / 8, scripts/mb_r3.py): the K loop of the forward step kernel plus the real epilogue's
+// ARITHMETIC and nothing else -- per tile and lane 80 v_exp_f32 + 80 v_rcp_f32 (quarter rate) + 640 full-rate FMAs on dummy
+// registers, no loads, no stores beyond the minimal tail.  MODE 0: as one lump after the K loop (where the epilogue is: other
+// waves' MFMAs are the only thing that can hide it); MODE 1: spread over the K loop from the hook between the two MFMA bursts of
+// every K tile (the wave's own MFMAs can hide it too).  Do VALU instructions co-execute with the matrix pipe at all here?
+template <int MODE>
+struct EpiLstmFwdValuProbeT {
+  float* h_out;
+  int H;
+  static constexpr int KHOOK_VM_OPS = 0;
+  struct KHook {
+    float v[5];
+  };
+  __device__ __forceinline__ static void work(float (&v)[5], int reps) {
+    for (int r = 0; r < reps; ++r) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {      // five independent chains, like the five activations of a hidden unit
+        float e, q;
+        asm volatile("v_exp_f32 %0, %1" : "=v"(e) : "v"(v[i]));
+        asm volatile("v_rcp_f32 %0, %1" : "=v"(q) : "v"(e));
+        asm volatile("v_fma_f32 %0, %1, %2, %3\n\tv_fma_f32 %0, %0, %2, %1\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %2, %3"
+                     : "=&v"(v[i]) : "v"(q), "v"(e), "v"(v[(i + 1) % 5]));
+      }
+    }
+  }
+  __device__ __forceinline__ void khook_init(KHook& s) const {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) s.v[i] = 0.001f * (threadIdx.x + i);
+  }
+  __device__ __forceinline__ void khook(KHook& s, int kt, int nk, int, int, int, int, unsigned) const {
+    // 32 K tiles per tile at H = 512: 80 / 32 = 2.5 exp per K tile -> alternate 3 and 2 rounds of (1 exp + 1 rcp + 4 fma) x 5 / 5
+    if constexpr (MODE == 1) {
+      float one[5] = {s.v[0], s.v[1], s.v[2], s.v[3], s.v[4]};
+      work(one, 1);                     // 5 exp + 5 rcp + 20 fma per K tile  (x 32 = 160 + 160 + 640: twice the trans of the real epilogue's 80 + 80)
+#pragma unroll
+      for (int i = 0; i < 5; ++i) s.v[i] = (kt & 1) ? one[i] : s.v[i] * 0.5f + one[i] * 0.5f;
+    }
+  }
+  __device__ __forceinline__ void khook_finish(KHook&, int, int, int, int) const {}
+  __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int vcol0, int lane, int M, int /*Nv*/,
+                                             float* scr) const {
+    float v[5] = {acc[0][0], acc[1][1], acc[2][2], acc[3][3], acc[0][4]};
+    if constexpr (MODE == 0) work(v, 32);      // the same 160 exp + 160 rcp + 640 fma, after the K loop
+    float4 a0[4];
+    f32x16 sum = acc[0] + acc[1] + acc[2] + acc[3];
+    sum[0] += v[0] + v[1] + v[2] + v[3] + v[4];
+    tile_to_rows(sum, scr, lane, a0);
+    const int j0 = (vcol0 >> 7) * 32 + (lane & 7) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = row0 + p * 8 + (lane >> 3);
+      if (row < M) *reinterpret_cast<float4*>(h_out + (long)row * H + j0) = a0[p];
+    }
+  }
+};
 #ifndef VD_TICK_EPI_SEQ
 #define VD_TICK_EPI_SEQ 1   // epilogue flavour of the encoder tick kernels: 1 = compiler-scheduled (3 spilled VGPRs in the persistent
                            // kernel at the 128-register cap), 0 = the hand-scheduled one of the throughput kernels (12 spills)
@@ -1530,6 +1585,12 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
         } else if (epi == 6) {
           EpiLstmFwdSpreadNoWaitT<2> e6{e.xproj, e.xld, e.tok_gather, e.gates, e.h_out, e.H};
           rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e6, rc_.stream[ch]);
+        } else if (epi == 7) {
+          EpiLstmFwdValuProbeT<0> e7{e.h_out, e.H};
+          rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e7, rc_.stream[ch]);
+        } else if (epi == 8) {
+          EpiLstmFwdValuProbeT<1> e8{e.h_out, e.H};
+          rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e8, rc_.stream[ch]);
         } else if (epi == 3) {
           EpiLstmFwdSpread e3{e.xproj, e.xld, e.tok_gather, e.gates, e.h_out, e.H};
           rc = launch_gemm_glds<CfgF9, false>(nr, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e3, rc_.stream[ch]);
