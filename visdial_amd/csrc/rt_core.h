@@ -87,6 +87,11 @@ struct vd_model {
   std::map<std::string, vdrt::DevBuf> ws;
   std::map<std::string, vdrt::DevBuf> ext_masks;
   hipStream_t s_main = nullptr, s_enc = nullptr, s_img = nullptr, s_hist = nullptr, s_tab = nullptr, s_copy = nullptr;
+  // parameter-gradient work of the nngraph encoders that nothing downstream in the backward pass waits for (image-attention
+  // weight gradients, the recurrences' weight / input gradients): middle priority = its own hardware queue beside the in-order
+  // queue of the other side streams (runtime.hip).  wg_active: the current backward uses it; wg_used: it holds un-joined work
+  hipStream_t s_wg = nullptr;
+  bool wg_active = false, wg_used = false;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_next = 0;
   hipEvent_t ev_enc_grads = nullptr;  // recorded behind the encoder backward: its gradient tensors are final
@@ -173,6 +178,15 @@ inline int fork_stream(vd_model* m, hipStream_t from, hipStream_t side) {
 }
 inline int join_stream(vd_model* m, hipStream_t side, hipStream_t to) { return fork_stream(m, side, to); }
 inline hipStream_t side_stream(vd_model* m, hipStream_t wanted, hipStream_t cur) { return m->streams ? wanted : cur; }
+// the stream for off-chain parameter-gradient work enqueued after everything on `cur` so far (cur itself when the feature is off)
+inline int wg_fork(vd_model* m, hipStream_t cur, hipStream_t* out) {
+  *out = cur;
+  if (!m->wg_active || !m->s_wg) return VD_OK;
+  VD_TRY(fork_stream(m, cur, m->s_wg));
+  m->wg_used = true;
+  *out = m->s_wg;
+  return VD_OK;
+}
 
 // nn.Dropout keep-mask for a call site (null in evaluate mode or p == 0); external masks pin the noise for parity runs
 inline int drop_mask(vd_model* m, const std::string& site, size_t numel, float p, hipStream_t s, uint8_t** out) {

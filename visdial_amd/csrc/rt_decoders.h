@@ -117,9 +117,21 @@ struct Disc : Decoder {
     // the encoder backward's ~110 launches enqueued BEFORE the option recurrence's (A/B knob): whichever chain is the critical path
     // of the step should not wait for the host to finish enqueueing the other one
     const bool enc_bwd_first = !dwh_first && vd_tune_get("VD_RT_ENC_BWD_FIRST", 0) != 0;
+    // off-chain parameter-gradient work of the encoder on its own (middle-priority) stream = its own hardware queue: the in-order
+    // queue of the encoder stream then carries the dependent chain (attention backward -> ticks) and the table gradient only.
+    // Default: on in a bf16 pass (the encoder chain is that step's critical path: 12.34 -> 12.02 ms, profiles/r03_experiments.txt
+    // section 21), off in fp32 (work-conserving on the matrix pipe).  Never joined into `se`: a wait there would be a barrier
+    // packet in front of the table-gradient chain.
+    m->wg_active = m->streams && m->s_wg && vd_tune_get("VD_RT_WG_STREAM", flags ? 1 : 0) != 0;
+    m->wg_used = false;
     auto enc_bwd = [&]() -> int {
       VD_TRY(m->enc->backward(m, se, b, d_enc));
-      VD_HIP(hipEventRecord(m->ev_enc_grads, se));                                  // encoder tensors final (data-parallel bucket 1)
+      if (m->wg_used) {   // encoder tensors final = the chain on `se` AND the gradient work on s_wg
+        VD_TRY(fork_stream(m, se, m->s_wg));
+        VD_HIP(hipEventRecord(m->ev_enc_grads, m->s_wg));
+      } else {
+        VD_HIP(hipEventRecord(m->ev_enc_grads, se));                                // encoder tensors final (data-parallel bucket 1)
+      }
       m->enc_grads_recorded = true;
       return VD_OK;
     };
@@ -161,6 +173,8 @@ struct Disc : Decoder {
     // writers (the encoder's scatters), and the product is off the main stream's critical path this way
     VD_TRY(vd_gemm_nt(dtab, 4 * H, Wopt, 4 * H, nullptr, Gp(m, "embed"), E, (int)V + 1, (int)E, (int)(4 * H), VD_ACT_NONE, 2, st));
     VD_TRY(join_stream(m, se, s));
+    if (m->wg_used) VD_TRY(join_stream(m, m->s_wg, s));
+    m->wg_active = m->wg_used = false;
     return join_stream(m, st, s);
   }
   int retrieve(vd_model* m, BatchSlot& b) override { return forward_backward(m, b, true); }   // model.lua:421-425

@@ -133,15 +133,17 @@ struct TextBranches {
     VD_TRY(vd_lstm2_backward(bw, 2, (int)H, s));
     const uint8_t* mk[2] = {m_h, m_q};
     const char* tag[2] = {"h", "q"};
+    hipStream_t sw;
+    VD_TRY(wg_fork(m, s, &sw));                 // the recurrences are done: only parameter gradients are left
     for (int k = 0; k < 2; ++k) {
       const long TN = (long)ss[k]->T * N;
       std::vector<float*> dx;
-      VD_TRY(L2[k]->param_grads(m, s, {false}, nullptr));
-      VD_TRY(L1[k]->param_grads(m, s, {true}, &dx));
+      VD_TRY(L2[k]->param_grads(m, sw, {false}, nullptr));
+      VD_TRY(L1[k]->param_grads(m, sw, {true}, &dx));
       float* dxo;
       VD_TRY(ws_get(m, std::string(tag[k]) + ".dxo", (size_t)TN * E, &dxo));
-      VD_TRY(vd_embed_gather(dx[0], ss[k]->inv_idx, nullptr, dxo, TN, (int)E, 1.f, s));      // back to batch order
-      VD_TRY(vd_embed_scatter_acc(Gp(m, "embed"), ss[k]->tok, mk[k], dxo, TN, (int)E, 2.f, s));
+      VD_TRY(vd_embed_gather(dx[0], ss[k]->inv_idx, nullptr, dxo, TN, (int)E, 1.f, sw));     // back to batch order
+      VD_TRY(vd_embed_scatter_acc(Gp(m, "embed"), ss[k]->tok, mk[k], dxo, TN, (int)E, 2.f, sw));
     }
     return VD_OK;
   }
@@ -280,14 +282,19 @@ struct SANBlock {
       VD_TRY(ws_get(m, "att.du0" + sf, (size_t)N * H, &dun));
       VD_TRY(vd_img_att_backward(iqc[i], Wp(m, "att" + sf + ".W"), pre, m1, m2[i], patt[i], dcur, Gp(m, "att" + sf + ".W"),
                                  Gp(m, "att" + sf + ".b"), dqc, dscore, N, R, S2, (int)H, (int)K, sc, s));   // iqc now holds dz
-      VD_TRY(vd_colsum_acc(iqc[i], K, N * S2, (int)K, Gp(m, "img_common" + sf + ".b"), s));
-      VD_TRY(vd_img_common_wgrad(iqc[i], pre, m1, Gp(m, "img_common" + sf + ".W"), N, R, S2, (int)H, (int)K, sc, s));
-      VD_TRY(vd_img_tr_backward(iqc[i], Wp(m, "img_common" + sf + ".W"), patt[i], dcur, m1, dpre, N, R, S2, (int)H, (int)K, sc, s));
+      // dz is final: what follows on `sw` feeds parameter gradients only (the chain to the text branches continues with dqc)
+      hipStream_t sw;
+      VD_TRY(wg_fork(m, s, &sw));
+      VD_TRY(vd_colsum_acc(iqc[i], K, N * S2, (int)K, Gp(m, "img_common" + sf + ".b"), sw));
+      VD_TRY(vd_img_common_wgrad(iqc[i], pre, m1, Gp(m, "img_common" + sf + ".W"), N, R, S2, (int)H, (int)K, sc, sw));
+      VD_TRY(vd_img_tr_backward(iqc[i], Wp(m, "img_common" + sf + ".W"), patt[i], dcur, m1, dpre, N, R, S2, (int)H, (int)K, sc, sw));
       VD_TRY(ques_common[i].backward(m, s, dqc, true, &duq));
       VD_TRY(vd_axpby(duq, dcur, dun, (long)N * H, 1.f, 1.f, s));                 // residual CAddTable (mn-att:102)
       dcur = dun;
     }
-    VD_TRY(img_proj.backward(m, s, dpre, false, nullptr));                        // tanh' + dW, db of mn-att:77
+    hipStream_t sw;
+    VD_TRY(wg_fork(m, s, &sw));
+    VD_TRY(img_proj.backward(m, sw, dpre, false, nullptr));                       // tanh' + dW, db of mn-att:77
     *du0 = const_cast<float*>(dcur);
     return VD_OK;
   }

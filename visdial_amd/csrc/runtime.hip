@@ -179,6 +179,9 @@ int vd_model_create(const vd_model_params* p, const char* encoder, const char* d
   // 0.7 and dWh 6.9 instead of 6.1 (profiles/r03_experiments.txt).  Default off.
   const int tab_prio = (least - greatest >= 2 && vd_tune_get("VD_RT_TAB_MID_PRIO", 0)) ? (least + greatest) / 2 : greatest;
   if (hipStreamCreateWithPriority(&m->s_tab, hipStreamNonBlocking, tab_prio) != hipSuccess) return fail(VD_ERR_HIP);
+  if (least - greatest >= 2 &&
+      hipStreamCreateWithPriority(&m->s_wg, hipStreamNonBlocking, (least + greatest) / 2) != hipSuccess)
+    return fail(VD_ERR_HIP);
   // No encoder uses both side branches, so the history branch of lf-* / hre-* shares the image-branch stream: HIP
   // multiplexes streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, default 4), and a sixth stream put the
   // table-gradient stream on the main stream's queue (measured: +0.75 ms per headline step).  Hosts that own the
@@ -227,7 +230,7 @@ void vd_model_destroy(vd_model* m) {
   if (m->ev_enc_grads) (void)hipEventDestroy(m->ev_enc_grads);
   for (auto& e : m->ev_prof)
     if (e) (void)hipEventDestroy(e);
-  for (hipStream_t s : {m->s_main, m->s_enc, m->s_img, m->s_tab, m->s_copy})
+  for (hipStream_t s : {m->s_main, m->s_enc, m->s_img, m->s_tab, m->s_copy, m->s_wg})
     if (s) {
       vd_stream_mark_side(s, false);
       (void)hipStreamDestroy(s);
@@ -606,7 +609,8 @@ int vd_model_option_rows(vd_model* m, int64_t* executed, int64_t* total) {
 
 int vd_model_synchronize(vd_model* m) {
   VD_CHECK_ARG(m, "vd_model_synchronize: null model");
-  for (hipStream_t s : {m->s_copy, m->s_enc, m->s_img, m->s_tab, m->s_main}) VD_HIP(hipStreamSynchronize(s));
+  for (hipStream_t s : {m->s_copy, m->s_enc, m->s_img, m->s_tab, m->s_wg, m->s_main})
+    if (s) VD_HIP(hipStreamSynchronize(s));
   return VD_OK;
 }
 
