@@ -52,6 +52,15 @@ struct VdStreamScratch {
 int vd_stream_scratch(hipStream_t stream, size_t wht_bytes, size_t sync_bytes, VdStreamScratch* out);
 int vd_num_cus();  // compute units of the current device (cached)
 
+// zero rows [nact[t], N) of every time slice of up to 6 dense [T x N x ncols[i]] buffers in one launch (elementwise.hip)
+struct VdZeroSet {
+  float* buf[6];
+  int ncols[6];
+  int n;
+  long quads_per_row;   // filled in by the launcher
+};
+int vd_zero_inactive_multi(const VdZeroSet& z, const int32_t* nact_dev, int T, int N, hipStream_t stream);
+
 // Streams that run BESIDE the throughput kernels of another stream (the step runtime's encoder / image / table-gradient
 // streams; A/B knob VD_SIDE_SMALL_LDS, default OFF).  The contraction entry points give a launch on a marked stream an LDS
 // request that fits the space three 41 KB throughput workgroups leave on a CU (20 / 32 KB), so it co-resides as a FOURTH

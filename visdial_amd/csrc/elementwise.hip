@@ -131,6 +131,24 @@ __global__ void zero_inactive_rows_kernel(float* __restrict__ buf, long tstride,
   }
 }
 
+// the same for up to 6 buffers of one [T x N] row layout in ONE launch (the step runtime's encoder stacks: gates1, h1, c1, h2, c2,
+// gates2 -- it used to memset five of them completely, 55 % of those bytes only to be overwritten by the recurrence)
+__global__ void zero_inactive_multi_kernel(VdZeroSet z, const int* __restrict__ nact, int N) {
+  const int t = blockIdx.y;
+  const int first = nact[t];
+  const long per_row = z.quads_per_row;                       // float4s per row over all buffers
+  const long total = (long)(N - first) * per_row;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / per_row;
+    int q = (int)(idx - r * per_row);
+    int b = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if (b == i && i + 1 < z.n && q >= (z.ncols[i] >> 2)) { q -= z.ncols[i] >> 2; b = i + 1; }
+    *reinterpret_cast<float4*>(z.buf[b] + ((long)t * N + first + r) * z.ncols[b] + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 // ------------------------------------------------------------------ token counting sort
 // Wave-aggregated atomics: lanes holding the same token as the wave's first active lane are
 // counted with one atomic (the pad token dominates option batches: ~50% of all ids are 0).
@@ -364,6 +382,24 @@ int vd_zero_inactive_rows(float* buf, int64_t tstride, int64_t ld, int ncols, co
   return VD_OK;
 }
 
+int vd_embed_gather(const float* emb, const int32_t* tok, const uint8_t* mask, float* out, int64_t rows, int E,
+                    float scale, void* stream);
+}  // extern "C"
+// (internal, common.h) dense [T x N x ncols[i]] buffers, rows [nact[t], N) of every time slice zeroed in one launch
+int vd_zero_inactive_multi(const VdZeroSet& z, const int32_t* nact_dev, int T, int N, hipStream_t stream) {
+  VD_CHECK_ARG(z.n >= 1 && z.n <= 6 && nact_dev && T >= 0 && N >= 0, "vd_zero_inactive_multi: bad args");
+  if (T == 0 || N == 0) return VD_OK;
+  VdZeroSet zz = z;
+  zz.quads_per_row = 0;
+  for (int i = 0; i < z.n; ++i) {
+    VD_CHECK_ARG(z.buf[i] && z.ncols[i] % 4 == 0, "vd_zero_inactive_multi: buffer %d", i);
+    zz.quads_per_row += z.ncols[i] >> 2;
+  }
+  hipLaunchKernelGGL(zero_inactive_multi_kernel, dim3(128, T), dim3(256), 0, stream, zz, nact_dev, N);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+extern "C" {
 int vd_embed_gather(const float* emb, const int32_t* tok, const uint8_t* mask, float* out, int64_t rows, int E,
                     float scale, void* stream) {
   VD_CHECK_ARG(emb && tok && out && rows >= 0 && E > 0 && E % 4 == 0, "vd_embed_gather: bad args (E=%d)", E);

@@ -68,12 +68,18 @@ struct TextBranches {
     VD_TRY(vd_gemm_nn(xs, E, l1.Wx(m), 4 * H, Wp(m, l1.name + ".b"), l1.gates, 4 * H, (int)TN, (int)(4 * H), (int)E, 0, s));
     // skipped (t, row) pairs must read as zeros: previous state of rows that become active later, da = 0 in the
     // weight-gradient contractions
-    VD_TRY(vd_zero_inactive_rows(l1.gates, (int64_t)ss.N * 4 * H, 4 * H, (int)(4 * H), ss.nact_dev, ss.T, ss.N, s));
-    VD_TRY(vd_memset(l1.h, 0, TN * H * 4, s));
-    VD_TRY(vd_memset(l1.c, 0, TN * H * 4, s));
-    VD_TRY(vd_memset(l2.h, 0, TN * H * 4, s));
-    VD_TRY(vd_memset(l2.c, 0, TN * H * 4, s));
-    VD_TRY(vd_memset(l2.gates, 0, TN * 4 * H * 4, s));
+    if (ss.sorted && vd_tune_get("VD_RT_ZERO_INACTIVE", 1)) {
+      // only the skipped pairs, all six buffers in one launch: the active rows are written by the recurrence before anything reads them
+      VdZeroSet z{{l1.gates, l1.h, l1.c, l2.h, l2.c, l2.gates}, {(int)(4 * H), (int)H, (int)H, (int)H, (int)H, (int)(4 * H)}, 6, 0};
+      VD_TRY(vd_zero_inactive_multi(z, ss.nact_dev, ss.T, ss.N, s));
+    } else {
+      VD_TRY(vd_zero_inactive_rows(l1.gates, (int64_t)ss.N * 4 * H, 4 * H, (int)(4 * H), ss.nact_dev, ss.T, ss.N, s));
+      VD_TRY(vd_memset(l1.h, 0, TN * H * 4, s));
+      VD_TRY(vd_memset(l1.c, 0, TN * H * 4, s));
+      VD_TRY(vd_memset(l2.h, 0, TN * H * 4, s));
+      VD_TRY(vd_memset(l2.c, 0, TN * H * 4, s));
+      VD_TRY(vd_memset(l2.gates, 0, TN * 4 * H * 4, s));
+    }
     l1.xs = {xs};
     l2.xs = {l1.h};
     l1.rows = l2.rows = ss.sorted ? &ss : nullptr;
