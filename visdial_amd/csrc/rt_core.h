@@ -65,6 +65,9 @@ struct BatchSlot {
   // the encoding depends on the tokens only); opt_uid[n * O + o] = its row among the opt.N unique rows, or null
   int32_t* opt_uid = nullptr;
   int opt_total = 0;           // N * O
+  // counting sort of the option tokens (the table gradient's row order), done on the copy stream at upload time: it depends on the
+  // batch alone, and inside the step it stood in front of the encoder backward in the side streams' in-order hardware queue
+  int32_t *opt_sort_off = nullptr, *opt_sort_perm = nullptr;
   hipEvent_t ready = nullptr;  // recorded on the copy stream when the upload has landed
   hipEvent_t done = nullptr;   // recorded on the main stream behind the last reader of this slot
   bool used = false;      // a step has read this slot (done is recorded)
@@ -92,6 +95,7 @@ struct vd_model {
   // queue of the other side streams (runtime.hip).  wg_active: the current backward uses it; wg_used: it holds un-joined work
   hipStream_t s_wg = nullptr;
   bool wg_active = false, wg_used = false;
+  const float* dtab_zeroed = nullptr;   // the option table-gradient buffer was re-zeroed behind its last reader of the previous step
   std::vector<hipEvent_t> ev_pool;
   size_t ev_next = 0;
   hipEvent_t ev_enc_grads = nullptr;  // recorded behind the encoder backward: its gradient tensors are final

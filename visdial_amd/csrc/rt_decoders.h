@@ -109,9 +109,18 @@ struct Disc : Decoder {
     VD_TRY(ws_get(m, "opt.sort_off", (size_t)V + 2, &offset));
     VD_TRY(ws_get(m, "opt.sort_work", (size_t)2 * (V + 1), &work));
     VD_TRY(ws_get(m, "opt.sort_perm", (size_t)To * NO, &perm));
-    VD_TRY(fork_stream(m, s, st));
-    VD_TRY(vd_token_sort(b.opt.tok, (long)To * NO, (int)V + 1, offset, work, perm, st));
-    VD_TRY(vd_memset(dtab, 0, (V + 1) * 4 * H * 4, st));
+    if (b.opt_sort_perm) {
+      perm = b.opt_sort_perm;                    // sorted at upload time (runtime.hip)
+    } else {
+      VD_TRY(fork_stream(m, s, st));
+      VD_TRY(vd_token_sort(b.opt.tok, (long)To * NO, (int)V + 1, offset, work, perm, st));
+    }
+    const bool dtab_defer = vd_tune_get("VD_RT_DTAB_DEFER_ZERO", 1) != 0;
+    if (!(dtab_defer && m->dtab_zeroed == dtab)) {
+      VD_TRY(fork_stream(m, s, st));
+      VD_TRY(vd_memset(dtab, 0, (V + 1) * 4 * H * 4, st));
+    }
+    m->dtab_zeroed = nullptr;
     VD_HIP(hipEventRecord(m->ev_prof[2], s));
     const bool dwh_first = vd_tune_get("VD_RT_DWH_FIRST", 0) != 0;   // host enqueue order (matters when streams share a hardware queue)
     // the encoder backward's ~110 launches enqueued BEFORE the option recurrence's (A/B knob): whichever chain is the critical path
@@ -175,7 +184,12 @@ struct Disc : Decoder {
     VD_TRY(join_stream(m, se, s));
     if (m->wg_used) VD_TRY(join_stream(m, m->s_wg, s));
     m->wg_active = m->wg_used = false;
-    return join_stream(m, st, s);
+    VD_TRY(join_stream(m, st, s));
+    if (dtab_defer) {   // re-zero the table gradient for the next step BEHIND the join: it runs beside the optimiser, not in front of a step
+      VD_TRY(vd_memset(dtab, 0, (V + 1) * 4 * H * 4, st));
+      m->dtab_zeroed = dtab;
+    }
+    return VD_OK;
   }
   int retrieve(vd_model* m, BatchSlot& b) override { return forward_backward(m, b, true); }   // model.lua:421-425
 };

@@ -437,6 +437,15 @@ int vd_model_upload_batch(vd_model* m, const vd_batch* hb) {
       }
     }
     if (!dedup) VD_TRY(upload_tokens(sl, sl.opt, "opt", hb->options, (int)NO, hb->To, false, s));   // [N x O x To] -> [To x N*O]
+    sl.opt_sort_off = sl.opt_sort_perm = nullptr;
+    if (vd_tune_get("VD_RT_SORT_AT_UPLOAD", 1)) {
+      const long V1 = (long)m->p.vocabSize + 1, n = (long)sl.opt.T * sl.opt.N;
+      int32_t* work;
+      VD_TRY(dev_get(sl.bufs, "opt.sort_off", (size_t)(V1 + 1) * sizeof(int32_t), (void**)&sl.opt_sort_off));
+      VD_TRY(dev_get(sl.bufs, "opt.sort_work", (size_t)2 * V1 * sizeof(int32_t), (void**)&work));
+      VD_TRY(dev_get(sl.bufs, "opt.sort_perm", (size_t)n * sizeof(int32_t), (void**)&sl.opt_sort_perm));
+      VD_TRY(vd_token_sort(sl.opt.tok, n, (int)V1, sl.opt_sort_off, work, sl.opt_sort_perm, s));
+    }
   }
   if (!disc && hb->answer_in && hb->answer_out) {
     VD_TRY(upload_tokens(sl, sl.ain, "ain", hb->answer_in, N, hb->Ta, false, s));
