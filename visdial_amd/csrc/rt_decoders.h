@@ -115,7 +115,7 @@ struct Disc : Decoder {
       VD_TRY(fork_stream(m, s, st));
       VD_TRY(vd_token_sort(b.opt.tok, (long)To * NO, (int)V + 1, offset, work, perm, st));
     }
-    const bool dtab_defer = vd_tune_get("VD_RT_DTAB_DEFER_ZERO", 1) != 0;
+    const bool dtab_defer = vd_tune_get("VD_RT_DTAB_DEFER_ZERO", 0) != 0;
     if (!(dtab_defer && m->dtab_zeroed == dtab)) {
       VD_TRY(fork_stream(m, s, st));
       VD_TRY(vd_memset(dtab, 0, (V + 1) * 4 * H * 4, st));
