@@ -120,6 +120,33 @@ __device__ __forceinline__ float4 vd_ld4_stream(const float* p) {
 #endif
 }
 
+// Buffer addressing for the step kernels' epilogues (VD_EPI_BUF): an SGPR descriptor per tensor + a 32-bit VGPR byte offset + an
+// SGPR byte offset for the uniform part (gate / row-group strides).  buffer_load / buffer_store compute the address in the
+// memory pipeline, so the ~130 64-bit VALU address instructions a tile's epilogue spent on `ptr + (long)row * ld + j` go away --
+// and VALU issue is what the epilogue costs (profiles/r03_experiments.txt section 13c).  The compiler tracks vmcnt for these
+// builtins (unlike inline asm).  No reliance on the hardware range check: the SGPR offset is not part of it on gfx9.
+#ifndef VD_EPI_BUF
+#define VD_EPI_BUF 1   // bit 0: forward step epilogue (shipped), bit 1: backward step epilogue (slower alone: r03_experiments 13e)
+#endif
+typedef unsigned vd_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned vd_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vd_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 vd_buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const vd_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void vd_buf_st4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float4& v) {
+  const vd_u32x4 t = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 0);
+}
+__device__ __forceinline__ void vd_buf_st4_bf16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float4& v) {
+  typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+  const bf4 t = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(vd_u32x2, t), r, voff, soff, 0);
+}
+
 // 4 consecutive fp32 -> 4 bf16 (RNE, v_cvt_pk_bf16_f32), one 8-byte store
 __device__ __forceinline__ void vd_st4_bf16(vd_bf16_bits* p, const float4& v) {
   typedef __bf16 bf4 __attribute__((ext_vector_type(4)));

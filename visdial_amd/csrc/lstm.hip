@@ -175,6 +175,23 @@ struct EpiLstmFwdT {
     tile_to_rows(acc[3], scr, lane, a[3]);
     VD_T(3);
     float4 x[4], cp;
+#if VD_EPI_BUF & 1
+    // descriptors (SGPRs) + 32-bit byte offsets: per row group one multiply-add for the gathered projection row and one for the
+    // clamped state row; the gate stride and the row-group stride are SGPR offsets
+    const __amdgpu_buffer_rsrc_t rx = vd_rsrc(xproj), rc = vd_rsrc(c_prev), rg = vd_rsrc(gates), rco = vd_rsrc(c_out),
+                                 rh = vd_rsrc(h_out), rh16 = vd_rsrc(h16);
+    const unsigned uH4 = (unsigned)H * 4u, uj4 = (unsigned)j * 4u, uxld4 = (unsigned)xld * 4u;
+    const unsigned vrow = ((unsigned)(row0 + rl)) * uH4 + uj4;          // byte offset of (row0 + rl, j) in an [M x H] tensor
+    auto issue = [&](int p) {
+      const unsigned xo = (unsigned)tk[p] * uxld4 + uj4;
+      x[0] = vd_buf_ld4(rx, xo, 0);
+      x[1] = vd_buf_ld4(rx, xo, uH4);
+      x[2] = vd_buf_ld4(rx, xo, 2 * uH4);
+      x[3] = vd_buf_ld4(rx, xo, 3 * uH4);
+      cp = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c_prev) cp = vd_buf_ld4(rc, (unsigned)rowc[p] * uH4 + uj4, 0);
+    };
+#else
     auto issue = [&](int p) {
       const float* xr = xproj + (long)tk[p] * xld + j;
       x[0] = *reinterpret_cast<const float4*>(xr);
@@ -184,6 +201,7 @@ struct EpiLstmFwdT {
       cp = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c_prev) cp = *reinterpret_cast<const float4*>(c_prev + (long)rowc[p] * H + j);
     };
+#endif
     issue(0);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -210,6 +228,17 @@ struct EpiLstmFwdT {
 #undef VD_CELL
       const int row = row0 + p * 8 + rl;
       if (row < M) {
+#if VD_EPI_BUF & 1
+        const unsigned sp = (unsigned)p * 8u * uH4;                  // row-group stride (uniform)
+        const unsigned vg = 4u * vrow - 3u * uj4;                    // (row0 + rl, j) in the [M x 4H] gates tensor
+        vd_buf_st4(rg, vg, 4u * sp, gi);                              // saved for the backward pass
+        vd_buf_st4(rg, vg, 4u * sp + uH4, gf);
+        vd_buf_st4(rg, vg, 4u * sp + 2 * uH4, go);
+        vd_buf_st4(rg, vg, 4u * sp + 3 * uH4, gg);
+        vd_buf_st4(rco, vrow, sp, c);
+        vd_buf_st4(rh, vrow, sp, h);
+        if (h16) vd_buf_st4_bf16(rh16, vrow >> 1, sp >> 1, h);
+#else
         float* gr = gates + (long)row * 4 * H + j;
         vd_st4_stream(gr, gi);           // saved for the backward pass: written once, read ~10 ms later
         vd_st4_stream(gr + H, gf);
@@ -218,6 +247,7 @@ struct EpiLstmFwdT {
         *reinterpret_cast<float4*>(c_out + (long)row * H + j) = c;
         *reinterpret_cast<float4*>(h_out + (long)row * H + j) = h;
         if (h16) vd_st4_bf16(h16 + (long)row * H + j, h);
+#endif
       }
     }
   }
@@ -425,10 +455,31 @@ struct EpiLstmBwd {
     const float* dh1 = dh_a ? dh_a : dh_b;   // the common case has at most one incoming-gradient operand
     L.dhx = dh1 ? *reinterpret_cast<const float4*>(dh1 + o) : z;
   }
+#if VD_EPI_BUF & 2
+  // buffer addressing (common.h): `o4` = byte offset of (row, j) in an [M x H] tensor; the gates tensor's is 4 * o4 - 12 * j
+  struct Rsrc {
+    __amdgpu_buffer_rsrc_t g, ct, cp, dc, dh1, dh2, g16;
+  };
+  __device__ __forceinline__ void load_slot_buf(Slot& L, const Rsrc& R, unsigned o4, unsigned og4, unsigned uH4) const {
+    L.g[0] = vd_buf_ld4(R.g, og4, 0);          // saved gates: read exactly once
+    L.g[1] = vd_buf_ld4(R.g, og4, uH4);
+    L.g[2] = vd_buf_ld4(R.g, og4, 2 * uH4);
+    L.g[3] = vd_buf_ld4(R.g, og4, 3 * uH4);
+    L.ct = vd_buf_ld4(R.ct, o4, 0);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    L.cp = c_prev ? vd_buf_ld4(R.cp, o4, 0) : z;
+    L.dcv = dc_first ? z : vd_buf_ld4(R.dc, o4, 0);
+    L.dhx = (dh_a || dh_b) ? vd_buf_ld4(R.dh1, o4, 0) : z;   // the common case has at most one incoming-gradient operand
+  }
+#endif
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[NT], int row0, int col0, int lane, int M,
                                              int N, float* scr) const {
     const int rl = lane >> 3, cl = (lane & 7) * 4;
     const bool two_dh = dh_a && dh_b;
+#if VD_EPI_BUF & 2
+    const Rsrc R{vd_rsrc(gates), vd_rsrc(c_t), vd_rsrc(c_prev), vd_rsrc(dc), vd_rsrc(dh_a ? dh_a : dh_b), vd_rsrc(dh_b), vd_rsrc(da16)};
+    const unsigned uH4 = (unsigned)H * 4u;
+#endif
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
       float4 d4[4];
@@ -438,11 +489,22 @@ struct EpiLstmBwd {
 #pragma unroll
       for (int pp = 0; pp < 4; pp += BATCH) {
         Slot L[BATCH];
+#if VD_EPI_BUF & 2
+        unsigned o4[BATCH], og4[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) {
+          const int row = row0 + (pp + q) * 8 + rl;
+          o4[q] = (unsigned)(row < M ? row : M - 1) * uH4 + (unsigned)jc * 4u;
+          og4[q] = 4u * o4[q] - 12u * (unsigned)jc;
+          load_slot_buf(L[q], R, o4[q], og4[q], uH4);
+        }
+#else
 #pragma unroll
         for (int q = 0; q < BATCH; ++q) {
           const int row = row0 + (pp + q) * 8 + rl;
           load_slot(L[q], row < M ? row : M - 1, jc);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < BATCH; ++q) {
@@ -450,11 +512,18 @@ struct EpiLstmBwd {
           float4 dh = d4[pp + q];
           dh.x += C.dhx.x; dh.y += C.dhx.y; dh.z += C.dhx.z; dh.w += C.dhx.w;
           const int row = row0 + (pp + q) * 8 + rl;
+#if VD_EPI_BUF & 2
+          if (two_dh) {
+            const float4 t = vd_buf_ld4(R.dh2, o4[q], 0);
+            dh.x += t.x; dh.y += t.y; dh.z += t.z; dh.w += t.w;
+          }
+#else
           const long o = (long)(row < M ? row : M - 1) * H + jc;
           if (two_dh) {
             const float4 t = *reinterpret_cast<const float4*>(dh_b + o);
             dh.x += t.x; dh.y += t.y; dh.z += t.z; dh.w += t.w;
           }
+#endif
           float4 ai, af, ao, ag, dn;
 #define VD_CELLB(E)                                                       \
           {                                                               \
@@ -469,6 +538,20 @@ struct EpiLstmBwd {
           VD_CELLB(x) VD_CELLB(y) VD_CELLB(z) VD_CELLB(w)
 #undef VD_CELLB
           if (row < M && j < N) {
+#if VD_EPI_BUF & 2
+            // (row < M and j < N here: the clamped offsets of the loads are the true ones)
+            vd_buf_st4(R.g, og4[q], 0, ai);
+            vd_buf_st4(R.g, og4[q], uH4, af);
+            vd_buf_st4(R.g, og4[q], 2 * uH4, ao);
+            vd_buf_st4(R.g, og4[q], 3 * uH4, ag);
+            vd_buf_st4(R.dc, o4[q], 0, dn);
+            if (da16) {
+              vd_buf_st4_bf16(R.g16, og4[q] >> 1, 0, ai);
+              vd_buf_st4_bf16(R.g16, og4[q] >> 1, uH4 >> 1, af);
+              vd_buf_st4_bf16(R.g16, og4[q] >> 1, uH4, ao);
+              vd_buf_st4_bf16(R.g16, og4[q] >> 1, 3 * (uH4 >> 1), ag);
+            }
+#else
             float* gr = gates + (long)row * 4 * H + j;
             *reinterpret_cast<float4*>(gr) = ai;
             *reinterpret_cast<float4*>(gr + H) = af;
@@ -482,6 +565,7 @@ struct EpiLstmBwd {
               vd_st4_bf16(g16 + 2 * H, ao);
               vd_st4_bf16(g16 + 3 * H, ag);
             }
+#endif
           }
         }
       }
