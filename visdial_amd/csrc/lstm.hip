@@ -455,7 +455,7 @@ struct EpiLstmBwd {
     const float* dh1 = dh_a ? dh_a : dh_b;   // the common case has at most one incoming-gradient operand
     L.dhx = dh1 ? *reinterpret_cast<const float4*>(dh1 + o) : z;
   }
-#if VD_EPI_BUF & 2
+#if VD_EPI_BUF & 6
   // buffer addressing (common.h): `o4` = byte offset of (row, j) in an [M x H] tensor; the gates tensor's is 4 * o4 - 12 * j
   struct Rsrc {
     __amdgpu_buffer_rsrc_t g, ct, cp, dc, dh1, dh2, g16;
@@ -476,7 +476,7 @@ struct EpiLstmBwd {
                                              int N, float* scr) const {
     const int rl = lane >> 3, cl = (lane & 7) * 4;
     const bool two_dh = dh_a && dh_b;
-#if VD_EPI_BUF & 2
+#if VD_EPI_BUF & 6
     const Rsrc R{vd_rsrc(gates), vd_rsrc(c_t), vd_rsrc(c_prev), vd_rsrc(dc), vd_rsrc(dh_a ? dh_a : dh_b), vd_rsrc(dh_b), vd_rsrc(da16)};
     const unsigned uH4 = (unsigned)H * 4u;
 #endif
@@ -489,14 +489,18 @@ struct EpiLstmBwd {
 #pragma unroll
       for (int pp = 0; pp < 4; pp += BATCH) {
         Slot L[BATCH];
-#if VD_EPI_BUF & 2
+#if VD_EPI_BUF & 6
         unsigned o4[BATCH], og4[BATCH];
 #pragma unroll
         for (int q = 0; q < BATCH; ++q) {
           const int row = row0 + (pp + q) * 8 + rl;
           o4[q] = (unsigned)(row < M ? row : M - 1) * uH4 + (unsigned)jc * 4u;
           og4[q] = 4u * o4[q] - 12u * (unsigned)jc;
+#if VD_EPI_BUF & 2
           load_slot_buf(L[q], R, o4[q], og4[q], uH4);
+#else
+          load_slot(L[q], row < M ? row : M - 1, jc);
+#endif
         }
 #else
 #pragma unroll
@@ -512,7 +516,7 @@ struct EpiLstmBwd {
           float4 dh = d4[pp + q];
           dh.x += C.dhx.x; dh.y += C.dhx.y; dh.z += C.dhx.z; dh.w += C.dhx.w;
           const int row = row0 + (pp + q) * 8 + rl;
-#if VD_EPI_BUF & 2
+#if VD_EPI_BUF & 6
           if (two_dh) {
             const float4 t = vd_buf_ld4(R.dh2, o4[q], 0);
             dh.x += t.x; dh.y += t.y; dh.z += t.z; dh.w += t.w;
@@ -538,7 +542,7 @@ struct EpiLstmBwd {
           VD_CELLB(x) VD_CELLB(y) VD_CELLB(z) VD_CELLB(w)
 #undef VD_CELLB
           if (row < M && j < N) {
-#if VD_EPI_BUF & 2
+#if VD_EPI_BUF & 4
             // (row < M and j < N here: the clamped offsets of the loads are the true ones)
             vd_buf_st4(R.g, og4[q], 0, ai);
             vd_buf_st4(R.g, og4[q], uH4, af);
@@ -552,6 +556,9 @@ struct EpiLstmBwd {
               vd_buf_st4_bf16(R.g16, og4[q] >> 1, 3 * (uH4 >> 1), ag);
             }
 #else
+#if VD_EPI_BUF & 6
+            const long o = (long)row * H + j;
+#endif
             float* gr = gates + (long)row * 4 * H + j;
             *reinterpret_cast<float4*>(gr) = ai;
             *reinterpret_cast<float4*>(gr + H) = af;
