@@ -86,6 +86,8 @@ int vd_colsum_acc(const float* X, int64_t ld, int M, int N, float* out, void* st
  * tok_mask ([T x N] or NULL) implements :maskZero(): rows with token 0 get h = c = gates = 0.
  * h0/c0 ([N x H] or both NULL = zeros) are userPrevOutput/userPrevCell (gen.lua:32-38).
  * Outputs: gates [T x N x 4H] post-activation (i,f,o,g), h and c [T x N x H].
+ * Limits: one step's slice of every tensor below 4 GB (N * 4H * 4 bytes; a projection table: its rows * x_ld * 4 bytes --
+ * 524 288 table rows at H = 512): the epilogue uses 32-bit byte offsets.  Larger batches: call per row range.
  * Throughput shapes (N >= 2048) run the whole recurrence as ONE persistent launch (tile queues + per-row-tile
  * arrival counters; csrc/lstm.hip) on the LDS-DMA pipeline; its work buffers (4H x H gate-interleaved transpose
  * of Wh, queue heads, counters) are library-owned per (device, stream), so calls on different streams may overlap. */

@@ -131,7 +131,8 @@ __device__ __forceinline__ float4 vd_ld4_stream(const float* p) {
 typedef unsigned vd_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned vd_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t vd_rsrc(const void* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+  // num_records = 2^32 - 1: byte offsets are 32-bit, every tensor addressed this way is < 4 GB per launch (checked by the callers)
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
 }
 __device__ __forceinline__ float4 vd_buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   const vd_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);

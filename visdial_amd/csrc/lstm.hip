@@ -1549,6 +1549,10 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
   VD_CHECK_ARG(xproj && Wh && gates && h && c, "vd_lstm_forward: null pointer");
   VD_CHECK_ARG((h0 == nullptr) == (c0 == nullptr), "vd_lstm_forward: h0 and c0 must both be set or both null");
   VD_CHECK_ARG(x_ld % 4 == 0, "vd_lstm_forward: x_ld must be a multiple of 4");
+  // the step epilogue addresses its tensors with 32-bit byte offsets (buffer descriptors, common.h): one step's slice of every
+  // tensor must stay below 4 GB (gates: N * 4H * 4 bytes; the dense projection: N * x_ld * 4; a projection TABLE: rows * x_ld * 4)
+  VD_CHECK_ARG((long)N * 4 * H * 4 < (1L << 32) && (tok_gather || (long)N * x_ld * 4 < (1L << 32)),
+               "vd_lstm_forward: N=%d rows x 4H=%d exceed 4 GB per step: split the batch", N, 4 * H);
   hipStream_t s = (hipStream_t)stream;
   const long NH = (long)N * H;
   // The recurrence is independent per row: throughput shapes run as row chains on separate streams so the

@@ -121,6 +121,9 @@ int vd_model_create(const vd_model_params* p, const char* encoder, const char* d
   VD_CHECK_ARG(p->rnnHiddenSize > 0 && p->rnnHiddenSize % 32 == 0 && p->embedSize > 0 && p->embedSize % 4 == 0 && p->vocabSize > 0 &&
                    p->maxQuesCount > 0 && p->numOptions > 0,
                "vd_model_create: rnnHiddenSize must be a positive multiple of 32, embedSize of 4; vocabSize, maxQuesCount, numOptions > 0");
+  // the projection table [V+1 x 4H] of the option / decoder recurrences is gathered with 32-bit byte offsets (common.h)
+  VD_CHECK_ARG(((long)p->vocabSize + 1) * 4 * p->rnnHiddenSize * 4 < (1L << 32),
+               "vd_model_create: (vocabSize + 1) x 4 x rnnHiddenSize floats exceed 4 GB");
   VD_CHECK_ARG(!use_im || (p->imgFeatureSize > 0 && p->imgFeatureSize % 4 == 0), "vd_model_create: imgFeatureSize must be a positive multiple of 4");
   VD_CHECK_ARG(!is_att || (p->commonEmbeddingSize > 0 && p->commonEmbeddingSize % 4 == 0 && p->imgSpatialSize > 0),
                "vd_model_create: commonEmbeddingSize must be a positive multiple of 4 and imgSpatialSize > 0 for attention encoders");
