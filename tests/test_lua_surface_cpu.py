@@ -5,6 +5,7 @@ import os
 import re
 import subprocess
 import sys
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_ENCODERS = ['lf-ques', 'lf-ques-im', 'lf-ques-hist', 'lf-ques-im-hist', 'lf-att-ques-im-hist', 'hre-ques-hist',
@@ -225,3 +226,32 @@ def test_lua_files_are_block_balanced():
             assert depth >= 0, name
         assert depth == 0, (name, depth)
         assert toks.count('(') == toks.count(')') and toks.count('{') == toks.count('}'), name
+
+
+def test_lua_files_parse_and_use_no_undeclared_names():
+    """tests/lua_lint.py: a full Lua 5.1 parser + scope walk in Python (no interpreter exists here).  Every hand-written and
+    generated Lua file must parse, read no global except `torch` (everything else is a local, a parameter or required into a
+    local) and create no global except the reference's `runningLoss` (train.lua:89,113 reads it)."""
+    import glob
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import lua_lint
+    # the checker itself: accepts the constructs the files use, rejects the slips that matter
+    good = ("local a, b = 1, 2 local function f(x, ...) local t = {1, x = 3, [4] = 5; ...} return #t .. 's', -x ^ 2 end "
+            "for i = 1, 10 do if i % 2 == 0 then a = a + i elseif i > 5 then b = b * 2 else break end end "
+            "for k, v in pairs({}) do f(k, v) end repeat local z = 1 until z == 1 local s = [[long]] --[[ c ]] "
+            "local o = {} function o.m(self) return self end function o:n(y) return self, y end f(1)(2) f{1} f'q' return a")
+    assert lua_lint.check(good) == []
+    for bad in ('local x = = 1', 'if a then', 'for i = 1 do end', 'f(', 'local t = {1, 2', 'x = 1 +', 'return 1 local a', 'a.b:c',
+                'local function() end', 'x = 1 2', 'local s = "abc', 'function f() return end end'):
+        with pytest.raises(lua_lint.LuaSyntaxError):
+            lua_lint.check(bad)
+    assert [n for n, _ in lua_lint.check('local a = 1\nprint(a, bb)\nlocal function g() return cc end')] == ['bb', 'cc']
+    files = sorted(glob.glob(os.path.join(ROOT, 'lua', '*.lua')) + glob.glob(os.path.join(ROOT, 'lua', '*', '*.lua')))
+    assert len(files) == 17
+    for f in files:
+        parser = lua_lint.Parser(open(f).read(), os.path.relpath(f, ROOT), lua_lint.LUA_GLOBALS)
+        parser.chunk()                                            # LuaSyntaxError with file:line on any syntax slip
+        reads = set(n for n, _ in parser.undeclared if n not in parser.assigned_globals)
+        assert reads <= {'torch'}, (f, sorted(reads))
+        assert parser.assigned_globals <= {'runningLoss'}, (f, sorted(parser.assigned_globals))
+
