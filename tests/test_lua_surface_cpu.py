@@ -255,3 +255,40 @@ def test_lua_files_parse_and_use_no_undeclared_names():
         assert reads <= {'torch'}, (f, sorted(reads))
         assert parser.assigned_globals <= {'runningLoss'}, (f, sorted(parser.assigned_globals))
 
+
+def test_lua_ffi_calls_pass_as_many_arguments_as_the_header_declares():
+    """every vd.call('vd_x', ...) / C.vd_x(...) in the hand-written Lua files passes exactly the number of arguments of the
+    prototype in include/visdial_hip.h (LuaJIT's ffi raises on a mismatch only when the line runs)"""
+    import glob
+    h = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'visdial_hip.h')).read(), flags=re.S)
+    protos = {}
+    for m in re.finditer(r'\b(vd_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;', h):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ('', 'void') else args.count(',') + 1
+    assert len(protos) >= 80
+    strip = lambda t: '\n'.join(l.split('--')[0] for l in t.splitlines())
+    sites = 0
+    for f in sorted(glob.glob(os.path.join(ROOT, 'lua', '*.lua')) + glob.glob(os.path.join(ROOT, 'lua', '*', '*.lua'))):
+        if f.endswith('visdial_ffi.lua'):
+            continue
+        src = strip(open(f).read())
+        for m in re.finditer(r"vd\.call\('(vd_[a-z0-9_]+)'|\bC\.(vd_[a-z0-9_]+)\(", src):
+            name, via_call = (m.group(1), True) if m.group(1) else (m.group(2), False)
+            j, depth, commas, seen = m.end(), 1, 0, False
+            while depth > 0:
+                ch = src[j]
+                if ch in '([{':
+                    depth += 1
+                elif ch in ')]}':
+                    depth -= 1
+                elif ch == ',' and depth == 1:
+                    commas += 1
+                if depth > 0 and not ch.isspace():
+                    seen = True
+                j += 1
+            n = commas if via_call else (commas + 1 if seen else 0)       # vd.call's first argument is the name
+            assert name in protos, (f, name)
+            assert n == protos[name], (os.path.relpath(f, ROOT), name, n, protos[name])
+            sites += 1
+    assert sites >= 80
+
