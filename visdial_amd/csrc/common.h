@@ -126,7 +126,7 @@ __device__ __forceinline__ float4 vd_ld4_stream(const float* p) {
 // and VALU issue is what the epilogue costs (profiles/r03_experiments.txt section 13c).  The compiler tracks vmcnt for these
 // builtins (unlike inline asm).  No reliance on the hardware range check: the SGPR offset is not part of it on gfx9.
 #ifndef VD_EPI_BUF
-#define VD_EPI_BUF 1   // bit 0: forward step epilogue (shipped), bit 1 / bit 2: backward step epilogue loads / stores (slower alone: r03_experiments 13d)
+#define VD_EPI_BUF 7   // bit 0: forward step epilogue; bits 1 / 2: backward epilogue loads / stores (with them the TWO-slot backward epilogue fits 128 VGPRs)
 #endif
 typedef unsigned vd_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned vd_u32x2 __attribute__((ext_vector_type(2)));

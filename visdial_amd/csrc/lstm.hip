@@ -1006,8 +1006,12 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
         if (nt4 == 2) return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 3, 41984>, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e4, s);
         return launch_gemm_glds<CfgF9, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e4, s);
       }
-      if (vd_tune_get("VD_LSTM_BWD_BATCH2", 0)) {
+      // the two-slot epilogue (loads of two slots in flight before either is consumed: half the serialised round trips).  With
+      // buffer addressing (-DVD_EPI_BUF & 6) it fits the 128-VGPR build (126, no spills) = 2, the default; with 64-bit global
+      // addressing it needs the 168-VGPR build (= 1) or spills 8 registers.  0 = one slot at a time.
+      if (const int b2 = vd_tune_get("VD_LSTM_BWD_BATCH2", (VD_EPI_BUF & 6) == 6 ? 2 : 0)) {
         EpiLstmBwd<2, 2> e2b{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
+        if (b2 == 2) return launch_gemm_glds<CfgB11, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e2b, s);
         return launch_gemm_glds<CfgB12, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e2b, s);
       }
       EpiLstmBwd<2> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
@@ -1733,6 +1737,7 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
   VD_CHECK_ARG(T >= 1 && N >= 0 && H > 0 && H % 32 == 0, "vd_lstm_backward: bad dims T=%d N=%d H=%d", T, N, H);
   VD_CHECK_ARG(Wh && gates && c && dc_work, "vd_lstm_backward: null pointer");
   VD_CHECK_ARG((h_seq == nullptr) == (dWh_acc == nullptr), "vd_lstm_backward: h_seq and dWh_acc go together");
+  VD_CHECK_ARG((long)N * 4 * H * 4 < (1L << 32), "vd_lstm_backward: N=%d rows x 4H=%d exceed 4 GB per step: split the batch", N, 4 * H);
   hipStream_t s = (hipStream_t)stream;
   const long NH = (long)N * H;
   if (dc_last && dc_last != dc_work) VD_HIP(hipMemcpyAsync(dc_work, dc_last, NH * sizeof(float), hipMemcpyDeviceToDevice, s));
