@@ -418,7 +418,10 @@ struct EpiLstmFwdValuProbeT {
 // da_t overwrites the saved gates of step t in place.
 // ---------------------------------------------------------------------------
 // BATCH = slots whose loads are issued together before any is consumed (1 or 2; see the comment inside).
-template <int NT, int BATCH = (NT == 1 ? 2 : 1)>
+// TWO = false: the caller guarantees at most ONE incoming-gradient operand (dh_b == nullptr: every step but the last of a
+// recurrence).  The second operand is fetched inside the consume phase, and the s_waitcnt behind that (uniformly skipped) load
+// drains the previous slot's stores even when the load is never executed.
+template <int NT, int BATCH = (NT == 1 ? 2 : 1), bool TWO = true>
 struct EpiLstmBwd {
   const float* dh_a;  // nullable [N x H]
   const float* dh_b;  // nullable [N x H]
@@ -475,7 +478,7 @@ struct EpiLstmBwd {
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[NT], int row0, int col0, int lane, int M,
                                              int N, float* scr) const {
     const int rl = lane >> 3, cl = (lane & 7) * 4;
-    const bool two_dh = dh_a && dh_b;
+    const bool two_dh = TWO && dh_a && dh_b;
 #if VD_EPI_BUF & 6
     const Rsrc R{vd_rsrc(gates), vd_rsrc(c_t), vd_rsrc(c_prev), vd_rsrc(dc), vd_rsrc(dh_a ? dh_a : dh_b), vd_rsrc(dh_b), vd_rsrc(da16)};
     const unsigned uH4 = (unsigned)H * 4u;
@@ -517,9 +520,11 @@ struct EpiLstmBwd {
           dh.x += C.dhx.x; dh.y += C.dhx.y; dh.z += C.dhx.z; dh.w += C.dhx.w;
           const int row = row0 + (pp + q) * 8 + rl;
 #if VD_EPI_BUF & 6
-          if (two_dh) {
-            const float4 t = vd_buf_ld4(R.dh2, o4[q], 0);
-            dh.x += t.x; dh.y += t.y; dh.z += t.z; dh.w += t.w;
+          if constexpr (TWO) {
+            if (two_dh) {
+              const float4 t = vd_buf_ld4(R.dh2, o4[q], 0);
+              dh.x += t.x; dh.y += t.y; dh.z += t.z; dh.w += t.w;
+            }
           }
 #else
           const long o = (long)(row < M ? row : M - 1) * H + jc;
@@ -579,6 +584,90 @@ struct EpiLstmBwd {
     }
   }
 };
+
+// The backward epilogue of the THROUGHPUT step kernel (fp32, a step with a recurrent product: at most one incoming-gradient
+// operand, no bf16 shadow), branch-free.  In EpiLstmBwd every optional operand (`ptr ? load : zero`), the tile-edge predicate around
+// the stores and the shadow stores are uniform BRANCHES; behind each join the compiler no longer knows how many memory
+// operations are in flight and falls back to s_waitcnt vmcnt(0) -- so the 8 slots of a tile were 8 load -> math -> store -> DRAIN
+// round trips (ISA: profiles/r03_experiments.txt section 13d).  Here every access is unconditional and is masked by the buffer
+// range check instead: a null operand gets a descriptor with num_records = 0 (loads return 0 = the value the branch supplied,
+// stores are dropped), rows past M fall outside num_records by themselves, columns past N get the out-of-range offset
+// 0x80000000.  The compiler then counts exactly: loads of two slots, vmcnt(8), math, 5 stores, vmcnt(5), math, 5 stores, next loads.
+// Needs every tensor of the step below 2 GB (num_records is a positive int).
+template <int NT>
+struct EpiLstmBwdLean {
+  const float* dh_a;  // nullable [N x H] (the one incoming-gradient operand)
+  float* gates;       // [N x 4H] in: gates_t, out: da_t
+  const float* c_t;   // [N x H]
+  const float* c_prev;  // nullable -> zeros
+  float* dc;            // [N x H] in: dc_next (ignored when dc_first), out: dc for step t-1
+  int dc_first;
+  int H;
+  struct Slot {
+    float4 g[4], ct, cp, dcv, dhx;
+  };
+  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? (int)bytes : 0, 0x00020000);
+  }
+  __device__ __forceinline__ void operator()(const f32x16 (&acc)[NT], int row0, int col0, int lane, int M, int N,
+                                             float* scr) const {
+    const int rl = lane >> 3, cl = (lane & 7) * 4;
+    const unsigned uH4 = (unsigned)H * 4u, bytes = (unsigned)M * uH4;
+    const __amdgpu_buffer_rsrc_t Rg = rsrc(gates, 4u * bytes), Rct = rsrc(c_t, bytes), Rcp = rsrc(c_prev, bytes),
+                                 Rdc = rsrc(dc, bytes), Rdcl = rsrc(dc_first ? nullptr : dc, bytes), Rdh = rsrc(dh_a, bytes);
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      float4 d4[4];
+      tile_to_rows(acc[jt], scr, lane, d4);  // row-vectorised: 4 consecutive hidden units per lane
+      const int j = col0 + jt * 32 + cl;
+      const bool jbad = j >= N;              // N = H here
+#pragma unroll
+      for (int pp = 0; pp < 4; pp += 2) {
+        Slot L[2];
+        unsigned o4[2], og4[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const unsigned row = (unsigned)(row0 + (pp + q) * 8 + rl);
+          o4[q] = jbad ? 0x80000000u : row * uH4 + (unsigned)j * 4u;           // rows >= M are out of range by themselves
+          og4[q] = jbad ? 0x80000000u : row * 4u * uH4 + (unsigned)j * 4u;
+          L[q].g[0] = vd_buf_ld4(Rg, og4[q], 0);          // saved gates: read exactly once
+          L[q].g[1] = vd_buf_ld4(Rg, og4[q], uH4);
+          L[q].g[2] = vd_buf_ld4(Rg, og4[q], 2 * uH4);
+          L[q].g[3] = vd_buf_ld4(Rg, og4[q], 3 * uH4);
+          L[q].ct = vd_buf_ld4(Rct, o4[q], 0);
+          L[q].cp = vd_buf_ld4(Rcp, o4[q], 0);
+          L[q].dcv = vd_buf_ld4(Rdcl, o4[q], 0);
+          L[q].dhx = vd_buf_ld4(Rdh, o4[q], 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const Slot& C = L[q];
+          float4 dh = d4[pp + q];
+          dh.x += C.dhx.x; dh.y += C.dhx.y; dh.z += C.dhx.z; dh.w += C.dhx.w;
+          float4 ai, af, ao, ag, dn;
+#define VD_CELLB(E)                                                       \
+          {                                                               \
+            const float tc = vd_tanh(C.ct.E);                             \
+            const float d = C.dcv.E + dh.E * C.g[2].E * (1.f - tc * tc);  \
+            ai.E = d * C.g[3].E * C.g[0].E * (1.f - C.g[0].E);            \
+            af.E = d * C.cp.E * C.g[1].E * (1.f - C.g[1].E);              \
+            ao.E = dh.E * tc * C.g[2].E * (1.f - C.g[2].E);               \
+            ag.E = d * C.g[0].E * (1.f - C.g[3].E * C.g[3].E);            \
+            dn.E = d * C.g[1].E;                                          \
+          }
+          VD_CELLB(x) VD_CELLB(y) VD_CELLB(z) VD_CELLB(w)
+#undef VD_CELLB
+          vd_buf_st4(Rg, og4[q], 0, ai);
+          vd_buf_st4(Rg, og4[q], uH4, af);
+          vd_buf_st4(Rg, og4[q], 2 * uH4, ao);
+          vd_buf_st4(Rg, og4[q], 3 * uH4, ag);
+          vd_buf_st4(Rdc, o4[q], 0, dn);
+        }
+      }
+    }
+  }
+};
+
 
 // throughput shapes (option LSTM: N = 20 000 rows).  Defaults chosen by on-device sweeps
 // (scripts/microbench.py, profiles/r01_config_sweep.txt): forward = 128x128 tile, BK = 16, single LDS
@@ -1010,8 +1099,16 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
       // buffer addressing (-DVD_EPI_BUF & 6) it fits the 128-VGPR build (126, no spills) = 2, the default; with 64-bit global
       // addressing it needs the 168-VGPR build (= 1) or spills 8 registers.  0 = one slot at a time.
       if (const int b2 = vd_tune_get("VD_LSTM_BWD_BATCH2", (VD_EPI_BUF & 6) == 6 ? 2 : 0)) {
+        if (b2 == 3 && !(dh_a && dh_b) && (long)N * 4 * H * 4 < (1L << 31)) {   // branch-free epilogue (range-check masking)
+          EpiLstmBwdLean<2> e3{dh_a ? dh_a : dh_b, gates, c_t, c_prev, dc, dc_first, H};
+          return launch_gemm_glds<CfgB11, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e3, s);
+        }
+        if (b2 >= 2 && !(dh_a && dh_b)) {   // (a step with a recurrent product has at most one incoming-gradient operand)
+          EpiLstmBwd<2, 2, false> e2c{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
+          return launch_gemm_glds<CfgB11, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e2c, s);
+        }
         EpiLstmBwd<2, 2> e2b{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
-        if (b2 == 2) return launch_gemm_glds<CfgB11, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e2b, s);
+        if (b2 >= 2) return launch_gemm_glds<CfgB11, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e2b, s);
         return launch_gemm_glds<CfgB12, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e2b, s);
       }
       EpiLstmBwd<2> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
