@@ -226,7 +226,7 @@ segment_rowsum_kernel(const float* __restrict__ X, long ldx, const int* __restri
   if (p0 >= n) return;
   const int cnt = (int)min((long)CHUNK, n - p0);
   // stage the chunk's row ids / tokens once (removes two dependent loads from every row visit)
-  if (threadIdx.x < cnt) {
+  if ((int)threadIdx.x < cnt) {
     const int r = perm[p0 + threadIdx.x];
     srow[threadIdx.x] = r;
     stok[threadIdx.x] = tok[r];
