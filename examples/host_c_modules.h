@@ -36,6 +36,7 @@ FN(int, p_segment_rowsum_acc, (const float*, int64_t, const int32_t*, const int3
 FN(int, p_tanh_backward, (const float*, const float*, float*, int64_t, void*))
 FN(int, p_score_ce, (const float*, const float*, const int32_t*, float*, float*, float*, float*, int, int, int, float, void*))
 FN(int, p_clamp_adam, (float*, float*, float*, float*, int64_t, float, float, float, float, float, float, void*))
+FN(int, p_logsoftmax_nll, (float*, int64_t, int64_t, int, const int32_t*, const int32_t*, float*, int, void*))
 FN(int, p_dropout_mask, (uint8_t*, int64_t, uint64_t, float, void*))
 FN(int, p_dropout_apply, (const float*, const uint8_t*, float*, int64_t, float, void*))
 FN(int, p_axpby, (const float*, const float*, float*, int64_t, float, float, void*))
@@ -65,11 +66,16 @@ __attribute__((unused)) static int32_t* dev_ints_from(const int32_t* host, int64
 __attribute__((unused)) static int64_t align4(int64_t n) { return (n + 3) / 4 * 4; }      /* every tensor 16-byte aligned inside the flat vectors */
 
 /* ---- module objects: parameter views into the flat vectors + saved activations ------------------------------------------------ */
-typedef struct {               /* nn.SeqLSTM(D, H) (encoders/lf-ques.lua:18-24, decoders/disc.lua:4) */
+typedef struct {               /* nn.SeqLSTM(D, H) (encoders/lf-ques.lua:18-24, decoders/disc.lua:4, decoders/gen.lua:17-22) */
   int D, H, T, N;
   float *W, *b, *dW, *db;      /* W = [Wx ; Wh]: [(D+H) x 4H], gate columns i,f,o,g */
   const float* x;              /* [T*N x D] input of the last forward */
-  float *gates, *h, *c;
+  float *gates, *h, *c;        /* .output = h [T x N x H], .cell = c */
+  /* the state hand-off fields of Element-Research's SeqLSTM that decoders/gen.lua:30-60 reads and writes (all [N x H], nullable) */
+  const float *userPrevOutput, *userPrevCell;       /* initial h / c of the next forward (consumed by it) */
+  const float *gradPrevOutput, *userNextGradCell;   /* extra gradient into the LAST step's h / c of the next backward (consumed by it) */
+  float *userGradPrevOutput, *userGradPrevCell;     /* out: gradients w.r.t. the initial h / c */
+  const float *h0, *c0;                             /* what the last forward started from */
 } SeqLSTM;
 
 __attribute__((unused)) static void lstm_forward(SeqLSTM* l, const float* x, int T, int N, const int32_t* tok_mask) {
@@ -78,7 +84,10 @@ __attribute__((unused)) static void lstm_forward(SeqLSTM* l, const float* x, int
   l->gates = dev_floats((int64_t)T * N * 4 * H); l->h = dev_floats((int64_t)T * N * H); l->c = dev_floats((int64_t)T * N * H);
   /* hoisted input projection x*Wx + b straight into the gates buffer, then the recurrence in place (maskZero via tok_mask) */
   CHECK(p_gemm_nn(x, l->D, l->W, 4 * H, l->b, l->gates, 4 * H, T * N, 4 * H, l->D, 0, NULL));
-  CHECK(p_lstm_forward(l->gates, (int64_t)N * 4 * H, 4 * H, NULL, tok_mask, l->W + (int64_t)l->D * 4 * H, NULL, NULL, l->gates, l->h, l->c,
+  l->h0 = l->userPrevOutput; l->c0 = l->userPrevCell;           /* consumed once, like the reference's module */
+  l->userPrevOutput = l->userPrevCell = NULL;
+  if ((l->h0 == NULL) != (l->c0 == NULL)) { fprintf(stderr, "SeqLSTM: userPrevOutput and userPrevCell go together\n"); exit(3); }
+  CHECK(p_lstm_forward(l->gates, (int64_t)N * 4 * H, 4 * H, NULL, tok_mask, l->W + (int64_t)l->D * 4 * H, l->h0, l->c0, l->gates, l->h, l->c,
                        T, N, H, 0, NULL));
 }
 /* returns dx [T*N x D] (or NULL); accumulates dW, db */
@@ -86,9 +95,23 @@ __attribute__((unused)) static float* lstm_backward(SeqLSTM* l, const float* dh_
   const int H = l->H, T = l->T, N = l->N;
   const int64_t TN = (int64_t)T * N;
   float* dc = dev_floats((int64_t)N * H);
-  CHECK(p_lstm_backward(l->W + (int64_t)l->D * 4 * H, l->gates, l->c, NULL, dh_seq, dh_last, NULL, dc, NULL, NULL, NULL, T, N, H, 0, NULL));
+  if (l->gradPrevOutput) {                                      /* gen.lua:49-51: the decoder's gradient w.r.t. this layer's final h */
+    if (!dh_last) dh_last = l->gradPrevOutput;
+    else {
+      float* t = dev_floats((int64_t)N * H);
+      CHECK(p_axpby(dh_last, l->gradPrevOutput, t, (int64_t)N * H, 1.f, 1.f, NULL));
+      dh_last = t;
+    }
+  }
+  const float* dc_last = l->userNextGradCell;
+  l->gradPrevOutput = l->userNextGradCell = NULL;
+  float* dh0 = l->h0 ? dev_floats((int64_t)N * H) : NULL;
+  CHECK(p_lstm_backward(l->W + (int64_t)l->D * 4 * H, l->gates, l->c, l->c0, dh_seq, dh_last, dc_last, dc, dh0, NULL, NULL, T, N, H, 0, NULL));
+  l->userGradPrevOutput = dh0;
+  l->userGradPrevCell = l->h0 ? dc : NULL;
   float* dWh = l->dW + (int64_t)l->D * 4 * H;                 /* da now lives in l->gates */
   if (T > 1) CHECK(p_gemm_tn_acc(l->h, H, l->gates + (int64_t)N * 4 * H, 4 * H, dWh, 4 * H, H, 4 * H, (T - 1) * N, 0, NULL));
+  if (l->h0) CHECK(p_gemm_tn_acc(l->h0, H, l->gates, 4 * H, dWh, 4 * H, H, 4 * H, N, 0, NULL));   /* step 0 multiplied the initial state */
   CHECK(p_colsum_acc(l->gates, 4 * H, (int)TN, 4 * H, l->db, NULL));
   CHECK(p_gemm_tn_acc(l->x, l->D, l->gates, 4 * H, l->dW, 4 * H, l->D, 4 * H, (int)TN, 0, NULL));
   if (!need_dx) return NULL;
@@ -138,6 +161,7 @@ static void load_entry_points(const char* path) {
   LOAD(p_lstm_forward, "vd_lstm_forward"); LOAD(p_lstm_backward, "vd_lstm_backward"); LOAD(p_embed_gather, "vd_embed_gather");
   LOAD(p_embed_scatter_acc, "vd_embed_scatter_acc"); LOAD(p_token_sort, "vd_token_sort"); LOAD(p_segment_rowsum_acc, "vd_segment_rowsum_acc");
   LOAD(p_tanh_backward, "vd_tanh_backward"); LOAD(p_score_ce, "vd_score_ce"); LOAD(p_clamp_adam, "vd_clamp_adam");
+  LOAD(p_logsoftmax_nll, "vd_logsoftmax_nll");
   LOAD(p_dropout_mask, "vd_dropout_mask"); LOAD(p_dropout_apply, "vd_dropout_apply"); LOAD(p_axpby, "vd_axpby");
   LOAD(p_mn_attention_forward, "vd_mn_attention_forward"); LOAD(p_mn_attention_backward, "vd_mn_attention_backward");
   LOAD(p_img_common_forward, "vd_img_common_forward"); LOAD(p_img_att_forward, "vd_img_att_forward");

@@ -60,8 +60,8 @@ int main(int argc, char** argv) {
 
   /* ---- the plug-in pair: encoders/lf-ques.lua (wordEmbed, 2 x SeqLSTM, Linear + Tanh) and decoders/disc.lua (shared table, one SeqLSTM) ---- */
   float *emb = Wf + off[0], *demb = Gf + off[0];
-  SeqLSTM ques1 = {E, H, 0, 0, Wf + off[1], Wf + off[2], Gf + off[1], Gf + off[2], NULL, NULL, NULL, NULL};
-  SeqLSTM ques2 = {H, H, 0, 0, Wf + off[3], Wf + off[4], Gf + off[3], Gf + off[4], NULL, NULL, NULL, NULL};
+  SeqLSTM ques1 = {E, H, 0, 0, Wf + off[1], Wf + off[2], Gf + off[1], Gf + off[2], NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL};
+  SeqLSTM ques2 = {H, H, 0, 0, Wf + off[3], Wf + off[4], Gf + off[3], Gf + off[4], NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL};
   LinearTanh fuse = {H, H, 0, Wf + off[5], Wf + off[6], Gf + off[5], Gf + off[6], NULL, NULL, 0};
   DiscDecoder dec = {V, E, H, 0, 0, emb, demb, Wf + off[7], Wf + off[8], Gf + off[7], Gf + off[8], NULL, NULL, NULL, NULL, NULL};
 

@@ -95,7 +95,7 @@ int main(int argc, char** argv) {
   CHECK(p_h2d(att_mask, mask_host, (int64_t)N * R, NULL));
 
   /* ---- module objects over the flat vectors ---- */
-#define LSTM(D, w, b) {D, H, 0, 0, Wf + off[w], Wf + off[b], Gf + off[w], Gf + off[b], NULL, NULL, NULL, NULL}
+#define LSTM(D, w, b) {D, H, 0, 0, Wf + off[w], Wf + off[b], Gf + off[w], Gf + off[b], NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL}
 #define LIN(nin, nout, w, b, plain) {nin, nout, 0, Wf + off[w], Wf + off[b], Gf + off[w], Gf + off[b], NULL, NULL, plain}
   float *emb = Wf + off[EMBED], *demb = Gf + off[EMBED];
   SeqLSTM hist1 = LSTM(E, HIST1_W, HIST1_B), hist2 = LSTM(H, HIST2_W, HIST2_B), ques1 = LSTM(E, QUES1_W, QUES1_B), ques2 = LSTM(H, QUES2_W, QUES2_B);

@@ -16,6 +16,7 @@ from visdial_amd.opts import derive
 SRC = os.path.join(ROOT, 'examples', 'host_c_train.c')
 SRC_PLUGIN = os.path.join(ROOT, 'examples', 'host_c_plugin_lf_ques.c')
 SRC_PLUGIN_MN = os.path.join(ROOT, 'examples', 'host_c_plugin_mn_att.c')
+SRC_PLUGIN_GEN = os.path.join(ROOT, 'examples', 'host_c_plugin_lf_ques_gen.c')
 
 
 def build(tmp_path, src=SRC):
@@ -30,6 +31,7 @@ def build(tmp_path, src=SRC):
 def test_header_is_valid_c_and_the_c_host_builds(tmp_path):
     build(tmp_path, SRC_PLUGIN)
     build(tmp_path, SRC_PLUGIN_MN)
+    build(tmp_path, SRC_PLUGIN_GEN)
     exe = build(tmp_path)
     # without a library the host fails loudly at dlopen -- no fallback of any kind
     r = subprocess.run([exe, '/nonexistent/libvisdial_hip.so', '/dev/null', '1', '0'], capture_output=True, text=True)
@@ -212,3 +214,59 @@ def test_c_plugin_flagship_pair_on_the_operator_level_abi_equals_the_library(tmp
     raw2 = np.fromfile(out2, np.float32)
     assert raw2.size == raw.size and np.isfinite(raw2).all()
     assert abs(float(raw2[0]) - float(raw[0])) > 1e-6 and float(np.abs(raw2[1:1 + n]).max()) > 0
+
+
+@pytest.mark.gpu
+def test_c_plugin_configs0_pair_lf_ques_gen_on_the_operator_level_abi_equals_the_library(tmp_path):
+    """examples/host_c_plugin_lf_ques_gen.c = BASELINE.json configs[0] (the reference's CPU-runnable `-encoder lf-ques -decoder gen`)
+    composed from OPERATOR-LEVEL entry points: encoder and decoder LSTM stacks with the state hand-off of decoders/gen.lua:30-60
+    (userPrevOutput / userPrevCell forward, userGradPrevOutput / userGradPrevCell / gradPrevOutput / userNextGradCell backward),
+    vocabulary projection + log-softmax + summed NLL.  Loss (the sum over tokens), every gradient tensor and the post-Adam
+    parameters must equal the library's own model-level implementation of the pair on the same parameters and batch."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from visdial_amd import _lib
+    from visdial_amd.dataloader import SyntheticDataloader
+    from visdial_amd.native import NativeModel
+    p = derive(small_params(encoder='lf-ques', decoder='gen'))
+    batch = SyntheticDataloader(p, seed=8).getTrainBatch(p)
+    m = NativeModel(dict(p), init_seed=3)
+    m.training(False)
+    P = m.get_parameters_dict()
+    names = [t[0] for t in m.tensors]
+    assert names == ['embed', 'ques1.W', 'ques1.b', 'ques2.W', 'ques2.b', 'fuse.W', 'fuse.b', 'dec1.W', 'dec1.b', 'dec2.W', 'dec2.b',
+                     'vocab.W', 'vocab.b']
+    B, R, Tq = batch['ques_fwd'].shape
+    Ta = batch['answer_in'].shape[2]
+    inp, outp = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
+    with open(inp, 'wb') as f:
+        f.write(struct.pack('<7i', p['vocabSize'], p['embedSize'], p['rnnHiddenSize'], B, R, Tq, Ta))
+        for k in names:
+            f.write(np.ascontiguousarray(P[k], np.float32).tobytes())
+        for k in ('ques_fwd', 'answer_in', 'answer_out'):
+            f.write(np.ascontiguousarray(batch[k], np.int32).tobytes())
+    exe = build(tmp_path, SRC_PLUGIN_GEN)
+    r = subprocess.run([exe, _lib.LIB_PATH, inp, outp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    raw = np.fromfile(outp, np.float32)
+    n = sum(P[k].size for k in names)
+    assert raw.size == 1 + 2 * n
+    loss = m.forwardBackward(batch)                                    # the SUM over non-pad tokens (model.lua:33-36)
+    G = m.get_gradients_dict()
+    m.update()
+    W1 = m.get_parameters_dict()
+    assert abs(float(raw[0]) - loss) < 1e-5 * max(1.0, abs(loss))
+    o = 1
+    for k in names:
+        g = raw[o:o + P[k].size].reshape(P[k].shape)
+        den = max(float(np.linalg.norm(G[k])), 1e-12)
+        assert float(np.linalg.norm(g - G[k])) / den < 1e-5, k         # same kernels; float-atomic sums differ in the last bits
+        o += P[k].size
+    for k in names:
+        w = raw[o:o + P[k].size].reshape(P[k].shape)
+        settled = np.abs(G[k]) > 1e-6                                  # Adam's first step is ~lr * sign(g)
+        assert np.abs(w - W1[k])[settled].max() < 1e-6 if settled.any() else True, k
+        o += P[k].size
+    m.close()
+
