@@ -1,12 +1,12 @@
 -- model_ops.lua -- class ModelOps: the reference's Model (model.lua:8-106, 249-342) over plug-in files that are composed IN LUA from
 -- module objects (lua/vdnn.lua, operator-level C ABI) -- lua/encoders/lf-ques.lua, lua/encoders/mn-att-ques-im-hist.lua (the
--- flagship) + lua/decoders/disc.lua today.  Same control flow
+-- flagship) + lua/decoders/disc.lua, and lua/encoders/lf-ques.lua + lua/decoders/gen.lua = BASELINE.json configs[0].  Same control flow
 -- as the reference, call for call: encoder:forward(inputs) -> forwardConnect -> decoder:forward({options, encOut}) ->
 -- criterion:forward / :backward -> decoder:backward -> encoder:backward(inputs, t[2]) (model.lua:297-337), wrapperW / wrapperdW from
 -- getParameters() (model.lua:55), clamp(-5, 5) + adam + learning-rate decay (model.lua:96-105).  lua/model.lua is the other host:
 -- the whole step behind the model-level ABI, any of the 11 x 2 pairs.
--- UNTESTED HERE (no Lua interpreter); transliteration of examples/host_c_plugin_lf_ques.c / host_c_plugin_mn_att.c, which are built
--- and checked on the GPU.
+-- UNTESTED HERE (no Lua interpreter); transliteration of examples/host_c_plugin_lf_ques.c / host_c_plugin_mn_att.c /
+-- host_c_plugin_lf_ques_gen.c, which are built and checked on the GPU.
 local vdnn = dofile('vdnn.lua')
 local vd = vdnn.vd
 
@@ -68,7 +68,24 @@ function ModelOps:forwardBackward(batch, onlyForward)
     self.wordEmbed:zeroPad()
     local encOut = self.encoder:forward(inputs)                                        -- model.lua:297
     self.forwardConnect(self.encoder, self.decoder, encOut, inputs[1].T)                -- model.lua:300
-    assert(p.decoder == 'disc', 'ModelOps: the Lua-composed decoders are disc only')
+    if p.decoder == 'gen' then
+        -- model.lua:306-324: decoder:forward(answerIn) -> criterion (LogSoftMax + masked NLL, SUMMED over tokens, and its gradient in place
+        -- of the logits: one kernel) -> decoder:backward -> backwardConnect -> encoder:backward(inputs, gradDecOut)
+        local answerIn, answerOut = timeMajor(batch['answer_in']), timeMajor(batch['answer_out'])
+        local rows = answerIn.T * answerIn.N
+        local decOut = self.decoder:forward(answerIn)                                   -- model.lua:313
+        local lossTok = vdnn.devFloats(rows)
+        vd.call('vd_logsoftmax_nll', decOut, self.decoder.Vp, rows, p.vocabSize, answerIn.tok, answerOut.tok, lossTok, onlyForward and 0 or 1, nil)
+        if not onlyForward then
+            self.decoder:backward(answerIn, decOut)                                     -- model.lua:319 (decOut now holds gradCriterionOut)
+            local gradDecOut = self.backwardConnect(self.encoder, self.decoder)         -- model.lua:322
+            self.encoder:backward(inputs, gradDecOut)                                   -- model.lua:323
+        end
+        local hostTok = torch.FloatTensor(rows)
+        vd.call('vd_stream_synchronize', nil)
+        vd.call('vd_memcpy_d2h', hostTok:data(), lossTok, rows * 4, nil)
+        return hostTok:sum(), batch['answer_out']:gt(0):sum()                           -- curLoss (the sum), numTokens (model.lua:76-85)
+    end
     local options = timeMajor(batch['options'])
     local O = options.N / N
     local gt = vdnn.devInts(batch['answer_ind']:int():view(-1):add(-1):contiguous())    -- 0-based targets
@@ -91,8 +108,10 @@ end
 function ModelOps:trainIteration(dataloader)
     self.fp:zeroGrad()                                                                  -- model.lua:68
     local batch = dataloader:getTrainBatch(self.params)
-    local curLoss = self:forwardBackward(batch)
-    if (runningLoss or 0) > 0 then runningLoss = 0.95 * runningLoss + 0.05 * curLoss else runningLoss = curLoss end   -- model.lua:88-92
+    local curLoss, numTokens = self:forwardBackward(batch)
+    local cur = curLoss
+    if self.params.decoder == 'gen' then cur = curLoss / numTokens end                  -- model.lua:76-85: the EMA is fed the per-token loss
+    if (runningLoss or 0) > 0 then runningLoss = 0.95 * runningLoss + 0.05 * cur else runningLoss = cur end   -- model.lua:88-92
     -- wrapperdW:clamp(-5, 5); adam(wrapperW, wrapperdW, optims)  (model.lua:96-99; optim_updates.lua:62-91)
     local o = self.optims
     o.t = o.t + 1

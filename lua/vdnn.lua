@@ -149,6 +149,10 @@ end
 
 function SeqLSTM:Wh() return self.W + self.D * 4 * self.H end
 
+-- The state hand-off fields of Element-Research's SeqLSTM that decoders/gen.lua:30-60 reads and writes (all device float* [N x H], nil = none):
+--   .userPrevOutput / .userPrevCell        initial h / c of the NEXT forward (consumed by it)
+--   .gradPrevOutput / .userNextGradCell    extra gradient into the last step's h / c of the NEXT backward (consumed by it)
+--   .userGradPrevOutput / .userGradPrevCell  out: gradients w.r.t. the initial h / c of the last forward
 -- x: [T*N x D] rows (time-major); tokMask: device int32 [T x N] or nil (maskZero); .output = h [T x N x H], .cell = c
 function SeqLSTM:forward(x, T, N, tokMask)
     local H = self.H
@@ -156,7 +160,10 @@ function SeqLSTM:forward(x, T, N, tokMask)
     self.gates = M.devFloats(T * N * 4 * H); self.output = M.devFloats(T * N * H); self.cell = M.devFloats(T * N * H)
     -- hoisted input projection x*Wx + b straight into the gates buffer, then the recurrence in place
     vd.call('vd_gemm_nn', x, self.D, self.W, 4 * H, self.b, self.gates, 4 * H, T * N, 4 * H, self.D, 0, nil)
-    vd.call('vd_lstm_forward', self.gates, N * 4 * H, 4 * H, nil, tokMask, self:Wh(), nil, nil, self.gates, self.output, self.cell,
+    self.h0, self.c0 = self.userPrevOutput, self.userPrevCell          -- consumed once, like the reference's module
+    self.userPrevOutput, self.userPrevCell = nil, nil
+    assert((self.h0 == nil) == (self.c0 == nil), 'SeqLSTM: userPrevOutput and userPrevCell go together')
+    vd.call('vd_lstm_forward', self.gates, N * 4 * H, 4 * H, nil, tokMask, self:Wh(), self.h0, self.c0, self.gates, self.output, self.cell,
             T, N, H, 0, nil)
     return self.output
 end
@@ -165,9 +172,24 @@ end
 function SeqLSTM:backward(dhSeq, dhLast, needDx)
     local H, T, N = self.H, self.T, self.N
     local dc = M.devFloats(N * H)
-    vd.call('vd_lstm_backward', self:Wh(), self.gates, self.cell, nil, dhSeq, dhLast, nil, dc, nil, nil, nil, T, N, H, 0, nil)
+    if self.gradPrevOutput ~= nil then                                   -- gen.lua:49-51: the decoder's gradient w.r.t. this layer's final h
+        if dhLast == nil then dhLast = self.gradPrevOutput
+        else
+            local t = M.devFloats(N * H)
+            vd.call('vd_axpby', dhLast, self.gradPrevOutput, t, N * H, 1.0, 1.0, nil)
+            dhLast = t
+        end
+    end
+    local dcLast = self.userNextGradCell
+    self.gradPrevOutput, self.userNextGradCell = nil, nil
+    local dh0 = nil
+    if self.h0 ~= nil then dh0 = M.devFloats(N * H) end
+    vd.call('vd_lstm_backward', self:Wh(), self.gates, self.cell, self.c0, dhSeq, dhLast, dcLast, dc, dh0, nil, nil, T, N, H, 0, nil)
+    self.userGradPrevOutput = dh0
+    self.userGradPrevCell = (self.h0 ~= nil) and dc or nil
     local dWh = self.dW + self.D * 4 * H                                   -- da now lives in self.gates
     if T > 1 then vd.call('vd_gemm_tn_acc', self.output, H, self.gates + N * 4 * H, 4 * H, dWh, 4 * H, H, 4 * H, (T - 1) * N, 0, nil) end
+    if self.h0 ~= nil then vd.call('vd_gemm_tn_acc', self.h0, H, self.gates, 4 * H, dWh, 4 * H, H, 4 * H, N, 0, nil) end   -- step 0 multiplied the initial state
     vd.call('vd_colsum_acc', self.gates, 4 * H, T * N, 4 * H, self.db, nil)
     vd.call('vd_gemm_tn_acc', self.x, self.D, self.gates, 4 * H, self.dW, 4 * H, self.D, 4 * H, T * N, 0, nil)
     if not needDx then return nil end

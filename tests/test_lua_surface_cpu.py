@@ -122,7 +122,8 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
     funcs, _ = header_symbols()
     rd = lambda *a: open(os.path.join(ROOT, *a)).read()
     hdr, c_lf, c_mn = rd('examples', 'host_c_modules.h'), rd('examples', 'host_c_plugin_lf_ques.c'), rd('examples', 'host_c_plugin_mn_att.c')
-    names = ('vdnn.lua', 'encoders/lf-ques.lua', 'encoders/mn-att-ques-im-hist.lua', 'decoders/disc.lua', 'model_ops.lua')
+    c_gen = rd('examples', 'host_c_plugin_lf_ques_gen.c')
+    names = ('vdnn.lua', 'encoders/lf-ques.lua', 'encoders/mn-att-ques-im-hist.lua', 'decoders/disc.lua', 'decoders/gen.lua', 'model_ops.lua')
     strip = lambda s: '\n'.join(l.split('--')[0] for l in s.splitlines())
     lua = {n: strip(rd('lua', n)) for n in names}
     mn = lua['encoders/mn-att-ques-im-hist.lua']
@@ -133,13 +134,17 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
         (_body(hdr, 'static float* linear_backward_ex(', '\n}\n'), _body(lua['vdnn.lua'], 'function LinearTanh:backward(', '\nend\n')),
         (_body(hdr, 'static const float* disc_forward(', '\n}\n'), _body(lua['decoders/disc.lua'], 'function dec:forward(', '\n    end\n')),
         (_body(hdr, 'static void disc_backward(', '\n}\n'), _body(lua['decoders/disc.lua'], 'function dec:backward(', '\n    end\n')),
+        (_body(c_gen, '/* ================= decoder:forward(answer_in)', '/* ================= criterion'),
+         _body(lua['decoders/gen.lua'], 'function dec:forward(', '\n    end\n')),
+         (_body(c_gen, '/* ================= decoder:backward(answer_in', '/* ================= backwardConnect'),
+         _body(lua['decoders/gen.lua'], 'function dec:backward(', '\n    end\n')),
         (_body(c_mn, '/* ================= encoder:forward', '/* ================= decoder:forward'), _body(mn, 'function enc:forward(', '\n    end\n')),
         (_body(c_mn, '/* ================= encoder:backward', '/* curLoss'), _body(mn, 'function enc:backward(', '\n    end\n')),
     ]
     drop = {'vd_malloc', 'vd_memset'}          # buffer allocation is interleaved differently (dev_floats / devFloats helpers)
     for k, (c_body, l_body) in enumerate(pairs):
         # (the flagship's embedding gathers / scatters are direct calls in C and self.wordEmbed methods in Lua: pinned just below)
-        skip = drop | ({'vd_embed_gather', 'vd_embed_scatter_acc'} if k >= len(pairs) - 2 else set())
+        skip = drop | ({'vd_embed_gather', 'vd_embed_scatter_acc'} if k >= len(pairs) - 4 else set())
         a = [x for x in _c_calls(c_body) if x not in skip]
         b = [x for x in _calls(l_body) if x not in skip]
         assert a == b and a, (a, b)
@@ -165,13 +170,26 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
     assert used_lua == used_c, (used_lua ^ used_c)
     assert used_lua <= funcs
     # both C hosts use nothing the shared header does not load
-    for c in (c_lf, c_mn):
+    for c in (c_lf, c_mn, c_gen):
         assert set(_c_calls(c)) <= used_c | {'vd_last_error'}, set(_c_calls(c)) - used_c
     # the plug-in files keep the reference's contract AND carry a Lua-side implementation
     for e in ('encoders/lf-ques.lua', 'encoders/mn-att-ques-im-hist.lua'):
         assert 'function enc:forward(inputs)' in lua[e] and 'function enc:backward(inputs, gradOutput)' in lua[e], e
         assert 'function enc:declare(spec)' in lua[e] and 'function enc:build(vdnn, fp, wordEmbed)' in lua[e], e
     assert 'function dec:forward(input)' in lua['decoders/disc.lua'] and 'return {nil, gradOutput[2]}' in lua['decoders/disc.lua']
+    # decoders/gen.lua: the three connect functions carry the hand-off of gen.lua:30-68 with the reference's field names, and the C twin
+    # performs the same assignments
+    gen = lua['decoders/gen.lua']
+    for needle in ('function dec:forward(answerIn)', 'function dec:backward(answerIn, gradOutput)', '.userPrevOutput = encOut',
+                   '.userNextGradCell = dec.rnnLayers[ii].userGradPrevCell', '.gradPrevOutput = dec.rnnLayers[ii].userGradPrevOutput',
+                   'return dec.rnnLayers[n].userGradPrevOutput', 'function decoderNet.decoderConnect(dec)'):
+        assert needle in gen, needle
+    for needle in ('.userPrevOutput = encOut', '.userNextGradCell = dec_rnn[l].userGradPrevCell', '.gradPrevOutput = dec_rnn[l].userGradPrevOutput',
+                   'gradDecOut = dec_rnn[NL - 1].userGradPrevOutput'):
+        assert needle in c_gen, needle
+    for call in ("self.decoder:forward(answerIn)", "vd.call('vd_logsoftmax_nll'", 'self.decoder:backward(answerIn, decOut)',
+                 'self.backwardConnect(self.encoder, self.decoder)', 'self.encoder:backward(inputs, gradDecOut)'):
+        assert call in lua['model_ops.lua'], call
     for call in ('self.encoder:forward(inputs)', 'self.decoder:forward({options, encOut})', 'self.decoder:backward({options, encOut}, {dOptH, dEnc})',
                  'self.encoder:backward(inputs, t[2])'):
         assert call in lua['model_ops.lua'], call
