@@ -217,34 +217,45 @@ def test_c_plugin_flagship_pair_on_the_operator_level_abi_equals_the_library(tmp
 
 
 @pytest.mark.gpu
-def test_c_plugin_configs0_pair_lf_ques_gen_on_the_operator_level_abi_equals_the_library(tmp_path):
-    """examples/host_c_plugin_lf_ques_gen.c = BASELINE.json configs[0] (the reference's CPU-runnable `-encoder lf-ques -decoder gen`)
-    composed from OPERATOR-LEVEL entry points: encoder and decoder LSTM stacks with the state hand-off of decoders/gen.lua:30-60
-    (userPrevOutput / userPrevCell forward, userGradPrevOutput / userGradPrevCell / gradPrevOutput / userNextGradCell backward),
-    vocabulary projection + log-softmax + summed NLL.  Loss (the sum over tokens), every gradient tensor and the post-Adam
-    parameters must equal the library's own model-level implementation of the pair on the same parameters and batch."""
+@pytest.mark.parametrize("encoder", ['lf-ques', 'lf-ques-im-hist'])
+def test_c_plugin_gen_pairs_on_the_operator_level_abi_equal_the_library(tmp_path, encoder):
+    """examples/host_c_plugin_lf_ques_gen.c = BASELINE.json configs[0] (the reference's CPU-runnable `-encoder lf-ques -decoder gen`) and
+    configs[1] (`-encoder lf-ques-im-hist -decoder gen`) composed from OPERATOR-LEVEL entry points: encoder and decoder LSTM stacks with the
+    state hand-off of decoders/gen.lua:30-60 (userPrevOutput / userPrevCell forward, userGradPrevOutput / userGradPrevCell / gradPrevOutput /
+    userNextGradCell backward), the late-fusion JoinTable of question / image / history, vocabulary projection + log-softmax + summed NLL.
+    Loss (the sum over tokens), every gradient tensor and the post-Adam parameters must equal the library's own model-level implementation
+    of the pair on the same parameters and batch."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from visdial_amd import _lib
     from visdial_amd.dataloader import SyntheticDataloader
     from visdial_amd.native import NativeModel
-    p = derive(small_params(encoder='lf-ques', decoder='gen'))
+    p = derive(small_params(encoder=encoder, decoder='gen'))
     batch = SyntheticDataloader(p, seed=8).getTrainBatch(p)
     m = NativeModel(dict(p), init_seed=3)
     m.training(False)
     P = m.get_parameters_dict()
     names = [t[0] for t in m.tensors]
-    assert names == ['embed', 'ques1.W', 'ques1.b', 'ques2.W', 'ques2.b', 'fuse.W', 'fuse.b', 'dec1.W', 'dec1.b', 'dec2.W', 'dec2.b',
-                     'vocab.W', 'vocab.b']
+    im_hist = encoder == 'lf-ques-im-hist'
+    hist_names = ['hist1.W', 'hist1.b', 'hist2.W', 'hist2.b'] if im_hist else []
+    assert names == ['embed', 'ques1.W', 'ques1.b', 'ques2.W', 'ques2.b'] + hist_names + ['fuse.W', 'fuse.b', 'dec1.W', 'dec1.b', 'dec2.W',
+                                                                                       'dec2.b', 'vocab.W', 'vocab.b']
     B, R, Tq = batch['ques_fwd'].shape
     Ta = batch['answer_in'].shape[2]
+    F = p['imgFeatureSize'] if im_hist else 0
+    Th = batch['hist'].shape[2] if im_hist else 0
     inp, outp = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
     with open(inp, 'wb') as f:
-        f.write(struct.pack('<7i', p['vocabSize'], p['embedSize'], p['rnnHiddenSize'], B, R, Tq, Ta))
+        f.write(struct.pack('<10i', p['vocabSize'], p['embedSize'], p['rnnHiddenSize'], B, R, Tq, Ta, int(im_hist), F, Th))
         for k in names:
             f.write(np.ascontiguousarray(P[k], np.float32).tobytes())
-        for k in ('ques_fwd', 'answer_in', 'answer_out'):
+        f.write(np.ascontiguousarray(batch['ques_fwd'], np.int32).tobytes())
+        if im_hist:
+            assert batch['img_feat'].shape == (B, F)
+            f.write(np.ascontiguousarray(batch['img_feat'], np.float32).tobytes())
+            f.write(np.ascontiguousarray(batch['hist'], np.int32).tobytes())
+        for k in ('answer_in', 'answer_out'):
             f.write(np.ascontiguousarray(batch[k], np.int32).tobytes())
     exe = build(tmp_path, SRC_PLUGIN_GEN)
     r = subprocess.run([exe, _lib.LIB_PATH, inp, outp], capture_output=True, text=True, timeout=300)
