@@ -69,6 +69,8 @@ int main(int argc, char** argv) {
   fclose(f);
   int32_t *ques = time_major(q_host, N, Tq), *ain = time_major(ai_host, N, Ta), *aout = time_major(ao_host, N, Ta);
   int32_t* hist = imHist ? time_major(h_host, N, Th) : NULL;
+  float* img = dev_floats((int64_t)ni);                         /* one feature row per dialog (model.lua:266-270 repeats it per round) */
+  if (imHist) CHECK(p_h2d(img, i_host, (int64_t)ni * 4, NULL));
 
 #define LSTM(D, w, b) {D, H, 0, 0, Wf + off[w], Wf + off[b], Gf + off[w], Gf + off[b], NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL}
   float *emb = Wf + off[0], *demb = Gf + off[0];
@@ -96,8 +98,6 @@ int main(int argc, char** argv) {
     for (int l = 0; l < NL; ++l) { lstm_forward(&hist_rnn[l], x, Th, N, hist); x = hist_rnn[l].h; }
     int32_t* rep = (int32_t*)malloc((size_t)N * 4);
     for (int n = 0; n < N; ++n) rep[n] = n / R;
-    float* img = dev_floats((int64_t)ni);
-    CHECK(p_h2d(img, i_host, (int64_t)ni * 4, NULL));
     float *img_rep = dev_floats((int64_t)N * F), *cat = dev_floats((int64_t)N * Dcat);
     CHECK(p_embed_gather(img, dev_ints_from(rep, N), NULL, img_rep, N, F, 1.f, NULL));
     CHECK(p_copy_2d(cat, Dcat, fuse_in, H, N, H, NULL));

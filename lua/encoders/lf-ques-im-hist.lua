@@ -1,13 +1,86 @@
--- encoders/lf-ques-im-hist.lua -- plug-in file contract of the reference (model.lua:19-25: the file is `dofile`d and must return a
--- table with model(params)).  Instead of building nn / nngraph modules it names the native graph; the object keeps
--- the fields decoders read: .wordEmbed (disc.lua:12, gen.lua:10) is the shared embedding, owned by the library.
+-- encoders/lf-ques-im-hist.lua -- the reference's plug-in file contract (model.lua:19-25) with BOTH surfaces (see lua/encoders/lf-ques.lua):
+--   * enc.native = 'lf-ques-im-hist': the name lua/model.lua hands to vd_model_create (model-level C ABI);
+--   * enc:declare / :build / :forward(inputs) / :backward(inputs, gradOutput) composed IN LUA from module objects over the operator-level
+--     C ABI (lua/vdnn.lua): the counterpart of encoders/lf-ques-im-hist.lua:3-62 of the reference -- question LSTM stack and history LSTM
+--     stack (on the concatenated dialog) -> Select(1,-1), JoinTable{question state, image feature, history state} -> Dropout -> Linear ->
+--     Tanh.  With lua/decoders/gen.lua this is BASELINE.json configs[1].  enc.rnnLayers = the QUESTION layers (what decoders/gen.lua
+--     connects to, gen.lua:31-35).
+-- Transliteration of examples/host_c_plugin_lf_ques_gen.c (imHist = 1), which is built with gcc and checked on the GPU against the
+-- library's model-level implementation (tests/test_abi_c_host.py); no Lua interpreter exists here.
 local encoderNet = {}
 
 function encoderNet.model(params)
     local enc = {native = 'lf-ques-im-hist', params = params}
-    enc.wordEmbed = {shared = 'embed'}           -- one table for question / history / option / answer tokens
-    -- the model-level runtime (csrc/runtime.hip) covers mn-att-ques-im-hist + disc so far; this encoder runs through the
-    -- operator-level entry points (host: visdial_amd/encoders/_late_fusion.py) -- vd_model_create reports it
+    enc.wordEmbed = {shared = 'embed'}           -- one table for question / history / option / answer tokens (model-level path)
+
+    -- parameter tensors in getParameters() order: {name, numel}
+    function enc:declare(spec)
+        local E, H, F = params.embedSize, params.rnnHiddenSize, params.imgFeatureSize
+        for _, name in ipairs({'ques', 'hist'}) do                            -- lf-ques-im-hist.lua:19-26, 38-45
+            for layer = 1, params.numLayers do
+                local D = (layer == 1) and E or H
+                table.insert(spec, {name .. layer .. '.W', (D + H) * 4 * H})
+                table.insert(spec, {name .. layer .. '.b', 4 * H})
+            end
+        end
+        table.insert(spec, {'fuse.W', H * (H + F + H)}); table.insert(spec, {'fuse.b', H})     -- lf-ques-im-hist.lua:58
+    end
+
+    function enc:build(vdnn, fp, wordEmbed)
+        local E, H, F = params.embedSize, params.rnnHiddenSize, params.imgFeatureSize
+        self.vdnn, self.wordEmbed, self.rnnLayers, self.histLayers = vdnn, wordEmbed, {}, {}
+        for layer = 1, params.numLayers do
+            self.rnnLayers[layer] = vdnn.SeqLSTM(fp, 'ques' .. layer, (layer == 1) and E or H, H)
+            self.histLayers[layer] = vdnn.SeqLSTM(fp, 'hist' .. layer, (layer == 1) and E or H, H)
+        end
+        self.fuse = vdnn.LinearTanh(fp, 'fuse', H + F + H, H)
+    end
+
+    -- inputs = {ques, img, hist} in the order of the reference's input table (model.lua:252-279): ques / hist = {tok = device int32
+    -- [T x N] time-major, T, N}; img = {data = device float [B x F], B}: one feature row per DIALOG (the repeatTensor over its rounds,
+    -- model.lua:266-270, is a row gather here).  Dropout: wrapper:evaluate() semantics, as in lua/encoders/lf-ques.lua.
+    function enc:forward(inputs)
+        local vd, vdnn = self.vdnn.vd, self.vdnn
+        local ques, img, hist = inputs[1], inputs[2], inputs[3]
+        local H, F, R = params.rnnHiddenSize, params.imgFeatureSize, params.maxQuesCount
+        local N, Tq, Th = ques.N, ques.T, hist.T
+        local L = #self.rnnLayers
+        local Dcat = H + F + H
+        local x = self.wordEmbed:forward(ques.tok, Tq * N)
+        for layer = 1, L do x = self.rnnLayers[layer]:forward(x, Tq, N, ques.tok) end
+        local qLast = x + (Tq - 1) * N * H                                  -- nn.Select(1, -1)
+        x = self.wordEmbed:forward(hist.tok, Th * N)
+        for layer = 1, L do x = self.histLayers[layer]:forward(x, Th, N, hist.tok) end
+        local hLast = x + (Th - 1) * N * H
+        local rep = torch.IntTensor(N)
+        for n = 1, N do rep[n] = math.floor((n - 1) / R) end                 -- round n belongs to dialog (n - 1) / R
+        local imgRep, cat = vdnn.devFloats(N * F), vdnn.devFloats(N * Dcat)
+        vd.call('vd_embed_gather', img.data, vdnn.devInts(rep), nil, imgRep, N, F, 1.0, nil)
+        vd.call('vd_copy_2d', cat, Dcat, qLast, H, N, H, nil)               -- nn.JoinTable(1, 1)
+        vd.call('vd_copy_2d', cat + H, Dcat, imgRep, F, N, F, nil)
+        vd.call('vd_copy_2d', cat + H + F, Dcat, hLast, H, N, H, nil)
+        self.N = N
+        self.output = self.fuse:forward(cat, N)
+        return self.output
+    end
+
+    function enc:backward(inputs, gradOutput)
+        local vd, vdnn = self.vdnn.vd, self.vdnn
+        local ques, hist = inputs[1], inputs[3]
+        local H, F = params.rnnHiddenSize, params.imgFeatureSize
+        local N, L, Dcat = self.N, #self.rnnLayers, H + F + H
+        local dCat = self.fuse:backward(gradOutput)
+        local dq, dhl = vdnn.devFloats(N * H), vdnn.devFloats(N * H)        -- JoinTable backward: question and history slices (the image needs none)
+        vd.call('vd_copy_2d', dq, H, dCat, Dcat, N, H, nil)
+        vd.call('vd_copy_2d', dhl, H, dCat + H + F, Dcat, N, H, nil)
+        local dSeq = self.histLayers[L]:backward(nil, dhl, true)
+        for layer = L - 1, 1, -1 do dSeq = self.histLayers[layer]:backward(dSeq, nil, true) end
+        self.wordEmbed:backward(hist.tok, hist.T * N, dSeq)
+        dSeq = self.rnnLayers[L]:backward(nil, dq, true)
+        for layer = L - 1, 1, -1 do dSeq = self.rnnLayers[layer]:backward(dSeq, nil, true) end
+        self.wordEmbed:backward(ques.tok, ques.T * N, dSeq)
+    end
+
     return enc
 end
 
