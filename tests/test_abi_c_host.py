@@ -17,6 +17,7 @@ SRC = os.path.join(ROOT, 'examples', 'host_c_train.c')
 SRC_PLUGIN = os.path.join(ROOT, 'examples', 'host_c_plugin_lf_ques.c')
 SRC_PLUGIN_MN = os.path.join(ROOT, 'examples', 'host_c_plugin_mn_att.c')
 SRC_PLUGIN_GEN = os.path.join(ROOT, 'examples', 'host_c_plugin_lf_ques_gen.c')
+SRC_PLUGIN_HRE = os.path.join(ROOT, 'examples', 'host_c_plugin_hre.c')
 
 
 def build(tmp_path, src=SRC):
@@ -32,6 +33,7 @@ def test_header_is_valid_c_and_the_c_host_builds(tmp_path):
     build(tmp_path, SRC_PLUGIN)
     build(tmp_path, SRC_PLUGIN_MN)
     build(tmp_path, SRC_PLUGIN_GEN)
+    build(tmp_path, SRC_PLUGIN_HRE)
     exe = build(tmp_path)
     # without a library the host fails loudly at dlopen -- no fallback of any kind
     r = subprocess.run([exe, '/nonexistent/libvisdial_hip.so', '/dev/null', '1', '0'], capture_output=True, text=True)
@@ -268,6 +270,60 @@ def test_c_plugin_gen_pairs_on_the_operator_level_abi_equal_the_library(tmp_path
     m.update()
     W1 = m.get_parameters_dict()
     assert abs(float(raw[0]) - loss) < 1e-5 * max(1.0, abs(loss))
+    o = 1
+    for k in names:
+        g = raw[o:o + P[k].size].reshape(P[k].shape)
+        den = max(float(np.linalg.norm(G[k])), 1e-12)
+        assert float(np.linalg.norm(g - G[k])) / den < 1e-5, k         # same kernels; float-atomic sums differ in the last bits
+        o += P[k].size
+    for k in names:
+        w = raw[o:o + P[k].size].reshape(P[k].shape)
+        settled = np.abs(G[k]) > 1e-6                                  # Adam's first step is ~lr * sign(g)
+        assert np.abs(w - W1[k])[settled].max() < 1e-6 if settled.any() else True, k
+        o += P[k].size
+    m.close()
+
+
+@pytest.mark.gpu
+def test_c_plugin_configs2_pair_hre_on_the_operator_level_abi_equals_the_library(tmp_path):
+    """examples/host_c_plugin_hre.c = BASELINE.json configs[2] (hre-ques-im-hist + disc) composed from OPERATOR-LEVEL entry points:
+    history and question LSTM stacks, the image embedding joined to the word embedding through MaskTime, the dialog-level recurrence
+    over the rounds with its two row permutations.  Loss, every gradient tensor and the post-Adam parameters must equal the library's
+    own model-level implementation of the pair on the same parameters and batch."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from visdial_amd import _lib
+    from visdial_amd.dataloader import SyntheticDataloader
+    from visdial_amd.native import NativeModel
+    p = derive(small_params(encoder='hre-ques-im-hist', decoder='disc'))
+    batch = SyntheticDataloader(p, seed=8).getTrainBatch(p)
+    m = NativeModel(dict(p), init_seed=3)
+    m.training(False)
+    P = m.get_parameters_dict()
+    names = [t[0] for t in m.tensors]
+    assert names == ['embed', 'hist1.W', 'hist1.b', 'hist2.W', 'hist2.b', 'img_embed.W', 'img_embed.b', 'ques1.W', 'ques1.b', 'ques2.W',
+                     'ques2.b', 'dialog.W', 'dialog.b', 'opt.W', 'opt.b']
+    B, R, Tq = batch['ques_fwd'].shape
+    Th, O, To = batch['hist'].shape[2], batch['options'].shape[1], batch['options'].shape[2]
+    inp, outp = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
+    with open(inp, 'wb') as f:
+        f.write(struct.pack('<11i', p['vocabSize'], p['embedSize'], p['rnnHiddenSize'], p['imgFeatureSize'], p['imgEmbedSize'], B, R, O, Tq, Th, To))
+        for k in names:
+            f.write(np.ascontiguousarray(P[k], np.float32).tobytes())
+        for k, dt in (('ques_fwd', np.int32), ('img_feat', np.float32), ('hist', np.int32), ('options', np.int32), ('answer_ind', np.int32)):
+            f.write(np.ascontiguousarray(batch[k], dt).tobytes())
+    exe = build(tmp_path, SRC_PLUGIN_HRE)
+    r = subprocess.run([exe, _lib.LIB_PATH, inp, outp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    raw = np.fromfile(outp, np.float32)
+    n = sum(P[k].size for k in names)
+    assert raw.size == 1 + 2 * n
+    loss = m.forwardBackward(batch)
+    G = m.get_gradients_dict()
+    m.update()
+    W1 = m.get_parameters_dict()
+    assert abs(float(raw[0]) - loss) < 1e-6 * max(1.0, abs(loss))
     o = 1
     for k in names:
         g = raw[o:o + P[k].size].reshape(P[k].shape)
