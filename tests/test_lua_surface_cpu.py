@@ -122,8 +122,9 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
     funcs, _ = header_symbols()
     rd = lambda *a: open(os.path.join(ROOT, *a)).read()
     hdr, c_lf, c_mn = rd('examples', 'host_c_modules.h'), rd('examples', 'host_c_plugin_lf_ques.c'), rd('examples', 'host_c_plugin_mn_att.c')
-    c_gen = rd('examples', 'host_c_plugin_lf_ques_gen.c')
-    names = ('vdnn.lua', 'encoders/lf-ques.lua', 'encoders/lf-ques-im-hist.lua', 'encoders/mn-att-ques-im-hist.lua', 'decoders/disc.lua',
+    c_gen, c_hre = rd('examples', 'host_c_plugin_lf_ques_gen.c'), rd('examples', 'host_c_plugin_hre.c')
+    names = ('vdnn.lua', 'encoders/lf-ques.lua', 'encoders/lf-ques-im-hist.lua', 'encoders/hre-ques-im-hist.lua',
+             'encoders/mn-att-ques-im-hist.lua', 'decoders/disc.lua',
              'decoders/gen.lua', 'model_ops.lua')
     strip = lambda s: '\n'.join(l.split('--')[0] for l in s.splitlines())
     lua = {n: strip(rd('lua', n)) for n in names}
@@ -135,6 +136,10 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
         (_body(hdr, 'static float* linear_backward_ex(', '\n}\n'), _body(lua['vdnn.lua'], 'function LinearTanh:backward(', '\nend\n')),
         (_body(hdr, 'static const float* disc_forward(', '\n}\n'), _body(lua['decoders/disc.lua'], 'function dec:forward(', '\n    end\n')),
         (_body(hdr, 'static void disc_backward(', '\n}\n'), _body(lua['decoders/disc.lua'], 'function dec:backward(', '\n    end\n')),
+        (_body(c_hre, '/* ================= encoder:forward', '/* ================= decoder:forward'),
+         _body(lua['encoders/hre-ques-im-hist.lua'], 'function enc:forward(', '\n    end\n')),
+        (_body(c_hre, '/* ================= encoder:backward', '/* curLoss'),
+         _body(lua['encoders/hre-ques-im-hist.lua'], 'function enc:backward(', '\n    end\n')),
         (_body(c_gen, '/* ================= encoder:forward({ques})', '/* ================= forwardConnect'),
          _body(lua['encoders/lf-ques-im-hist.lua'], 'function enc:forward(', '\n    end\n')),
         (_body(c_gen, '/* ================= encoder:backward(inputs, gradDecOut)', '/* curLoss'),
@@ -149,7 +154,7 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
     drop = {'vd_malloc', 'vd_memset'}          # buffer allocation is interleaved differently (dev_floats / devFloats helpers)
     for k, (c_body, l_body) in enumerate(pairs):
         # (the flagship's embedding gathers / scatters are direct calls in C and self.wordEmbed methods in Lua: pinned just below)
-        skip = drop | ({'vd_embed_gather', 'vd_embed_scatter_acc'} if k >= len(pairs) - 6 else set())
+        skip = drop | ({'vd_embed_gather', 'vd_embed_scatter_acc'} if k >= len(pairs) - 8 else set())
         a = [x for x in _c_calls(c_body) if x not in skip]
         b = [x for x in _calls(l_body) if x not in skip]
         assert a == b and a, (a, b)
@@ -175,10 +180,10 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
     assert used_lua == used_c, (used_lua ^ used_c)
     assert used_lua <= funcs
     # both C hosts use nothing the shared header does not load
-    for c in (c_lf, c_mn, c_gen):
+    for c in (c_lf, c_mn, c_gen, c_hre):
         assert set(_c_calls(c)) <= used_c | {'vd_last_error'}, set(_c_calls(c)) - used_c
     # the plug-in files keep the reference's contract AND carry a Lua-side implementation
-    for e in ('encoders/lf-ques.lua', 'encoders/lf-ques-im-hist.lua', 'encoders/mn-att-ques-im-hist.lua'):
+    for e in ('encoders/lf-ques.lua', 'encoders/lf-ques-im-hist.lua', 'encoders/hre-ques-im-hist.lua', 'encoders/mn-att-ques-im-hist.lua'):
         assert 'function enc:forward(inputs)' in lua[e] and 'function enc:backward(inputs, gradOutput)' in lua[e], e
         assert 'function enc:declare(spec)' in lua[e] and 'function enc:build(vdnn, fp, wordEmbed)' in lua[e], e
     assert 'function dec:forward(input)' in lua['decoders/disc.lua'] and 'return {nil, gradOutput[2]}' in lua['decoders/disc.lua']
