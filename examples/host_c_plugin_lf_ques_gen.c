@@ -14,7 +14,7 @@
  * the GPU against the library's model-level implementation of the pair (tests/test_abi_c_host.py).
  *
  *   ./host_c_plugin_lf_ques_gen <libvisdial_hip.so> <in.bin> <out.bin>
- * in.bin : int32 {V, E, H, B, R, Tq, Ta, imHist, F, Th}, the parameter tensors in getParameters() order as float32 (embed, ques1.W/.b,
+ * in.bin : int32 {V, E, H, B, R, Tq, Ta, imHist (bit 0: image part, bit 1: history part), F, Th}, the parameter tensors in getParameters() order as float32 (embed, ques1.W/.b,
  *          ques2.W/.b, [hist1.W/.b, hist2.W/.b,] fuse.W/.b, dec1.W/.b, dec2.W/.b, vocab.W [V x H], vocab.b [V]), ques_fwd [B*R x Tq],
  *          [img_feat [B x F] float32, hist [B*R x Th],] answer_in [B*R x Ta], answer_out [B*R x Ta] (int32; answers left-aligned, 0 = pad).
  * out.bin: float32 loss (the SUM), the flat gradient, the flat parameters after clamp(-5,5) + adam.   Dropout off (wrapper:evaluate()). */
@@ -39,7 +39,8 @@ int main(int argc, char** argv) {
   int32_t hd[10];
   if (fread(hd, 4, 10, f) != 10) return 4;
   const int V = hd[0], E = hd[1], H = hd[2], B = hd[3], R = hd[4], Tq = hd[5], Ta = hd[6], imHist = hd[7], F = hd[8], Th = hd[9];
-  const int N = B * R, Vp = (V + 3) / 4 * 4, Dcat = imHist ? H + F + H : H;
+  const int useIm = imHist & 1, useHist = (imHist >> 1) & 1;      /* the capability flags the reference derives from the encoder NAME (opts.lua:54-59) */
+  const int N = B * R, Vp = (V + 3) / 4 * 4, Dcat = H + (useIm ? F : 0) + (useHist ? H : 0);
 
   /* ---- wrapper:getParameters() ---- */
   const int64_t l1 = (int64_t)(E + H) * 4 * H, l2 = (int64_t)2 * H * 4 * H;
@@ -47,7 +48,7 @@ int main(int argc, char** argv) {
   int nt = 0, Q1W, Q2W, H1W = -1, H2W = -1, FW, D1W, D2W, VW;
   sizes[nt++] = (int64_t)(V + 1) * E;                                             /* embed */
   Q1W = nt; sizes[nt++] = l1; sizes[nt++] = 4 * H; Q2W = nt; sizes[nt++] = l2; sizes[nt++] = 4 * H;
-  if (imHist) { H1W = nt; sizes[nt++] = l1; sizes[nt++] = 4 * H; H2W = nt; sizes[nt++] = l2; sizes[nt++] = 4 * H; }
+  if (useHist) { H1W = nt; sizes[nt++] = l1; sizes[nt++] = 4 * H; H2W = nt; sizes[nt++] = l2; sizes[nt++] = 4 * H; }
   FW = nt; sizes[nt++] = (int64_t)H * Dcat; sizes[nt++] = H;
   D1W = nt; sizes[nt++] = l1; sizes[nt++] = 4 * H; D2W = nt; sizes[nt++] = l2; sizes[nt++] = 4 * H;
   VW = nt; sizes[nt++] = (int64_t)V * H; sizes[nt++] = V;
@@ -59,23 +60,24 @@ int main(int argc, char** argv) {
   for (int i = 0; i < nt; ++i)
     if (fread(host + off[i], 4, (size_t)sizes[i], f) != (size_t)sizes[i]) return 4;
   CHECK(p_h2d(Wf, host, numel * 4, NULL));
-  const size_t nq = (size_t)N * Tq, na = (size_t)N * Ta, nh = (size_t)N * Th, ni = (size_t)B * F;
+  const size_t nq = (size_t)N * Tq, na = (size_t)N * Ta, nh = useHist ? (size_t)N * Th : 0, ni = useIm ? (size_t)B * F : 0;
   int32_t *q_host = (int32_t*)malloc(nq * 4), *ai_host = (int32_t*)malloc(na * 4), *ao_host = (int32_t*)malloc(na * 4);
   int32_t* h_host = (int32_t*)malloc((nh ? nh : 1) * 4);
   float* i_host = (float*)malloc((ni ? ni : 1) * 4);
   if (fread(q_host, 4, nq, f) != nq) return 4;
-  if (imHist && (fread(i_host, 4, ni, f) != ni || fread(h_host, 4, nh, f) != nh)) return 4;
+  if (useIm && fread(i_host, 4, ni, f) != ni) return 4;
+  if (useHist && fread(h_host, 4, nh, f) != nh) return 4;
   if (fread(ai_host, 4, na, f) != na || fread(ao_host, 4, na, f) != na) return 4;
   fclose(f);
   int32_t *ques = time_major(q_host, N, Tq), *ain = time_major(ai_host, N, Ta), *aout = time_major(ao_host, N, Ta);
-  int32_t* hist = imHist ? time_major(h_host, N, Th) : NULL;
+  int32_t* hist = useHist ? time_major(h_host, N, Th) : NULL;
   float* img = dev_floats((int64_t)ni);                         /* one feature row per dialog (model.lua:266-270 repeats it per round) */
-  if (imHist) CHECK(p_h2d(img, i_host, (int64_t)ni * 4, NULL));
+  if (useIm) CHECK(p_h2d(img, i_host, (int64_t)ni * 4, NULL));
 
 #define LSTM(D, w, b) {D, H, 0, 0, Wf + off[w], Wf + off[b], Gf + off[w], Gf + off[b], NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL}
   float *emb = Wf + off[0], *demb = Gf + off[0];
   SeqLSTM enc_rnn[NL] = {LSTM(E, Q1W, Q1W + 1), LSTM(H, Q2W, Q2W + 1)};          /* enc.rnnLayers (lf-ques.lua:18-24) */
-  SeqLSTM hist_rnn[NL] = {LSTM(E, imHist ? H1W : Q1W, imHist ? H1W + 1 : Q1W + 1), LSTM(H, imHist ? H2W : Q2W, imHist ? H2W + 1 : Q2W + 1)};
+  SeqLSTM hist_rnn[NL] = {LSTM(E, useHist ? H1W : Q1W, useHist ? H1W + 1 : Q1W + 1), LSTM(H, useHist ? H2W : Q2W, useHist ? H2W + 1 : Q2W + 1)};
   SeqLSTM dec_rnn[NL] = {LSTM(E, D1W, D1W + 1), LSTM(H, D2W, D2W + 1)};          /* dec.rnnLayers (gen.lua:17-22) */
   LinearTanh fuse = {Dcat, H, 0, Wf + off[FW], Wf + off[FW + 1], Gf + off[FW], Gf + off[FW + 1], NULL, NULL, 0};
   float *Wv = Wf + off[VW], *bv = Wf + off[VW + 1], *dWv = Gf + off[VW], *dbv = Gf + off[VW + 1];
@@ -89,20 +91,27 @@ int main(int argc, char** argv) {
   const float* x = qx;
   for (int l = 0; l < NL; ++l) { lstm_forward(&enc_rnn[l], x, Tq, N, ques); x = enc_rnn[l].h; }
   const float* fuse_in = enc_rnn[NL - 1].h + (int64_t)(Tq - 1) * N * H;            /* nn.Select(1, -1) */
-  if (imHist) {
-    /* lf-ques-im-hist.lua:28-56: the history stack on the concatenated dialog, the image feature of the dialog repeated for its rounds
-     * (model.lua:266-270: a row gather here), nn.JoinTable of the three parts */
-    float* hx = dev_floats((int64_t)Th * N * E);
-    CHECK(p_embed_gather(emb, hist, NULL, hx, (int64_t)Th * N, E, 1.f, NULL));
-    x = hx;
-    for (int l = 0; l < NL; ++l) { lstm_forward(&hist_rnn[l], x, Th, N, hist); x = hist_rnn[l].h; }
-    int32_t* rep = (int32_t*)malloc((size_t)N * 4);
-    for (int n = 0; n < N; ++n) rep[n] = n / R;
-    float *img_rep = dev_floats((int64_t)N * F), *cat = dev_floats((int64_t)N * Dcat);
-    CHECK(p_embed_gather(img, dev_ints_from(rep, N), NULL, img_rep, N, F, 1.f, NULL));
+  if (useIm || useHist) {
+    /* lf-ques-im-hist.lua:28-56 (lf-ques-im.lua, lf-ques-hist.lua: one of the two extra parts): the history stack on the concatenated
+     * dialog, the image feature of the dialog repeated for its rounds (model.lua:266-270: a row gather here), nn.JoinTable of the parts */
+    float* cat = dev_floats((int64_t)N * Dcat);
+    int at = H;
     CHECK(p_copy_2d(cat, Dcat, fuse_in, H, N, H, NULL));
-    CHECK(p_copy_2d(cat + H, Dcat, img_rep, F, N, F, NULL));
-    CHECK(p_copy_2d(cat + H + F, Dcat, hist_rnn[NL - 1].h + (int64_t)(Th - 1) * N * H, H, N, H, NULL));
+    if (useIm) {
+      int32_t* rep = (int32_t*)malloc((size_t)N * 4);
+      for (int n = 0; n < N; ++n) rep[n] = n / R;
+      float* img_rep = dev_floats((int64_t)N * F);
+      CHECK(p_embed_gather(img, dev_ints_from(rep, N), NULL, img_rep, N, F, 1.f, NULL));
+      CHECK(p_copy_2d(cat + at, Dcat, img_rep, F, N, F, NULL));
+      at += F;
+    }
+    if (useHist) {
+      float* hx = dev_floats((int64_t)Th * N * E);
+      CHECK(p_embed_gather(emb, hist, NULL, hx, (int64_t)Th * N, E, 1.f, NULL));
+      x = hx;
+      for (int l = 0; l < NL; ++l) { lstm_forward(&hist_rnn[l], x, Th, N, hist); x = hist_rnn[l].h; }
+      CHECK(p_copy_2d(cat + at, Dcat, hist_rnn[NL - 1].h + (int64_t)(Th - 1) * N * H, H, N, H, NULL));
+    }
     fuse_in = cat;
   }
   float* encOut = linear_forward(&fuse, fuse_in, N);
@@ -148,13 +157,16 @@ int main(int argc, char** argv) {
 
   /* ================= encoder:backward(inputs, gradDecOut)  (model.lua:323) ================= */
   const float* dLast = linear_backward(&fuse, gradDecOut);
-  if (imHist) {                                                  /* JoinTable backward: the question and history slices (the image needs none) */
-    float *dq = dev_floats((int64_t)N * H), *dhl = dev_floats((int64_t)N * H);
+  if (useIm || useHist) {                                        /* JoinTable backward: the question and history slices (the image needs none) */
+    float* dq = dev_floats((int64_t)N * H);
     CHECK(p_copy_2d(dq, H, dLast, Dcat, N, H, NULL));
-    CHECK(p_copy_2d(dhl, H, dLast + H + F, Dcat, N, H, NULL));
-    float* dhx = lstm_backward(&hist_rnn[NL - 1], NULL, dhl, 1);
-    for (int l = NL - 2; l >= 0; --l) dhx = lstm_backward(&hist_rnn[l], dhx, NULL, 1);
-    CHECK(p_embed_scatter_acc(demb, hist, NULL, dhx, (int64_t)Th * N, E, 1.f, NULL));
+    if (useHist) {
+      float* dhl = dev_floats((int64_t)N * H);
+      CHECK(p_copy_2d(dhl, H, dLast + H + (useIm ? F : 0), Dcat, N, H, NULL));
+      float* dhx = lstm_backward(&hist_rnn[NL - 1], NULL, dhl, 1);
+      for (int l = NL - 2; l >= 0; --l) dhx = lstm_backward(&hist_rnn[l], dhx, NULL, 1);
+      CHECK(p_embed_scatter_acc(demb, hist, NULL, dhx, (int64_t)Th * N, E, 1.f, NULL));
+    }
     dLast = dq;
   }
   float* dqx = lstm_backward(&enc_rnn[NL - 1], NULL, dLast, 1);
@@ -182,6 +194,6 @@ int main(int argc, char** argv) {
   for (int i = 0; i < nt; ++i) fwrite(grad_host + off[i], 4, (size_t)sizes[i], o);
   for (int i = 0; i < nt; ++i) fwrite(host + off[i], 4, (size_t)sizes[i], o);
   fclose(o);
-  printf("%s + gen through the operator-level ABI: summed loss %.6f, %lld parameters\n", imHist ? "lf-ques-im-hist" : "lf-ques", loss, (long long)numel);
+  printf("%s + gen through the operator-level ABI: summed loss %.6f, %lld parameters\n", imHist == 3 ? "lf-ques-im-hist" : imHist == 1 ? "lf-ques-im" : imHist == 2 ? "lf-ques-hist" : "lf-ques", loss, (long long)numel);
   return 0;
 }

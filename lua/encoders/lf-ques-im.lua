@@ -1,13 +1,76 @@
--- encoders/lf-ques-im.lua -- plug-in file contract of the reference (model.lua:19-25: the file is `dofile`d and must return a
--- table with model(params)).  Instead of building nn / nngraph modules it names the native graph; the object keeps
--- the fields decoders read: .wordEmbed (disc.lua:12, gen.lua:10) is the shared embedding, owned by the library.
+-- encoders/lf-ques-im.lua -- the reference's plug-in file contract (model.lua:19-25) with BOTH surfaces (see lua/encoders/lf-ques.lua):
+--   * enc.native = 'lf-ques-im': the name lua/model.lua hands to vd_model_create (model-level C ABI);
+--   * enc:declare / :build / :forward(inputs) / :backward(inputs, gradOutput) composed IN LUA from module objects over the operator-level
+--     C ABI (lua/vdnn.lua): the counterpart of encoders/lf-ques-im.lua of the reference -- question LSTM stack -> Select(1,-1),
+--     JoinTable{question state, image feature} -> Dropout -> Linear -> Tanh.  enc.rnnLayers = the question layers (what decoders/gen.lua
+--     connects to, gen.lua:31-35).
+-- Transliteration of examples/host_c_plugin_lf_ques_gen.c (imHist = 1: image part only), which is built with gcc and checked on the GPU against the
+-- library's model-level implementation (tests/test_abi_c_host.py); no Lua interpreter exists here.
 local encoderNet = {}
 
 function encoderNet.model(params)
     local enc = {native = 'lf-ques-im', params = params}
-    enc.wordEmbed = {shared = 'embed'}           -- one table for question / history / option / answer tokens
-    -- the model-level runtime (csrc/runtime.hip) covers mn-att-ques-im-hist + disc so far; this encoder runs through the
-    -- operator-level entry points (host: visdial_amd/encoders/_late_fusion.py) -- vd_model_create reports it
+    enc.wordEmbed = {shared = 'embed'}           -- one table for question / history / option / answer tokens (model-level path)
+
+    -- parameter tensors in getParameters() order: {name, numel}
+    function enc:declare(spec)
+        local E, H, F = params.embedSize, params.rnnHiddenSize, params.imgFeatureSize
+        for _, name in ipairs({'ques'}) do
+            for layer = 1, params.numLayers do
+                local D = (layer == 1) and E or H
+                table.insert(spec, {name .. layer .. '.W', (D + H) * 4 * H})
+                table.insert(spec, {name .. layer .. '.b', 4 * H})
+            end
+        end
+        table.insert(spec, {'fuse.W', H * (H + F)}); table.insert(spec, {'fuse.b', H})
+    end
+
+    function enc:build(vdnn, fp, wordEmbed)
+        local E, H, F = params.embedSize, params.rnnHiddenSize, params.imgFeatureSize
+        self.vdnn, self.wordEmbed, self.rnnLayers = vdnn, wordEmbed, {}
+        for layer = 1, params.numLayers do
+            self.rnnLayers[layer] = vdnn.SeqLSTM(fp, 'ques' .. layer, (layer == 1) and E or H, H)
+        end
+        self.fuse = vdnn.LinearTanh(fp, 'fuse', H + F, H)
+    end
+
+    -- inputs = {ques, img} in the order of the reference's input table (model.lua:252-279): ques / hist = {tok = device int32
+    -- [T x N] time-major, T, N}; img = {data = device float [B x F], B}: one feature row per DIALOG (the repeatTensor over its rounds,
+    -- model.lua:266-270, is a row gather here).  Dropout: wrapper:evaluate() semantics, as in lua/encoders/lf-ques.lua.
+    function enc:forward(inputs)
+        local vd, vdnn = self.vdnn.vd, self.vdnn
+        local ques, img = inputs[1], inputs[2]
+        local H, F, R = params.rnnHiddenSize, params.imgFeatureSize, params.maxQuesCount
+        local N, Tq = ques.N, ques.T
+        local L = #self.rnnLayers
+        local Dcat = H + F
+        local x = self.wordEmbed:forward(ques.tok, Tq * N)
+        for layer = 1, L do x = self.rnnLayers[layer]:forward(x, Tq, N, ques.tok) end
+        local qLast = x + (Tq - 1) * N * H                                  -- nn.Select(1, -1)
+        local rep = torch.IntTensor(N)
+        for n = 1, N do rep[n] = math.floor((n - 1) / R) end                 -- round n belongs to dialog (n - 1) / R
+        local imgRep, cat = vdnn.devFloats(N * F), vdnn.devFloats(N * Dcat)
+        vd.call('vd_embed_gather', img.data, vdnn.devInts(rep), nil, imgRep, N, F, 1.0, nil)
+        vd.call('vd_copy_2d', cat, Dcat, qLast, H, N, H, nil)               -- nn.JoinTable(1, 1)
+        vd.call('vd_copy_2d', cat + H, Dcat, imgRep, F, N, F, nil)
+        self.N = N
+        self.output = self.fuse:forward(cat, N)
+        return self.output
+    end
+
+    function enc:backward(inputs, gradOutput)
+        local vd, vdnn = self.vdnn.vd, self.vdnn
+        local ques = inputs[1]
+        local H, F = params.rnnHiddenSize, params.imgFeatureSize
+        local N, L, Dcat = self.N, #self.rnnLayers, H + F
+        local dCat = self.fuse:backward(gradOutput)
+        local dq = vdnn.devFloats(N * H)                                    -- JoinTable backward: the question slice (the image needs none)
+        vd.call('vd_copy_2d', dq, H, dCat, Dcat, N, H, nil)
+        local dSeq = self.rnnLayers[L]:backward(nil, dq, true)
+        for layer = L - 1, 1, -1 do dSeq = self.rnnLayers[layer]:backward(dSeq, nil, true) end
+        self.wordEmbed:backward(ques.tok, ques.T * N, dSeq)
+    end
+
     return enc
 end
 

@@ -219,10 +219,10 @@ def test_c_plugin_flagship_pair_on_the_operator_level_abi_equals_the_library(tmp
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("encoder", ['lf-ques', 'lf-ques-im-hist'])
+@pytest.mark.parametrize("encoder", ['lf-ques', 'lf-ques-im', 'lf-ques-hist', 'lf-ques-im-hist'])
 def test_c_plugin_gen_pairs_on_the_operator_level_abi_equal_the_library(tmp_path, encoder):
     """examples/host_c_plugin_lf_ques_gen.c = BASELINE.json configs[0] (the reference's CPU-runnable `-encoder lf-ques -decoder gen`) and
-    configs[1] (`-encoder lf-ques-im-hist -decoder gen`) composed from OPERATOR-LEVEL entry points: encoder and decoder LSTM stacks with the
+    configs[1] (`-encoder lf-ques-im-hist -decoder gen`), and the two encoders between them (lf-ques-im, lf-ques-hist), composed from OPERATOR-LEVEL entry points: encoder and decoder LSTM stacks with the
     state hand-off of decoders/gen.lua:30-60 (userPrevOutput / userPrevCell forward, userGradPrevOutput / userGradPrevCell / gradPrevOutput /
     userNextGradCell backward), the late-fusion JoinTable of question / image / history, vocabulary projection + log-softmax + summed NLL.
     Loss (the sum over tokens), every gradient tensor and the post-Adam parameters must equal the library's own model-level implementation
@@ -239,23 +239,24 @@ def test_c_plugin_gen_pairs_on_the_operator_level_abi_equal_the_library(tmp_path
     m.training(False)
     P = m.get_parameters_dict()
     names = [t[0] for t in m.tensors]
-    im_hist = encoder == 'lf-ques-im-hist'
-    hist_names = ['hist1.W', 'hist1.b', 'hist2.W', 'hist2.b'] if im_hist else []
+    use_im, use_hist = '-im' in encoder, 'hist' in encoder             # the capability flags of opts.lua:54-59
+    hist_names = ['hist1.W', 'hist1.b', 'hist2.W', 'hist2.b'] if use_hist else []
     assert names == ['embed', 'ques1.W', 'ques1.b', 'ques2.W', 'ques2.b'] + hist_names + ['fuse.W', 'fuse.b', 'dec1.W', 'dec1.b', 'dec2.W',
                                                                                        'dec2.b', 'vocab.W', 'vocab.b']
     B, R, Tq = batch['ques_fwd'].shape
     Ta = batch['answer_in'].shape[2]
-    F = p['imgFeatureSize'] if im_hist else 0
-    Th = batch['hist'].shape[2] if im_hist else 0
+    F = p['imgFeatureSize'] if use_im else 0
+    Th = batch['hist'].shape[2] if use_hist else 0
     inp, outp = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
     with open(inp, 'wb') as f:
-        f.write(struct.pack('<10i', p['vocabSize'], p['embedSize'], p['rnnHiddenSize'], B, R, Tq, Ta, int(im_hist), F, Th))
+        f.write(struct.pack('<10i', p['vocabSize'], p['embedSize'], p['rnnHiddenSize'], B, R, Tq, Ta, int(use_im) + 2 * int(use_hist), F, Th))
         for k in names:
             f.write(np.ascontiguousarray(P[k], np.float32).tobytes())
         f.write(np.ascontiguousarray(batch['ques_fwd'], np.int32).tobytes())
-        if im_hist:
+        if use_im:
             assert batch['img_feat'].shape == (B, F)
             f.write(np.ascontiguousarray(batch['img_feat'], np.float32).tobytes())
+        if use_hist:
             f.write(np.ascontiguousarray(batch['hist'], np.int32).tobytes())
         for k in ('answer_in', 'answer_out'):
             f.write(np.ascontiguousarray(batch[k], np.int32).tobytes())
