@@ -1,4 +1,4 @@
-/* host_c_plugin_hre.c -- BASELINE.json configs[2], encoders/hre-ques-im-hist.lua + decoders/disc.lua, written against the OPERATOR-LEVEL
+/* host_c_plugin_hre.c -- BASELINE.json configs[2], encoders/hre-ques-im-hist.lua (and its image-less sibling hre-ques-hist.lua) + decoders/disc.lua, written against the OPERATOR-LEVEL
  * C ABI by a host without a tensor library, module object by module object of the reference's graph (hre-ques-im-hist.lua:5-97) --
  *   history  : wordEmbed -> numLayers x SeqLSTM:maskZero() -> Select(1,-1)                                              hre:28-41
  *   question : JoinTable{wordEmbed(ques), MaskTime(Linear(F, imgEmbedSize)(img))} -> numLayers x SeqLSTM:maskZero() -> Select   hre:43-82
@@ -9,7 +9,7 @@
  * (tests/test_abi_c_host.py).
  *
  *   ./host_c_plugin_hre <libvisdial_hip.so> <in.bin> <out.bin>
- * in.bin : int32 {V, E, H, F, DI, B, R, O, Tq, Th, To}, the 15 parameter tensors in getParameters() order as float32 (embed, hist1.W/.b,
+ * in.bin : int32 {V, E, H, F, DI, B, R, O, Tq, Th, To, useIm}, the 15 (13 without the image part) parameter tensors in getParameters() order as float32 (embed, hist1.W/.b,
  *          hist2.W/.b, img_embed.W [DI x F]/.b, ques1.W [(E+DI+H) x 4H]/.b, ques2.W/.b, dialog.W [(2H+H) x 4H]/.b, opt.W/.b), ques_fwd
  *          [B*R x Tq], img_feat [B x F] float32, hist [B*R x Th], options [B*R*O x To], answer_ind [B*R] (1-based).
  * out.bin: float32 loss, the flat gradient, the flat parameters after clamp(-5,5) + adam.   Dropout off (wrapper:evaluate()). */
@@ -31,28 +31,34 @@ int main(int argc, char** argv) {
   load_entry_points(argv[1]);
   FILE* f = fopen(argv[2], "rb");
   if (!f) { perror(argv[2]); return 4; }
-  int32_t hd[11];
-  if (fread(hd, 4, 11, f) != 11) return 4;
-  const int V = hd[0], E = hd[1], H = hd[2], F = hd[3], DI = hd[4], B = hd[5], R = hd[6], O = hd[7], Tq = hd[8], Th = hd[9], To = hd[10];
+  int32_t hd[12];
+  if (fread(hd, 4, 12, f) != 12) return 4;
+  const int V = hd[0], E = hd[1], H = hd[2], F = hd[3], B = hd[5], R = hd[6], O = hd[7], Tq = hd[8], Th = hd[9], To = hd[10], useIm = hd[11];
+  const int DI = useIm ? hd[4] : 0;
   const int N = B * R, NO = N * O, DQ = E + DI;
 
-  enum { EMBED, H1W, H1B, H2W, H2B, IEW, IEB, Q1W, Q1B, Q2W, Q2B, DLW, DLB, OPW, OPB };
   const int64_t l2 = (int64_t)2 * H * 4 * H;
-  const int64_t sizes[NT] = {(int64_t)(V + 1) * E, (int64_t)(E + H) * 4 * H, 4 * H, l2, 4 * H, (int64_t)DI * F, DI, (int64_t)(DQ + H) * 4 * H, 4 * H,
-                             l2, 4 * H, (int64_t)(2 * H + H) * 4 * H, 4 * H, (int64_t)(E + H) * 4 * H, 4 * H};
+  int64_t sizes[NT];
+  int nt = 0, H1W, H2W, IEW = -1, Q1W, Q2W, DLW, OPW;
+  sizes[nt++] = (int64_t)(V + 1) * E;                                             /* embed */
+  H1W = nt; sizes[nt++] = (int64_t)(E + H) * 4 * H; sizes[nt++] = 4 * H; H2W = nt; sizes[nt++] = l2; sizes[nt++] = 4 * H;
+  if (useIm) { IEW = nt; sizes[nt++] = (int64_t)DI * F; sizes[nt++] = DI; }
+  Q1W = nt; sizes[nt++] = (int64_t)(DQ + H) * 4 * H; sizes[nt++] = 4 * H; Q2W = nt; sizes[nt++] = l2; sizes[nt++] = 4 * H;
+  DLW = nt; sizes[nt++] = (int64_t)(2 * H + H) * 4 * H; sizes[nt++] = 4 * H;
+  OPW = nt; sizes[nt++] = (int64_t)(E + H) * 4 * H; sizes[nt++] = 4 * H;
   int64_t off[NT + 1];
   off[0] = 0;
-  for (int i = 0; i < NT; ++i) off[i + 1] = off[i] + align4(sizes[i]);
-  const int64_t numel = off[NT];
+  for (int i = 0; i < nt; ++i) off[i + 1] = off[i] + align4(sizes[i]);
+  const int64_t numel = off[nt];
   float *Wf = dev_floats(numel), *Gf = dev_floats(numel), *Mf = dev_floats(numel), *Vf = dev_floats(numel);
   float* host = (float*)calloc((size_t)numel, 4);
-  for (int i = 0; i < NT; ++i)
+  for (int i = 0; i < nt; ++i)
     if (fread(host + off[i], 4, (size_t)sizes[i], f) != (size_t)sizes[i]) return 4;
   CHECK(p_h2d(Wf, host, numel * 4, NULL));
-  const size_t nq = (size_t)N * Tq, nh = (size_t)N * Th, ni = (size_t)B * F, no = (size_t)NO * To;
+  const size_t nq = (size_t)N * Tq, nh = (size_t)N * Th, ni = useIm ? (size_t)B * F : 0, no = (size_t)NO * To;
   int32_t *q_host = (int32_t*)malloc(nq * 4), *h_host = (int32_t*)malloc(nh * 4), *o_host = (int32_t*)malloc(no * 4), *a_host = (int32_t*)malloc((size_t)N * 4);
-  float* i_host = (float*)malloc(ni * 4);
-  if (fread(q_host, 4, nq, f) != nq || fread(i_host, 4, ni, f) != ni || fread(h_host, 4, nh, f) != nh || fread(o_host, 4, no, f) != no ||
+  float* i_host = (float*)malloc((ni ? ni : 1) * 4);
+  if (fread(q_host, 4, nq, f) != nq || (useIm && fread(i_host, 4, ni, f) != ni) || fread(h_host, 4, nh, f) != nh || fread(o_host, 4, no, f) != no ||
       fread(a_host, 4, (size_t)N, f) != (size_t)N) return 4;
   fclose(f);
 
@@ -60,7 +66,7 @@ int main(int argc, char** argv) {
   for (int n = 0; n < N; ++n) a_host[n] -= 1;
   int32_t *ques = time_major(q_host, N, Tq), *hist = time_major(h_host, N, Th), *opts = time_major(o_host, NO, To), *gt = dev_ints_from(a_host, N);
   float* img = dev_floats((int64_t)ni);
-  CHECK(p_h2d(img, i_host, (int64_t)ni * 4, NULL));
+  if (useIm) CHECK(p_h2d(img, i_host, (int64_t)ni * 4, NULL));
   int32_t *rep_h = (int32_t*)malloc((size_t)N * 4), *rb_h = (int32_t*)malloc((size_t)N * 4), *n_h = (int32_t*)malloc((size_t)N * 4);
   for (int n = 0; n < N; ++n) {
     rep_h[n] = n / R;                       /* image row of QA round n = b * R + r */
@@ -70,12 +76,13 @@ int main(int argc, char** argv) {
   int32_t *rep = dev_ints_from(rep_h, N), *to_rb = dev_ints_from(rb_h, N), *to_n = dev_ints_from(n_h, N);
 
 #define LSTM(D, w, b) {D, H, 0, 0, Wf + off[w], Wf + off[b], Gf + off[w], Gf + off[b], NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL}
-  float *emb = Wf + off[EMBED], *demb = Gf + off[EMBED];
-  SeqLSTM hist_rnn[NL] = {LSTM(E, H1W, H1B), LSTM(H, H2W, H2B)};
-  SeqLSTM ques_rnn[NL] = {LSTM(DQ, Q1W, Q1B), LSTM(H, Q2W, Q2B)};
-  SeqLSTM dialog = LSTM(2 * H, DLW, DLB);
-  LinearTanh img_embed = {F, DI, 0, Wf + off[IEW], Wf + off[IEB], Gf + off[IEW], Gf + off[IEB], NULL, NULL, 1};     /* plain nn.Linear (hre:46) */
-  DiscDecoder dec = {V, E, H, 0, 0, emb, demb, Wf + off[OPW], Wf + off[OPB], Gf + off[OPW], Gf + off[OPB], NULL, NULL, NULL, NULL, NULL};
+  float *emb = Wf + off[0], *demb = Gf + off[0];
+  SeqLSTM hist_rnn[NL] = {LSTM(E, H1W, H1W + 1), LSTM(H, H2W, H2W + 1)};
+  SeqLSTM ques_rnn[NL] = {LSTM(DQ, Q1W, Q1W + 1), LSTM(H, Q2W, Q2W + 1)};
+  SeqLSTM dialog = LSTM(2 * H, DLW, DLW + 1);
+  const int iw = useIm ? IEW : 0;                                                                  /* (unused without the image part) */
+  LinearTanh img_embed = {F, DI, 0, Wf + off[iw], Wf + off[iw + 1], Gf + off[iw], Gf + off[iw + 1], NULL, NULL, 1};   /* plain nn.Linear (hre:46) */
+  DiscDecoder dec = {V, E, H, 0, 0, emb, demb, Wf + off[OPW], Wf + off[OPW + 1], Gf + off[OPW], Gf + off[OPW + 1], NULL, NULL, NULL, NULL, NULL};
 
   CHECK(p_memset(Gf, 0, numel * 4, NULL));                      /* wrapper:zeroGradParameters() */
   CHECK(p_memset(emb, 0, (int64_t)E * 4, NULL));                /* LookupTableMaskZero: pad row */
@@ -88,14 +95,18 @@ int main(int argc, char** argv) {
   const float* hh = hist_rnn[NL - 1].h + (int64_t)(Th - 1) * N * H;
   /* question branch: the image embedding is repeated over the time steps of its round, zero at pad steps (MaskTime), and joined to the
    * word embedding column-wise */
-  float *qx = dev_floats((int64_t)Tq * N * E), *img_rep = dev_floats((int64_t)N * F), *xi = dev_floats((int64_t)Tq * N * DI);
+  float* qx = dev_floats((int64_t)Tq * N * E);
   CHECK(p_embed_gather(emb, ques, NULL, qx, (int64_t)Tq * N, E, 1.f, NULL));
-  CHECK(p_embed_gather(img, rep, NULL, img_rep, N, F, 1.f, NULL));
-  const float* imgE = linear_forward(&img_embed, img_rep, N);                                   /* hre:43-48 */
-  CHECK(p_mask_time_forward(imgE, ques, xi, Tq, N, DI, NULL));                                  /* hre:50-53 */
-  float* qcat = dev_floats((int64_t)Tq * N * DQ);
-  CHECK(p_copy_2d(qcat, DQ, qx, E, (int64_t)Tq * N, E, NULL));                                  /* nn.JoinTable(2, 2) */
-  CHECK(p_copy_2d(qcat + E, DQ, xi, DI, (int64_t)Tq * N, DI, NULL));
+  const float* qcat = qx;                                                                        /* hre-ques-hist.lua: the word embedding alone */
+  if (useIm) {
+    float *img_rep = dev_floats((int64_t)N * F), *xi = dev_floats((int64_t)Tq * N * DI), *cat = dev_floats((int64_t)Tq * N * DQ);
+    CHECK(p_embed_gather(img, rep, NULL, img_rep, N, F, 1.f, NULL));
+    const float* imgE = linear_forward(&img_embed, img_rep, N);                                   /* hre:43-48 */
+    CHECK(p_mask_time_forward(imgE, ques, xi, Tq, N, DI, NULL));                                  /* hre:50-53 */
+    CHECK(p_copy_2d(cat, DQ, qx, E, (int64_t)Tq * N, E, NULL));                                   /* nn.JoinTable(2, 2) */
+    CHECK(p_copy_2d(cat + E, DQ, xi, DI, (int64_t)Tq * N, DI, NULL));
+    qcat = cat;
+  }
   x = qcat;
   for (int l = 0; l < NL; ++l) { lstm_forward(&ques_rnn[l], x, Tq, N, ques); x = ques_rnn[l].h; }
   const float* hq = ques_rnn[NL - 1].h + (int64_t)(Tq - 1) * N * H;
@@ -129,12 +140,16 @@ int main(int argc, char** argv) {
   CHECK(p_embed_scatter_acc(demb, hist, NULL, dhx, (int64_t)Th * N, E, 1.f, NULL));
   float* dqcat = lstm_backward(&ques_rnn[NL - 1], NULL, dq, 1);
   for (int l = NL - 2; l >= 0; --l) dqcat = lstm_backward(&ques_rnn[l], dqcat, NULL, 1);
-  float *dqx = dev_floats((int64_t)Tq * N * E), *dxi = dev_floats((int64_t)Tq * N * DI), *dimgE = dev_floats((int64_t)N * DI);
-  CHECK(p_copy_2d(dqx, E, dqcat, DQ, (int64_t)Tq * N, E, NULL));                                /* JoinTable backward */
-  CHECK(p_copy_2d(dxi, DI, dqcat + E, DQ, (int64_t)Tq * N, DI, NULL));
-  CHECK(p_embed_scatter_acc(demb, ques, NULL, dqx, (int64_t)Tq * N, E, 1.f, NULL));
-  CHECK(p_mask_time_backward(dxi, ques, dimgE, Tq, N, DI, NULL));
-  linear_backward_ex(&img_embed, dimgE, 0);
+  if (useIm) {
+    float *dqx = dev_floats((int64_t)Tq * N * E), *dxi = dev_floats((int64_t)Tq * N * DI), *dimgE = dev_floats((int64_t)N * DI);
+    CHECK(p_copy_2d(dqx, E, dqcat, DQ, (int64_t)Tq * N, E, NULL));                                /* JoinTable backward */
+    CHECK(p_copy_2d(dxi, DI, dqcat + E, DQ, (int64_t)Tq * N, DI, NULL));
+    CHECK(p_embed_scatter_acc(demb, ques, NULL, dqx, (int64_t)Tq * N, E, 1.f, NULL));
+    CHECK(p_mask_time_backward(dxi, ques, dimgE, Tq, N, DI, NULL));
+    linear_backward_ex(&img_embed, dimgE, 0);
+  } else {
+    CHECK(p_embed_scatter_acc(demb, ques, NULL, dqcat, (int64_t)Tq * N, E, 1.f, NULL));
+  }
 
   /* curLoss, then wrapperdW:clamp(-5,5) + adam (model.lua:96-99; optim_updates.lua:62-91), t = 1 */
   float* lr_host = (float*)malloc((size_t)N * 4);
@@ -155,9 +170,9 @@ int main(int argc, char** argv) {
   if (!o) { perror(argv[3]); return 4; }
   const float lossf = (float)loss;
   fwrite(&lossf, 4, 1, o);
-  for (int i = 0; i < NT; ++i) fwrite(grad_host + off[i], 4, (size_t)sizes[i], o);
-  for (int i = 0; i < NT; ++i) fwrite(host + off[i], 4, (size_t)sizes[i], o);
+  for (int i = 0; i < nt; ++i) fwrite(grad_host + off[i], 4, (size_t)sizes[i], o);
+  for (int i = 0; i < nt; ++i) fwrite(host + off[i], 4, (size_t)sizes[i], o);
   fclose(o);
-  printf("hre-ques-im-hist + disc through the operator-level ABI: loss %.6f, %lld parameters\n", loss, (long long)numel);
+  printf("%s + disc through the operator-level ABI: loss %.6f, %lld parameters\n", useIm ? "hre-ques-im-hist" : "hre-ques-hist", loss, (long long)numel);
   return 0;
 }

@@ -286,7 +286,8 @@ def test_c_plugin_gen_pairs_on_the_operator_level_abi_equal_the_library(tmp_path
 
 
 @pytest.mark.gpu
-def test_c_plugin_configs2_pair_hre_on_the_operator_level_abi_equals_the_library(tmp_path):
+@pytest.mark.parametrize("encoder", ['hre-ques-im-hist', 'hre-ques-hist'])
+def test_c_plugin_configs2_pair_hre_on_the_operator_level_abi_equals_the_library(tmp_path, encoder):
     """examples/host_c_plugin_hre.c = BASELINE.json configs[2] (hre-ques-im-hist + disc) composed from OPERATOR-LEVEL entry points:
     history and question LSTM stacks, the image embedding joined to the word embedding through MaskTime, the dialog-level recurrence
     over the rounds with its two row permutations.  Loss, every gradient tensor and the post-Adam parameters must equal the library's
@@ -297,23 +298,26 @@ def test_c_plugin_configs2_pair_hre_on_the_operator_level_abi_equals_the_library
     from visdial_amd import _lib
     from visdial_amd.dataloader import SyntheticDataloader
     from visdial_amd.native import NativeModel
-    p = derive(small_params(encoder='hre-ques-im-hist', decoder='disc'))
+    p = derive(small_params(encoder=encoder, decoder='disc'))
     batch = SyntheticDataloader(p, seed=8).getTrainBatch(p)
     m = NativeModel(dict(p), init_seed=3)
     m.training(False)
     P = m.get_parameters_dict()
     names = [t[0] for t in m.tensors]
-    assert names == ['embed', 'hist1.W', 'hist1.b', 'hist2.W', 'hist2.b', 'img_embed.W', 'img_embed.b', 'ques1.W', 'ques1.b', 'ques2.W',
-                     'ques2.b', 'dialog.W', 'dialog.b', 'opt.W', 'opt.b']
+    use_im = '-im-' in encoder
+    assert names == ['embed', 'hist1.W', 'hist1.b', 'hist2.W', 'hist2.b'] + (['img_embed.W', 'img_embed.b'] if use_im else []) + [
+        'ques1.W', 'ques1.b', 'ques2.W', 'ques2.b', 'dialog.W', 'dialog.b', 'opt.W', 'opt.b']
     B, R, Tq = batch['ques_fwd'].shape
     Th, O, To = batch['hist'].shape[2], batch['options'].shape[1], batch['options'].shape[2]
     inp, outp = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
     with open(inp, 'wb') as f:
-        f.write(struct.pack('<11i', p['vocabSize'], p['embedSize'], p['rnnHiddenSize'], p['imgFeatureSize'], p['imgEmbedSize'], B, R, O, Tq, Th, To))
+        f.write(struct.pack('<12i', p['vocabSize'], p['embedSize'], p['rnnHiddenSize'], p['imgFeatureSize'], p['imgEmbedSize'], B, R, O, Tq, Th, To,
+                            int(use_im)))
         for k in names:
             f.write(np.ascontiguousarray(P[k], np.float32).tobytes())
         for k, dt in (('ques_fwd', np.int32), ('img_feat', np.float32), ('hist', np.int32), ('options', np.int32), ('answer_ind', np.int32)):
-            f.write(np.ascontiguousarray(batch[k], dt).tobytes())
+            if k != 'img_feat' or use_im:
+                f.write(np.ascontiguousarray(batch[k], dt).tobytes())
     exe = build(tmp_path, SRC_PLUGIN_HRE)
     r = subprocess.run([exe, _lib.LIB_PATH, inp, outp], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

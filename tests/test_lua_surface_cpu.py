@@ -124,7 +124,7 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
     hdr, c_lf, c_mn = rd('examples', 'host_c_modules.h'), rd('examples', 'host_c_plugin_lf_ques.c'), rd('examples', 'host_c_plugin_mn_att.c')
     c_gen, c_hre = rd('examples', 'host_c_plugin_lf_ques_gen.c'), rd('examples', 'host_c_plugin_hre.c')
     names = ('vdnn.lua', 'encoders/lf-ques.lua', 'encoders/lf-ques-im.lua', 'encoders/lf-ques-hist.lua', 'encoders/lf-ques-im-hist.lua',
-             'encoders/hre-ques-im-hist.lua',
+             'encoders/hre-ques-im-hist.lua', 'encoders/hre-ques-hist.lua',
              'encoders/mn-att-ques-im-hist.lua', 'decoders/disc.lua',
              'decoders/gen.lua', 'model_ops.lua')
     strip = lambda s: '\n'.join(l.split('--')[0] for l in s.splitlines())
@@ -185,7 +185,7 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
         assert set(_c_calls(c)) <= used_c | {'vd_last_error'}, set(_c_calls(c)) - used_c
     # the plug-in files keep the reference's contract AND carry a Lua-side implementation
     for e in ('encoders/lf-ques.lua', 'encoders/lf-ques-im.lua', 'encoders/lf-ques-hist.lua', 'encoders/lf-ques-im-hist.lua',
-              'encoders/hre-ques-im-hist.lua', 'encoders/mn-att-ques-im-hist.lua'):
+              'encoders/hre-ques-im-hist.lua', 'encoders/hre-ques-hist.lua', 'encoders/mn-att-ques-im-hist.lua'):
         assert 'function enc:forward(inputs)' in lua[e] and 'function enc:backward(inputs, gradOutput)' in lua[e], e
         assert 'function enc:declare(spec)' in lua[e] and 'function enc:build(vdnn, fp, wordEmbed)' in lua[e], e
     assert 'function dec:forward(input)' in lua['decoders/disc.lua'] and 'return {nil, gradOutput[2]}' in lua['decoders/disc.lua']
