@@ -18,6 +18,7 @@ SRC_PLUGIN = os.path.join(ROOT, 'examples', 'host_c_plugin_lf_ques.c')
 SRC_PLUGIN_MN = os.path.join(ROOT, 'examples', 'host_c_plugin_mn_att.c')
 SRC_PLUGIN_GEN = os.path.join(ROOT, 'examples', 'host_c_plugin_lf_ques_gen.c')
 SRC_PLUGIN_HRE = os.path.join(ROOT, 'examples', 'host_c_plugin_hre.c')
+SRC_PLUGIN_GRAPH = os.path.join(ROOT, 'examples', 'host_c_plugin_graph.c')
 
 
 def build(tmp_path, src=SRC):
@@ -34,6 +35,7 @@ def test_header_is_valid_c_and_the_c_host_builds(tmp_path):
     build(tmp_path, SRC_PLUGIN_MN)
     build(tmp_path, SRC_PLUGIN_GEN)
     build(tmp_path, SRC_PLUGIN_HRE)
+    build(tmp_path, SRC_PLUGIN_GRAPH)
     exe = build(tmp_path)
     # without a library the host fails loudly at dlopen -- no fallback of any kind
     r = subprocess.run([exe, '/nonexistent/libvisdial_hip.so', '/dev/null', '1', '0'], capture_output=True, text=True)
@@ -334,6 +336,67 @@ def test_c_plugin_configs2_pair_hre_on_the_operator_level_abi_equals_the_library
         g = raw[o:o + P[k].size].reshape(P[k].shape)
         den = max(float(np.linalg.norm(G[k])), 1e-12)
         assert float(np.linalg.norm(g - G[k])) / den < 1e-5, k         # same kernels; float-atomic sums differ in the last bits
+        o += P[k].size
+    for k in names:
+        w = raw[o:o + P[k].size].reshape(P[k].shape)
+        settled = np.abs(G[k]) > 1e-6                                  # Adam's first step is ~lr * sign(g)
+        assert np.abs(w - W1[k])[settled].max() < 1e-6 if settled.any() else True, k
+        o += P[k].size
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,encoder", [(1, 'mn-ques-hist'), (2, 'mn-ques-im-hist'), (3, 'lf-att-ques-im-hist')])
+def test_c_plugin_graph_siblings_on_the_operator_level_abi_equal_the_library(tmp_path, variant, encoder):
+    """examples/host_c_plugin_graph.c composes the three nngraph siblings of the flagship encoder (+ decoders/disc.lua) from
+    OPERATOR-LEVEL entry points: text branches, the memory network, JoinTable + Linear + Tanh fusions (qi, qh), the stacked image
+    attention.  Loss, every gradient tensor and the post-Adam parameters must equal the library's own model-level implementation."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from visdial_amd import _lib
+    from visdial_amd.dataloader import SyntheticDataloader
+    from visdial_amd.native import NativeModel
+    p = derive(small_params(encoder=encoder, decoder='disc'))
+    batch = SyntheticDataloader(p, seed=8).getTrainBatch(p)
+    m = NativeModel(dict(p), init_seed=3)
+    m.training(False)
+    P = m.get_parameters_dict()
+    names = [t[0] for t in m.tensors]
+    text = ['embed'] + [n + s for n in ('hist1', 'hist2', 'ques1', 'ques2') for s in ('.W', '.b')]
+    mem = ['mn1.W', 'mn1.b', 'mn2.W', 'mn2.b']
+    san = [n + s for n in ('img_proj', 'img_common', 'ques_common', 'att', 'out') for s in ('.W', '.b')]
+    assert names == text + {1: mem, 2: ['qi.W', 'qi.b'] + mem, 3: ['qh.W', 'qh.b'] + san}[variant] + ['opt.W', 'opt.b']
+    B, R, Tq = batch['ques_fwd'].shape
+    Th, O, To = batch['hist'].shape[2], batch['options'].shape[1], batch['options'].shape[2]
+    inp, outp = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
+    with open(inp, 'wb') as f:
+        f.write(struct.pack('<14i', variant, p['vocabSize'], p['embedSize'], p['rnnHiddenSize'], p['imgFeatureSize'], p['imgSpatialSize'],
+                            p['commonEmbeddingSize'], p['imgFeatureSize'], B, R, O, Tq, Th, To))
+        for k in names:
+            f.write(np.ascontiguousarray(P[k], np.float32).tobytes())
+        for k, dt in (('ques_fwd', np.int32), ('hist', np.int32), ('img_feat', np.float32), ('options', np.int32), ('answer_ind', np.int32)):
+            if k != 'img_feat' or variant != 1:
+                f.write(np.ascontiguousarray(batch[k], dt).tobytes())
+    exe = build(tmp_path, SRC_PLUGIN_GRAPH)
+    r = subprocess.run([exe, _lib.LIB_PATH, inp, outp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    raw = np.fromfile(outp, np.float32)
+    n = sum(P[k].size for k in names)
+    assert raw.size == 1 + 2 * n
+    loss = m.forwardBackward(batch)
+    G = m.get_gradients_dict()
+    m.update()
+    W1 = m.get_parameters_dict()
+    assert abs(float(raw[0]) - loss) < 1e-6 * max(1.0, abs(loss))
+    o = 1
+    for k in names:
+        g = raw[o:o + P[k].size].reshape(P[k].shape)
+        if k == 'att.b':                                               # the softmax is shift-invariant: the true gradient is 0
+            assert float(np.abs(g).max()) < 1e-6 and float(np.abs(G[k]).max()) < 1e-6, k
+        else:
+            den = max(float(np.linalg.norm(G[k])), 1e-12)
+            assert float(np.linalg.norm(g - G[k])) / den < 1e-5, k     # same kernels; float-atomic sums differ in the last bits
         o += P[k].size
     for k in names:
         w = raw[o:o + P[k].size].reshape(P[k].shape)
