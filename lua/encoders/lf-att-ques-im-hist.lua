@@ -1,13 +1,116 @@
--- encoders/lf-att-ques-im-hist.lua -- plug-in file contract of the reference (model.lua:19-25: the file is `dofile`d and must return a
--- table with model(params)).  Instead of building nn / nngraph modules it names the native graph; the object keeps
--- the fields decoders read: .wordEmbed (disc.lua:12, gen.lua:10) is the shared embedding, owned by the library.
+-- encoders/lf-att-ques-im-hist.lua -- the reference's plug-in file contract (model.lua:19-25) with BOTH surfaces (see lua/encoders/lf-ques.lua):
+--   * enc.native = 'lf-att-ques-im-hist': the name lua/model.lua hands to vd_model_create (model-level C ABI);
+--   * enc:declare / :build / :forward(inputs) / :backward(inputs, gradOutput) composed IN LUA from module objects over the operator-level
+--     C ABI (lua/vdnn.lua), node for node of the reference's nngraph: text branches; u = Tanh(Linear(JoinTable{question state,
+--     history state})) (lf-att-ques-im-hist.lua:43); stacked attention over the S x S image regions, one hop, and the output layer (:45-86).
+-- A sibling of lua/encoders/mn-att-ques-im-hist.lua (same blocks).  Transliteration of examples/host_c_plugin_graph.c (variant 3), which is
+-- built with gcc and checked on the GPU against the library's model-level implementation (tests/test_abi_c_host.py); no Lua interpreter exists here.
 local encoderNet = {}
 
 function encoderNet.model(params)
     local enc = {native = 'lf-att-ques-im-hist', params = params}
-    enc.wordEmbed = {shared = 'embed'}           -- one table for question / history / option / answer tokens
-    -- the model-level runtime (csrc/runtime.hip) covers mn-att-ques-im-hist + disc so far; this encoder runs through the
-    -- operator-level entry points (host: visdial_amd/encoders/lf_att_ques_im_hist.py) -- vd_model_create reports it
+    enc.wordEmbed = {shared = 'embed'}           -- one table for question / history / option / answer tokens (model-level path)
+
+    -- parameter tensors in getParameters() order: {name, numel}
+    function enc:declare(spec)
+        local E, H, C, K = params.embedSize, params.rnnHiddenSize, params.imgFeatureSize, params.commonEmbeddingSize
+        for _, name in ipairs({'hist', 'ques'}) do                            -- two layers per branch are hard-coded in the nngraph encoders
+            table.insert(spec, {name .. '1.W', (E + H) * 4 * H}); table.insert(spec, {name .. '1.b', 4 * H})
+            table.insert(spec, {name .. '2.W', (H + H) * 4 * H}); table.insert(spec, {name .. '2.b', 4 * H})
+        end
+        table.insert(spec, {'qh.W', H * 2 * H}); table.insert(spec, {'qh.b', H})
+        table.insert(spec, {'img_proj.W', H * C}); table.insert(spec, {'img_proj.b', H})
+        table.insert(spec, {'img_common.W', K * H}); table.insert(spec, {'img_common.b', K})
+        table.insert(spec, {'ques_common.W', K * H}); table.insert(spec, {'ques_common.b', K})
+        table.insert(spec, {'att.W', K}); table.insert(spec, {'att.b', 1})
+        table.insert(spec, {'out.W', H * H}); table.insert(spec, {'out.b', H})
+    end
+
+    function enc:build(vdnn, fp, wordEmbed)
+        local E, H, C, K = params.embedSize, params.rnnHiddenSize, params.imgFeatureSize, params.commonEmbeddingSize
+        self.vdnn, self.fp, self.wordEmbed = vdnn, fp, wordEmbed
+        self.hist1, self.hist2 = vdnn.SeqLSTM(fp, 'hist1', E, H), vdnn.SeqLSTM(fp, 'hist2', H, H)
+        self.ques1, self.ques2 = vdnn.SeqLSTM(fp, 'ques1', E, H), vdnn.SeqLSTM(fp, 'ques2', H, H)
+        self.rnnLayers = {self.ques1, self.ques2}
+        self.drop = vdnn.Dropout(0.5)             -- the nngraph encoders hard-code Dropout(0.5)
+        self.qh = vdnn.LinearTanh(fp, 'qh', 2 * H, H)
+        self.img_proj = vdnn.LinearTanh(fp, 'img_proj', C, H)
+        self.ques_common = vdnn.Linear(fp, 'ques_common', H, K)
+        self.out = vdnn.LinearTanh(fp, 'out', H, H)
+    end
+
+    -- inputs = {ques, img, hist} in the order of the reference's input table (model.lua:255-279); img = {data = device float [B*S2 x C], B}:
+    -- ONE map per image (the repeatTensor over the rounds is folded into the attention kernels' loaders)
+    function enc:forward(inputs)
+        local vd, vdnn, fp, drop = self.vdnn.vd, self.vdnn, self.fp, self.drop
+        local ques, img, hist = inputs[1], inputs[2], inputs[3]
+        local E, H, K, R = params.embedSize, params.rnnHiddenSize, params.commonEmbeddingSize, params.maxQuesCount
+        local S2 = params.imgSpatialSize * params.imgSpatialSize
+        local N, Tq, Th = ques.N, ques.T, hist.T
+        local B = N / R
+        local S5 = drop.scale
+        -- text branches: embedding + Dropout fused in the gather; maskZero via the token matrix
+        self.m_h, self.m_q = drop:mask(Th * N * E), drop:mask(Tq * N * E)
+        local hx = self.wordEmbed:forward(hist.tok, Th * N, self.m_h, S5)
+        local qx = self.wordEmbed:forward(ques.tok, Tq * N, self.m_q, S5)
+        self.hist1:forward(hx, Th, N, hist.tok); self.hist2:forward(self.hist1.output, Th, N, hist.tok)
+        self.ques1:forward(qx, Tq, N, ques.tok); self.ques2:forward(self.ques1.output, Tq, N, ques.tok)
+        local h3 = self.hist2.output + (Th - 1) * N * H                               -- nn.Select(1, -1)
+        local q3 = self.ques2.output + (Tq - 1) * N * H
+        self.h3, self.q3, self.N, self.B = h3, q3, N, B
+        -- question and history states fused (lf-att-ques-im-hist.lua:43)
+        local cat = vdnn.devFloats(N * 2 * H)
+        vd.call('vd_copy_2d', cat, 2 * H, q3, H, N, H, nil)
+        vd.call('vd_copy_2d', cat + H, 2 * H, h3, H, N, H, nil)
+        local u = self.qh:forward(cat, N)
+        -- stacked attention over the S x S regions, one hop (mn-att:68-104): per-IMAGE projection, per-round Dropout masks in the loaders
+        self.pre = self.img_proj:forward(img.data, B * S2)                            -- Tanh(Linear(img)), pre-Dropout
+        self.m1, self.m2 = drop:mask(N * S2 * H), drop:mask(N * S2 * K)
+        self.sc = self.m1 ~= nil and S5 or 1.0
+        local qc = self.ques_common:forward(u, N)                                    -- mn-att:88
+        local Wc, _ = fp:view('img_common.W'); local bc, _ = fp:view('img_common.b')
+        local wa, _ = fp:view('att.W'); local ba, _ = fp:view('att.b')
+        self.iqc, self.patt = vdnn.devFloats(N * S2 * K), vdnn.devFloats(N * S2)
+        local u1 = vdnn.devFloats(N * H)
+        vd.call('vd_img_common_forward', self.pre, self.m1, Wc, bc, qc, self.m2, self.iqc, N, R, S2, H, K, self.sc, nil)     -- mn-att:83-92
+        vd.call('vd_img_att_forward', self.iqc, wa, ba, self.pre, self.m1, u, self.patt, u1, N, R, S2, H, K, self.sc, nil)  -- mn-att:93-102
+        self.m_u = drop:mask(N * H)
+        self.output = self.out:forward(drop:apply(u1, self.m_u, N * H), N)              -- mn-att:106
+        return self.output
+    end
+
+    function enc:backward(inputs, gradOutput)
+        local vd, vdnn, fp, drop = self.vdnn.vd, self.vdnn, self.fp, self.drop
+        local ques, hist = inputs[1], inputs[3]
+        local H, K, R = params.rnnHiddenSize, params.commonEmbeddingSize, params.maxQuesCount
+        local S2 = params.imgSpatialSize * params.imgSpatialSize
+        local N, B, sc, S5 = self.N, self.B, self.sc, drop.scale
+        local Wc, dWc = fp:view('img_common.W'); local _, dbc = fp:view('img_common.b')
+        local wa, dwa = fp:view('att.W'); local _, dba = fp:view('att.b')
+        local du = drop:apply(self.out:backward(gradOutput), self.m_u, N * H)           -- d att of the hop + its residual
+        local dpre, dqc, work = vdnn.devFloats(B * S2 * H), vdnn.devFloats(N * K), vdnn.devFloats(N * S2)
+        vd.call('vd_img_att_backward', self.iqc, wa, self.pre, self.m1, self.m2, self.patt, du, dwa, dba, dqc, work, N, R, S2, H, K, sc, nil)
+        local dz = self.iqc                                                             -- iqc now holds dz
+        vd.call('vd_colsum_acc', dz, K, N * S2, K, dbc, nil)
+        vd.call('vd_img_common_wgrad', dz, self.pre, self.m1, dWc, N, R, S2, H, K, sc, nil)
+        vd.call('vd_img_tr_backward', dz, Wc, self.patt, du, self.m1, dpre, N, R, S2, H, K, sc, nil)        -- += into dpre
+        local du_q = self.ques_common:backward(dqc)
+        local dsum = vdnn.devFloats(N * H)
+        vd.call('vd_axpby', du_q, du, dsum, N * H, 1.0, 1.0, nil)                        -- residual CAddTable (mn-att:102)
+        self.img_proj:backward(dpre, false)                                             -- tanh' + dW, db of mn-att:77
+        local dcat = self.qh:backward(dsum)                                  -- JoinTable backward
+        local dq3, dh3 = vdnn.devFloats(N * H), vdnn.devFloats(N * H)
+        vd.call('vd_copy_2d', dq3, H, dcat, 2 * H, N, H, nil)
+        vd.call('vd_copy_2d', dh3, H, dcat + H, 2 * H, N, H, nil)
+        -- text branches: the gradient arrives at the last step of the top layers only
+        local dh1_seq = self.hist2:backward(nil, dh3, true)
+        local dhx = self.hist1:backward(dh1_seq, nil, true)
+        local dq1_seq = self.ques2:backward(nil, dq3, true)
+        local dqx = self.ques1:backward(dq1_seq, nil, true)
+        self.wordEmbed:backward(hist.tok, hist.T * N, dhx, self.m_h, S5)
+        self.wordEmbed:backward(ques.tok, ques.T * N, dqx, self.m_q, S5)
+    end
+
     return enc
 end
 

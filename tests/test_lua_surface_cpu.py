@@ -174,6 +174,24 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
         # (evaluation order inside one statement: C writes linear_forward(&mn1, drop_apply(...)), Lua self.mn1:forward(drop:apply(...)) --
         #  the same nesting, so the textual order agrees too)
         assert a == b and len(a) >= 13, (a, b)
+    # the three nngraph siblings share ONE C twin with a variant switch: every sibling's forward / backward must be an ORDER-PRESERVING
+    # selection of the twin's calls (its variant's path), and together they must use every call of the twin
+    c_graph = rd('examples', 'host_c_plugin_graph.c')
+    sib_skip = drop | {'vd_embed_gather', 'vd_embed_scatter_acc', 'vd_memcpy_h2d'}
+    def subsequence(small, big):
+        it = iter(big)
+        return all(x in it for x in small)
+    for sec_c, fn in (((('/* ================= encoder:forward', '/* ================= decoder:forward')), 'function enc:forward('),
+                      ((('/* ================= encoder:backward', '/* curLoss')), 'function enc:backward(')):
+        big = [x for x in _c_calls(_body(c_graph, *sec_c)) if x not in sib_skip]
+        seen = set()
+        for e in ('mn-ques-hist', 'mn-ques-im-hist', 'lf-att-ques-im-hist'):
+            src = strip(rd('lua', 'encoders', e + '.lua'))
+            small = [x for x in _calls(_body(src, fn, '\n    end\n')) if x not in sib_skip]
+            assert small and subsequence(small, big), (e, fn, small, big)
+            seen |= set(small)
+            lua['encoders/' + e + '.lua'] = src
+        assert seen == set(big), (fn, seen ^ set(big))
     used_lua = set()
     for v in lua.values():
         used_lua |= set(re.findall(r"vd\.call\('(vd_[a-z0-9_]+)'", v))
@@ -181,11 +199,12 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
     assert used_lua == used_c, (used_lua ^ used_c)
     assert used_lua <= funcs
     # both C hosts use nothing the shared header does not load
-    for c in (c_lf, c_mn, c_gen, c_hre):
+    for c in (c_lf, c_mn, c_gen, c_hre, c_graph):
         assert set(_c_calls(c)) <= used_c | {'vd_last_error'}, set(_c_calls(c)) - used_c
     # the plug-in files keep the reference's contract AND carry a Lua-side implementation
     for e in ('encoders/lf-ques.lua', 'encoders/lf-ques-im.lua', 'encoders/lf-ques-hist.lua', 'encoders/lf-ques-im-hist.lua',
-              'encoders/hre-ques-im-hist.lua', 'encoders/hre-ques-hist.lua', 'encoders/mn-att-ques-im-hist.lua'):
+              'encoders/hre-ques-im-hist.lua', 'encoders/hre-ques-hist.lua', 'encoders/mn-att-ques-im-hist.lua', 'encoders/mn-ques-hist.lua',
+              'encoders/mn-ques-im-hist.lua', 'encoders/lf-att-ques-im-hist.lua'):
         assert 'function enc:forward(inputs)' in lua[e] and 'function enc:backward(inputs, gradOutput)' in lua[e], e
         assert 'function enc:declare(spec)' in lua[e] and 'function enc:build(vdnn, fp, wordEmbed)' in lua[e], e
     assert 'function dec:forward(input)' in lua['decoders/disc.lua'] and 'return {nil, gradOutput[2]}' in lua['decoders/disc.lua']
