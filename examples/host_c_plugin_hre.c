@@ -1,4 +1,4 @@
-/* host_c_plugin_hre.c -- BASELINE.json configs[2], encoders/hre-ques-im-hist.lua (and its image-less sibling hre-ques-hist.lua) + decoders/disc.lua, written against the OPERATOR-LEVEL
+/* host_c_plugin_hre.c -- BASELINE.json configs[2], encoders/hre-ques-im-hist.lua (its image-less sibling hre-ques-hist.lua and its attention sibling hrea-ques-im-hist.lua) + decoders/disc.lua, written against the OPERATOR-LEVEL
  * C ABI by a host without a tensor library, module object by module object of the reference's graph (hre-ques-im-hist.lua:5-97) --
  *   history  : wordEmbed -> numLayers x SeqLSTM:maskZero() -> Select(1,-1)                                              hre:28-41
  *   question : JoinTable{wordEmbed(ques), MaskTime(Linear(F, imgEmbedSize)(img))} -> numLayers x SeqLSTM:maskZero() -> Select   hre:43-82
@@ -9,7 +9,9 @@
  * (tests/test_abi_c_host.py).
  *
  *   ./host_c_plugin_hre <libvisdial_hip.so> <in.bin> <out.bin>
- * in.bin : int32 {V, E, H, F, DI, B, R, O, Tq, Th, To, useIm}, the 15 (13 without the image part) parameter tensors in getParameters() order as float32 (embed, hist1.W/.b,
+ * hrea-ques-im-hist.lua:83-131: every question attends over the history states of the rounds up to its own (two Linear(H, 1) scores,
+ * MaskFuture, ReplaceZero(-inf), SoftMax, weighted sum) and the attended history replaces the history state in front of the dialog LSTM.
+ * in.bin : int32 {V, E, H, F, DI, B, R, O, Tq, Th, To, useIm, attention}, the 15 (13 without the image part, 19 with attention) parameter tensors in getParameters() order as float32 (embed, hist1.W/.b,
  *          hist2.W/.b, img_embed.W [DI x F]/.b, ques1.W [(E+DI+H) x 4H]/.b, ques2.W/.b, dialog.W [(2H+H) x 4H]/.b, opt.W/.b), ques_fwd
  *          [B*R x Tq], img_feat [B x F] float32, hist [B*R x Th], options [B*R*O x To], answer_ind [B*R] (1-based).
  * out.bin: float32 loss, the flat gradient, the flat parameters after clamp(-5,5) + adam.   Dropout off (wrapper:evaluate()). */
@@ -23,7 +25,7 @@
 #include "visdial_hip.h"
 #include "host_c_modules.h"
 
-#define NT 15
+#define NT 19
 #define NL 2
 
 int main(int argc, char** argv) {
@@ -31,19 +33,21 @@ int main(int argc, char** argv) {
   load_entry_points(argv[1]);
   FILE* f = fopen(argv[2], "rb");
   if (!f) { perror(argv[2]); return 4; }
-  int32_t hd[12];
-  if (fread(hd, 4, 12, f) != 12) return 4;
-  const int V = hd[0], E = hd[1], H = hd[2], F = hd[3], B = hd[5], R = hd[6], O = hd[7], Tq = hd[8], Th = hd[9], To = hd[10], useIm = hd[11];
+  int32_t hd[13];
+  if (fread(hd, 4, 13, f) != 13) return 4;
+  const int V = hd[0], E = hd[1], H = hd[2], F = hd[3], B = hd[5], R = hd[6], O = hd[7], Tq = hd[8], Th = hd[9], To = hd[10], useIm = hd[11],
+            attention = hd[12];
   const int DI = useIm ? hd[4] : 0;
   const int N = B * R, NO = N * O, DQ = E + DI;
 
   const int64_t l2 = (int64_t)2 * H * 4 * H;
   int64_t sizes[NT];
-  int nt = 0, H1W, H2W, IEW = -1, Q1W, Q2W, DLW, OPW;
+  int nt = 0, H1W, H2W, IEW = -1, Q1W, Q2W, AQW = -1, AHW = -1, DLW, OPW;
   sizes[nt++] = (int64_t)(V + 1) * E;                                             /* embed */
   H1W = nt; sizes[nt++] = (int64_t)(E + H) * 4 * H; sizes[nt++] = 4 * H; H2W = nt; sizes[nt++] = l2; sizes[nt++] = 4 * H;
   if (useIm) { IEW = nt; sizes[nt++] = (int64_t)DI * F; sizes[nt++] = DI; }
   Q1W = nt; sizes[nt++] = (int64_t)(DQ + H) * 4 * H; sizes[nt++] = 4 * H; Q2W = nt; sizes[nt++] = l2; sizes[nt++] = 4 * H;
+  if (attention) { AQW = nt; sizes[nt++] = H; sizes[nt++] = 1; AHW = nt; sizes[nt++] = H; sizes[nt++] = 1; }     /* two nn.Linear(H, 1) (hrea:83-85) */
   DLW = nt; sizes[nt++] = (int64_t)(2 * H + H) * 4 * H; sizes[nt++] = 4 * H;
   OPW = nt; sizes[nt++] = (int64_t)(E + H) * 4 * H; sizes[nt++] = 4 * H;
   int64_t off[NT + 1];
@@ -111,9 +115,19 @@ int main(int argc, char** argv) {
   for (int l = 0; l < NL; ++l) { lstm_forward(&ques_rnn[l], x, Tq, N, ques); x = ques_rnn[l].h; }
   const float* hq = ques_rnn[NL - 1].h + (int64_t)(Tq - 1) * N * H;
   /* dialog-level recurrence over the rounds (hre:84-95): rows to round-major, JoinTable{question, history}, SeqLSTM(2H, H), rows back */
+  const float *first = hq, *second = hh;
+  float *sq = NULL, *sh = NULL, *P = NULL;
+  if (attention) {                                                                               /* hrea:83-131; JoinTable{attended history, question} */
+    sq = dev_floats(N); sh = dev_floats(N); P = dev_floats((int64_t)N * R);
+    float* att = dev_floats((int64_t)N * H);
+    CHECK(p_rowdot_forward(hq, Wf + off[AQW], Wf + off[AQW + 1], sq, N, H, NULL));
+    CHECK(p_rowdot_forward(hh, Wf + off[AHW], Wf + off[AHW + 1], sh, N, H, NULL));
+    CHECK(p_hrea_attention_forward(sq, sh, hh, P, att, B, R, H, NULL));
+    first = att; second = hq;
+  }
   float *f_rb = dev_floats((int64_t)N * H), *s_rb = dev_floats((int64_t)N * H), *dcat = dev_floats((int64_t)N * 2 * H);
-  CHECK(p_embed_gather(hq, to_rb, NULL, f_rb, N, H, 1.f, NULL));
-  CHECK(p_embed_gather(hh, to_rb, NULL, s_rb, N, H, 1.f, NULL));
+  CHECK(p_embed_gather(first, to_rb, NULL, f_rb, N, H, 1.f, NULL));
+  CHECK(p_embed_gather(second, to_rb, NULL, s_rb, N, H, 1.f, NULL));
   CHECK(p_copy_2d(dcat, 2 * H, f_rb, H, N, H, NULL));
   CHECK(p_copy_2d(dcat + H, 2 * H, s_rb, H, N, H, NULL));
   lstm_forward(&dialog, dcat, R, B, NULL);
@@ -135,6 +149,16 @@ int main(int argc, char** argv) {
   CHECK(p_copy_2d(ds_rb, H, ddcat + H, 2 * H, N, H, NULL));
   CHECK(p_embed_gather(df_rb, to_n, NULL, dq, N, H, 1.f, NULL));
   CHECK(p_embed_gather(ds_rb, to_n, NULL, dh, N, H, 1.f, NULL));
+  if (attention) {                                               /* dq holds d attended history, dh holds d question state (JoinTable order) */
+    float *dsq = dev_floats(N), *dsh = dev_floats(N), *dh_att = dev_floats((int64_t)N * H), *dq_s = dev_floats((int64_t)N * H), *dh_s = dev_floats((int64_t)N * H);
+    CHECK(p_hrea_attention_backward(hh, P, dq, dsq, dsh, dh_att, B, R, H, NULL));
+    CHECK(p_rowdot_backward(hq, Wf + off[AQW], dsq, Gf + off[AQW], Gf + off[AQW + 1], dq_s, N, H, NULL));
+    CHECK(p_rowdot_backward(hh, Wf + off[AHW], dsh, Gf + off[AHW], Gf + off[AHW + 1], dh_s, N, H, NULL));
+    float *dq2 = dev_floats((int64_t)N * H), *dh2 = dev_floats((int64_t)N * H);
+    CHECK(p_axpby(dh, dq_s, dq2, (int64_t)N * H, 1.f, 1.f, NULL));
+    CHECK(p_axpby(dh_att, dh_s, dh2, (int64_t)N * H, 1.f, 1.f, NULL));
+    dq = dq2; dh = dh2;
+  }
   float* dhx = lstm_backward(&hist_rnn[NL - 1], NULL, dh, 1);
   for (int l = NL - 2; l >= 0; --l) dhx = lstm_backward(&hist_rnn[l], dhx, NULL, 1);
   CHECK(p_embed_scatter_acc(demb, hist, NULL, dhx, (int64_t)Th * N, E, 1.f, NULL));
@@ -173,6 +197,6 @@ int main(int argc, char** argv) {
   for (int i = 0; i < nt; ++i) fwrite(grad_host + off[i], 4, (size_t)sizes[i], o);
   for (int i = 0; i < nt; ++i) fwrite(host + off[i], 4, (size_t)sizes[i], o);
   fclose(o);
-  printf("%s + disc through the operator-level ABI: loss %.6f, %lld parameters\n", useIm ? "hre-ques-im-hist" : "hre-ques-hist", loss, (long long)numel);
+  printf("%s + disc through the operator-level ABI: loss %.6f, %lld parameters\n", attention ? "hrea-ques-im-hist" : useIm ? "hre-ques-im-hist" : "hre-ques-hist", loss, (long long)numel);
   return 0;
 }
