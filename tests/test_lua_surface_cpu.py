@@ -124,7 +124,7 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
     hdr, c_lf, c_mn = rd('examples', 'host_c_modules.h'), rd('examples', 'host_c_plugin_lf_ques.c'), rd('examples', 'host_c_plugin_mn_att.c')
     c_gen, c_hre = rd('examples', 'host_c_plugin_lf_ques_gen.c'), rd('examples', 'host_c_plugin_hre.c')
     names = ('vdnn.lua', 'encoders/lf-ques.lua', 'encoders/lf-ques-im.lua', 'encoders/lf-ques-hist.lua', 'encoders/lf-ques-im-hist.lua',
-             'encoders/hre-ques-im-hist.lua', 'encoders/hre-ques-hist.lua',
+             'encoders/hre-ques-im-hist.lua', 'encoders/hre-ques-hist.lua', 'encoders/hrea-ques-im-hist.lua',
              'encoders/mn-att-ques-im-hist.lua', 'decoders/disc.lua',
              'decoders/gen.lua', 'model_ops.lua')
     strip = lambda s: '\n'.join(l.split('--')[0] for l in s.splitlines())
@@ -137,10 +137,6 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
         (_body(hdr, 'static float* linear_backward_ex(', '\n}\n'), _body(lua['vdnn.lua'], 'function LinearTanh:backward(', '\nend\n')),
         (_body(hdr, 'static const float* disc_forward(', '\n}\n'), _body(lua['decoders/disc.lua'], 'function dec:forward(', '\n    end\n')),
         (_body(hdr, 'static void disc_backward(', '\n}\n'), _body(lua['decoders/disc.lua'], 'function dec:backward(', '\n    end\n')),
-        (_body(c_hre, '/* ================= encoder:forward', '/* ================= decoder:forward'),
-         _body(lua['encoders/hre-ques-im-hist.lua'], 'function enc:forward(', '\n    end\n')),
-        (_body(c_hre, '/* ================= encoder:backward', '/* curLoss'),
-         _body(lua['encoders/hre-ques-im-hist.lua'], 'function enc:backward(', '\n    end\n')),
         (_body(c_gen, '/* ================= encoder:forward({ques})', '/* ================= forwardConnect'),
          _body(lua['encoders/lf-ques-im-hist.lua'], 'function enc:forward(', '\n    end\n')),
         (_body(c_gen, '/* ================= encoder:backward(inputs, gradDecOut)', '/* curLoss'),
@@ -155,7 +151,7 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
     drop = {'vd_malloc', 'vd_memset'}          # buffer allocation is interleaved differently (dev_floats / devFloats helpers)
     for k, (c_body, l_body) in enumerate(pairs):
         # (the flagship's embedding gathers / scatters are direct calls in C and self.wordEmbed methods in Lua: pinned just below)
-        skip = drop | ({'vd_embed_gather', 'vd_embed_scatter_acc'} if k >= len(pairs) - 8 else set())
+        skip = drop | ({'vd_embed_gather', 'vd_embed_scatter_acc'} if k >= len(pairs) - 6 else set())
         a = [x for x in _c_calls(c_body) if x not in skip]
         b = [x for x in _calls(l_body) if x not in skip]
         assert a == b and a, (a, b)
@@ -192,6 +188,16 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
             seen |= set(small)
             lua['encoders/' + e + '.lua'] = src
         assert seen == set(big), (fn, seen ^ set(big))
+    # the three hierarchical encoders share the hre C twin the same way (useIm / attention switches)
+    for sec_c, fn in (((('/* ================= encoder:forward', '/* ================= decoder:forward')), 'function enc:forward('),
+                      ((('/* ================= encoder:backward', '/* curLoss')), 'function enc:backward(')):
+        big = [x for x in _c_calls(_body(c_hre, *sec_c)) if x not in sib_skip]
+        seen = set()
+        for e in ('hre-ques-hist', 'hre-ques-im-hist', 'hrea-ques-im-hist'):
+            small = [x for x in _calls(_body(lua['encoders/' + e + '.lua'], fn, '\n    end\n')) if x not in sib_skip | {'vd_dropout_mask', 'vd_dropout_apply'}]
+            assert small and subsequence(small, big), (e, fn, small, big)
+            seen |= set(small)
+        assert seen == set(big), (fn, seen ^ set(big))
     used_lua = set()
     for v in lua.values():
         used_lua |= set(re.findall(r"vd\.call\('(vd_[a-z0-9_]+)'", v))
@@ -203,7 +209,8 @@ def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
         assert set(_c_calls(c)) <= used_c | {'vd_last_error'}, set(_c_calls(c)) - used_c
     # the plug-in files keep the reference's contract AND carry a Lua-side implementation
     for e in ('encoders/lf-ques.lua', 'encoders/lf-ques-im.lua', 'encoders/lf-ques-hist.lua', 'encoders/lf-ques-im-hist.lua',
-              'encoders/hre-ques-im-hist.lua', 'encoders/hre-ques-hist.lua', 'encoders/mn-att-ques-im-hist.lua', 'encoders/mn-ques-hist.lua',
+              'encoders/hre-ques-im-hist.lua', 'encoders/hre-ques-hist.lua', 'encoders/hrea-ques-im-hist.lua', 'encoders/mn-att-ques-im-hist.lua',
+              'encoders/mn-ques-hist.lua',
               'encoders/mn-ques-im-hist.lua', 'encoders/lf-att-ques-im-hist.lua'):
         assert 'function enc:forward(inputs)' in lua[e] and 'function enc:backward(inputs, gradOutput)' in lua[e], e
         assert 'function enc:declare(spec)' in lua[e] and 'function enc:build(vdnn, fp, wordEmbed)' in lua[e], e
