@@ -35,6 +35,7 @@ FN(int, p_token_sort, (const int32_t*, int64_t, int, int32_t*, int32_t*, int32_t
 FN(int, p_segment_rowsum_acc, (const float*, int64_t, const int32_t*, const int32_t*, int64_t, int, float*, int64_t, void*))
 FN(int, p_tanh_backward, (const float*, const float*, float*, int64_t, void*))
 FN(int, p_score_ce, (const float*, const float*, const int32_t*, float*, float*, float*, float*, int, int, int, float, void*))
+FN(int, p_ranks, (const float*, int32_t*, int, int, void*))
 FN(int, p_clamp_adam, (float*, float*, float*, float*, int64_t, float, float, float, float, float, float, void*))
 FN(int, p_hrea_attention_forward, (const float*, const float*, const float*, float*, float*, int, int, int, void*))
 FN(int, p_hrea_attention_backward, (const float*, const float*, const float*, float*, float*, float*, int, int, int, void*))
@@ -167,7 +168,7 @@ static void load_entry_points(const char* path) {
   LOAD(p_gemm_nn, "vd_gemm_nn"); LOAD(p_gemm_tn_acc, "vd_gemm_tn_acc"); LOAD(p_colsum_acc, "vd_colsum_acc");
   LOAD(p_lstm_forward, "vd_lstm_forward"); LOAD(p_lstm_backward, "vd_lstm_backward"); LOAD(p_embed_gather, "vd_embed_gather");
   LOAD(p_embed_scatter_acc, "vd_embed_scatter_acc"); LOAD(p_token_sort, "vd_token_sort"); LOAD(p_segment_rowsum_acc, "vd_segment_rowsum_acc");
-  LOAD(p_tanh_backward, "vd_tanh_backward"); LOAD(p_score_ce, "vd_score_ce"); LOAD(p_clamp_adam, "vd_clamp_adam");
+  LOAD(p_tanh_backward, "vd_tanh_backward"); LOAD(p_score_ce, "vd_score_ce"); LOAD(p_clamp_adam, "vd_clamp_adam"); LOAD(p_ranks, "vd_ranks");
   LOAD(p_hrea_attention_forward, "vd_hrea_attention_forward"); LOAD(p_hrea_attention_backward, "vd_hrea_attention_backward");
   LOAD(p_rowdot_forward, "vd_rowdot_forward"); LOAD(p_rowdot_backward, "vd_rowdot_backward");
   LOAD(p_mask_time_forward, "vd_mask_time_forward"); LOAD(p_mask_time_backward, "vd_mask_time_backward");

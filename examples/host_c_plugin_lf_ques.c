@@ -12,7 +12,8 @@
  * in.bin : int32 {V, E, H, B, R, O, Tq, To}, then the parameters in getParameters() order as float32 (embed [(V+1) x E],
  *          ques1.W [(E+H) x 4H], ques1.b [4H], ques2.W [2H x 4H], ques2.b, fuse.W [H x H], fuse.b [H], opt.W [(E+H) x 4H], opt.b),
  *          ques_fwd [B*R x Tq] int32, options [B*R*O x To] int32, answer_ind [B*R] int32 (1-based).
- * out.bin: float32 loss, then the flat gradient, then the flat parameters after clamp(-5,5) + adam.
+ * out.bin: float32 loss, then the flat gradient, then the flat parameters after clamp(-5,5) + adam, then the rank of the ground-truth
+ *          option of every round on the INITIAL parameters (Model:retrieveBatch).
  * Dropout is off (wrapper:evaluate()): the comparison side does the same. */
 #include <dlfcn.h>
 #include <math.h>
@@ -82,6 +83,11 @@ int main(int argc, char** argv) {
   /* criterion:forward + :backward (model.lua:330,334): nn.MM + CrossEntropyCriterion and both gradients in one kernel */
   float *scores = dev_floats((int64_t)N * O), *loss_rows = dev_floats(N), *d_optH = dev_floats((int64_t)NO * H), *d_enc = dev_floats((int64_t)N * H);
   CHECK(p_score_ce(optH, encOut, gt, scores, loss_rows, d_optH, d_enc, N, O, H, 1.0f / N, NULL));
+  /* Model:retrieveBatch (model.lua:344-430, disc branch): the same forward, then utils.computeRanks (utils.lua:106-128) on the scores --
+   * the 1-based rank of the ground-truth option of every round */
+  void* ranks_dev = NULL;
+  CHECK(p_malloc(&ranks_dev, (int64_t)N * O * 4));
+  CHECK(p_ranks(scores, (int32_t*)ranks_dev, N, O, NULL));
 
   /* decoder:backward (model.lua:335) */
   disc_backward(&dec, d_optH);
@@ -113,6 +119,9 @@ int main(int argc, char** argv) {
   fwrite(&lossf, 4, 1, o);
   for (int i = 0; i < 9; ++i) fwrite(grad_host + off[i], 4, (size_t)sizes[i], o);
   for (int i = 0; i < 9; ++i) fwrite(host + off[i], 4, (size_t)sizes[i], o);
+  int32_t* ranks_host = (int32_t*)malloc((size_t)N * O * 4);
+  CHECK(p_d2h(ranks_host, ranks_dev, (int64_t)N * O * 4, NULL));
+  for (int n = 0; n < N; ++n) { const float r = (float)ranks_host[(size_t)n * O + a_host[n]]; fwrite(&r, 4, 1, o); }   /* GT ranks (a_host is 0-based here) */
   fclose(o);
   printf("lf-ques + disc through the operator-level ABI: loss %.6f, %lld parameters\n", loss, (long long)numel);
   return 0;

@@ -7,6 +7,7 @@
 -- the whole step behind the model-level ABI, any of the 11 x 2 pairs.
 -- UNTESTED HERE (no Lua interpreter); transliteration of examples/host_c_plugin_lf_ques.c / host_c_plugin_mn_att.c /
 -- host_c_plugin_lf_ques_gen.c, which are built and checked on the GPU.
+local ffi = require 'ffi'
 local vdnn = dofile('vdnn.lua')
 local vd = vdnn.vd
 
@@ -102,7 +103,24 @@ function ModelOps:forwardBackward(batch, onlyForward)
     local host = torch.FloatTensor(N)
     vd.call('vd_stream_synchronize', nil)
     vd.call('vd_memcpy_d2h', host:data(), lossRows, N * 4, nil)
-    return host:mean()
+    return host:mean(), scores, N, O
+end
+
+-- Model:retrieveBatch (model.lua:344-430, disc branch): the forward pass, then utils.computeRanks (utils.lua:106-128) on the option scores;
+-- returns the ground-truth ranks [B x R] (params.useGt) or all ranks [N x O], as DoubleTensors like the reference
+function ModelOps:retrieveBatch(batch)
+    assert(self.params.decoder == 'disc', 'ModelOps:retrieveBatch: candidate log-likelihood retrieval of the gen decoder runs through lua/model.lua')
+    local _, scores, N, O = self:forwardBackward(batch, true)
+    local ranksDev = ffi.cast('int32_t*', vdnn.devBytes(N * O * 4))
+    vd.call('vd_ranks', scores, ranksDev, N, O, nil)
+    local ranks = torch.IntTensor(N, O)
+    vd.call('vd_stream_synchronize', nil)
+    vd.call('vd_memcpy_d2h', ranks:data(), ranksDev, N * O * 4, nil)
+    if not self.params.useGt then return ranks:double() end
+    local gtPos = batch['answer_ind']:view(-1)
+    local out = torch.DoubleTensor(N)
+    for n = 1, N do out[n] = ranks[n][gtPos[n]] end
+    return out:view(-1, self.params.maxQuesCount)
 end
 
 function ModelOps:trainIteration(dataloader)

@@ -131,7 +131,9 @@ def test_c_plugin_pair_on_the_operator_level_abi_equals_the_library(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     raw = np.fromfile(outp, np.float32)
     n = sum(P[k].size for k in names)
-    assert raw.size == 1 + 2 * n
+    assert raw.size == 1 + 2 * n + B * R
+    ranks = m.retrieveBatch(batch, useGt=True)                         # initial parameters, evaluate mode: same kernels -> equal ranks
+    np.testing.assert_array_equal(raw[1 + 2 * n:].astype(np.int64), np.asarray(ranks).reshape(-1))
     loss = m.forwardBackward(batch)
     G = m.get_gradients_dict()
     m.update()
