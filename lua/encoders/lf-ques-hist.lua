@@ -33,10 +33,11 @@ function encoderNet.model(params)
             self.histLayers[layer] = vdnn.SeqLSTM(fp, 'hist' .. layer, (layer == 1) and E or H, H)
         end
         self.fuse = vdnn.LinearTanh(fp, 'fuse', H + H, H)
+        self.drop = vdnn.Dropout(params.dropout or 0.5)                      -- nn.Dropout(dropout) in front of the Linear (lf-ques-im-hist.lua:55-57)
     end
 
     -- inputs = {ques, hist} in the order of the reference's input table (model.lua:252-279): ques / hist = {tok = device int32
-    -- [T x N] time-major, T, N}.  Dropout: wrapper:evaluate() semantics, as in lua/encoders/lf-ques.lua.
+    -- [T x N] time-major, T, N}.  Dropout: the vdnn.Dropout module, as in lua/encoders/lf-ques.lua.
     function enc:forward(inputs)
         local vd, vdnn = self.vdnn.vd, self.vdnn
         local ques, hist = inputs[1], inputs[2]
@@ -54,7 +55,8 @@ function encoderNet.model(params)
         vd.call('vd_copy_2d', cat, Dcat, qLast, H, N, H, nil)               -- nn.JoinTable(1, 1)
         vd.call('vd_copy_2d', cat + H, Dcat, hLast, H, N, H, nil)
         self.N = N
-        self.output = self.fuse:forward(cat, N)
+        self.m_f = ((params.dropout or 0.5) > 0) and self.drop:mask(N * Dcat) or nil    -- nil = identity (evaluate(), or dropout = 0)
+        self.output = self.fuse:forward(self.drop:apply(cat, self.m_f, N * Dcat), N)
         return self.output
     end
 
@@ -63,7 +65,7 @@ function encoderNet.model(params)
         local ques, hist = inputs[1], inputs[2]
         local H = params.rnnHiddenSize
         local N, L, Dcat = self.N, #self.rnnLayers, H + H
-        local dCat = self.fuse:backward(gradOutput)
+        local dCat = self.drop:apply(self.fuse:backward(gradOutput), self.m_f, N * Dcat)
         local dq, dhl = vdnn.devFloats(N * H), vdnn.devFloats(N * H)        -- JoinTable backward: question and history slices
         vd.call('vd_copy_2d', dq, H, dCat, Dcat, N, H, nil)
         vd.call('vd_copy_2d', dhl, H, dCat + H, Dcat, N, H, nil)

@@ -34,11 +34,12 @@ function encoderNet.model(params)
             self.histLayers[layer] = vdnn.SeqLSTM(fp, 'hist' .. layer, (layer == 1) and E or H, H)
         end
         self.fuse = vdnn.LinearTanh(fp, 'fuse', H + F + H, H)
+        self.drop = vdnn.Dropout(params.dropout or 0.5)                      -- nn.Dropout(dropout) in front of the Linear (lf-ques-im-hist.lua:55-57)
     end
 
     -- inputs = {ques, img, hist} in the order of the reference's input table (model.lua:252-279): ques / hist = {tok = device int32
     -- [T x N] time-major, T, N}; img = {data = device float [B x F], B}: one feature row per DIALOG (the repeatTensor over its rounds,
-    -- model.lua:266-270, is a row gather here).  Dropout: wrapper:evaluate() semantics, as in lua/encoders/lf-ques.lua.
+    -- model.lua:266-270, is a row gather here).  Dropout: the vdnn.Dropout module, as in lua/encoders/lf-ques.lua.
     function enc:forward(inputs)
         local vd, vdnn = self.vdnn.vd, self.vdnn
         local ques, img, hist = inputs[1], inputs[2], inputs[3]
@@ -60,7 +61,8 @@ function encoderNet.model(params)
         vd.call('vd_copy_2d', cat + H, Dcat, imgRep, F, N, F, nil)
         vd.call('vd_copy_2d', cat + H + F, Dcat, hLast, H, N, H, nil)
         self.N = N
-        self.output = self.fuse:forward(cat, N)
+        self.m_f = ((params.dropout or 0.5) > 0) and self.drop:mask(N * Dcat) or nil    -- nil = identity (evaluate(), or dropout = 0)
+        self.output = self.fuse:forward(self.drop:apply(cat, self.m_f, N * Dcat), N)
         return self.output
     end
 
@@ -69,7 +71,7 @@ function encoderNet.model(params)
         local ques, hist = inputs[1], inputs[3]
         local H, F = params.rnnHiddenSize, params.imgFeatureSize
         local N, L, Dcat = self.N, #self.rnnLayers, H + F + H
-        local dCat = self.fuse:backward(gradOutput)
+        local dCat = self.drop:apply(self.fuse:backward(gradOutput), self.m_f, N * Dcat)
         local dq, dhl = vdnn.devFloats(N * H), vdnn.devFloats(N * H)        -- JoinTable backward: question and history slices (the image needs none)
         vd.call('vd_copy_2d', dq, H, dCat, Dcat, N, H, nil)
         vd.call('vd_copy_2d', dhl, H, dCat + H + F, Dcat, N, H, nil)

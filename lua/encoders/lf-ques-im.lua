@@ -32,11 +32,12 @@ function encoderNet.model(params)
             self.rnnLayers[layer] = vdnn.SeqLSTM(fp, 'ques' .. layer, (layer == 1) and E or H, H)
         end
         self.fuse = vdnn.LinearTanh(fp, 'fuse', H + F, H)
+        self.drop = vdnn.Dropout(params.dropout or 0.5)                      -- nn.Dropout(dropout) in front of the Linear (lf-ques-im-hist.lua:55-57)
     end
 
     -- inputs = {ques, img} in the order of the reference's input table (model.lua:252-279): ques / hist = {tok = device int32
     -- [T x N] time-major, T, N}; img = {data = device float [B x F], B}: one feature row per DIALOG (the repeatTensor over its rounds,
-    -- model.lua:266-270, is a row gather here).  Dropout: wrapper:evaluate() semantics, as in lua/encoders/lf-ques.lua.
+    -- model.lua:266-270, is a row gather here).  Dropout: the vdnn.Dropout module, as in lua/encoders/lf-ques.lua.
     function enc:forward(inputs)
         local vd, vdnn = self.vdnn.vd, self.vdnn
         local ques, img = inputs[1], inputs[2]
@@ -54,7 +55,8 @@ function encoderNet.model(params)
         vd.call('vd_copy_2d', cat, Dcat, qLast, H, N, H, nil)               -- nn.JoinTable(1, 1)
         vd.call('vd_copy_2d', cat + H, Dcat, imgRep, F, N, F, nil)
         self.N = N
-        self.output = self.fuse:forward(cat, N)
+        self.m_f = ((params.dropout or 0.5) > 0) and self.drop:mask(N * Dcat) or nil    -- nil = identity (evaluate(), or dropout = 0)
+        self.output = self.fuse:forward(self.drop:apply(cat, self.m_f, N * Dcat), N)
         return self.output
     end
 
@@ -63,7 +65,7 @@ function encoderNet.model(params)
         local ques = inputs[1]
         local H, F = params.rnnHiddenSize, params.imgFeatureSize
         local N, L, Dcat = self.N, #self.rnnLayers, H + F
-        local dCat = self.fuse:backward(gradOutput)
+        local dCat = self.drop:apply(self.fuse:backward(gradOutput), self.m_f, N * Dcat)
         local dq = vdnn.devFloats(N * H)                                    -- JoinTable backward: the question slice (the image needs none)
         vd.call('vd_copy_2d', dq, H, dCat, Dcat, N, H, nil)
         local dSeq = self.rnnLayers[L]:backward(nil, dq, true)

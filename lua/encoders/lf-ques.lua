@@ -31,23 +31,26 @@ function encoderNet.model(params)
             self.rnnLayers[layer] = vdnn.SeqLSTM(fp, 'ques' .. layer, (layer == 1) and E or H, H)
         end
         self.fuse = vdnn.LinearTanh(fp, 'fuse', H, H)
+        self.drop = vdnn.Dropout(params.dropout or 0.5)                      -- lf-ques.lua:29-31: nn.Dropout(dropout) in front of the Linear
     end
 
-    -- inputs = {ques}: device int32 [Tq x N] time-major (+ .T, .N); returns encOut [N x H].  Dropout: wrapper:evaluate() semantics
-    -- (identity); training-mode noise is vd_dropout_mask + vd_dropout_apply around the fuse input, as visdial_amd/encoders/_late_fusion.py
+    -- inputs = {ques}: device int32 [Tq x N] time-major (+ .T, .N); returns encOut [N x H].  Dropout: the vdnn.Dropout module (identity
+    -- after ModelOps:evaluate(); the C twin runs in evaluate mode, the training-mode plumbing is the flagship twin's)
     function enc:forward(inputs)
         local ques = inputs[1]
         local T, N, H = ques.T, ques.N, params.rnnHiddenSize
         local x = self.wordEmbed:forward(ques.tok, T * N)
         for layer = 1, #self.rnnLayers do x = self.rnnLayers[layer]:forward(x, T, N, ques.tok) end
         local last = x + (T - 1) * N * H                                  -- nn.Select(1, -1)
-        self.output = self.fuse:forward(last, N)
+        self.N = N
+        self.m_f = ((params.dropout or 0.5) > 0) and self.drop:mask(N * H) or nil    -- nil = identity (evaluate(), or dropout = 0)
+        self.output = self.fuse:forward(self.drop:apply(last, self.m_f, N * H), N)
         return self.output
     end
 
     function enc:backward(inputs, gradOutput)
         local ques = inputs[1]
-        local dLast = self.fuse:backward(gradOutput)
+        local dLast = self.drop:apply(self.fuse:backward(gradOutput), self.m_f, self.N * params.rnnHiddenSize)
         local L = #self.rnnLayers
         local dSeq = self.rnnLayers[L]:backward(nil, dLast, true)        -- the gradient arrives at the last step only
         for layer = L - 1, 1, -1 do dSeq = self.rnnLayers[layer]:backward(dSeq, nil, true) end
