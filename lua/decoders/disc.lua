@@ -47,8 +47,7 @@ function decoderNet.model(params, enc)
         end
         -- gradient of the gathered table: counting sort of the tokens + segmented row sum of da, then its three consumers
         local ffi = require 'ffi'
-        local function devBytes(n) local p = ffi.new('void*[1]'); vd.call('vd_malloc', p, n); return p[0] end
-        local offs, work, perm = devBytes((V + 2) * 4), devBytes(2 * (V + 1) * 4), devBytes(T * NO * 4)
+        local offs, work, perm = vdnn.devBytes((V + 2) * 4), vdnn.devBytes(2 * (V + 1) * 4), vdnn.devBytes(T * NO * 4)
         local dtab = vdnn.devFloats((V + 1) * 4 * H)
         vd.call('vd_token_sort', opts.tok, T * NO, V + 1, ffi.cast('int32_t*', offs), ffi.cast('int32_t*', work), ffi.cast('int32_t*', perm), nil)
         vd.call('vd_segment_rowsum_acc', l.gates, 4 * H, opts.tok, ffi.cast('const int32_t*', perm), T * NO, 4 * H, dtab, 4 * H, nil)

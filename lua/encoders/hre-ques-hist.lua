@@ -48,7 +48,7 @@ function encoderNet.model(params)
             toN[i] = (n % R) * B + math.floor(n / R)            -- and back
         end
         self.idxN = N
-        self.toRb, self.toN = self.vdnn.devInts(toRb), self.vdnn.devInts(toN)
+        self.vdnn.persistent(function() self.toRb, self.toN = self.vdnn.devInts(toRb), self.vdnn.devInts(toN) end)   -- cached across steps
         return self.toRb, self.toN
     end
 

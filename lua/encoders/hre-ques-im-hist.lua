@@ -52,7 +52,9 @@ function encoderNet.model(params)
             toN[i] = (n % R) * B + math.floor(n / R)            -- and back
         end
         self.idxN = N
-        self.rep, self.toRb, self.toN = self.vdnn.devInts(rep), self.vdnn.devInts(toRb), self.vdnn.devInts(toN)
+        self.vdnn.persistent(function()                                                  -- cached across steps
+            self.rep, self.toRb, self.toN = self.vdnn.devInts(rep), self.vdnn.devInts(toRb), self.vdnn.devInts(toN)
+        end)
         return self.rep, self.toRb, self.toN
     end
 

@@ -55,7 +55,9 @@ function encoderNet.model(params)
             toN[i] = (n % R) * B + math.floor(n / R)            -- and back
         end
         self.idxN = N
-        self.rep, self.toRb, self.toN = self.vdnn.devInts(rep), self.vdnn.devInts(toRb), self.vdnn.devInts(toN)
+        self.vdnn.persistent(function()                                                  -- cached across steps
+            self.rep, self.toRb, self.toN = self.vdnn.devInts(rep), self.vdnn.devInts(toRb), self.vdnn.devInts(toN)
+        end)
         return self.rep, self.toRb, self.toN
     end
 
@@ -75,7 +77,7 @@ function encoderNet.model(params)
         local qx = self.wordEmbed:forward(ques.tok, Tq * N)
         local imgRep, xi = vdnn.devFloats(N * F), vdnn.devFloats(Tq * N * DI)
         vd.call('vd_embed_gather', img.data, rep, nil, imgRep, N, F, 1.0, nil)
-        self.m_img = self.drop:mask(N * F)
+        self.m_img = self.drop:mask(N * F, 'img')
         local imgE = self.img_embed:forward(self.drop:apply(imgRep, self.m_img, N * F), N)        -- hrea:43-48
         vd.call('vd_mask_time_forward', imgE, ques.tok, xi, Tq, N, DI, nil)                       -- hre:50-53
         local qcat = vdnn.devFloats(Tq * N * DQ)

@@ -55,7 +55,7 @@ function encoderNet.model(params)
         vd.call('vd_copy_2d', cat, Dcat, qLast, H, N, H, nil)               -- nn.JoinTable(1, 1)
         vd.call('vd_copy_2d', cat + H, Dcat, hLast, H, N, H, nil)
         self.N = N
-        self.m_f = ((params.dropout or 0.5) > 0) and self.drop:mask(N * Dcat) or nil    -- nil = identity (evaluate(), or dropout = 0)
+        self.m_f = ((params.dropout or 0.5) > 0) and self.drop:mask(N * Dcat, 'fuse') or nil    -- nil = identity (evaluate(), or dropout = 0)
         self.output = self.fuse:forward(self.drop:apply(cat, self.m_f, N * Dcat), N)
         return self.output
     end

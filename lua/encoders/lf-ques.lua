@@ -43,7 +43,7 @@ function encoderNet.model(params)
         for layer = 1, #self.rnnLayers do x = self.rnnLayers[layer]:forward(x, T, N, ques.tok) end
         local last = x + (T - 1) * N * H                                  -- nn.Select(1, -1)
         self.N = N
-        self.m_f = ((params.dropout or 0.5) > 0) and self.drop:mask(N * H) or nil    -- nil = identity (evaluate(), or dropout = 0)
+        self.m_f = ((params.dropout or 0.5) > 0) and self.drop:mask(N * H, 'fuse') or nil    -- nil = identity (evaluate(), or dropout = 0)
         self.output = self.fuse:forward(self.drop:apply(last, self.m_f, N * H), N)
         return self.output
     end

@@ -56,7 +56,7 @@ function encoderNet.model(params)
         local B = N / R
         local S5 = drop.scale
         -- text branches (mn-att:21-45): embedding + Dropout fused in the gather; maskZero via the token matrix
-        self.m_h, self.m_q = drop:mask(Th * N * E), drop:mask(Tq * N * E)
+        self.m_h, self.m_q = drop:mask(Th * N * E, 'h_emb'), drop:mask(Tq * N * E, 'q_emb')
         local hx = self.wordEmbed:forward(hist.tok, Th * N, self.m_h, S5)
         local qx = self.wordEmbed:forward(ques.tok, Tq * N, self.m_q, S5)
         self.hist1:forward(hx, Th, N, hist.tok); self.hist2:forward(self.hist1.output, Th, N, hist.tok)
@@ -68,14 +68,14 @@ function encoderNet.model(params)
         self.prob = vdnn.devFloats(N * R)
         local hatt = vdnn.devFloats(N * H)
         vd.call('vd_mn_attention_forward', q3, h3, mask, self.prob, hatt, B, R, H, nil)
-        self.m_hatt = drop:mask(N * H)
+        self.m_hatt = drop:mask(N * H, 'hatt')
         local hattTr = self.mn1:forward(drop:apply(hatt, self.m_hatt, N * H), N)
         local s2 = vdnn.devFloats(N * H)
         vd.call('vd_axpby', hattTr, q3, s2, N * H, 1.0, 1.0, nil)                                      -- nn.CAddTable
         local qh2 = self.mn2:forward(s2, N)
         -- stacked attention over the S x S regions, one hop (mn-att:68-104): per-IMAGE projection, per-round Dropout masks in the loaders
         self.pre = self.img_proj:forward(img.data, B * S2)                            -- Tanh(Linear(img)), pre-Dropout
-        self.m1, self.m2 = drop:mask(N * S2 * H), drop:mask(N * S2 * K)
+        self.m1, self.m2 = drop:mask(N * S2 * H, 'img_tr'), drop:mask(N * S2 * K, 'iqc')
         self.sc = self.m1 ~= nil and S5 or 1.0
         local qc = self.ques_common:forward(qh2, N)                                    -- mn-att:88
         local Wc, _ = fp:view('img_common.W'); local bc, _ = fp:view('img_common.b')
@@ -84,7 +84,7 @@ function encoderNet.model(params)
         local u1 = vdnn.devFloats(N * H)
         vd.call('vd_img_common_forward', self.pre, self.m1, Wc, bc, qc, self.m2, self.iqc, N, R, S2, H, K, self.sc, nil)     -- mn-att:83-92
         vd.call('vd_img_att_forward', self.iqc, wa, ba, self.pre, self.m1, qh2, self.patt, u1, N, R, S2, H, K, self.sc, nil)  -- mn-att:93-102
-        self.m_u = drop:mask(N * H)
+        self.m_u = drop:mask(N * H, 'u')
         self.output = self.out:forward(drop:apply(u1, self.m_u, N * H), N)              -- mn-att:106
         return self.output
     end

@@ -42,7 +42,7 @@ function encoderNet.model(params)
         local B = N / R
         local S5 = drop.scale
         -- text branches: embedding + Dropout fused in the gather; maskZero via the token matrix
-        self.m_h, self.m_q = drop:mask(Th * N * E), drop:mask(Tq * N * E)
+        self.m_h, self.m_q = drop:mask(Th * N * E, 'h_emb'), drop:mask(Tq * N * E, 'q_emb')
         local hx = self.wordEmbed:forward(hist.tok, Th * N, self.m_h, S5)
         local qx = self.wordEmbed:forward(ques.tok, Tq * N, self.m_q, S5)
         self.hist1:forward(hx, Th, N, hist.tok); self.hist2:forward(self.hist1.output, Th, N, hist.tok)
@@ -56,7 +56,7 @@ function encoderNet.model(params)
         self.prob = vdnn.devFloats(N * R)
         local hatt = vdnn.devFloats(N * H)
         vd.call('vd_mn_attention_forward', query, h3, mask, self.prob, hatt, B, R, H, nil)
-        self.m_hatt = drop:mask(N * H)
+        self.m_hatt = drop:mask(N * H, 'hatt')
         local hattTr = self.mn1:forward(drop:apply(hatt, self.m_hatt, N * H), N)
         local s2 = vdnn.devFloats(N * H)
         vd.call('vd_axpby', hattTr, query, s2, N * H, 1.0, 1.0, nil)                                   -- nn.CAddTable

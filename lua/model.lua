@@ -57,6 +57,7 @@ function Model:__init(params)
     self.optims = {learningRate = params.learningRate}
     self.havePrefetched = false
     self.numTokens = 0
+    self.numOptions = p.numOptions                                     -- what the library ranks over (100 in the reference: model.lua:148,199)
 end
 
 -- `model.wrapperW` (train.lua:79,100,120; evaluate.lua:91; generate.lua:83) is a real host FloatTensor: checked out
@@ -159,7 +160,7 @@ function Model:retrieveBatch(batch)
     self:upload(batch); self.havePrefetched = false
     vd.call('vd_model_retrieve', self.h)                               -- disc: option scores; gen: candidate log-likelihoods
     local N = batch['ques_fwd']:size(1) * batch['ques_fwd']:size(2)
-    local O = self.params.numOptions or 100
+    local O = self.numOptions
     local useGt = self.params.useGt and 1 or 0
     local out = torch.IntTensor(useGt == 1 and N or N * O)
     vd.call('vd_model_ranks', self.h, useGt, out:data())
@@ -198,8 +199,8 @@ end
 function Model:rankSplit(dataloader, dtype, useGt)
     self:setMode(false)
     self.params.useGt = useGt
-    self.params.numOptions = 100
-    local O, R = self.params.numOptions, self.params.maxQuesCount
+    self.params.numOptions = self.numOptions                           -- model.lua:148,199 write the constant 100 here
+    local O, R = self.numOptions, self.params.maxQuesCount
     local total = dataloader.numThreads[dtype]
     local ranks = useGt and torch.Tensor(total, R) or torch.Tensor(total, R, O)
     ranks:fill(O + 1)                                                  -- rounds never ranked keep rank 101
@@ -336,6 +337,12 @@ function Model:generateAnswers(dataloader, dtype, params)
     return answerTable
 end
 
+-- The library's tensors in the order of the REFERENCE's `wrapper:getParameters()` flat vector, so that `modelW` of a checkpoint
+-- written by the reference's train.lua loads tensor for tensor (and one written through this host loads in the reference):
+-- the library declares embed | encoder | decoder in module order, which IS the reference's order for the Sequential-built
+-- lf-* encoders; the hre-* files put the image Linear of their ConcatTable BEFORE the history branch
+-- (encoders/hre-ques-im-hist.lua:56-60) while the library declares it after -- moved here, exactly like
+-- visdial_amd/t7.py:reference_order.  (The four nngraph encoders: order derived from nngraph's node order, t7.py.)
 function Model:tensors()
     local out, name = {}, ffi.new('char[64]')
     local off, rows, cols = ffi.new('int64_t[1]'), ffi.new('int64_t[1]'), ffi.new('int64_t[1]')
@@ -343,7 +350,28 @@ function Model:tensors()
         vd.call('vd_model_tensor_info', self.h, i, name, off, rows, cols)
         table.insert(out, {name = ffi.string(name), numel = tonumber(rows[0] * cols[0])})
     end
+    if string.match(self.params.encoder, '^hre') then
+        local img, rest = {}, {}
+        for _, t in ipairs(out) do
+            if string.match(t.name, '^img_embed%.') then img[#img + 1] = t else rest[#rest + 1] = t end
+        end
+        out = {}
+        for i, t in ipairs(rest) do
+            out[#out + 1] = t
+            if i == 1 then for _, u in ipairs(img) do out[#out + 1] = u end end       -- right behind the shared embedding
+        end
+    end
     return out
+end
+
+-- pin the noise of the Dropout nodes for the NEXT steps (parity runs against a CPU restatement): masks = {site = ByteTensor keep-mask},
+-- sites as in vd_model_set_dropout_mask (q_emb, h_emb, hatt, img_tr, iqc, u, fuse, img); nil clears every pin
+function Model:setDropoutMasks(masks)
+    vd.call('vd_model_set_dropout_mask', self.h, nil, nil, 0)
+    for site, keep in pairs(masks or {}) do
+        local k = keep:byte():contiguous()
+        vd.call('vd_model_set_dropout_mask', self.h, site, k:data(), k:nElement())
+    end
 end
 
 function Model:getFlatParameters()

@@ -46,6 +46,7 @@ function ModelOps:evaluate() vdnn.training = false end
 
 function ModelOps:forwardBackward(batch, onlyForward)
     local p = self.params
+    vdnn.releaseStep()                                                                  -- the previous step's activations (vdnn.lua: step-scoped arena)
     -- the reference's input table, in its order (model.lua:252-294): ques [, img] [, hist] [, mask]
     local inputs = {timeMajor(batch['ques_fwd'])}
     if p.useIm == true then
@@ -89,7 +90,8 @@ function ModelOps:forwardBackward(batch, onlyForward)
     end
     local options = timeMajor(batch['options'])
     local O = options.N / N
-    local gt = vdnn.devInts(batch['answer_ind']:int():view(-1):add(-1):contiguous())    -- 0-based targets
+    -- 0-based targets; :clone() first -- :int() of an IntTensor is the SAME tensor and :add is in place: the caller's batch must not change
+    local gt = vdnn.devInts(batch['answer_ind']:int():contiguous():view(-1):clone():add(-1))
     local decOut = self.decoder:forward({options, encOut})                              -- model.lua:329
     -- criterion:forward(decOut, answerInd) + :backward (model.lua:330,334): nn.MM + CrossEntropyCriterion and both gradients, one kernel
     local scores, lossRows = vdnn.devFloats(N * O), vdnn.devFloats(N)

@@ -15,26 +15,49 @@ local vd = dofile('visdial_ffi.lua')
 local M = {}
 
 -- ---- device memory (the host has no CUDA tensor type: vd_malloc, vd_memcpy_*) -------------------------------------------------
-function M.devFloats(n)                                   -- torch.CudaTensor(n):zero()
+-- Activations are STEP-SCOPED: every buffer a module allocates during forward / backward is recorded in the current arena and freed by
+-- M.releaseStep(), which the Model calls at the top of each forwardBackward (the reference gets the same lifetime from Torch's
+-- allocator reusing module.output / gradInput across iterations).  Parameters, gradients and Adam moments are allocated under
+-- M.persistent(fn) and live as long as the model.
+local arena, keepAlive = {}, false
+
+local function dmalloc(bytes)
     local p = ffi.new('void*[1]')
-    local bytes = math.max(n, 4) * 4
     vd.call('vd_malloc', p, bytes)
-    vd.call('vd_memset', p[0], 0, bytes, nil)
-    return ffi.cast('float*', p[0])
+    if not keepAlive then arena[#arena + 1] = p[0] end
+    return p[0]
+end
+
+function M.persistent(fn)
+    local before = keepAlive
+    keepAlive = true
+    local r = fn()
+    keepAlive = before
+    return r
+end
+
+function M.releaseStep()
+    vd.call('vd_stream_synchronize', nil)                 -- nothing in flight may still read them
+    for i = 1, #arena do vd.call('vd_free', arena[i]) end
+    arena = {}
+end
+
+function M.devFloats(n)                                   -- torch.CudaTensor(n):zero()
+    local bytes = math.max(n, 4) * 4
+    local p = dmalloc(bytes)
+    vd.call('vd_memset', p, 0, bytes, nil)
+    return ffi.cast('float*', p)
 end
 
 function M.devInts(intTensor)                             -- IntTensor (host, contiguous) -> device int32
     local n = intTensor:nElement()
-    local p = ffi.new('void*[1]')
-    vd.call('vd_malloc', p, n * 4)
-    vd.call('vd_memcpy_h2d', p[0], intTensor:data(), n * 4, nil)
-    return ffi.cast('int32_t*', p[0])
+    local p = dmalloc(n * 4)
+    vd.call('vd_memcpy_h2d', p, intTensor:data(), n * 4, nil)
+    return ffi.cast('int32_t*', p)
 end
 
 function M.devBytes(n)                                    -- raw device bytes (byte masks, sort scratch)
-    local p = ffi.new('void*[1]')
-    vd.call('vd_malloc', p, math.max(n, 4))
-    return p[0]
+    return dmalloc(math.max(n, 4))
 end
 
 function M.devBytesFrom(byteTensor)                       -- ByteTensor (host, contiguous) -> device uint8
@@ -54,8 +77,19 @@ local dropSeed = 1234
 
 function M.Dropout(p) return setmetatable({p = p, scale = 1.0 / (1.0 - p)}, Dropout) end
 
-function Dropout:mask(n)
+-- site: the name of the Dropout node (q_emb / h_emb / hatt / img_tr / iqc / u of the nngraph encoders, fuse of lf-*, img of hrea --
+-- the same names vd_model_set_dropout_mask takes).  M.pinMasks{site = ByteTensor keep-mask, ...} makes the NEXT forward passes use
+-- the given noise instead of drawing it (parity runs against a CPU restatement); M.pinMasks(nil) returns to drawing.
+local pinned = nil
+function M.pinMasks(t) pinned = t end
+
+function Dropout:mask(n, site)
     if not M.training then return nil end
+    if pinned ~= nil and site ~= nil and pinned[site] ~= nil then
+        local keep = pinned[site]:byte():contiguous()
+        assert(keep:nElement() == n, string.format('pinned Dropout mask %s has %d elements, the node draws %d', site, keep:nElement(), n))
+        return M.devBytesFrom(keep)
+    end
     local m = ffi.cast('uint8_t*', M.devBytes(n))
     vd.call('vd_dropout_mask', m, n, dropSeed, self.p, nil)
     dropSeed = dropSeed + 1
@@ -84,7 +118,9 @@ function M.FlatParams(spec)
         o = o + align4(e[2])
     end
     self.numel = o
-    self.W = M.devFloats(o); self.dW = M.devFloats(o); self.m = M.devFloats(o); self.v = M.devFloats(o)
+    M.persistent(function()
+        self.W = M.devFloats(o); self.dW = M.devFloats(o); self.m = M.devFloats(o); self.v = M.devFloats(o)
+    end)
     return self
 end
 
