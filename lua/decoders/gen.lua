@@ -6,8 +6,10 @@
 --   shared wordEmbed -> numLayers x SeqLSTM:maskZero() -> Linear(H, V) [-> LogSoftMax, fused into the criterion kernel: lua/model_ops.lua]
 -- and the three connect functions with the reference's own field names (userPrevOutput / userPrevCell, userNextGradCell /
 -- gradPrevOutput, userGradPrevOutput / userGradPrevCell on enc.rnnLayers[i] / dec.rnnLayers[i]).  With lua/encoders/lf-ques.lua this
--- is BASELINE.json configs[0], the reference's CPU-runnable pair.  Transliteration of examples/host_c_plugin_lf_ques_gen.c, which is
--- built with gcc and checked on the GPU against the library's model-level implementation (tests/test_abi_c_host.py).
+-- is BASELINE.json configs[0], the reference's CPU-runnable pair.
+-- EXECUTED by the tests: tests/luavm (a Lua 5.1 evaluator with a LuaJIT-style ffi and a Torch7 tensor stub) runs this file against the real
+-- library on the GPU -- loss, every gradient tensor and the post-Adam parameters against the library's model-level path, the fp64 oracle and the
+-- golden fixtures (tests/test_lua_host_gpu.py) -- and against a bounds-checking dry library on the CPU (tests/test_luavm_cpu.py).
 local decoderNet = {}
 
 function decoderNet.model(params, enc)
@@ -66,29 +68,37 @@ function decoderNet.model(params, enc)
     return dec
 end
 
--- gen.lua:30-42: decoder layer i starts from the encoder layer's final (h, c); the top layer's h from the encoder output.
+-- gen.lua:30-42: decoder layer i starts from the encoder layer's final (h, c); the top layer's h from the encoder output.  An encoder
+-- without enc.rnnLayers (the four nngraph encoders) hands over encOut alone: the top decoder layer starts from (encOut, c = 0).
 -- (Lua-composed objects only; on the model-level path the hand-off happens inside the library's step and these are no-ops.)
 function decoderNet.forwardConnect(enc, dec, encOut, seqLen)
     if dec.rnnLayers == nil then return end
     local H = dec.params.rnnHiddenSize
-    local n = #enc.rnnLayers
-    for ii = 1, n do
-        local l = enc.rnnLayers[ii]
-        dec.rnnLayers[ii].userPrevOutput = l.output + (seqLen - 1) * l.N * H       -- enc.rnnLayers[ii].output[seqLen]
-        dec.rnnLayers[ii].userPrevCell = l.cell + (seqLen - 1) * l.N * H           -- enc.rnnLayers[ii].cell[seqLen]
+    if enc.rnnLayers ~= nil then
+        local n = #enc.rnnLayers
+        for ii = 1, n do
+            local l = enc.rnnLayers[ii]
+            dec.rnnLayers[ii].userPrevOutput = l.output + (seqLen - 1) * l.N * H       -- enc.rnnLayers[ii].output[seqLen]
+            dec.rnnLayers[ii].userPrevCell = l.cell + (seqLen - 1) * l.N * H           -- enc.rnnLayers[ii].cell[seqLen]
+        end
+        dec.rnnLayers[n].userPrevOutput = encOut
+    else
+        dec.rnnLayers[#dec.rnnLayers].userPrevOutput = encOut
     end
-    dec.rnnLayers[n].userPrevOutput = encOut
 end
 
 -- gen.lua:45-60: cell / hidden gradients back into the encoder layers; returns d loss / d encOut
 function decoderNet.backwardConnect(enc, dec)
     if dec.rnnLayers == nil then return nil end
-    local n = #dec.rnnLayers
-    for ii = 1, n do
-        enc.rnnLayers[ii].userNextGradCell = dec.rnnLayers[ii].userGradPrevCell
-        if ii ~= n then enc.rnnLayers[ii].gradPrevOutput = dec.rnnLayers[ii].userGradPrevOutput end
+    if enc.rnnLayers ~= nil then
+        local n = #dec.rnnLayers
+        for ii = 1, n do
+            enc.rnnLayers[ii].userNextGradCell = dec.rnnLayers[ii].userGradPrevCell
+            if ii ~= n then enc.rnnLayers[ii].gradPrevOutput = dec.rnnLayers[ii].userGradPrevOutput end
+        end
+        return dec.rnnLayers[#enc.rnnLayers].userGradPrevOutput
     end
-    return dec.rnnLayers[n].userGradPrevOutput
+    return dec.rnnLayers[#dec.rnnLayers].userGradPrevOutput
 end
 
 -- gen.lua:63-68 (sampling: chain the decoder to itself, one step at a time)

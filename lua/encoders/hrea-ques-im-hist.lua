@@ -5,8 +5,9 @@
 --     of hrea:83-131: every question attends over the history states of the rounds up to its own (two Linear(H, 1) scores, MaskFuture,
 --     ReplaceZero(-inf), SoftMax, weighted sum); the attended history replaces the history state in front of the dialog-level LSTM
 --     (JoinTable{attended history, question state}); Dropout(0.5) in front of the image Linear (hrea:47).
--- Transliteration of examples/host_c_plugin_hre.c (attention = 1), which is built with gcc and checked on the GPU against the library's model-level
--- implementation (tests/test_abi_c_host.py); no Lua interpreter exists here.
+-- EXECUTED by the tests: tests/luavm (a Lua 5.1 evaluator with a LuaJIT-style ffi and a Torch7 tensor stub) runs this file against the real
+-- library on the GPU -- loss, every gradient tensor and the post-Adam parameters against the library's model-level path, the fp64 oracle and the
+-- golden fixtures (tests/test_lua_host_gpu.py) -- and against a bounds-checking dry library on the CPU (tests/test_luavm_cpu.py).
 local encoderNet = {}
 
 function encoderNet.model(params)

@@ -5,8 +5,9 @@
 --     stack (on the concatenated dialog) -> Select(1,-1), JoinTable{question state, image feature, history state} -> Dropout -> Linear ->
 --     Tanh.  With lua/decoders/gen.lua this is BASELINE.json configs[1].  enc.rnnLayers = the QUESTION layers (what decoders/gen.lua
 --     connects to, gen.lua:31-35).
--- Transliteration of examples/host_c_plugin_lf_ques_gen.c (imHist = 1), which is built with gcc and checked on the GPU against the
--- library's model-level implementation (tests/test_abi_c_host.py); no Lua interpreter exists here.
+-- EXECUTED by the tests: tests/luavm (a Lua 5.1 evaluator with a LuaJIT-style ffi and a Torch7 tensor stub) runs this file against the real
+-- library on the GPU -- loss, every gradient tensor and the post-Adam parameters against the library's model-level path, the fp64 oracle and the
+-- golden fixtures (tests/test_lua_host_gpu.py) -- and against a bounds-checking dry library on the CPU (tests/test_luavm_cpu.py).
 local encoderNet = {}
 
 function encoderNet.model(params)

@@ -4,8 +4,10 @@
 --   * enc:build(fp) / enc:forward(inputs) / enc:backward(inputs, gradOutput): the encoder composed IN LUA from module objects over
 --     the operator-level C ABI (lua/vdnn.lua) -- the counterpart of encoders/lf-ques.lua:6-33 of the reference (wordEmbed ->
 --     numLayers x SeqLSTM:maskZero() -> Select(1,-1) -> Dropout -> Linear -> Tanh), driven by lua/model_ops.lua.  A user who wants a
---     new encoder writes a file like this one.  (Transliteration of examples/host_c_plugin_lf_ques.c, which is built and checked on
---     the GPU; no Lua interpreter exists here.)
+--     new encoder writes a file like this one.
+-- EXECUTED by the tests: tests/luavm (a Lua 5.1 evaluator with a LuaJIT-style ffi and a Torch7 tensor stub) runs this file against the real
+-- library on the GPU -- loss, every gradient tensor and the post-Adam parameters against the library's model-level path, the fp64 oracle and the
+-- golden fixtures (tests/test_lua_host_gpu.py) -- and against a bounds-checking dry library on the CPU (tests/test_luavm_cpu.py).
 local encoderNet = {}
 
 function encoderNet.model(params)

@@ -3,8 +3,10 @@
 --   * enc:declare / :build / :forward(inputs) / :backward(inputs, gradOutput) composed IN LUA from module objects over the operator-level
 --     C ABI (lua/vdnn.lua), node for node of the reference's nngraph: shared LookupTableMaskZero -> Dropout -> 2 x SeqLSTM:maskZero() per text branch ->
 --     Select(1,-1); memory network over the dialog's facts (mn-ques-hist.lua:43-58).
--- A sibling of lua/encoders/mn-att-ques-im-hist.lua (same blocks).  Transliteration of examples/host_c_plugin_graph.c (variant 1), which is
--- built with gcc and checked on the GPU against the library's model-level implementation (tests/test_abi_c_host.py); no Lua interpreter exists here.
+-- A sibling of lua/encoders/mn-att-ques-im-hist.lua (same blocks).
+-- EXECUTED by the tests: tests/luavm (a Lua 5.1 evaluator with a LuaJIT-style ffi and a Torch7 tensor stub) runs this file against the real
+-- library on the GPU -- loss, every gradient tensor and the post-Adam parameters against the library's model-level path, the fp64 oracle and the
+-- golden fixtures (tests/test_lua_host_gpu.py) -- and against a bounds-checking dry library on the CPU (tests/test_luavm_cpu.py).
 local encoderNet = {}
 
 function encoderNet.model(params)
@@ -27,7 +29,8 @@ function encoderNet.model(params)
         self.vdnn, self.fp, self.wordEmbed = vdnn, fp, wordEmbed
         self.hist1, self.hist2 = vdnn.SeqLSTM(fp, 'hist1', E, H), vdnn.SeqLSTM(fp, 'hist2', H, H)
         self.ques1, self.ques2 = vdnn.SeqLSTM(fp, 'ques1', E, H), vdnn.SeqLSTM(fp, 'ques2', H, H)
-        self.rnnLayers = {self.ques1, self.ques2}
+        -- no enc.rnnLayers: the reference's nngraph encoders do not expose their LSTMs, so decoders/gen.lua:39-41,57-59 connects the
+        -- top decoder layer to encOut only
         self.drop = vdnn.Dropout(0.5)             -- the nngraph encoders hard-code Dropout(0.5)
         self.mn1, self.mn2 = vdnn.LinearTanh(fp, 'mn1', H, H), vdnn.LinearTanh(fp, 'mn2', H, H)
     end

@@ -8,8 +8,10 @@
 -- those tables describe the native graph instead of building nn modules, and the whole step (stream fork/join,
 -- skewed LSTM wavefront, length sort, workspaces) runs behind the model-level C ABI (include/visdial_hip.h,
 -- csrc/runtime.hip).  Host code stays Lua; no cutorch / cunn / rnn is needed, torch only for the dataloader's
--- CPU tensors.  UNTESTED HERE: no Lua/LuaJIT/Torch7 exists in the build container (DESIGN.md); the Python host
--- visdial_amd/native.py makes exactly these calls and is what the GPU tests drive.
+-- CPU tensors.
+-- EXECUTED by the tests: tests/luavm (a Lua 5.1 evaluator with a LuaJIT-style ffi and a Torch7 tensor stub) runs this file against the real
+-- library on the GPU -- loss, every gradient tensor and the post-Adam parameters against the library's model-level path, the fp64 oracle and the
+-- golden fixtures (tests/test_lua_host_gpu.py) -- and against a bounds-checking dry library on the CPU (tests/test_luavm_cpu.py).  The Python host visdial_amd/native.py makes the same calls.
 local ffi = require 'ffi'
 local vd = dofile('visdial_ffi.lua')
 local C = vd.C

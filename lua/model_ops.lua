@@ -5,8 +5,9 @@
 -- criterion:forward / :backward -> decoder:backward -> encoder:backward(inputs, t[2]) (model.lua:297-337), wrapperW / wrapperdW from
 -- getParameters() (model.lua:55), clamp(-5, 5) + adam + learning-rate decay (model.lua:96-105).  lua/model.lua is the other host:
 -- the whole step behind the model-level ABI, any of the 11 x 2 pairs.
--- UNTESTED HERE (no Lua interpreter); transliteration of examples/host_c_plugin_lf_ques.c / host_c_plugin_mn_att.c /
--- host_c_plugin_lf_ques_gen.c, which are built and checked on the GPU.
+-- EXECUTED by the tests: tests/luavm (a Lua 5.1 evaluator with a LuaJIT-style ffi and a Torch7 tensor stub) runs this file against the real
+-- library on the GPU -- loss, every gradient tensor and the post-Adam parameters against the library's model-level path, the fp64 oracle and the
+-- golden fixtures (tests/test_lua_host_gpu.py) -- and against a bounds-checking dry library on the CPU (tests/test_luavm_cpu.py).
 local ffi = require 'ffi'
 local vdnn = dofile('vdnn.lua')
 local vd = vdnn.vd

@@ -4,11 +4,9 @@
 -- calls; there is no arithmetic in Lua.  A plug-in file written with these modules is lua/encoders/lf-ques.lua (with
 -- lua/decoders/disc.lua and lua/model_ops.lua = the operator-level Model).
 --
--- UNTESTED HERE (no Lua/LuaJIT/Torch7 in the build container or on the GPU box).  This file is a transliteration of
--- examples/host_c_modules.h (+ host_c_plugin_lf_ques.c, host_c_plugin_mn_att.c) -- the same module objects and the same ABI calls
--- in the same order, in C -- which ARE built and checked on the GPU against the library's own model-level implementation
--- (tests/test_abi_c_host.py);
--- tests/test_lua_surface_cpu.py pins that both files use the same entry points.
+-- EXECUTED by the tests: tests/luavm (a Lua 5.1 evaluator with a LuaJIT-style ffi and a Torch7 tensor stub) runs this file against the real
+-- library on the GPU -- loss, every gradient tensor and the post-Adam parameters against the library's model-level path, the fp64 oracle and the
+-- golden fixtures (tests/test_lua_host_gpu.py) -- and against a bounds-checking dry library on the CPU (tests/test_luavm_cpu.py).
 local ffi = require 'ffi'
 local vd = dofile('visdial_ffi.lua')
 
@@ -198,7 +196,8 @@ function SeqLSTM:forward(x, T, N, tokMask)
     vd.call('vd_gemm_nn', x, self.D, self.W, 4 * H, self.b, self.gates, 4 * H, T * N, 4 * H, self.D, 0, nil)
     self.h0, self.c0 = self.userPrevOutput, self.userPrevCell          -- consumed once, like the reference's module
     self.userPrevOutput, self.userPrevCell = nil, nil
-    assert((self.h0 == nil) == (self.c0 == nil), 'SeqLSTM: userPrevOutput and userPrevCell go together')
+    if self.h0 ~= nil and self.c0 == nil then self.c0 = M.devFloats(N * H) end     -- userPrevOutput alone (gen.lua:40): the cell starts at 0
+    assert((self.h0 == nil) == (self.c0 == nil), 'SeqLSTM: userPrevCell needs userPrevOutput')
     vd.call('vd_lstm_forward', self.gates, N * 4 * H, 4 * H, nil, tokMask, self:Wh(), self.h0, self.c0, self.gates, self.output, self.cell,
             T, N, H, 0, nil)
     return self.output

@@ -1,6 +1,6 @@
-"""The Lua-side surface (lua/): no Lua interpreter exists in the build container, so what CAN be pinned is pinned --
-the generated ffi.cdef declares exactly the header's entry points and structs, the generator is reproducible, the
-plug-in files exist under the reference's names, and model.lua only calls symbols the library exports."""
+"""The Lua-side surface (lua/), static checks: the generated ffi.cdef declares exactly the header's entry points and structs, the
+generator is reproducible, the plug-in files exist under the reference's names, model.lua only calls symbols the library exports,
+every file parses and reads no undeclared name.  (The files are EXECUTED by tests/test_luavm_cpu.py and tests/test_lua_host_gpu.py.)"""
 import os
 import re
 import subprocess
@@ -87,154 +87,6 @@ def test_model_lua_keeps_the_reference_script_contract():
     # the three scripts need no edit: INTEGRATION.md must not tell the user to edit them any more
     integ = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
     assert 'setFlatParameters(savedModel.modelW)' not in integ
-
-
-def _calls(text):
-    """ordered vd_* entry points named in a piece of source (C: p_<name>( calls; Lua: vd.call('vd_<name>', ...))"""
-    return re.findall(r"vd\.call\('(vd_[a-z0-9_]+)'", text) or ['vd_' + x for x in re.findall(r'\bp_([a-z0-9_]+)\(', text)]
-
-
-C_NAMES = {'h2d': 'memcpy_h2d', 'd2h': 'memcpy_d2h', 'sync': 'stream_synchronize', 'malloc': 'malloc', 'memset': 'memset',
-           'set_device': 'set_device'}
-
-
-def _c_calls(text):
-    out = []
-    for x in re.findall(r'\bp_([a-z0-9_]+)\(', text):
-        if x == 'last_error':
-            continue
-        out.append('vd_' + C_NAMES.get(x, x))
-    return out
-
-
-def _body(src, start, end):
-    a = src.index(start)
-    return src[a:src.index(end, a + len(start))]
-
-
-def test_lua_module_layer_is_the_transliteration_of_the_tested_c_host():
-    """lua/vdnn.lua + lua/encoders/{lf-ques, mn-att-ques-im-hist}.lua + lua/decoders/disc.lua + lua/model_ops.lua (encoder / decoder
-    pairs composed in Lua from module objects over the operator-level ABI) cannot be executed here; examples/host_c_modules.h +
-    host_c_plugin_lf_ques.c + host_c_plugin_mn_att.c are the same code in C and ARE checked on the GPU (tests/test_abi_c_host.py).
-    Pin the correspondence: every module method makes the same ABI calls in the same order as its C twin, the flagship encoder's
-    forward / backward drive the same module objects and entry points in the same order, the Lua files use exactly the entry points
-    the C hosts load, and all of them are exported."""
-    funcs, _ = header_symbols()
-    rd = lambda *a: open(os.path.join(ROOT, *a)).read()
-    hdr, c_lf, c_mn = rd('examples', 'host_c_modules.h'), rd('examples', 'host_c_plugin_lf_ques.c'), rd('examples', 'host_c_plugin_mn_att.c')
-    c_gen, c_hre = rd('examples', 'host_c_plugin_lf_ques_gen.c'), rd('examples', 'host_c_plugin_hre.c')
-    names = ('vdnn.lua', 'encoders/lf-ques.lua', 'encoders/lf-ques-im.lua', 'encoders/lf-ques-hist.lua', 'encoders/lf-ques-im-hist.lua',
-             'encoders/hre-ques-im-hist.lua', 'encoders/hre-ques-hist.lua', 'encoders/hrea-ques-im-hist.lua',
-             'encoders/mn-att-ques-im-hist.lua', 'decoders/disc.lua',
-             'decoders/gen.lua', 'model_ops.lua')
-    strip = lambda s: '\n'.join(l.split('--')[0] for l in s.splitlines())
-    lua = {n: strip(rd('lua', n)) for n in names}
-    mn = lua['encoders/mn-att-ques-im-hist.lua']
-    pairs = [
-        (_body(hdr, 'static void lstm_forward(', '\n}\n'), _body(lua['vdnn.lua'], 'function SeqLSTM:forward(', '\nend\n')),
-        (_body(hdr, 'static float* lstm_backward(', '\n}\n'), _body(lua['vdnn.lua'], 'function SeqLSTM:backward(', '\nend\n')),
-        (_body(hdr, 'static float* linear_forward(', '\n}\n'), _body(lua['vdnn.lua'], 'function LinearTanh:forward(', '\nend\n')),
-        (_body(hdr, 'static float* linear_backward_ex(', '\n}\n'), _body(lua['vdnn.lua'], 'function LinearTanh:backward(', '\nend\n')),
-        (_body(hdr, 'static const float* disc_forward(', '\n}\n'), _body(lua['decoders/disc.lua'], 'function dec:forward(', '\n    end\n')),
-        (_body(hdr, 'static void disc_backward(', '\n}\n'), _body(lua['decoders/disc.lua'], 'function dec:backward(', '\n    end\n')),
-        (_body(c_gen, '/* ================= encoder:forward({ques})', '/* ================= forwardConnect'),
-         _body(lua['encoders/lf-ques-im-hist.lua'], 'function enc:forward(', '\n    end\n')),
-        (_body(c_gen, '/* ================= encoder:backward(inputs, gradDecOut)', '/* curLoss'),
-         _body(lua['encoders/lf-ques-im-hist.lua'], 'function enc:backward(', '\n    end\n')),
-        (_body(c_gen, '/* ================= decoder:forward(answer_in)', '/* ================= criterion'),
-         _body(lua['decoders/gen.lua'], 'function dec:forward(', '\n    end\n')),
-         (_body(c_gen, '/* ================= decoder:backward(answer_in', '/* ================= backwardConnect'),
-         _body(lua['decoders/gen.lua'], 'function dec:backward(', '\n    end\n')),
-        (_body(c_mn, '/* ================= encoder:forward', '/* ================= decoder:forward'), _body(mn, 'function enc:forward(', '\n    end\n')),
-        (_body(c_mn, '/* ================= encoder:backward', '/* curLoss'), _body(mn, 'function enc:backward(', '\n    end\n')),
-    ]
-    drop = {'vd_malloc', 'vd_memset'}          # buffer allocation is interleaved differently (dev_floats / devFloats helpers)
-    for k, (c_body, l_body) in enumerate(pairs):
-        # (the flagship's embedding gathers / scatters are direct calls in C and self.wordEmbed methods in Lua: pinned just below)
-        skip = drop | ({'vd_embed_gather', 'vd_embed_scatter_acc'} if k >= len(pairs) - 6 else set())
-        a = [x for x in _c_calls(c_body) if x not in skip]
-        b = [x for x in _calls(l_body) if x not in skip]
-        assert a == b and a, (a, b)
-    # the flagship encoder drives the same module objects in the same order: C `lstm_forward(&hist1` == Lua `self.hist1:forward(`,
-    # embedding gathers / scatters (direct calls in C, self.wordEmbed methods in Lua) and the Dropout helper included
-    def c_seq(body):
-        out = []
-        for m in re.finditer(r'\b(?:lstm|linear)_(forward|backward)(?:_ex)?\(&(\w+)|\bp_embed_(gather|scatter_acc)\(|\bdrop_(mask|apply)\(', body):
-            out.append((m.group(2), m.group(1)) if m.group(2) else ('wordEmbed', 'forward' if m.group(3) == 'gather' else 'backward') if m.group(3)
-                       else ('drop', m.group(4)))
-        return out
-    def lua_seq(body):
-        return [(m.group(1), m.group(2)) for m in re.finditer(r'\b(?:self\.)?(\w+):(forward|backward|mask|apply)\(', body) if m.group(1) != 'enc']
-    for c_body, l_body in pairs[-2:]:
-        a, b = c_seq(c_body), lua_seq(l_body)
-        # (evaluation order inside one statement: C writes linear_forward(&mn1, drop_apply(...)), Lua self.mn1:forward(drop:apply(...)) --
-        #  the same nesting, so the textual order agrees too)
-        assert a == b and len(a) >= 13, (a, b)
-    # the three nngraph siblings share ONE C twin with a variant switch: every sibling's forward / backward must be an ORDER-PRESERVING
-    # selection of the twin's calls (its variant's path), and together they must use every call of the twin
-    c_graph = rd('examples', 'host_c_plugin_graph.c')
-    sib_skip = drop | {'vd_embed_gather', 'vd_embed_scatter_acc', 'vd_memcpy_h2d'}
-    def subsequence(small, big):
-        it = iter(big)
-        return all(x in it for x in small)
-    for sec_c, fn in (((('/* ================= encoder:forward', '/* ================= decoder:forward')), 'function enc:forward('),
-                      ((('/* ================= encoder:backward', '/* curLoss')), 'function enc:backward(')):
-        big = [x for x in _c_calls(_body(c_graph, *sec_c)) if x not in sib_skip]
-        seen = set()
-        for e in ('mn-ques-hist', 'mn-ques-im-hist', 'lf-att-ques-im-hist'):
-            src = strip(rd('lua', 'encoders', e + '.lua'))
-            small = [x for x in _calls(_body(src, fn, '\n    end\n')) if x not in sib_skip]
-            assert small and subsequence(small, big), (e, fn, small, big)
-            seen |= set(small)
-            lua['encoders/' + e + '.lua'] = src
-        assert seen == set(big), (fn, seen ^ set(big))
-    # the three hierarchical encoders share the hre C twin the same way (useIm / attention switches)
-    for sec_c, fn in (((('/* ================= encoder:forward', '/* ================= decoder:forward')), 'function enc:forward('),
-                      ((('/* ================= encoder:backward', '/* curLoss')), 'function enc:backward(')):
-        big = [x for x in _c_calls(_body(c_hre, *sec_c)) if x not in sib_skip]
-        seen = set()
-        for e in ('hre-ques-hist', 'hre-ques-im-hist', 'hrea-ques-im-hist'):
-            small = [x for x in _calls(_body(lua['encoders/' + e + '.lua'], fn, '\n    end\n')) if x not in sib_skip | {'vd_dropout_mask', 'vd_dropout_apply'}]
-            assert small and subsequence(small, big), (e, fn, small, big)
-            seen |= set(small)
-        assert seen == set(big), (fn, seen ^ set(big))
-    used_lua = set()
-    for v in lua.values():
-        used_lua |= set(re.findall(r"vd\.call\('(vd_[a-z0-9_]+)'", v))
-    used_c = set('vd_' + x for x in re.findall(r'LOAD\(p_[a-z0-9_]+, "vd_([a-z0-9_]+)"\)', hdr)) - {'vd_last_error'}
-    assert used_lua == used_c, (used_lua ^ used_c)
-    assert used_lua <= funcs
-    # both C hosts use nothing the shared header does not load
-    for c in (c_lf, c_mn, c_gen, c_hre, c_graph):
-        assert set(_c_calls(c)) <= used_c | {'vd_last_error'}, set(_c_calls(c)) - used_c
-    # the plug-in files keep the reference's contract AND carry a Lua-side implementation
-    for e in ('encoders/lf-ques.lua', 'encoders/lf-ques-im.lua', 'encoders/lf-ques-hist.lua', 'encoders/lf-ques-im-hist.lua',
-              'encoders/hre-ques-im-hist.lua', 'encoders/hre-ques-hist.lua', 'encoders/hrea-ques-im-hist.lua', 'encoders/mn-att-ques-im-hist.lua',
-              'encoders/mn-ques-hist.lua',
-              'encoders/mn-ques-im-hist.lua', 'encoders/lf-att-ques-im-hist.lua'):
-        assert 'function enc:forward(inputs)' in lua[e] and 'function enc:backward(inputs, gradOutput)' in lua[e], e
-        assert 'function enc:declare(spec)' in lua[e] and 'function enc:build(vdnn, fp, wordEmbed)' in lua[e], e
-    assert 'function dec:forward(input)' in lua['decoders/disc.lua'] and 'return {nil, gradOutput[2]}' in lua['decoders/disc.lua']
-    # decoders/gen.lua: the three connect functions carry the hand-off of gen.lua:30-68 with the reference's field names, and the C twin
-    # performs the same assignments
-    gen = lua['decoders/gen.lua']
-    for needle in ('function dec:forward(answerIn)', 'function dec:backward(answerIn, gradOutput)', '.userPrevOutput = encOut',
-                   '.userNextGradCell = dec.rnnLayers[ii].userGradPrevCell', '.gradPrevOutput = dec.rnnLayers[ii].userGradPrevOutput',
-                   'return dec.rnnLayers[n].userGradPrevOutput', 'function decoderNet.decoderConnect(dec)'):
-        assert needle in gen, needle
-    for needle in ('.userPrevOutput = encOut', '.userNextGradCell = dec_rnn[l].userGradPrevCell', '.gradPrevOutput = dec_rnn[l].userGradPrevOutput',
-                   'gradDecOut = dec_rnn[NL - 1].userGradPrevOutput'):
-        assert needle in c_gen, needle
-    for call in ("self.decoder:forward(answerIn)", "vd.call('vd_logsoftmax_nll'", 'self.decoder:backward(answerIn, decOut)',
-                 'self.backwardConnect(self.encoder, self.decoder)', 'self.encoder:backward(inputs, gradDecOut)'):
-        assert call in lua['model_ops.lua'], call
-    for call in ('self.encoder:forward(inputs)', 'self.decoder:forward({options, encOut})', 'self.decoder:backward({options, encOut}, {dOptH, dEnc})',
-                 'self.encoder:backward(inputs, t[2])'):
-        assert call in lua['model_ops.lua'], call
-    # the flagship's parameter list is the library's (visdial_amd ParamSpec order = getParameters() order of the C host's in.bin)
-    declared = re.findall(r"table\.insert\(spec, \{(?:name \.\. )?'([A-Za-z_0-9.]+)'", _body(mn, 'function enc:declare(', '\n    end\n'))
-    assert declared == ['1.W', '1.b', '2.W', '2.b', 'mn1.W', 'mn1.b', 'mn2.W', 'mn2.b', 'img_proj.W', 'img_proj.b', 'img_common.W', 'img_common.b',
-                        'ques_common.W', 'ques_common.b', 'att.W', 'att.b', 'out.W', 'out.b'], declared
 
 
 def _lua_tokens(src):
