@@ -59,14 +59,22 @@ FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2
 STEP_GFLOP_PER_ROUND = 21.934          # nominal dense math of the reference graph per QA round
 
 
-def headline_params(rank=0, batch=20, config=3):
-    """config 3 = BASELINE.json configs[3] (the headline: 14x14x512 pool5 map, fp32); config 4 = configs[4]
-    (ResNet-200 7x7x2048 features, bf16 operands for the option recurrence; informative, never the default)"""
+def config_params(config, rank=0, batch=20):
+    """BASELINE.json configs[config] at its quoted size (batch 20, V = 11 322, H = 512, E = 300):
+      1 = lf-ques-im-hist + gen, VGG-16 fc7 (4096-d);            2 = hre-ques-im-hist + disc, fc7, 100 options;
+      3 = mn-att-ques-im-hist + disc, 14x14x512 pool5 (HEADLINE); 4 = the same with ResNet-200 7x7x2048 features and bf16 operands
+      in the option recurrence (informative, never the default)"""
     from visdial_amd.opts import default_params
-    kw = dict(imgFeatureSize=512, imgSpatialSize=14) if config == 3 else dict(imgFeatureSize=2048, imgSpatialSize=7,
-                                                                              lstmPrecision='bf16')
-    return default_params(encoder='mn-att-ques-im-hist', decoder='disc', batchSize=batch, vocabSize=11322,
-                          gpuid=int(os.environ.get('LOCAL_RANK', 0)), rank=rank, maxHistoryLenPerRound=40, **kw)
+    kw = {1: dict(encoder='lf-ques-im-hist', decoder='gen', imgFeatureSize=4096),
+          2: dict(encoder='hre-ques-im-hist', decoder='disc', imgFeatureSize=4096),
+          3: dict(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=512, imgSpatialSize=14),
+          4: dict(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=2048, imgSpatialSize=7, lstmPrecision='bf16')}[config]
+    return default_params(batchSize=batch, vocabSize=11322, gpuid=int(os.environ.get('LOCAL_RANK', 0)), rank=rank,
+                          maxHistoryLenPerRound=40, **kw)
+
+
+def headline_params(rank=0, batch=20, config=3):
+    return config_params(config, rank=rank, batch=batch)
 
 
 def dominant_kernel_alone(p, N, iters=3):

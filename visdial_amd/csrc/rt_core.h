@@ -121,6 +121,7 @@ struct vd_model {
   int N = 0, O = 0;
   // capability flags from the encoder NAME (opts.lua:54-67)
   bool use_im = false, use_hist = false, is_att = false, is_graph = false;
+  bool prof_hist = false;   // ev_prof[0..3] bracket the history branch of a Sequential encoder (gen pairs: vd_model_family_ms)
   ~vd_model();
 };
 

@@ -272,16 +272,19 @@ struct Gen : Decoder {
     VD_TRY(ws_get(m, "dec.loss_rows", (size_t)rows, &loss_rows));
     VD_TRY(vd_embed_gather(Wp(m, "embed"), b.ain.tok, nullptr, x, rows, (int)E, 1.f, s));
     VD_TRY(lstm_stack_forward(m, s, rnn, {x}, Ta, N, b.ain.tok, &h));
+    m->prof_valid = false;
+    m->prof_hist = false;
+    VD_HIP(hipEventRecord(m->ev_prof[4], s));          // family 3 of a gen pair: vocabulary projection + criterion + their gradients
     VD_TRY(vd_gemm_nt(h, H, Wp(m, "vocab.W"), H, Wp(m, "vocab.b"), logits, Vp, (int)rows, (int)V, (int)H, VD_ACT_NONE, 0, s));
     VD_TRY(vd_logsoftmax_nll(logits, Vp, rows, (int)V, b.ain.tok, b.aout.tok, loss_rows, only_forward ? 0 : 1, s));   // model.lua:309-311
     VD_TRY(stage_loss(m, loss_rows, rows, true, s));
-    m->prof_valid = false;
     if (only_forward) return VD_OK;
     float* dh;                                                                      // logits now hold d loss / d logits
     VD_TRY(ws_get(m, "dec.dh", (size_t)rows * H, &dh));
     VD_TRY(vd_gemm_tn_acc(logits, Vp, h, H, Gp(m, "vocab.W"), H, (int)V, (int)H, (int)rows, 0, s));
     VD_TRY(vd_colsum_acc(logits, Vp, (int)rows, (int)V, Gp(m, "vocab.b"), s));
     VD_TRY(vd_gemm_nn(logits, Vp, Wp(m, "vocab.W"), H, nullptr, dh, H, (int)rows, (int)H, (int)V, 0, s));
+    VD_HIP(hipEventRecord(m->ev_prof[5], s));
     std::vector<float*> dx;
     VD_TRY(lstm_stack_backward(m, s, rnn, nullptr, dh, &dx));                       // model.lua:316
     VD_TRY(vd_embed_scatter_acc(Gp(m, "embed"), b.ain.tok, nullptr, dx[0], rows, (int)E, 1.f, s));
@@ -290,6 +293,7 @@ struct Gen : Decoder {
     VD_TRY(m->enc->backward(m, s, b, gradDecOut));                                  // model.lua:322
     VD_HIP(hipEventRecord(m->ev_enc_grads, s));
     m->enc_grads_recorded = true;
+    m->prof_valid = m->prof_hist;       // [history branch fwd, history branch bwd, vocabulary family] (vd_model_family_ms)
     return VD_OK;
   }
   // Model:retrieveBatch gen branch (model.lua:392-420) + utils.computeLhood (utils.lua:86-102).  The reference loops

@@ -52,18 +52,20 @@ struct TextBranches {
     E = m->p.embedSize; H = m->p.rnnHiddenSize;
     hist1.init("hist1", E, H); hist2.init("hist2", H, H); ques1.init("ques1", E, H); ques2.init("ques2", H, H);
   }
-  int prepare(vd_model* m, hipStream_t s, const SeqTok& ss, const std::string& tag, SeqLSTM& l1, SeqLSTM& l2, uint8_t** mask_out,
-              float** xs_out) {
+  // drop: the nn.Dropout(0.5) behind the shared embedding of the nngraph encoders (mn-att:24-25); the Sequential encoders have none
+  static int prepare(vd_model* m, hipStream_t s, const SeqTok& ss, const std::string& tag, SeqLSTM& l1, SeqLSTM& l2, uint8_t** mask_out,
+                     float** xs_out, bool drop = true) {
+    const long E = l1.D, H = l1.H;
     const long TN = (long)ss.T * ss.N;
     uint8_t* mk = nullptr;
-    VD_TRY(drop_mask(m, tag + "_emb", (size_t)TN * E, 0.5f, s, &mk));
+    if (drop) VD_TRY(drop_mask(m, tag + "_emb", (size_t)TN * E, 0.5f, s, &mk));
     float *x, *xs;
     VD_TRY(ws_get(m, tag + ".x", (size_t)TN * E, &x));
     VD_TRY(ws_get(m, tag + ".xs", (size_t)TN * E, &xs));
     VD_TRY(l1.alloc(m, ss.T, ss.N));
     VD_TRY(l2.alloc(m, ss.T, ss.N));
     l1.h0 = l1.c0 = l2.h0 = l2.c0 = nullptr;
-    VD_TRY(vd_embed_gather(Wp(m, "embed"), ss.tok, mk, x, TN, (int)E, 2.0f, s));
+    VD_TRY(vd_embed_gather(Wp(m, "embed"), ss.tok, mk, x, TN, (int)E, drop ? 2.0f : 1.0f, s));
     VD_TRY(vd_embed_gather(x, ss.fwd_idx, nullptr, xs, TN, (int)E, 1.0f, s));      // permute rows per step (length sort)
     VD_TRY(vd_gemm_nn(xs, E, l1.Wx(m), 4 * H, Wp(m, l1.name + ".b"), l1.gates, 4 * H, (int)TN, (int)(4 * H), (int)E, 0, s));
     // skipped (t, row) pairs must read as zeros: previous state of rows that become active later, da = 0 in the
@@ -87,7 +89,7 @@ struct TextBranches {
     *xs_out = xs;
     return VD_OK;
   }
-  void fill_fwd(vd_model* m, const SeqTok& ss, SeqLSTM& l1, SeqLSTM& l2, vd_lstm2_fwd_t* o) {
+  static void fill_fwd(vd_model* m, const SeqTok& ss, SeqLSTM& l1, SeqLSTM& l2, vd_lstm2_fwd_t* o) {
     o->T = ss.T; o->N = ss.N;
     o->tok_mask = ss.tok_sorted;
     o->Wh1 = l1.Wh(m); o->Wx2 = l2.Wx(m); o->b2 = Wp(m, l2.name + ".b"); o->Wh2 = l2.Wh(m);
@@ -152,6 +154,56 @@ struct TextBranches {
       VD_TRY(vd_embed_scatter_acc(Gp(m, "embed"), ss[k]->tok, mk[k], dxo, TN, (int)E, 2.f, sw));
     }
     return VD_OK;
+  }
+};
+
+// The history branch of the Sequential encoders (encoders/lf-ques-hist.lua:38-45, lf-ques-im-hist.lua:38-45, hre-*.lua:30-38):
+// numLayers x SeqLSTM:maskZero() whose only consumer is Select(1,-1) of the top layer.  With the default two layers it runs like
+// the text branches of the nngraph encoders: rows sorted by length at upload (right-aligned input: the leading pad steps of the
+// shorter rows are skipped, maskZero's zero state is what they would produce), both layers as ONE skewed wavefront
+// (vd_lstm2_forward / vd_lstm2_backward: T + 1 launches instead of 2 T), weight gradients over the non-pad (t, row) pairs.  At
+// lf-ques-im-hist's Th <= 300 (the concatenated dialog, dataloader.lua:243-255) that branch IS the step (configs[1]).
+struct HistWave {
+  float *xs = nullptr;
+  static bool usable(const BatchSlot& b, const std::vector<SeqLSTM>& hist) { return hist.size() == 2 && b.h.sorted; }
+  int forward(vd_model* m, hipStream_t s, BatchSlot& b, SeqLSTM& l1, SeqLSTM& l2, const float** last) {
+    const int N = b.h.N;
+    const long H = l1.H;
+    uint8_t* mk;
+    VD_TRY(TextBranches::prepare(m, s, b.h, "h", l1, l2, &mk, &xs, false));
+    vd_lstm2_fwd_t fw;
+    TextBranches::fill_fwd(m, b.h, l1, l2, &fw);
+    VD_TRY(vd_lstm2_forward(&fw, 1, (int)H, s));
+    float* hl;
+    VD_TRY(ws_get(m, "h.last", (size_t)N * H, &hl));
+    VD_TRY(vd_embed_gather(l2.out_at(b.h.T - 1), b.h.inv, nullptr, hl, N, (int)H, 1.f, s));   // Select(1,-1), back to batch order
+    *last = hl;
+    return VD_OK;
+  }
+  int backward(vd_model* m, hipStream_t s, BatchSlot& b, SeqLSTM& l1, SeqLSTM& l2, const float* dlast) {
+    const int N = b.h.N;
+    const long H = l1.H, E = l1.D;
+    const size_t TN = (size_t)b.h.T * N;
+    float *dls, *dhseq, *dc1, *dc2, *dxo;
+    VD_TRY(ws_get(m, "h.dlast", (size_t)N * H, &dls));
+    VD_TRY(vd_embed_gather(dlast, b.h.perm, nullptr, dls, N, (int)H, 1.f, s));
+    VD_TRY(ws_get(m, l1.name + ".dhseq", TN * H, &dhseq));
+    VD_TRY(ws_get(m, l1.name + ".dc", (size_t)N * H, &dc1));
+    VD_TRY(ws_get(m, l2.name + ".dc", (size_t)N * H, &dc2));
+    vd_lstm2_bwd_t bw;
+    bw.T = b.h.T; bw.N = N;
+    bw.Wh1 = l1.Wh(m); bw.Wx2 = l2.Wx(m); bw.Wh2 = l2.Wh(m);
+    bw.gates1 = l1.gates; bw.c1 = l1.c; bw.gates2 = l2.gates; bw.c2 = l2.c;
+    bw.dh_last2 = dls;
+    bw.dh1_seq = dhseq; bw.dc1 = dc1; bw.dc2 = dc2;
+    bw.nact = b.h.nact.data();
+    VD_TRY(vd_lstm2_backward(&bw, 1, (int)H, s));
+    std::vector<float*> dx;
+    VD_TRY(l2.param_grads(m, s, {false}, nullptr));
+    VD_TRY(l1.param_grads(m, s, {true}, &dx));
+    VD_TRY(ws_get(m, "h.dxo", TN * E, &dxo));
+    VD_TRY(vd_embed_gather(dx[0], b.h.inv_idx, nullptr, dxo, (long)TN, (int)E, 1.f, s));       // back to batch order
+    return vd_embed_scatter_acc(Gp(m, "embed"), b.h.tok, nullptr, dxo, (long)TN, (int)E, 1.f, s);
   }
 };
 
@@ -394,6 +446,7 @@ struct GraphEncoder : Encoder {
 struct LateFusion : Encoder {
   bool use_im, use_hist;
   std::vector<SeqLSTM> rnn, hist;
+  HistWave wave;
   CatLinear fuse;
   long E = 0, H = 0, F = 0;
   float pdrop = 0.5f;
@@ -429,11 +482,18 @@ struct LateFusion : Encoder {
     if (use_hist) {
       VD_TRY(fork_stream(m, s, sh));
       const int Th = b.h.T;
-      float *hx, *ht;
-      VD_TRY(ws_get(m, "h.x", (size_t)Th * N * E, &hx));
-      VD_TRY(vd_embed_gather(Wp(m, "embed"), b.h.tok, nullptr, hx, (long)Th * N, (int)E, 1.f, sh));
-      VD_TRY(lstm_stack_forward(m, sh, hist, {hx}, Th, N, b.h.tok, &ht));
-      hh_last = hist.back().out_at(Th - 1);
+      const bool prof = m->dec_name == "gen";     // (disc pairs: ev_prof belongs to the option-LSTM families)
+      if (prof) VD_HIP(hipEventRecord(m->ev_prof[0], sh));
+      if (HistWave::usable(b, hist)) {
+        VD_TRY(wave.forward(m, sh, b, hist[0], hist[1], &hh_last));
+      } else {
+        float *hx, *ht;
+        VD_TRY(ws_get(m, "h.x", (size_t)Th * N * E, &hx));
+        VD_TRY(vd_embed_gather(Wp(m, "embed"), b.h.tok, nullptr, hx, (long)Th * N, (int)E, 1.f, sh));
+        VD_TRY(lstm_stack_forward(m, sh, hist, {hx}, Th, N, b.h.tok, &ht));
+        hh_last = hist.back().out_at(Th - 1);
+      }
+      if (prof) VD_HIP(hipEventRecord(m->ev_prof[1], sh));
     }
     float *qx, *qt;
     VD_TRY(ws_get(m, "q.x", (size_t)Tq * N * E, &qx));
@@ -465,9 +525,17 @@ struct LateFusion : Encoder {
     hipStream_t sh = side_stream(m, m->s_hist, s);
     if (use_hist) {
       VD_TRY(fork_stream(m, s, sh));
-      std::vector<float*> dx;
-      VD_TRY(lstm_stack_backward(m, sh, hist, g.back(), nullptr, &dx));
-      VD_TRY(vd_embed_scatter_acc(Gp(m, "embed"), b.h.tok, nullptr, dx[0], (long)b.h.T * b.h.N, (int)E, 1.f, sh));
+      const bool prof = m->dec_name == "gen";
+      if (prof) VD_HIP(hipEventRecord(m->ev_prof[2], sh));
+      if (HistWave::usable(b, hist)) {
+        VD_TRY(wave.backward(m, sh, b, hist[0], hist[1], g.back()));
+      } else {
+        std::vector<float*> dx;
+        VD_TRY(lstm_stack_backward(m, sh, hist, g.back(), nullptr, &dx));
+        VD_TRY(vd_embed_scatter_acc(Gp(m, "embed"), b.h.tok, nullptr, dx[0], (long)b.h.T * b.h.N, (int)E, 1.f, sh));
+      }
+      if (prof) VD_HIP(hipEventRecord(m->ev_prof[3], sh));
+      m->prof_hist = prof;
     }
     std::vector<float*> dx;
     VD_TRY(lstm_stack_backward(m, s, rnn, g[0], nullptr, &dx));
@@ -483,6 +551,7 @@ struct LateFusion : Encoder {
 struct Hre : Encoder {
   bool use_im, attention;
   std::vector<SeqLSTM> rnn, hist;
+  HistWave wave;
   SeqLSTM dialog;
   Linear img_embed;
   long E = 0, H = 0, F = 0, DI = 0;
@@ -533,11 +602,17 @@ struct Hre : Encoder {
     VD_TRY(indices(m, N, &rep, &to_rb, &to_n));
     hipStream_t sh = side_stream(m, m->s_hist, s);
     VD_TRY(fork_stream(m, s, sh));
-    float *hx, *ht;
-    VD_TRY(ws_get(m, "h.x", (size_t)Th * N * E, &hx));
-    VD_TRY(vd_embed_gather(Wp(m, "embed"), b.h.tok, nullptr, hx, (long)Th * N, (int)E, 1.f, sh));
-    VD_TRY(lstm_stack_forward(m, sh, hist, {hx}, Th, N, b.h.tok, &ht));
-    hh = hist.back().out_at(Th - 1);
+    if (HistWave::usable(b, hist)) {
+      const float* last;
+      VD_TRY(wave.forward(m, sh, b, hist[0], hist[1], &last));
+      hh = const_cast<float*>(last);
+    } else {
+      float *hx, *ht;
+      VD_TRY(ws_get(m, "h.x", (size_t)Th * N * E, &hx));
+      VD_TRY(vd_embed_gather(Wp(m, "embed"), b.h.tok, nullptr, hx, (long)Th * N, (int)E, 1.f, sh));
+      VD_TRY(lstm_stack_forward(m, sh, hist, {hx}, Th, N, b.h.tok, &ht));
+      hh = hist.back().out_at(Th - 1);
+    }
     float* qx;
     VD_TRY(ws_get(m, "q.x", (size_t)Tq * N * E, &qx));
     VD_TRY(vd_embed_gather(Wp(m, "embed"), b.q.tok, nullptr, qx, (long)Tq * N, (int)E, 1.f, s));
@@ -616,7 +691,9 @@ struct Hre : Encoder {
     }
     hipStream_t sh = side_stream(m, m->s_hist, s);
     VD_TRY(fork_stream(m, s, sh));
-    {
+    if (HistWave::usable(b, hist)) {
+      VD_TRY(wave.backward(m, sh, b, hist[0], hist[1], dh));
+    } else {
       std::vector<float*> dx;
       VD_TRY(lstm_stack_backward(m, sh, hist, dh, nullptr, &dx));
       VD_TRY(vd_embed_scatter_acc(Gp(m, "embed"), b.h.tok, nullptr, dx[0], (long)b.h.T * N, (int)E, 1.f, sh));

@@ -386,7 +386,9 @@ int vd_model_upload_batch(vd_model* m, const vd_batch* hb) {
   const long NO = (long)N * O;
   for (SeqTok* t : {&sl.q, &sl.h, &sl.opt, &sl.ain, &sl.aout, &sl.oin, &sl.oout}) t->present = false;
   VD_TRY(upload_tokens(sl, sl.q, "q", hb->ques_fwd, N, hb->Tq, m->is_graph, s));
-  if (m->use_hist) VD_TRY(upload_tokens(sl, sl.h, "h", hb->hist, N, hb->Th, m->is_graph, s));
+  // the history branch of the Sequential encoders runs as a length-sorted two-layer wavefront too (rt_encoders.h: HistWave)
+  const bool hist_wave = !m->is_graph && m->p.numLayers == 2 && vd_tune_get("VD_RT_HIST_WAVE", 1) != 0;
+  if (m->use_hist) VD_TRY(upload_tokens(sl, sl.h, "h", hb->hist, N, hb->Th, m->is_graph || hist_wave, s));
   if (m->use_im) {
     // [B x S*S x C] for the attention encoders (model.lua:262-265 keeps one map per image), [B x F] otherwise
     const size_t img_n = (size_t)hb->B * (m->is_att ? (size_t)m->p.imgSpatialSize * m->p.imgSpatialSize : 1) * m->p.imgFeatureSize;
@@ -603,8 +605,9 @@ int vd_model_ranks(vd_model* m, int use_gt, int32_t* ranks_out) {
   return VD_OK;
 }
 
-// device time of the three option-LSTM kernel families inside the last training step of a `disc` pair, ms:
-// [fwd, bwd, dWh]; zeros when the last call was not such a step
+// device time of three kernel families inside the last training step, ms.  `disc` pairs: the option LSTM [fwd, bwd, dWh];
+// `gen` pairs over a Sequential encoder with a history branch: [history branch fwd, history branch bwd, vocabulary projection +
+// criterion + their gradients]; zeros when the last call was not such a step
 int vd_model_family_ms(vd_model* m, float* ms3) {
   VD_CHECK_ARG(m && ms3, "vd_model_family_ms: null");
   ms3[0] = ms3[1] = ms3[2] = 0.f;
