@@ -104,6 +104,116 @@ def dominant_kernel_alone(p, N, iters=3):
     return {"avg_launch_ms": round(ms, 4), "achieved": round(tf, 2), "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
 
 
+def csrc_digest():
+    """SHA-256 over the kernel sources: ties a stored PMC measurement (profiles/pmc_summary.json) to the build it was taken on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'visdial_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'visdial_amd', 'csrc', '*.h'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def option_families(p, N, prof, steps_for_prof):
+    """per-family figures of the option LSTM (decoder disc) from HIP-event times: {tag: {...}}"""
+    NO, E, H, To = N * p['numOptions'], p['embedSize'], p['rnnHiddenSize'], p['maxAnsLen']
+    fams = {}
+    for tag, nominal, executed, klaunch in (
+            ('opt_lstm_fwd', 2.0 * NO * (E + H) * 4 * H * To, 2.0 * NO * H * 4 * H * (To - 1), To - 1),
+            ('opt_lstm_bwd', 2.0 * NO * (E + H) * 4 * H * To, 2.0 * NO * H * 4 * H * (To - 1), To - 1),
+            ('opt_lstm_dWh', 2.0 * NO * (To - 1) * H * 4 * H, 2.0 * NO * (To - 1) * H * 4 * H, 1)):
+        if tag in prof:
+            ms, n = prof[tag]                       # n family invocations (one per step) took ms in total
+            per_family = ms / n
+            fams[tag] = dict(ms_total_per_step=ms / steps_for_prof, kernel_launches_per_step=klaunch * n / steps_for_prof,
+                             avg_launch_ms=per_family / klaunch, gflop_executed_per_launch=executed / klaunch / 1e9,
+                             tflops_nominal=nominal / per_family / 1e9, tflops_executed=executed / per_family / 1e9)
+    return fams
+
+
+def bf16_option_roofline(fams, dom):
+    # bf16 operands make the matrix work 16x cheaper: the recurrence is priced by its bytes (DESIGN.md section 4)
+    alg = {'opt_lstm_fwd': 19 * 496e6 + 410e6, 'opt_lstm_bwd': 19 * 660e6 + 250e6, 'opt_lstm_dWh': 3.9e9}[dom]
+    gbs = alg / (fams[dom]['ms_total_per_step'] * 1e-3) / 1e9      # bytes of the whole family / its event time
+    return {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(gbs / 8000.0, 4), "traffic": None, "avg_launch_ms": round(fams[dom]['avg_launch_ms'], 4),
+            "note": "bf16 operands / fp32 accumulation in the option recurrence: bound by HBM bytes (gates, h, c, "
+                    "table gather), algorithmic bytes per direction / HIP-event time; MFMA side: %.0f TFLOP/s of the "
+                    "2 500 TFLOP/s dense bf16 peak" % fams[dom]['tflops_executed'],
+            "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
+
+
+def other_config(cfg, steps=10, warmup=3):
+    """one of the non-headline single-GPU configurations (BASELINE.json configs[1], [2], [4]): ms/step of the same pipelined
+    trainIteration + the roofline of ITS dominant kernel family from the library's HIP events in the last step"""
+    import numpy as np
+    from visdial_amd.dataloader import SyntheticDataloader
+    from visdial_amd.native import NativeModel
+    p = config_params(cfg)
+    model = NativeModel(p)
+    dl = SyntheticDataloader(p, seed=4321, fast=True)
+    served = []
+    inner = dl.getTrainBatch
+
+    def recording(params, **kw):
+        b = inner(params, **kw)
+        served.append(b)
+        del served[:-3]
+        return b
+    dl.getTrainBatch = recording
+    for _ in range(warmup):
+        model.trainIteration(dl)
+    model.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = model.trainIteration(dl)
+    model.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    f = model.family_ms()
+    N, H = p['batchSize'] * p['maxQuesCount'], p['rnnHiddenSize']
+    out = {"workload": "BASELINE.json configs[%d]: %s + %s, batch %d, %s" % (
+               cfg, p['encoder'], p['decoder'], p['batchSize'],
+               {1: "VGG-16 fc7 4096-d features", 2: "fc7 4096-d features, 100 options", 4: "ResNet-200 7x7x2048 features, 100 options"}[cfg]),
+           "dtype": "f32" if cfg != 4 else "bf16 operands / f32 accumulate (option recurrence only), f32 elsewhere",
+           "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3), "qa_rounds_per_s": round(N / ms * 1e3, 1),
+           "loss": round(float(loss), 5)}
+    if p['decoder'] == 'disc':
+        fams = option_families(p, N, {'opt_lstm_fwd': (f[0], 1), 'opt_lstm_bwd': (f[1], 1), 'opt_lstm_dWh': (f[2], 1)}, 1)
+        dom = max(fams, key=lambda k: fams[k]['ms_total_per_step'])
+        if cfg == 4:
+            out["roofline"] = bf16_option_roofline(fams, dom)
+        else:
+            a = fams[dom]['tflops_executed']
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(a, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(a / FP32_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(fams[dom]['avg_launch_ms'], 4),
+                               "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
+        out["option_rows_executed_of_total"] = list(model.option_rows())
+    else:
+        # gen over a Sequential encoder: the history branch (two-layer length-sorted wavefront, Th + 1 ticks per direction) is the
+        # step.  Executed FLOPs of the batch the LAST step trained on: per tick and active row h*Wh1, h1*Wx2, h2*Wh2 (forward; twice
+        # that backward: da*Wh^T products + ... counted as the reference does: bwd = the same three products transposed).
+        b = served[-2] if len(served) >= 2 else served[-1]          # the last step trained on the batch BEFORE the prefetched one
+        hist = np.asarray(b['hist']).reshape(-1, b['hist'].shape[-1])
+        lens = (hist != 0).sum(1)
+        Th = hist.shape[1]
+        nact = np.array([(lens >= Th - t).sum() for t in range(Th)])           # right-aligned: row active from step Th - len on
+        flop = 2.0 * nact.sum() * 3 * H * 4 * H
+        fam = {"hist_fwd": {"ms": round(f[0], 4), "ticks": Th + 1, "gflop_executed": round(flop / 1e9, 2), "tflops": round(flop / max(f[0], 1e-6) / 1e9, 2)},
+               "hist_bwd": {"ms": round(f[1], 4), "ticks": Th + 1, "gflop_executed": round(flop / 1e9, 2), "tflops": round(flop / max(f[1], 1e-6) / 1e9, 2)},
+               "vocab": {"ms": round(f[2], 4), "gflop_executed": round(3 * 2.0 * np.asarray(b['answer_in']).size * p['vocabSize'] * H / 1e9, 2)}}
+        fam["vocab"]["tflops"] = round(fam["vocab"]["gflop_executed"] / max(f[2], 1e-6), 2)
+        dom = max(fam, key=lambda k: fam[k]['ms'])
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": fam[dom]['tflops'], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(fam[dom]['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4),
+                           "avg_launch_ms": round(fam[dom]['ms'] / fam[dom].get('ticks', 1), 4),
+                           "note": "a chain of Th + 1 DEPENDENT launches over <= 200 rows each (N = B x 10 rounds): latency-bound, not a "
+                                   "throughput kernel; executed FLOPs = active (t, row) pairs x (h*Wh1 + h1*Wx2 + h2*Wh2)",
+                           "families": fam, "history_steps": int(Th), "mean_active_rows": round(float(nact.mean()), 1)}
+    model.close()
+    return out
+
+
 def cpu_baseline(seconds_budget=30.0, batch=20):
     """oracle/cpu_step.cpp -- the repo's C++17/OpenMP fp32 restatement of the same training step, organised like the
     reference's CPU path (per-timestep GEMMs, 10x image replication, no table hoist) -- timed on all host cores on
@@ -160,6 +270,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=20, help='dialogs per GPU (headline: 20)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the configs[1], [2], [4] legs after the headline')
     ap.add_argument('--same-batch', action='store_true', help='reuse one resident batch (round-1 behaviour; A/B only)')
     ap.add_argument('--no-streams', action='store_true', help='whole step on one HIP stream (A/B only)')
     ap.add_argument('--config', type=int, choices=[3, 4], default=3,
@@ -280,41 +391,29 @@ def main():
         # per direction and step (the first step has h0 = 0 and no recurrent product), one launch for dWh.  The HIP
         # events bracket the whole family on its stream; figures are per KERNEL LAUNCH so they can be compared with
         # the rocprofv3 average duration of the same kernel (profiles/r02_kernel_stats_bench.txt).
-        NO, E, H, To = N * p['numOptions'], p['embedSize'], p['rnnHiddenSize'], p['maxAnsLen']
-        fams = {}
-        for tag, nominal, executed, klaunch in (
-                ('opt_lstm_fwd', 2.0 * NO * (E + H) * 4 * H * To, 2.0 * NO * H * 4 * H * (To - 1), To - 1),
-                ('opt_lstm_bwd', 2.0 * NO * (E + H) * 4 * H * To, 2.0 * NO * H * 4 * H * (To - 1), To - 1),
-                ('opt_lstm_dWh', 2.0 * NO * (To - 1) * H * 4 * H, 2.0 * NO * (To - 1) * H * 4 * H, 1)):
-            if tag in prof:
-                ms, n = prof[tag]                       # n family invocations (one per step) took ms in total
-                per_family = ms / n
-                fams[tag] = dict(ms_total_per_step=ms / args_steps_for_prof, kernel_launches_per_step=klaunch * n / args_steps_for_prof,
-                                 avg_launch_ms=per_family / klaunch, gflop_executed_per_launch=executed / klaunch / 1e9,
-                                 tflops_nominal=nominal / per_family / 1e9, tflops_executed=executed / per_family / 1e9)
+        fams = option_families(p, N, prof, args_steps_for_prof)
         dom = max(fams, key=lambda k: fams[k]['ms_total_per_step']) if fams else None
-        traffic = None
+        # HBM-side bytes per launch of the dominant kernel: a STORED rocprofv3 PMC measurement, reported only while the kernel
+        # sources are the ones it was taken on (profiles/pmc_summary.json carries their digest)
+        traffic, traffic_build = None, None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom, {}).get('hbm_bytes_per_launch')
+                summ = json.load(open(pmc))
+                traffic_build = summ.get('csrc_sha256')
+                if traffic_build == csrc_digest():
+                    traffic = summ.get(dom, {}).get('hbm_bytes_per_launch')
             except Exception:
                 traffic = None
         roof = None
         if dom and args.config == 4:
-            # bf16 operands make the matrix work 16x cheaper: the recurrence is priced by its bytes
-            alg = {'opt_lstm_fwd': 19 * 496e6 + 410e6, 'opt_lstm_bwd': 19 * 660e6 + 250e6, 'opt_lstm_dWh': 3.9e9}[dom]
-            gbs = alg / (fams[dom]['ms_total_per_step'] * 1e-3) / 1e9      # bytes of the whole family / its event time
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(gbs / 8000.0, 4), "traffic": None, "avg_launch_ms": round(fams[dom]['avg_launch_ms'], 4),
-                    "note": "bf16 operands / fp32 accumulation in the option recurrence: bound by HBM bytes (fp32 gates, h, c, "
-                            "table gather), algorithmic bytes per direction / HIP-event time; MFMA side: %.0f TFLOP/s of the "
-                            "2 500 TFLOP/s dense bf16 peak" % fams[dom]['tflops_executed'],
-                    "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
+            roof = bf16_option_roofline(fams, dom)
         elif dom:
             a = fams[dom]['tflops_executed']
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(a, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(a / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_build": {"pmc_taken_on_csrc": traffic_build, "this_build_csrc": csrc_digest(),
+                                      "note": "traffic is null when the kernel sources changed since the PMC pass"},
                     "achieved_nominal": round(fams[dom]['tflops_nominal'], 2),
                     "avg_launch_ms": round(fams[dom]['avg_launch_ms'], 4),
                     "note": "achieved = EXECUTED FLOPs of the dominant kernel per launch (the recurrent h*Wh / da*Wh^T "
@@ -352,6 +451,16 @@ def main():
                        "option_rows_executed_of_total": (list(model.option_rows()) if args.host == 'native' else None)},
             "roofline": roof,
         }
+        if world == 1 and args.config == 3 and not args.no_other_configs:
+            # the other single-GPU configurations of BASELINE.json, driver-visible (the headline `value` above is unaffected:
+            # they run after its timed region, on their own models)
+            model.close() if hasattr(model, 'close') else None
+            out["other_configs"] = []
+            for cfg in (1, 2, 4):
+                try:
+                    out["other_configs"].append(other_config(cfg))
+                except Exception as exc:
+                    out["other_configs"].append({"workload": "BASELINE.json configs[%d]" % cfg, "error": str(exc)[:200]})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         else:

@@ -64,6 +64,10 @@ for k in ('fwd', 'bwd', 'dWh'):
     e = summ['opt_lstm_' + k]
     e.update(hbm_bytes_per_launch=int(round(tot * 1e6)), fetch_raw_bytes=int(round(fe * 1e6)), write_bytes=int(round(wr * 1e6)),
              mfma_busy=round(mb / (g * 32), 3), grbm_cycles=g)
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_digest
+summ['csrc_sha256'] = csrc_digest()     # the kernel sources the PMC pass was taken on: bench.py reports roofline.traffic only while they match
 json.dump(summ, open(P + 'pmc_summary.json', 'w'), indent=1)
 old = open(P + TAG + '_pmc_option_lstm_kernels.txt').read().split('\n')
 out, keep = [], False
