@@ -43,10 +43,6 @@ int vd_memcpy_h2d(void* dst, const void* src_host, int64_t bytes, void* stream);
 int vd_memcpy_d2h(void* dst_host, const void* src, int64_t bytes, void* stream);
 int vd_memcpy_d2d(void* dst, const void* src, int64_t bytes, void* stream);
 int vd_stream_synchronize(void* stream);
-/* Runtime tuning knobs (kernel-configuration A/B switches, e.g. "VD_LSTM_PERSIST_FWD", "VD_TN_BLOCKS"): a value set
- * here overrides the environment variable of the same name; read at launch time.  No reference counterpart. */
-int vd_tune_set(const char* key, int value);
-int vd_tune_clear(void);
 /* strided 2-D device copy of rows x cols floats (nn.JoinTable / nn.Narrow on column blocks,
  * encoders/lf-ques-im-hist.lua:49-55) */
 int vd_copy_2d(float* dst, int64_t dst_ld, const float* src, int64_t src_ld, int64_t rows, int64_t cols,
@@ -105,10 +101,6 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
                      const float* dh_last, const float* dc_last, float* dc_work, float* dh0, const float* h_seq,
                      float* dWh_acc, int T, int N, int H, int flags, void* stream);
 
-/* Synchronises `stream` and reports whether a bounded spin of the last persistent recurrence launched on it timed
- * out (0 = no; results are undefined if 1).  Diagnostic: the dependency protocol never waits on unfinished work in
- * a correct run. */
-int vd_lstm_seq_status(void* stream, int* timed_out);
 
 /* Two stacked nn.SeqLSTM layers (the pattern of every encoder branch: mn-att:27-45, lf-ques.lua:17-24)
  * advanced as a skewed wavefront, up to 2 independent stacks per call (history + question branches):

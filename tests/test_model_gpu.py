@@ -448,8 +448,6 @@ def test_full_size_step_matches_cpp_restatement(gpu):
     loss = model.forwardBackward(batch)
     g = model.get_gradients_dict()
     scores = model.decoder.output.cpu().numpy()
-    from visdial_amd import ops
-    assert not ops.lstm_seq_status()
     spec = vo.param_spec(p['encoder'], p['decoder'], p)
     cs = cpu_step.CpuStep(p, spec, P0)
     ref_loss, ref_scores = cs.step(batch, masks, want_scores=True)

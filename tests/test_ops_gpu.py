@@ -55,18 +55,13 @@ def test_gemm_nt(ops, M, N, K, act):
 
 @pytest.mark.parametrize("M,N,K", [(11323, 300, 2048), (1500, 512, 304), (1100, 130, 4096)])
 def test_gemm_nt_atomic_accumulate_splits_k(ops, M, N, K):
-    """accumulate = 2 (hardware float atomics; dEmb += dTable * Wx^T beside the encoder's scatters): throughput shapes split K over
-    several workgroups per tile (VD_NT_SPLITK) so the launch fills the chip -- same sum, ragged last K slice included"""
+    """accumulate = 2 (hardware float atomics; dEmb += dTable * Wx^T beside the encoder's scatters), ragged last K slice included"""
     rng = np.random.RandomState(M + N + K + 7)
     A, W = f32(rng, M, K), f32(rng, N, K) * 0.1
     C0 = f32(rng, M, N)
     Cd = dev(C0)
     ref = C0 + A.astype(np.float64) @ W.astype(np.float64).T
-    ops.tune_set("VD_NT_SPLITK", 1)                      # opt-in (neutral in the training step: profiles/r03_experiments.txt section 19)
-    try:
-        ops.gemm_nt(dev(A), dev(W), Cd, bias=None, act=0, accumulate=2)
-    finally:
-        ops.tune_clear()
+    ops.gemm_nt(dev(A), dev(W), Cd, bias=None, act=0, accumulate=2)
     assert relerr(Cd, ref) < 1e-5
     Ce = dev(C0)
     ops.gemm_nt(dev(A), dev(W), Ce, bias=None, act=0, accumulate=2)
@@ -120,23 +115,13 @@ def test_colsum(ops):
 
 # N >= 2048 rows take the LDS-DMA pipeline: H = 32 / 64 / 96 give 2, 4 and 6 K tiles in the forward step (fewer
 # than, equal to and more than the 3 LDS buffers), ragged last row tile, masked and gathered input rows
-# (N >= 2048 and T > 1: the whole recurrence is ONE persistent launch, tile queues + arrival counters; `persist` = 0
-#  re-runs the same shapes as one launch per step.)  (6, 2300, 512, table): the headline's H = 512 table-gather mode.
-@pytest.mark.parametrize("persist", [1, 0])
+# (6, 2300, 512, table): the headline's H = 512 table-gather mode.
 @pytest.mark.parametrize("T,N,H,masked,table", [(5, 200, 64, True, False), (4, 2500, 64, False, True),
                                                 (3, 2100, 512, True, False), (6, 37, 32, True, False),
                                                 (3, 2049, 32, False, True), (3, 2177, 96, True, True),
                                                 (6, 2300, 512, False, True)])
-def test_lstm_forward_backward(ops, T, N, H, masked, table, persist):
-    if persist == 0 and N < 2048:
-        pytest.skip("latency shapes never take the persistent path")
-    ops.tune_set("VD_LSTM_PERSIST_FWD", persist)
-    ops.tune_set("VD_LSTM_PERSIST_BWD", persist)
-    try:
-        _lstm_forward_backward(ops, T, N, H, masked, table)
-        assert not ops.lstm_seq_status()
-    finally:
-        ops.tune_clear()
+def test_lstm_forward_backward(ops, T, N, H, masked, table):
+    _lstm_forward_backward(ops, T, N, H, masked, table)
 
 
 def _lstm_forward_backward(ops, T, N, H, masked, table):
@@ -190,111 +175,30 @@ def _lstm_forward_backward(ops, T, N, H, masked, table):
     assert relerr(dWh, dWh0 + dW_ref[D:]) < 2e-5
 
 
-@pytest.mark.parametrize("stagger", [0, 30])
-def test_lstm_persistent_equals_per_step_launches(ops, stagger):
-    """The persistent recurrence executes exactly the per-step kernels' tile code, so its outputs must be
-    BIT-IDENTICAL to the one-launch-per-step path -- under load that makes the dependency waits real: 20 000 rows x
-    12 steps of short tiles (H = 64: K loop of 4 tiles), a competing stream hammering HBM, consumer L1s warm.
-    Every word of h / c / gates (forward) and da / dc (backward) is compared."""
-    T, N, H, V = 12, 20000, 64, 50
-    rng = np.random.RandomState(7)
-    Wh = dev((f32(rng, H, 4 * H) / np.sqrt(H)).astype(np.float32))
-    tab = dev(f32(rng, V + 1, 4 * H) * 0.5)
-    tok = dev(rng.randint(0, V + 1, size=(T, N)).astype(np.int32))
-    dh_last = dev(f32(rng, N, H))
-    side = torch.cuda.Stream()
-    junk = torch.empty(64 << 20, device="cuda")
-    out = {}
-    for persist in (0, 1):
-        ops.tune_set("VD_LSTM_PERSIST_FWD", persist)
-        ops.tune_set("VD_LSTM_PERSIST_BWD", persist)
-        ops.tune_set("VD_LSTM_STAGGER_US", stagger if persist else 0)
-        gates = torch.empty(T, N, 4 * H, device="cuda")
-        h = torch.empty(T, N, H, device="cuda")
-        c = torch.empty(T, N, H, device="cuda")
-        dc = torch.empty(N, H, device="cuda")
-        torch.cuda.synchronize()
-        with torch.cuda.stream(side):           # uneven background load on the memory system
-            for _ in range(40):
-                junk.mul_(1.0001)
-        ops.lstm_forward(tab, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok)
-        assert not ops.lstm_seq_status()
-        fwd = (gates.clone(), h.clone(), c.clone())
-        with torch.cuda.stream(side):
-            for _ in range(40):
-                junk.mul_(1.0001)
-        ops.lstm_backward(Wh, gates, c, dc, T, N, H, dh_last=dh_last)
-        assert not ops.lstm_seq_status()
-        torch.cuda.synchronize()
-        out[persist] = fwd + (gates.clone(), dc.clone())
-    ops.tune_clear()
-    for a, b, name in zip(out[0], out[1], ("gates", "h", "c", "da", "dc")):
-        assert torch.equal(a, b), "%s differs between per-step and persistent launches (%d words)" % (
-            name, int((a != b).sum()))
-
-
-def test_lstm_step_queue_equals_per_step_launches(ops):
-    """VD_LSTM_STEP_QUEUE=1: every step of a throughput recurrence is one round of resident workgroups pulling tiles
-    from per-XCD queues (the persistent kernel with a one-step work list).  Same tile code -> BIT-IDENTICAL outputs."""
-    T, N, H, V = 6, 20000, 64, 50
-    rng = np.random.RandomState(3)
-    Wh = dev((f32(rng, H, 4 * H) / np.sqrt(H)).astype(np.float32))
-    tab = dev(f32(rng, V + 1, 4 * H) * 0.5)
-    tok = dev(rng.randint(0, V + 1, size=(T, N)).astype(np.int32))
-    dh_last = dev(f32(rng, N, H))
-    out = {}
-    for mode in (0, 1):
-        ops.tune_set("VD_LSTM_STEP_QUEUE", mode)
-        gates = torch.empty(T, N, 4 * H, device="cuda")
-        h = torch.empty(T, N, H, device="cuda")
-        c = torch.empty(T, N, H, device="cuda")
-        dc = torch.empty(N, H, device="cuda")
-        ops.lstm_forward(tab, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok)
-        fwd = (gates.clone(), h.clone(), c.clone())
-        ops.lstm_backward(Wh, gates, c, dc, T, N, H, dh_last=dh_last)
-        assert not ops.lstm_seq_status()
-        torch.cuda.synchronize()
-        out[mode] = fwd + (gates.clone(), dc.clone())
-    ops.tune_clear()
-    for a, b, name in zip(out[0], out[1], ("gates", "h", "c", "da", "dc")):
-        assert torch.equal(a, b), "%s differs between per-step launches and tile-queue launches (%d words)" % (
-            name, int((a != b).sum()))
-
-
 def test_bf16_weight_gradient_on_producer_shadows(ops):
     """BASELINE.json configs[4] (opt-in bf16 option recurrence): the LSTM step kernels of a bf16 pass also write bf16
     copies of h and da, and the dWh contraction multiplies those copies directly (LDS-DMA + ds_read_b64_tr_b16, no
     conversion while staging).  Checked against the fp32 product of the SAME h / da the pass produced: the only difference
-    is the bf16 rounding of the operands (rel-L2 < 1e-2), and against the staging kernel (VD_BF16_SHADOW=0), which rounds
-    the same values the same way (rel-L2 < 1e-5: summation order only).  K = 5 x 4160 rows is not a multiple of 32 x 7:
-    the tail rows take the staging kernel."""
+    is the bf16 rounding of the operands (rel-L2 < 1e-2).  K = 5 x 4168 rows is not a multiple of 32: the tail rows take
+    the staging kernel."""
     T, N, H, V = 6, 4168, 128, 40
     rng = np.random.RandomState(5)
     Wh = dev((f32(rng, H, 4 * H) / np.sqrt(H)).astype(np.float32))
     tab = dev(f32(rng, V + 1, 4 * H) * 0.5)
     tok = dev(rng.randint(0, V + 1, size=(T, N)).astype(np.int32))
     dh_last = dev(f32(rng, N, H))
-    res = {}
-    for shadow in (1, 0):
-        ops.tune_set("VD_BF16_SHADOW", shadow)
-        gates = torch.empty(T, N, 4 * H, device="cuda")
-        h = torch.empty(T, N, H, device="cuda")
-        c = torch.empty(T, N, H, device="cuda")
-        dc = torch.empty(N, H, device="cuda")
-        ops.lstm_forward(tab, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok, flags=1)
-        ops.lstm_backward(Wh, gates, c, dc, T, N, H, dh_last=dh_last, flags=1)
-        dWh = torch.zeros(H, 4 * H, device="cuda")
-        K = (T - 1) * N
-        ops.gemm_tn_acc(h.view(T * N, H), gates.view(T * N, 4 * H)[N:], dWh, M=H, N=4 * H, K=K, flags=1)
-        torch.cuda.synchronize()
-        ref = h.view(T * N, H)[:K].double().T @ gates.view(T * N, 4 * H)[N:].double()
-        res[shadow] = (dWh.double(), ref)
-    ops.tune_clear()
-    for shadow, (got, ref) in res.items():
-        err = float((got - ref).norm() / ref.norm())
-        assert err < 1e-2, (shadow, err)
-    a, b = res[1][0], res[0][0]
-    assert float((a - b).norm() / b.norm()) < 1e-5     # same rounded operands, different summation order
+    gates = torch.empty(T, N, 4 * H, device="cuda")
+    h = torch.empty(T, N, H, device="cuda")
+    c = torch.empty(T, N, H, device="cuda")
+    dc = torch.empty(N, H, device="cuda")
+    ops.lstm_forward(tab, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok, flags=1)
+    ops.lstm_backward(Wh, gates, c, dc, T, N, H, dh_last=dh_last, flags=1)
+    dWh = torch.zeros(H, 4 * H, device="cuda")
+    K = (T - 1) * N
+    ops.gemm_tn_acc(h.view(T * N, H), gates.view(T * N, 4 * H)[N:], dWh, M=H, N=4 * H, K=K, flags=1)
+    torch.cuda.synchronize()
+    ref = h.view(T * N, H)[:K].double().T @ gates.view(T * N, 4 * H)[N:].double()
+    assert float((dWh.double() - ref).norm() / ref.norm()) < 1e-2
 
 
 def test_embed_gather_scatter(ops):

@@ -57,9 +57,6 @@ PROTOTYPES = {
     "vd_memcpy_d2h": [_p, _p, _l, _p],
     "vd_memcpy_d2d": [_p, _p, _l, _p],
     "vd_stream_synchronize": [_p],
-    "vd_tune_set": [C.c_char_p, _i],
-    "vd_tune_clear": [],
-    "vd_lstm_seq_status": [_p, C.POINTER(C.c_int)],
     "vd_copy_2d": [_p, _l, _p, _l, _l, _l, _p],
     "vd_mask_time_forward": [_p, _p, _p, _i, _i, _i, _p],
     "vd_mask_time_backward": [_p, _p, _p, _i, _i, _i, _p],

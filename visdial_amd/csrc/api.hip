@@ -19,24 +19,6 @@ void vd_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// ---- runtime tuning knobs ---------------------------------------------------------------------------------
-static std::mutex g_tune_mu;
-static std::map<std::string, int>& tune_table() {
-  static std::map<std::string, int> t;
-  return t;
-}
-
-int vd_tune_get(const char* key, int dflt) {
-  {
-    std::lock_guard<std::mutex> lk(g_tune_mu);
-    auto& t = tune_table();
-    auto it = t.find(key);
-    if (it != t.end()) return it->second;
-  }
-  const char* ev = getenv(key);
-  return ev ? atoi(ev) : dflt;
-}
-
 // ---- per-(device, stream) scratch -----------------------------------------------------------------------
 static std::mutex g_scr_mu;
 static std::map<std::pair<int, hipStream_t>, VdStreamScratch>& scratch_table() {
@@ -62,8 +44,6 @@ int vd_stream_scratch(hipStream_t stream, size_t wht_bytes, size_t sync_bytes, V
     s.sync = nullptr;
     s.sync_bytes = 0;
     VD_HIP(hipMalloc((void**)&s.sync, sync_bytes));
-    // a fresh buffer reads as "no time-out recorded": vd_lstm_seq_status looks at its sticky word even when no persistent
-    // launch has initialised the buffer yet (paths that only borrow the scratch for the transposed weights)
     VD_HIP(hipMemset(s.sync, 0, sync_bytes));
     s.sync_bytes = sync_bytes;
   }
@@ -116,29 +96,6 @@ void vd_bf16_shadow_invalidate(const float* p, size_t floats) {
     if (s.base && p < s.base + s.floats && s.base < p + floats) s.base = nullptr;
 }
 
-// ---- side streams (common.h) ---------------------------------------------------------------------------------------
-namespace {
-std::mutex g_side_mu;
-hipStream_t g_side[16];
-int g_side_n = 0;
-}  // namespace
-void vd_stream_mark_side(hipStream_t stream, bool on) {
-  std::lock_guard<std::mutex> lk(g_side_mu);
-  for (int i = 0; i < g_side_n; ++i)
-    if (g_side[i] == stream) {
-      if (!on) g_side[i] = g_side[--g_side_n];
-      return;
-    }
-  if (on && stream && g_side_n < 16) g_side[g_side_n++] = stream;
-}
-bool vd_stream_is_side(hipStream_t stream) {
-  if (!stream) return false;
-  std::lock_guard<std::mutex> lk(g_side_mu);
-  for (int i = 0; i < g_side_n; ++i)
-    if (g_side[i] == stream) return true;
-  return false;
-}
-
 int vd_num_cus() {
   static thread_local int cached_dev = -1, cached = 256;
   int dev = 0;
@@ -154,19 +111,6 @@ int vd_num_cus() {
 extern "C" {
 
 const char* vd_last_error(void) { return g_err; }
-
-int vd_tune_set(const char* key, int value) {
-  VD_CHECK_ARG(key && key[0], "vd_tune_set: empty key");
-  std::lock_guard<std::mutex> lk(g_tune_mu);
-  tune_table()[key] = value;
-  return VD_OK;
-}
-
-int vd_tune_clear(void) {
-  std::lock_guard<std::mutex> lk(g_tune_mu);
-  tune_table().clear();
-  return VD_OK;
-}
 
 int vd_abi_version(void) { return 1; }
 

@@ -36,10 +36,6 @@ void vd_set_error(const char* fmt, ...);
 
 static inline int vd_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// Runtime tuning knobs (api.hip): value set by vd_tune_set(key, v), else the environment variable `key`,
-// else `dflt`.  Read at launch time, so one process can A/B several settings (scripts/microbench.py).
-int vd_tune_get(const char* key, int dflt);
-
 // Library-owned per-(device, stream) scratch (api.hip): work buffers whose lifetime is one stream-ordered call
 // (the gate-interleaved Wh^T copy and the tile queues / arrival counters of the persistent recurrence kernels).
 // Calls on different streams get different buffers, so they may overlap freely.
@@ -60,16 +56,6 @@ struct VdZeroSet {
   long quads_per_row;   // filled in by the launcher
 };
 int vd_zero_inactive_multi(const VdZeroSet& z, const int32_t* nact_dev, int T, int N, hipStream_t stream);
-
-// Streams that run BESIDE the throughput kernels of another stream (the step runtime's encoder / image / table-gradient
-// streams; A/B knob VD_SIDE_SMALL_LDS, default OFF).  The contraction entry points give a launch on a marked stream an LDS
-// request that fits the space three 41 KB throughput workgroups leave on a CU (20 / 32 KB), so it co-resides as a FOURTH
-// workgroup instead of waiting for one of the three to retire -- beside the one-round dWh contraction, whose workgroups
-// live for the whole kernel, the 41 KB requests of the encoder's weight gradients wait for milliseconds.  Measured: the
-// side kernels then run at their stand-alone speed, and dWh loses exactly their matrix-pipe time (the step is
-// work-conserving on the MFMA pipe): 24.47 / 24.72 vs 24.36 / 24.50 ms (profiles/r03_experiments.txt section 20).
-void vd_stream_mark_side(hipStream_t stream, bool on);
-bool vd_stream_is_side(hipStream_t stream);
 
 // bf16 shadows of fp32 activations (opt-in bf16 option recurrence, VD_FLAG_BF16; api.hip).  The producing kernels of a
 // bf16 pass (LSTM forward: h; LSTM backward: da) also write a bf16 copy of what they store, into a library-owned buffer

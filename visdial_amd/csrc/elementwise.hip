@@ -448,7 +448,7 @@ int vd_segment_rowsum_acc(const float* X, int64_t ldx, const int32_t* tok, const
   VD_CHECK_ARG(X && tok && perm && out && n >= 0 && ncol > 0 && ncol % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0,
                "vd_segment_rowsum_acc: bad args");
   if (n == 0) return VD_OK;
-  static const int chunk_env = getenv("VD_SEG_CHUNK") ? atoi(getenv("VD_SEG_CHUNK")) : 256;
+  static const int chunk_env = 256;
   if (chunk_env == 128) {
     hipLaunchKernelGGL(segment_rowsum_kernel<128>, grid1d(n, 128), dim3(256), 0, (hipStream_t)stream, X,
                        (long)ldx, tok, perm, (long)n, ncol, out, (long)ldo);

@@ -164,22 +164,6 @@ struct EpiPreOf<Epi, std::void_t<typename Epi::Pre>> {
 };
 #endif
 
-// Epilogue functors may declare `struct KHook` + khook_init / khook(state, kt, nk, ...) / khook_finish: work issued from
-// INSIDE the K loop of the LDS-DMA pipeline, once per K tile between the barrier and the second half of the MFMA burst
-// (diagnostic: memory traffic of the epilogue's volume spread over the K loop, lstm.hip EpiLstmFwdT<3>).
-template <class Epi, class = void>
-struct EpiKHookOf {
-  static constexpr bool value = false;
-  static constexpr int vm_ops = 0;
-  using type = EpiNoPre;
-};
-template <class Epi>
-struct EpiKHookOf<Epi, std::void_t<typename Epi::KHook>> {
-  static constexpr bool value = true;
-  static constexpr int vm_ops = Epi::KHOOK_VM_OPS;   // fire-and-forget VM operations per hook call
-  using type = typename Epi::KHook;
-};
-
 // XCD-aware bijective remap of the flat workgroup id (guide T1).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7;
@@ -660,8 +644,6 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
     }
   };
 
-  typename EpiKHookOf<Epi>::type hook_state;
-  if constexpr (EpiKHookOf<Epi>::value) epi.khook_init(hook_state);
   if (nk > 0) {
     Frag f0, f1;
     // request order inside every group is B first, then A: the operand with fewer buffers is always the
@@ -688,9 +670,7 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
       // the barrier and expose the fragment-read latency in front of it)
       __builtin_amdgcn_sched_barrier(0);
       if (kt + NBA <= nk) {  // steady state: constant allowance, one immediate
-        // (+ the VM operations a K-loop hook issues per iteration without ever waiting for them: they sit between the
-        //  tiles' requests in the in-order queue and must not be mistaken for a tile)
-        constexpr int STEADY = NIA * (NBA - 2) + NIB * (NBB - 2) + EpiKHookOf<Epi>::vm_ops;
+        constexpr int STEADY = NIA * (NBA - 2) + NIB * (NBB - 2);
         if constexpr (STEADY == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if constexpr (STEADY == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else if constexpr (STEADY == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -707,8 +687,6 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
       if (kt + NBB < nk) issue_b(kt + NBB, cb);
       if (kt + NBA < nk) issue_a(kt + NBA, ca);
       if (kt + 1 < nk) read_frags(na, nb, 0, f0);
-      if constexpr (EpiKHookOf<Epi>::value)
-        epi.khook(hook_state, kt, nk, row_base + wm * 32, col_base, lane, M, ldsA + (NBA * ABUF + NBB * BBUF) * 4);
       mfma16(f1);
       ca = na;
       cb = nb;
@@ -716,7 +694,6 @@ __device__ __forceinline__ void gemm_block_glds(int M, int N, int ks, int ke, in
     VD_T(2);
     VD_TREAL(9);
   }
-  if constexpr (EpiKHookOf<Epi>::value) epi.khook_finish(hook_state, row_base + wm * 32, col_base, lane, M);
   if constexpr (NT == 8) {
     // 256-column tiles (two gate groups of 32 hidden units per wave, 128 accumulator registers): the epilogue functors
     // are written for ONE group of four 32 x 32 tiles and run once per group
@@ -738,30 +715,8 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW)
 gemm_f32_glds_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, int rotate, const float* A, long lda,
                      const float* B, long ldb, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // workgroup -> tile.  bits 8.. of `rotate` select the XCD partition (block b runs on XCD b % 8):
-  //   0  every XCD owns a contiguous range of tiles in n-fastest order (all column tiles of ~tiles_m/8 row tiles)
-  //   1  every XCD owns tiles_n/8 COLUMN tiles for all row tiles: its slice of the B operand (the recurrent weights)
-  //      stays resident in its private L2, the A panels stream through (needs tiles_n % 8 == 0, no split-K)
-  //   2  2 x 4: XCD x owns column group x & 3 (tiles_n/4 tiles) of row half x >> 2 (needs tiles_n % 4 == 0)
-  const int xmap = rotate >> 8;
-  rotate &= 255;
-  int tile_n, tile_m, split = 0;
-  if (xmap == 1) {
-    const int cpx = tiles_n >> 3, xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
-    tile_n = xcd * cpx + li % cpx;
-    tile_m = li / cpx;
-  } else if (xmap == 2) {
-    const int cpx = tiles_n >> 2, xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
-    const int half0 = (tiles_m + 1) >> 1;
-    tile_n = (xcd & 3) * cpx + li % cpx;
-    tile_m = (xcd >> 2) * half0 + li / cpx;
-    if (tile_m >= tiles_m) return;           // the grid is padded to 8 x half0 x cpx
-  } else {
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    tile_n = wg % tiles_n;
-    tile_m = (wg / tiles_n) % tiles_m;
-    split = wg / (tiles_n * tiles_m);
-  }
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = wg % tiles_n, tile_m = (wg / tiles_n) % tiles_m, split = wg / (tiles_n * tiles_m);
   const int ks = split * kchunk, ke = min(K, ks + kchunk);
   gemm_block_glds<Cfg, KMAJ>(M, N, ks, ke, tile_m * Cfg::BM, tile_n * Cfg::BN,
                              rotate ? tile_m * 5 + tile_n * 3 + split : -1, A, lda, B, ldb, epi, smem);
@@ -792,17 +747,9 @@ static int launch_gemm_glds(int M, int N, int K, int splits, const float* A, lon
                                160 * 1024));
     attr_set = true;
   }
-  int rotate = rotate_in >= 0 ? rotate_in : vd_tune_get("VD_GEMM_ROTATE", 1);
-  // A/B knobs (scripts/microbench.py): XCD partition of the step kernels' tiles, and an LDS request padded beyond
-  // what the kernel uses (occupancy shaping: 41 KB -> 3 workgroups per CU, 70 KB -> 2, 100 KB -> 1)
-  int grid = tiles_m * tiles_n * splits;
-  int xmap = (!KMAJ && splits == 1) ? vd_tune_get("VD_GLDS_XMAP", 0) : 0;
-  if (xmap == 1 && tiles_n % 8 != 0) xmap = 0;
-  if (xmap == 2 && tiles_n % 4 != 0) xmap = 0;
-  if (xmap == 2) grid = 8 * ((tiles_m + 1) / 2) * (tiles_n / 4);
-  rotate |= xmap << 8;
-  int lds = Cfg::LDS_BYTES;
-  if (!KMAJ) lds = max(lds, min(160 * 1024, vd_tune_get("VD_GLDS_LDS_BYTES", 0)));
+  const int rotate = rotate_in >= 0 ? rotate_in : 1;
+  const int grid = tiles_m * tiles_n * splits;
+  const int lds = Cfg::LDS_BYTES;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds, stream, M, N, K,
                      kchunk, tiles_m, tiles_n, rotate, A, lda, B, ldb, e);
   VD_LAUNCH_CHECK();
@@ -854,147 +801,6 @@ static int launch_grouped(GroupArgs<Prob, MAXP>& g, hipStream_t stream) {
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(total), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, g);
-  VD_LAUNCH_CHECK();
-  return VD_OK;
-}
-
-// ---------------------------------------------------------------------------
-// LDS-DMA pipeline for LATENCY shapes (the encoder's forward ticks: <= 200 rows): a 32 x (NT*32) output tile, FOUR waves that
-// split every 16-wide K tile between them (wave w multiplies k = 4w .. 4w+3) and reduce through LDS at the end.  Both operands
-// are k-contiguous rows (A[M x K], Bt[N x K]); tiles go global -> LDS by DMA into a ring of three [rows][16 floats] buffers
-// (10 KB per K tile at NT = 4, 30 KB in all: what the throughput workgroups leave free on a CU), so two K tiles are always in
-// flight without holding a single staging register -- the register-staged twin (gemm_block, WK = 4) can keep ONE tile in flight
-// before it spills, and in the training step its K loop is a chain of dependent 2-3 us round trips.  Chunk swizzle on the source
-// side and counted vmcnt as in gemm_block_glds; one barrier per K tile.
-// ---------------------------------------------------------------------------
-template <int NT, class Epi>
-__device__ __forceinline__ void gemm_block_glds_wk(int M, int N, int K, int row_base, int col_base, const float* A, long lda,
-                                                   const float* Bt, long ldb, const Epi& epi, float* smem) {
-  constexpr int BN = NT * 32, ATILE = 32 * 16, BTILE = BN * 16, TILE = ATILE + BTILE;   // floats
-  constexpr int NIB = BN / 16;                 // B instructions per K tile (one instruction = 16 rows x 64 B)
-  static_assert(NIB % 4 == 0, "the B tile must split evenly over the four waves");
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nk = K / 16;
-  f32x16 acc[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-  // this wave's DMA instructions: B row groups wk * NIB/4 .. + NIB/4 - 1; waves 0 and 1 also one A row group each
-  constexpr int NBW = NIB / 4;
-  unsigned voffb[NBW], voffa = 0;
-#pragma unroll
-  for (int i = 0; i < NBW; ++i) {
-    const int r = (wk * NBW + i) * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((r >> 2) & 3);
-    voffb[i] = (unsigned)(((long)min(col_base + r, N - 1) * ldb + c * 4) * 4);
-  }
-  if (wk < 2) {
-    const int r = wk * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((r >> 2) & 3);
-    voffa = (unsigned)(((long)min(row_base + r, M - 1) * lda + c * 4) * 4);
-  }
-  const unsigned lds0 = (unsigned)(uintptr_t)smem;
-  auto issue = [&](int kt, int buf) {
-    const unsigned base = lds0 + buf * (TILE * 4);
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) glds16(voffb[i], Bt + (long)kt * 16, base + ATILE * 4 + (wk * NBW + i) * 1024);
-    if (wk < 2) glds16(voffa, A + (long)kt * 16, base + wk * 1024);
-  };
-  auto wait_landed = [&](bool more) {          // tile kt has landed when at most the next tile's requests are in flight
-    if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (wk < 2) {
-      if constexpr (NBW + 1 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else if constexpr (NBW + 1 == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else if constexpr (NBW == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  };
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int slot = (wk ^ ((l31 >> 2) & 3)) * 4;   // this wave's 4 k of a row sit in LDS slot (chunk ^ swizzle)
-  if (nk > 0) {
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      wait_landed(kt + 1 < nk);
-      asm volatile("s_barrier" ::: "memory");   // everybody's share of tile kt is in LDS; tile kt - 1 is fully consumed
-      if (kt + 2 < nk) issue(kt + 2, buf == 0 ? 2 : buf - 1);
-      const float* sa = smem + buf * TILE;
-      const float* sb = sa + ATILE;
-      const float4 a4 = *reinterpret_cast<const float4*>(sa + l31 * 16 + slot);
-      float4 b4[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) b4[j] = *reinterpret_cast<const float4*>(sb + (j * 32 + l31) * 16 + slot);
-      // 32x32x2: lanes 0-31 feed k, lanes 32-63 k + 1
-      const float a0 = hi ? a4.y : a4.x, a1 = hi ? a4.w : a4.z;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, hi ? b4[j].y : b4[j].x, acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, hi ? b4[j].w : b4[j].z, acc[j], 0, 0, 0);
-      buf = buf == 2 ? 0 : buf + 1;
-    }
-  }
-  // intra-block split-K reduction (as gemm_block): waves 1..3 park their partial sums one 32 x 32 tile at a time
-  float* red = smem;
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    __syncthreads();
-    if (wk > 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[((wk - 1) * 16 + r) * 64 + lane] = acc[j][r];
-    }
-    __syncthreads();
-    if (wk == 0) {
-#pragma unroll
-      for (int w = 0; w < 3; ++w)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] += red[(w * 16 + r) * 64 + lane];
-    }
-  }
-  if (wk > 0) return;
-  epi(acc, row_base, col_base, lane, M, N, smem);
-}
-
-// grouped launch of gemm_block_glds_wk: Prob = {M, N, K, tiles_n, a (row pointer + ld), bt (transposed weights + ld), e}
-template <int NT, class Prob, int MAXP>
-__global__ void __launch_bounds__(256, 4) gemm_f32_grouped_glds_wk_kernel(GroupArgs<Prob, MAXP> g) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __builtin_amdgcn_s_setprio(3);
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < MAXP; ++i)
-    if (i < g.nprob && wg >= g.tile_start[i]) pi = i;
-  const Prob& P = g.p[pi];
-  const int t = wg - g.tile_start[pi];
-  const int tile_n = t % P.tiles_n, tile_m = t / P.tiles_n;
-  gemm_block_glds_wk<NT>(P.M, P.N, P.K, tile_m * 32, tile_n * NT * 32, P.a, P.lda, P.bt, P.ldb, P.e, smem);
-}
-
-template <int NT, class Prob, int MAXP>
-static int launch_grouped_glds_wk(GroupArgs<Prob, MAXP>& g, hipStream_t stream) {
-  int total = 0;
-  for (int i = 0; i < g.nprob; ++i) {
-    g.p[i].tiles_n = vd_cdiv(g.p[i].N, NT * 32);
-    g.tile_start[i] = total;
-    total += vd_cdiv(g.p[i].M, 32) * g.p[i].tiles_n;
-  }
-  g.tile_start[g.nprob] = total;
-  if (total == 0) return VD_OK;
-  constexpr int LDS = 3 * (32 + NT * 32) * 16 * 4;
-  auto kern = gemm_f32_grouped_glds_wk_kernel<NT, Prob, MAXP>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(total), dim3(256), LDS, stream, g);
   VD_LAUNCH_CHECK();
   return VD_OK;
 }
@@ -1075,7 +881,7 @@ static int launch_gemm(int M, int N, int K, int splits, ASrc a, BSrc b, Epi e, h
     attr_set = true;
   }
   const int grid = tiles_m * tiles_n * splits;
-  const int rotate = vd_tune_get("VD_GEMM_ROTATE", 1);
+  const int rotate = (1);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, M, N, K, kchunk, tiles_m,
                      tiles_n, rotate, a, b, e);
   VD_LAUNCH_CHECK();

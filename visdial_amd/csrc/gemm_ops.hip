@@ -149,8 +149,7 @@ gemm_bf16_tn_tr_kernel(const vd_bf16_bits* __restrict__ A, const vd_bf16_bits* _
 static int launch_gemm_bf16_tn_tr(const vd_bf16_bits* A, const vd_bf16_bits* B, float* C, long ldc, int M, int N, int K,
                                   hipStream_t stream) {
   const int tiles_m = M / 128, tiles_n = N / 128;
-  const int target = vd_tune_get("VD_TN_BLOCKS", 768);
-  long splits = vd_cdiv(target, (long)tiles_m * tiles_n);
+  long splits = vd_cdiv(768, (long)tiles_m * tiles_n);       // one full round of workgroups (3 per CU x 256 CUs)
   int kchunk = vd_cdiv(vd_cdiv(K, splits), 32) * 32;
   if (kchunk < 32) kchunk = 32;
   splits = vd_cdiv(K, kchunk);
@@ -170,11 +169,6 @@ static int launch_gemm_bf16_tn_tr(const vd_bf16_bits* A, const vd_bf16_bits* B, 
 extern "C" {
 
 // C[M x N] (+)= act(A[M x K] * W[N x K]^T + bias)
-// Launches on a SIDE stream (common.h: beside another stream's throughput kernels) take these: the same kernels with
-// an LDS request that fits beside three 41 KB workgroups -- 20 KB register-staged, 32 KB LDS-DMA (2 + 2 buffers).
-using CfgSideStaged = GemmCfg<4, 1, 4, 16, 0, 4, 0>;
-using CfgSideDma = GemmCfg<4, 1, 4, 16, 0, 4, 32768>;
-
 int vd_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C,
                int64_t ldc, int M, int N, int K, int act, int accumulate, void* stream) {
   VD_CHECK_ARG(A && W && C && M >= 0 && N >= 0 && K >= 0 && K % 4 == 0, "vd_gemm_nt: bad args M=%d N=%d K=%d", M,
@@ -189,18 +183,8 @@ int vd_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const f
   }
   EpiStore<4> e{C, ldc, bias, act, accumulate};
   // both operands are k-contiguous rows: throughput shapes take the LDS-DMA pipeline (gemm_core.h)
-  static const int nt_glds = getenv("VD_NT_GLDS") ? atoi(getenv("VD_NT_GLDS")) : 1;
-  if (nt_glds && M >= 1024 && K >= 64 && K % 16 == 0 && (long)M * lda * 4 < (1L << 32) && (long)N * ldw * 4 < (1L << 32)) {
-    // atomic accumulation (accumulate == 2, no bias / activation: the shared embedding gradient dEmb += dTable * Wx^T, 267 tiles
-    // of K = 2048 -- one latency-bound wave of workgroups at the very end of the step): split K so the launch fills the chip
-    int splits = 1;
-    if (accumulate == 2 && !bias && act == VD_ACT_NONE && vd_tune_get("VD_NT_SPLITK", 0)) {
-      const long tiles = (long)vd_cdiv(M, 128) * vd_cdiv(N, 128);
-      splits = (int)std::max(1L, std::min((long)K / 256, 768 / tiles));
-    }
-    if (vd_stream_is_side(s)) return launch_gemm_glds<CfgSideDma, false>(M, N, K, splits, A, lda, W, ldw, e, s, -1, splits > 1);
-    return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 41984>, false>(M, N, K, splits, A, lda, W, ldw, e, s, -1, splits > 1);
-  }
+  if (M >= 1024 && K >= 64 && K % 16 == 0 && (long)M * lda * 4 < (1L << 32) && (long)N * ldw * 4 < (1L << 32))
+    return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 41984>, false>(M, N, K, 1, A, lda, W, ldw, e, s);
   return launch_gemm<CfgBig>(M, N, K, 1, a, b, e, s);
 }
 
@@ -242,23 +226,19 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
   // rotation: 133.9 TFLOP/s on the option dWh shape (M=512, N=2048, K=380 000) vs 119.6 for the register-staged
   // kernel at 1024 blocks (profiles/r02_dwh_sweep.txt; with 1024 blocks the ranking was the opposite in round 1:
   // the 1.33-round tail, not the pipeline, decided).
-  const int cfg = vd_tune_get("VD_TN_CFG", 20);
-  const bool kmaj = cfg == 20 && !(flags & VD_FLAG_BF16) && M % 128 == 0 && N % 128 == 0 &&
-                    K >= vd_tune_get("VD_TN_KMAJ_MINK", 1024);
+  const bool kmaj = !(flags & VD_FLAG_BF16) && M % 128 == 0 && N % 128 == 0 && K >= 1024;
   if (kmaj && K % 16 != 0) {
     // the k-major pipeline moves whole 16-row K tiles: contract the first floor(K / 16) * 16 rows with it and the last
     // < 16 rows with the register-staged kernel (one short launch; e.g. the encoder's (T-1)*N = 7 800 rows)
     const int K1 = K & ~15;
     if (int rc = vd_gemm_tn_acc(A, lda, B, ldb, C, ldc, M, N, K1, flags, stream)) return rc;
     SrcK a2{A + (long)K1 * lda, lda}, b2{B + (long)K1 * ldb, ldb};
-    if (vd_stream_is_side((hipStream_t)stream)) return launch_gemm<CfgSideStaged>(M, N, K - K1, 1, a2, b2, e, (hipStream_t)stream);
     return launch_gemm<GemmCfg<4, 1, 4, 16, 0, 4, 41984>>(M, N, K - K1, 1, a2, b2, e, (hipStream_t)stream);
   }
   // split-K target: one full round of workgroups for the big k-major shape; the register-staged shapes (encoder weight
   // gradients, K <= 11 323) take fewer, longer slices -- every slice ends in 64 KB of float atomics per tile
-  const int target = kmaj ? vd_tune_get("VD_TN_BLOCKS", 768) : vd_tune_get("VD_TN_BLOCKS_SMALL", 768);
-  long splits = vd_cdiv(target, tiles);
-  const long max_splits = vd_cdiv(K, vd_tune_get("VD_TN_MIN_KCHUNK", 1024));   // (sweep in the full step: 26.03 -> 25.70 ms vs 1024 blocks / 64-row slices)
+  long splits = vd_cdiv(768, tiles);
+  const long max_splits = vd_cdiv(K, 1024);   // (sweep in the full step: 26.03 -> 25.70 ms vs 1024 blocks / 64-row slices)
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   if (flags & VD_FLAG_BF16) {   // opt-in reduced precision: bf16 operands, fp32 accumulation
@@ -276,21 +256,10 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
     }
     return launch_gemm<GemmCfg<4, 1, 4, 32, 0, 3, 0, 1>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
   }
-  const bool side = vd_stream_is_side((hipStream_t)stream);
-  if (kmaj && side)
-    return launch_gemm_glds<CfgSideDma, true>(M, N, K, (int)splits, A, lda, B, ldb, e, (hipStream_t)stream,
-                                              vd_tune_get("VD_TN_ROTATE", 0));
   if (kmaj)
-    return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 41984>, true>(M, N, K, (int)splits, A, lda, B, ldb, e,
-                                                                      (hipStream_t)stream, vd_tune_get("VD_TN_ROTATE", 0));
-  if ((cfg == 20 || cfg == 5) && side) return launch_gemm<CfgSideStaged>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
-  if (cfg == 20 || cfg == 5)   // (cfg 20 on a shape the k-major pipeline does not take: the register-staged default)
-    return launch_gemm<GemmCfg<4, 1, 4, 16, 0, 4, 41984>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
-  if (cfg == 1) return launch_gemm<CfgBig>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
-  if (cfg == 2) return launch_gemm<GemmCfg<4, 1, 4, 16, 0, 3>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
-  if (cfg == 3) return launch_gemm<GemmCfg<4, 1, 4, 16, 2, 3>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
-  if (cfg == 4) return launch_gemm<GemmCfg<4, 1, 4, 32, 2, 3>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
-  return launch_gemm<CfgBigDB>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
+    return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 41984>, true>(M, N, K, (int)splits, A, lda, B, ldb, e, (hipStream_t)stream, 0);
+  // a shape the k-major pipeline does not take: the register-staged kernel
+  return launch_gemm<GemmCfg<4, 1, 4, 16, 0, 4, 41984>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
 }
 
 // C[M x N] += sum_k A[a_rows[k], :M]^T * B[b_rows[k], :N]: the weight-gradient contraction over an explicit list of K
@@ -307,11 +276,10 @@ int vd_gemm_tn_rows_acc(const float* A, int64_t lda, const int32_t* a_rows, cons
   EpiAtomic<4> e{C, ldc};
   using Cfg = GemmCfg<4, 1, 4, 16, 0, 4, 41984>;
   const long tiles = (long)vd_cdiv(M, Cfg::BM) * vd_cdiv(N, Cfg::BN);
-  long splits = vd_cdiv(vd_tune_get("VD_TN_BLOCKS_SMALL", 768), tiles);
-  const long max_splits = vd_cdiv(K, vd_tune_get("VD_TN_MIN_KCHUNK", 1024));
+  long splits = vd_cdiv(768, tiles);
+  const long max_splits = vd_cdiv(K, 1024);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  if (vd_stream_is_side((hipStream_t)stream)) return launch_gemm<CfgSideStaged>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
   return launch_gemm<Cfg>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
 }
 

@@ -95,7 +95,6 @@ struct vd_model {
   // queue of the other side streams (runtime.hip).  wg_active: the current backward uses it; wg_used: it holds un-joined work
   hipStream_t s_wg = nullptr;
   bool wg_active = false, wg_used = false;
-  const float* dtab_zeroed = nullptr;   // the option table-gradient buffer was re-zeroed behind its last reader of the previous step
   std::vector<hipEvent_t> ev_pool;
   size_t ev_next = 0;
   hipEvent_t ev_enc_grads = nullptr;  // recorded behind the encoder backward: its gradient tensors are final
@@ -407,15 +406,14 @@ struct SeqLSTM {
     const long TN = (long)T * N;
     float* dW = Gp(m, name + ".W");
     float* dWh = dW + D * 4 * H;
-    const bool by_rows = rows && rows->act && vd_tune_get("VD_SKIP_PAD_WGRAD", 1) != 0;
+    const bool by_rows = rows && rows->act;
     // Where the shape fits the k-major LDS-DMA contraction (M, N multiples of 128: the recurrent weights and the
     // layer-2 input weights at H = 512) the DENSE product over all T*N rows on that kernel beats the index-list
     // contraction of the non-pad pairs: the pad pairs hold da = 0 (rt_encoders.h zero-fills them), the kernel streams at
     // the option dWh kernel's rate, and its workgroups live ~0.1 ms instead of ~0.8 ms -- the index-list kernel is a chain
     // of dependent (row index -> row) loads per K tile whose long-lived workgroups take the third slot of a third of the
     // CUs away from the option-LSTM backward kernels for most of their run.
-    const int dense_mode = vd_tune_get("VD_WGRAD_DENSE", 1);
-    auto dense_fits = [&](long Mrows, long K) { return dense_mode != 0 && Mrows % 128 == 0 && (4 * H) % 128 == 0 && K >= 1024; };
+    auto dense_fits = [&](long Mrows, long K) { return Mrows % 128 == 0 && (4 * H) % 128 == 0 && K >= 1024; };
     if (by_rows && !(T > 1 && dense_fits(H, (long)(T - 1) * N))) {
       if (rows->n_act1 > 0)
         VD_TRY(vd_gemm_tn_rows_acc(h, H, rows->prev1, gates, 4 * H, rows->act1, dWh, 4 * H, (int)H, (int)(4 * H), rows->n_act1, s));

@@ -69,13 +69,11 @@ struct Disc : Decoder {
     const int flags = m->p.lstmBf16 ? VD_FLAG_BF16 : 0;
     VD_TRY(fork_stream(m, s, se));
     float* enc_out = nullptr;
-    const bool enc_first = vd_tune_get("VD_RT_ENC_FIRST", 0) != 0;     // host enqueue order (A/B knob)
-    if (enc_first) VD_TRY(m->enc->forward(m, se, b, &enc_out));
     VD_TRY(vd_gemm_nn(Wp(m, "embed"), E, Wopt, 4 * H, Wp(m, "opt.b"), table, 4 * H, (int)V + 1, (int)(4 * H), (int)E, 0, s));
     VD_HIP(hipEventRecord(m->ev_prof[0], s));
     VD_TRY(vd_lstm_forward(table, 0, 4 * H, b.opt.tok, nullptr, Wopt + E * 4 * H, nullptr, nullptr, gates, h, c, To, NO, (int)H, flags, s));
     VD_HIP(hipEventRecord(m->ev_prof[1], s));
-    if (!enc_first) VD_TRY(m->enc->forward(m, se, b, &enc_out));                   // model.lua:297
+    VD_TRY(m->enc->forward(m, se, b, &enc_out));                                   // model.lua:297
     VD_TRY(join_stream(m, se, s));
     // criterion (+ nn.MM backward) in one kernel (model.lua:330-335)
     const float* optH = h + (long)(To - 1) * NO * H;
@@ -103,35 +101,18 @@ struct Disc : Decoder {
     // decoder backward on the main stream, encoder backward beside it (model.lua:335-337)
     VD_TRY(fork_stream(m, s, se));
     float *dc, *dtab;
-    int32_t *offset, *work, *perm;
+    int32_t* perm = b.opt_sort_perm;               // sorted at upload time (runtime.hip)
     VD_TRY(ws_get(m, "opt.dc", (size_t)NO * H, &dc));
     VD_TRY(ws_get(m, "opt.dtable", (size_t)(V + 1) * 4 * H, &dtab));
-    VD_TRY(ws_get(m, "opt.sort_off", (size_t)V + 2, &offset));
-    VD_TRY(ws_get(m, "opt.sort_work", (size_t)2 * (V + 1), &work));
-    VD_TRY(ws_get(m, "opt.sort_perm", (size_t)To * NO, &perm));
-    if (b.opt_sort_perm) {
-      perm = b.opt_sort_perm;                    // sorted at upload time (runtime.hip)
-    } else {
-      VD_TRY(fork_stream(m, s, st));
-      VD_TRY(vd_token_sort(b.opt.tok, (long)To * NO, (int)V + 1, offset, work, perm, st));
-    }
-    const bool dtab_defer = vd_tune_get("VD_RT_DTAB_DEFER_ZERO", 0) != 0;
-    if (!(dtab_defer && m->dtab_zeroed == dtab)) {
-      VD_TRY(fork_stream(m, s, st));
-      VD_TRY(vd_memset(dtab, 0, (V + 1) * 4 * H * 4, st));
-    }
-    m->dtab_zeroed = nullptr;
+    VD_CHECK_ARG(perm, "decoder 'disc': the batch slot carries no option-token sort");
+    VD_TRY(fork_stream(m, s, st));
+    VD_TRY(vd_memset(dtab, 0, (V + 1) * 4 * H * 4, st));
     VD_HIP(hipEventRecord(m->ev_prof[2], s));
-    const bool dwh_first = vd_tune_get("VD_RT_DWH_FIRST", 0) != 0;   // host enqueue order (matters when streams share a hardware queue)
-    // the encoder backward's ~110 launches enqueued BEFORE the option recurrence's (A/B knob): whichever chain is the critical path
-    // of the step should not wait for the host to finish enqueueing the other one
-    const bool enc_bwd_first = !dwh_first && vd_tune_get("VD_RT_ENC_BWD_FIRST", 0) != 0;
-    // off-chain parameter-gradient work of the encoder on its own (middle-priority) stream = its own hardware queue: the in-order
-    // queue of the encoder stream then carries the dependent chain (attention backward -> ticks) and the table gradient only.
-    // Default: on in a bf16 pass (the encoder chain is that step's critical path: 12.34 -> 12.02 ms, profiles/r03_experiments.txt
-    // section 21), off in fp32 (work-conserving on the matrix pipe).  Never joined into `se`: a wait there would be a barrier
-    // packet in front of the table-gradient chain.
-    m->wg_active = m->streams && m->s_wg && vd_tune_get("VD_RT_WG_STREAM", flags ? 1 : 0) != 0;
+    // off-chain parameter-gradient work of the encoder on its own (middle-priority) stream = its own hardware queue in a bf16 pass
+    // (the encoder chain is that step's critical path: 12.34 -> 12.02 ms, profiles/r03_experiments.txt section 21); in fp32 the step
+    // is work-conserving on the matrix pipe and it stays on the encoder stream.  Never joined into `se`: a wait there would be a
+    // barrier packet in front of the table-gradient chain.
+    m->wg_active = m->streams && m->s_wg && flags != 0;
     m->wg_used = false;
     auto enc_bwd = [&]() -> int {
       VD_TRY(m->enc->backward(m, se, b, d_enc));
@@ -144,29 +125,9 @@ struct Disc : Decoder {
       m->enc_grads_recorded = true;
       return VD_OK;
     };
-    // A/B knob VD_RT_ENC_BWD_SPLIT = k (0 = off): the option-LSTM backward runs steps To-1 .. k ALONE, and the encoder
-    // backward only starts beside steps k-1 .. 0 and the dWh contraction (the backward step kernels lose 30 % beside the
-    // encoder, the one-round dWh kernel 7 %).  Two calls of the recurrence: the hand-off is the library's own
-    // (dh0, dc) of the first slice = (dh_last, dc_last) of the second.
-    const int split_k = (!flags && To > 2 && !enc_bwd_first) ? vd_tune_get("VD_RT_ENC_BWD_SPLIT", 0) : 0;
-    bool enc_started = false;
-    if (enc_bwd_first) { VD_TRY(enc_bwd()); enc_started = true; }
-    if (split_k > 0 && split_k < To) {
-      const long NH = (long)NO * H;
-      float* dh_mid;
-      VD_TRY(ws_get(m, "opt.dh_mid", (size_t)NO * H, &dh_mid));
-      VD_TRY(vd_lstm_backward(Wopt + E * 4 * H, gates + (long)split_k * 4 * NH, c + (long)split_k * NH, c + (long)(split_k - 1) * NH, nullptr,
-                              d_optH, nullptr, dc, dh_mid, nullptr, nullptr, To - split_k, NO, (int)H, flags, s));
-      VD_TRY(fork_stream(m, s, se));      // the encoder backward may start now
-      if (!dwh_first) { VD_TRY(enc_bwd()); enc_started = true; }
-      VD_TRY(vd_lstm_backward(Wopt + E * 4 * H, gates, c, nullptr, nullptr, dh_mid, dc, dc, nullptr, nullptr, nullptr, split_k, NO, (int)H,
-                              flags, s));
-    } else {
-      VD_TRY(vd_lstm_backward(Wopt + E * 4 * H, gates, c, nullptr, nullptr, d_optH, nullptr, dc, nullptr, nullptr, nullptr, To, NO, (int)H, flags,
-                              s));
-    }
+    VD_TRY(vd_lstm_backward(Wopt + E * 4 * H, gates, c, nullptr, nullptr, d_optH, nullptr, dc, nullptr, nullptr, nullptr, To, NO, (int)H, flags, s));
     VD_HIP(hipEventRecord(m->ev_prof[3], s));
-    if (!dwh_first && !enc_started) VD_TRY(enc_bwd());
+    VD_TRY(enc_bwd());       // enqueued behind the option recurrence: it runs beside it on the encoder stream
     // table gradient + its consumers beside the dWh contraction
     VD_TRY(fork_stream(m, s, st));
     VD_TRY(vd_segment_rowsum_acc(gates, 4 * H, b.opt.tok, perm, (long)To * NO, (int)(4 * H), dtab, 4 * H, st));
@@ -177,7 +138,6 @@ struct Disc : Decoder {
       VD_TRY(vd_gemm_tn_acc(h, H, gates + (long)NO * 4 * H, 4 * H, Gp(m, "opt.W") + E * 4 * H, 4 * H, (int)H, (int)(4 * H), (To - 1) * NO, flags,
                             s));
     VD_HIP(hipEventRecord(m->ev_prof[5], s));
-    if (dwh_first) VD_TRY(enc_bwd());
     // dEmb += dTable * Wx^T on the table stream, with float atomics: the SHARED embedding gradient has concurrent atomic
     // writers (the encoder's scatters), and the product is off the main stream's critical path this way
     VD_TRY(vd_gemm_nt(dtab, 4 * H, Wopt, 4 * H, nullptr, Gp(m, "embed"), E, (int)V + 1, (int)E, (int)(4 * H), VD_ACT_NONE, 2, st));
@@ -185,10 +145,6 @@ struct Disc : Decoder {
     if (m->wg_used) VD_TRY(join_stream(m, m->s_wg, s));
     m->wg_active = m->wg_used = false;
     VD_TRY(join_stream(m, st, s));
-    if (dtab_defer) {   // re-zero the table gradient for the next step BEHIND the join: it runs beside the optimiser, not in front of a step
-      VD_TRY(vd_memset(dtab, 0, (V + 1) * 4 * H * 4, st));
-      m->dtab_zeroed = dtab;
-    }
     return VD_OK;
   }
   int retrieve(vd_model* m, BatchSlot& b) override { return forward_backward(m, b, true); }   // model.lua:421-425

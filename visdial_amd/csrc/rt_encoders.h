@@ -70,7 +70,7 @@ struct TextBranches {
     VD_TRY(vd_gemm_nn(xs, E, l1.Wx(m), 4 * H, Wp(m, l1.name + ".b"), l1.gates, 4 * H, (int)TN, (int)(4 * H), (int)E, 0, s));
     // skipped (t, row) pairs must read as zeros: previous state of rows that become active later, da = 0 in the
     // weight-gradient contractions
-    if (ss.sorted && vd_tune_get("VD_RT_ZERO_INACTIVE", 1)) {
+    if (ss.sorted) {
       // only the skipped pairs, all six buffers in one launch: the active rows are written by the recurrence before anything reads them
       VdZeroSet z{{l1.gates, l1.h, l1.c, l2.h, l2.c, l2.gates}, {(int)(4 * H), (int)H, (int)H, (int)H, (int)H, (int)(4 * H)}, 6, 0};
       VD_TRY(vd_zero_inactive_multi(z, ss.nact_dev, ss.T, ss.N, s));

@@ -173,14 +173,9 @@ int vd_model_create(const vd_model_params* p, const char* encoder, const char* d
   if (hipStreamCreateWithPriority(&m->s_main, hipStreamNonBlocking, least) != hipSuccess) return fail(VD_ERR_HIP);
   for (hipStream_t* s : {&m->s_enc, &m->s_img, &m->s_copy})
     if (hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest) != hipSuccess) return fail(VD_ERR_HIP);
-  // A/B knob VD_RT_TAB_MID_PRIO=1: the table-gradient stream at the MIDDLE priority.  HIP gives every priority class its
-  // own hardware queue (rocprofv3 kernel trace, GPU_MAX_HW_QUEUES=1: main -> one queue, all `greatest` streams ->
-  // another); inside a queue packets start in submission order, so the table-gradient chain (segmented row sum, dTable
-  // products -- enqueued behind the encoder backward's ~100 packets) only starts when the encoder backward has drained
-  // and ends ~0.5 ms after the dWh contraction.  On its own queue it starts with dWh instead -- and LOSES 0.5 ms per
-  // step (24.97 / 25.14 vs 24.46 / 24.53 ms): beside the MFMA-bound dWh the HBM-bound row sum takes 2.9 ms instead of
-  // 0.7 and dWh 6.9 instead of 6.1 (profiles/r03_experiments.txt).  Default off.
-  const int tab_prio = (least - greatest >= 2 && vd_tune_get("VD_RT_TAB_MID_PRIO", 0)) ? (least + greatest) / 2 : greatest;
+  // the table-gradient stream shares the `greatest` class (one hardware queue per priority class): on a queue of its own its
+  // HBM-bound row sum would start beside the MFMA-bound dWh contraction and cost 0.5 ms per step (profiles/r03_experiments.txt)
+  const int tab_prio = greatest;
   if (hipStreamCreateWithPriority(&m->s_tab, hipStreamNonBlocking, tab_prio) != hipSuccess) return fail(VD_ERR_HIP);
   if (least - greatest >= 2 &&
       hipStreamCreateWithPriority(&m->s_wg, hipStreamNonBlocking, (least + greatest) / 2) != hipSuccess)
@@ -192,8 +187,6 @@ int vd_model_create(const vd_model_params* p, const char* encoder, const char* d
   // of the step multiplexed onto ONE hardware queue the cross-stream event waits resolve inside the command processor
   // and the headline step is 0.75-1.0 ms (3-4 %) faster (profiles/r02_hw_queues.txt).
   m->s_hist = m->s_img;
-  if (vd_tune_get("VD_SIDE_SMALL_LDS", 0))   // A/B knob, default off: see common.h
-    for (hipStream_t s : {m->s_enc, m->s_img, m->s_tab}) vd_stream_mark_side(s, true);
   m->ev_pool.resize(64);
   for (auto& e : m->ev_pool)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(VD_ERR_HIP);
@@ -237,7 +230,6 @@ void vd_model_destroy(vd_model* m) {
     if (e) (void)hipEventDestroy(e);
   for (hipStream_t s : {m->s_main, m->s_enc, m->s_img, m->s_tab, m->s_copy, m->s_wg})
     if (s) {
-      vd_stream_mark_side(s, false);
       (void)hipStreamDestroy(s);
     }
   delete m;
@@ -387,7 +379,7 @@ int vd_model_upload_batch(vd_model* m, const vd_batch* hb) {
   for (SeqTok* t : {&sl.q, &sl.h, &sl.opt, &sl.ain, &sl.aout, &sl.oin, &sl.oout}) t->present = false;
   VD_TRY(upload_tokens(sl, sl.q, "q", hb->ques_fwd, N, hb->Tq, m->is_graph, s));
   // the history branch of the Sequential encoders runs as a length-sorted two-layer wavefront too (rt_encoders.h: HistWave)
-  const bool hist_wave = !m->is_graph && m->p.numLayers == 2 && vd_tune_get("VD_RT_HIST_WAVE", 1) != 0;
+  const bool hist_wave = !m->is_graph && m->p.numLayers == 2;
   if (m->use_hist) VD_TRY(upload_tokens(sl, sl.h, "h", hb->hist, N, hb->Th, m->is_graph || hist_wave, s));
   if (m->use_im) {
     // [B x S*S x C] for the attention encoders (model.lua:262-265 keeps one map per image), [B x F] otherwise
@@ -407,7 +399,7 @@ int vd_model_upload_batch(vd_model* m, const vd_batch* hb) {
     sl.opt_total = (int)NO;
     const int To = hb->To;
     bool dedup = false;
-    if (vd_tune_get("VD_DISC_DEDUP", 1) && NO > 1) {
+    if (NO > 1) {
       std::vector<int32_t> uid((size_t)NO), uniq;
       uniq.reserve((size_t)NO * To);
       const size_t cap = (size_t)1 << (64 - __builtin_clzll((unsigned long long)(2 * NO)));   // power of two >= 2 NO
@@ -445,14 +437,12 @@ int vd_model_upload_batch(vd_model* m, const vd_batch* hb) {
     }
     if (!dedup) VD_TRY(upload_tokens(sl, sl.opt, "opt", hb->options, (int)NO, hb->To, false, s));   // [N x O x To] -> [To x N*O]
     sl.opt_sort_off = sl.opt_sort_perm = nullptr;
-    if (vd_tune_get("VD_RT_SORT_AT_UPLOAD", 1)) {
+    {   // counting sort of the option tokens on the copy stream (the table gradient's row order depends on the batch alone)
       const long V1 = (long)m->p.vocabSize + 1, n = (long)sl.opt.T * sl.opt.N;
       int32_t* work;
       VD_TRY(dev_get(sl.bufs, "opt.sort_off", (size_t)(V1 + 1) * sizeof(int32_t), (void**)&sl.opt_sort_off));
       VD_TRY(dev_get(sl.bufs, "opt.sort_work", (size_t)2 * V1 * sizeof(int32_t), (void**)&work));
       VD_TRY(dev_get(sl.bufs, "opt.sort_perm", (size_t)n * sizeof(int32_t), (void**)&sl.opt_sort_perm));
-      // A/B knob: order the sort behind the optimiser launch (it shares HBM with clamp_adam otherwise: 65 -> 104 us)
-      if (m->updated_recorded && vd_tune_get("VD_RT_SORT_AFTER_UPDATE", 0)) VD_HIP(hipStreamWaitEvent(s, m->ev_updated, 0));
       VD_TRY(vd_token_sort(sl.opt.tok, n, (int)V1, sl.opt_sort_off, work, sl.opt_sort_perm, s));
     }
   }

@@ -7,7 +7,6 @@ clones ARE one batch of N*100 option sequences: the option LSTM runs as a single
 (exact: no dropout on option embeddings, disc.lua:12-14), and scoring + cross-entropy + their
 gradients are one wave-reduction kernel.
 """
-import os
 
 import torch
 
@@ -84,9 +83,7 @@ class Decoder(object):
             ops.token_sort(tokf, V + 1, offset, work, perm)
             ops.zero(dtab)
         t0 = ops.prof_begin('opt_lstm_bwd')
-        fused = os.environ.get('VD_LSTM_WGRAD_OVERLAP', '0') == '1'   # dWh chunks trail the steps (opt-in)
-        ops.lstm_backward(self.Wh, self.gates, self.c, dc, To, NO, H, dh_last=d_optH, flags=self.flags,
-                          h_seq=self.h if fused else None, dWh=self.dWh if fused else None)
+        ops.lstm_backward(self.Wh, self.gates, self.c, dc, To, NO, H, dh_last=d_optH, flags=self.flags)
         ops.prof_end('opt_lstm_bwd', t0, 1)
         da = self.gates.view(To * NO, 4 * H)
         # gradient of the gathered table (segmented row sums over the token-sorted rows: one HBM-bound pass over da)
@@ -99,7 +96,7 @@ class Decoder(object):
             # dEmb += dTable * Wx^T with float atomics (accumulate = 2): the SHARED embedding gradient has concurrent
             # atomic writers (the encoder's scatters); off the main stream's critical path here
             ops.gemm_nt(dtab, self.Wx, self.demb, accumulate=2, M=V + 1, N=self.E, K=4 * H)
-        if To > 1 and not fused:
+        if To > 1:
             t0 = ops.prof_begin('opt_lstm_dWh')
             ops.gemm_tn_acc(self.h.view(To * NO, H), da[NO:], self.dWh, M=H, N=4 * H, K=(To - 1) * NO,
                             flags=self.flags)

@@ -306,21 +306,3 @@ def zero(t):
     """t[...] = 0 through vd_memset (hipMemsetAsync on the current stream); contiguous tensors only"""
     call("vd_memset", _p(t), 0, t.numel() * t.element_size(), _stream())
     return t
-
-
-# ---------------------------------------------------------------- tuning knobs / diagnostics
-def tune_set(key, value):
-    """kernel-configuration A/B switch (overrides the environment variable of the same name)"""
-    call("vd_tune_set", key.encode(), int(value))
-
-
-def tune_clear():
-    call("vd_tune_clear")
-
-
-def lstm_seq_status():
-    """synchronises the current stream; True if a bounded spin of the last persistent recurrence timed out"""
-    import ctypes
-    v = ctypes.c_int(0)
-    call("vd_lstm_seq_status", _stream(), ctypes.byref(v))
-    return bool(v.value)
