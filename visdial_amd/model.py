@@ -66,7 +66,7 @@ class Model(SplitEval):
         self.fp.load_host(init_host(spec, params['rnnHiddenSize'], int(params.get('seed', 1234))))
         self.ws = Workspace(self.device)
         self.drop = DropoutState(self.ws, seed=int(params.get('seed', 1234)) + 7919 * int(params.get('rank', 0)))
-        self.streams = StreamPool(self.device, enabled=os.environ.get('VD_STREAMS', '1') != '0')
+        self.streams = StreamPool(self.device, enabled=True)
         self.encoder = self.encFile.model(params, self.fp, self.ws, self.drop, self.streams)
         self.decoder = self.decFile.model(params, self.encoder, self.fp, self.ws, self.drop)
         self.decoder.streams = self.streams
@@ -123,7 +123,7 @@ class Model(SplitEval):
         inputs = []
         q = batch['ques_fwd']
         B = q.shape[0]
-        sort_rows = os.environ.get('VD_SORT_ROWS', '1') != '0' and (p['encoder'].startswith('mn') or
+        sort_rows = (p['encoder'].startswith('mn') or
                                                                       p['encoder'].startswith('lf-att'))
 
         def tokens(a):
@@ -149,7 +149,7 @@ class Model(SplitEval):
             o = batch['options']
             rows = np.ascontiguousarray(o.reshape(-1, o.shape[2]), dtype=np.int32)   # [N*O x To]
             uid = None
-            if os.environ.get('VD_DISC_DEDUP', '1') != '0' and rows.shape[0] > 1:
+            if rows.shape[0] > 1:
                 # encode every DISTINCT candidate once (decoders/disc.lua:4-15: the encoding depends on the tokens only);
                 # same rule as the native runtime (csrc/runtime.hip: vd_model_upload_batch)
                 uniq, inv = np.unique(rows, axis=0, return_inverse=True)
@@ -192,8 +192,7 @@ class Model(SplitEval):
         torch.cuda.current_stream().wait_event(ready)
         pending = self.forwardBackward(batch, prepared=prepared, deferLoss=True)
         self.update()
-        if os.environ.get('VD_PREFETCH', '1') != '0':
-            self._next = self._fetch(dataloader) + (dataloader,)
+        self._next = self._fetch(dataloader) + (dataloader,)       # software pipeline: prefetch the next batch
         curLoss = pending()
         # The loss leaves the device right after the criterion, i.e. BEFORE this step's backward has finished reading
         # the uploaded inputs: keep them referenced until the NEXT step's loss has arrived (stream order then

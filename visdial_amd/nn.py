@@ -205,8 +205,7 @@ class SeqLSTM(object):
         # ... except where the shape fits the k-major LDS-DMA contraction (M, N multiples of 128): there the DENSE
         # product over all T*N rows is faster than the index-list kernel (pad pairs hold da = 0) -- same rule as
         # csrc/rt_core.h SeqLSTM::param_grads
-        dense = os.environ.get('VD_WGRAD_DENSE', '1') != '0'
-        fits = lambda m, kk: dense and m % 128 == 0 and (4 * H) % 128 == 0 and kk >= 1024
+        fits = lambda m, kk: m % 128 == 0 and (4 * H) % 128 == 0 and kk >= 1024
         if rows is not None and not (T > 1 and fits(H, (T - 1) * N)):
             act, act1, prev1 = rows
             if act1.numel():
@@ -265,7 +264,7 @@ class SeqSort(object):
             if T else np.zeros(0, np.int32)
         n0 = int(self.nact[0]) if T else 0
         self.rows = None
-        if os.environ.get('VD_SKIP_PAD_WGRAD', '1') != '0' and act.size:
+        if act.size:
             self.rows = (dev(act), dev(act[n0:]), dev(act[n0:] - N))
 
 
