@@ -275,6 +275,10 @@ def main():
     ap.add_argument('--no-streams', action='store_true', help='whole step on one HIP stream (A/B only)')
     ap.add_argument('--config', type=int, choices=[3, 4], default=3,
                     help='BASELINE.json configs index: 3 = headline (fp32, 14x14x512); 4 = 7x7x2048 features + bf16 option recurrence')
+    ap.add_argument('--recurrence', choices=['fp32', 'split9', 'split6'], default='fp32',
+                    help='arithmetic of the option recurrence at --config 3: fp32 = v_mfma_f32_32x32x2_f32 (DEFAULT, the headline); '
+                         'split9 = exact 3-way bf16 split of both operands, 9 bf16 MFMAs per fp32 one (opt-in, fp32-grade: '
+                         'tests/test_ops_gpu.py::test_split_error_table); split6 = 6 products (data only)')
     ap.add_argument('--collective', choices=['library', 'torch'], default='library',
                     help='native host, N > 1: library = RCCL behind the C ABI (default); torch = host-side torch.distributed')
     ap.add_argument('--host', choices=['python', 'native'], default=os.environ.get('VD_BENCH_HOST', 'native'),
@@ -339,6 +343,9 @@ def main():
     from visdial_amd.model import Model
 
     p = headline_params(rank=rank, batch=args.batch, config=args.config)
+    if args.recurrence != 'fp32':
+        assert args.config == 3, "--recurrence applies to the fp32 headline configuration"
+        p['lstmPrecision'] = args.recurrence
     if args.no_streams:
         p['useStreams'] = 0
     if args.host == 'native':
@@ -408,6 +415,19 @@ def main():
         roof = None
         if dom and args.config == 4:
             roof = bf16_option_roofline(fams, dom)
+        elif dom and args.recurrence != 'fp32':
+            nprod = 9 if args.recurrence == 'split9' else 6
+            step_fam = max(('opt_lstm_fwd', 'opt_lstm_bwd'), key=lambda k: fams[k]['ms_total_per_step'])    # (dWh stays on the fp32 MFMA)
+            a32 = fams[step_fam]['tflops_executed']
+            roof = {"bound": "mfma", "kernel": step_fam, "achieved": round(nprod * a32, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                    "frac": round(nprod * a32 / 2500.0, 4), "traffic": None,
+                    "fp32_equivalent_tflops": round(a32, 2), "fp32_equivalent_frac_of_fp32_mfma_peak": round(a32 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "avg_launch_ms": round(fams[step_fam]['avg_launch_ms'], 4),
+                    "note": "OPT-IN arithmetic, not the headline: every fp32 recurrent product h*Wh / da*Wh^T issued as %d bf16 MFMAs "
+                            "(v_mfma_f32_32x32x16_bf16) on the exact hi/mid/lo split of both operands; achieved = executed bf16-MFMA FLOPs "
+                            "(%d x the fp32 product's) / HIP-event time, priced against the 2.5 PFLOP/s dense bf16 peak; the dWh contraction "
+                            "still runs on v_mfma_f32_32x32x2_f32" % (nprod, nprod),
+                    "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
         elif dom:
             a = fams[dom]['tflops_executed']
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(a, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
@@ -424,7 +444,7 @@ def main():
                             "FETCH_SIZE + WRITE_SIZE), a stored measurement, not a live counter",
                     "step_tflops_nominal": round(STEP_GFLOP_PER_ROUND * value / 1e3, 2),
                     "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
-        if roof and roof.get("bound") == "mfma" and world == 1:
+        if roof and roof.get("bound") == "mfma" and world == 1 and args.recurrence == 'fp32':
             try:
                 roof["alone"] = dominant_kernel_alone(p, N)     # same kernel, same shapes, nothing else on the chip
             except Exception as exc:                            # never let the extra figure break the bench line
@@ -438,7 +458,10 @@ def main():
                                                                                             round(float(np.percentile(ps, 90)), 3)],
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.config == 3 else "bf16 operands / f32 accumulate (option recurrence only), f32 elsewhere",
+            "dtype": ("f32" if args.recurrence == 'fp32' else
+                      "f32 results from the exact 3-way bf16 split of both operands (%s bf16 MFMA products per fp32 product, f32 accumulate) "
+                      "in the option recurrence, f32 MFMA elsewhere" % args.recurrence[-1]) if args.config == 3
+            else "bf16 operands / f32 accumulate (option recurrence only), f32 elsewhere",
             "data": "synthetic" + (" (one resident batch reused)" if args.same_batch else
                                    " (a fresh batch every step: host generation + length sort + H2D upload inside the timed region, overlapped)"),
             "config": {"workload": "mn-att-ques-im-hist + disc, B=%d dialogs/GPU x 10 rounds x 100 options, "
@@ -451,7 +474,7 @@ def main():
                        "option_rows_executed_of_total": (list(model.option_rows()) if args.host == 'native' else None)},
             "roofline": roof,
         }
-        if world == 1 and args.config == 3 and not args.no_other_configs:
+        if world == 1 and args.config == 3 and args.recurrence == 'fp32' and not args.no_other_configs:
             # the other single-GPU configurations of BASELINE.json, driver-visible (the headline `value` above is unaffected:
             # they run after its timed region, on their own models)
             model.close() if hasattr(model, 'close') else None

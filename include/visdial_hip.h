@@ -52,6 +52,13 @@ int vd_copy_2d(float* dst, int64_t dst_ld, const float* src, int64_t src_ld, int
  * multiplies them on the bf16 MFMA with fp32 accumulation -- the opt-in "bf16 LSTM step" of BASELINE.json
  * configs[4].  0 = exact fp32 (the reference's arithmetic, the headline configuration). */
 #define VD_FLAG_BF16 1
+/* VD_FLAG_SPLIT9 (vd_lstm_forward / vd_lstm_backward, throughput shapes): the recurrent product h*Wh / da*Wh^T as the EXACT
+ * three-way bf16 split of both fp32 operands -- nine bf16 MFMAs with fp32 accumulation per fp32 one, every product exact
+ * (csrc/split_core.h): fp32-grade results at 9/16 of the matrix-pipe time.  Opt-in; VD_FLAG_SPLIT6 / VD_FLAG_SPLIT3 drop the
+ * smallest products (NOT fp32-grade: they exist for the error table of tests/test_split_gpu.py). */
+#define VD_FLAG_SPLIT9 2
+#define VD_FLAG_SPLIT6 4
+#define VD_FLAG_SPLIT3 8
 
 /* ---- dense contractions (nn.Linear / hoisted SeqLSTM input projection / weight grads) -- */
 /* C[MxN] (+)= act(A[MxK] * W[NxK]^T + bias)   -- nn.Linear:updateOutput (+nn.Tanh),
@@ -238,7 +245,7 @@ typedef struct vd_model_params {   /* the `params` keys Model() consumes: opts.l
           numAttentionLayers, maxQuesCount, numOptions;
   float learningRate, lrDecayRate, minLRate;     /* opts.lua:35-38 */
   uint64_t seed;                                 /* dropout noise stream */
-  int32_t lstmBf16;                              /* opt-in bf16 operands of the option recurrence (configs[4]) */
+  int32_t lstmBf16;                              /* option recurrence: 0 = fp32 (default); 1 = bf16 operands (configs[4]); 9 = exact 3-way bf16 split, 9 products (fp32-grade, opt-in); 6 / 3 = fewer products (data only) */
   int32_t useStreams;                            /* 0 = everything on one stream (debug) */
   int32_t numLayers;                             /* -numLayers (opts.lua:27): lf-*, hre-* encoders and the gen decoder; <1 = 2 */
   int32_t imgEmbedSize;                          /* -imgEmbedSize (opts.lua:24): hre-ques-im-hist, hrea-ques-im-hist */

@@ -44,7 +44,9 @@ function Model:__init(params)
     p.maxQuesCount = params.maxQuesCount;     p.numOptions = params.numOptions or 100
     p.learningRate = params.learningRate;     p.lrDecayRate = params.lrDecayRate
     p.minLRate = params.minLRate;             p.seed = 1234
-    p.lstmBf16 = 0;                           p.useStreams = 1
+    -- option recurrence arithmetic (-lstmPrecision, new relative to the reference): fp32 (default) | split9 | bf16
+    p.lstmBf16 = ({fp32 = 0, bf16 = 1, split9 = 9, split6 = 6, split3 = 3})[params.lstmPrecision or 'fp32']
+    p.useStreams = 1
     p.numLayers = params.numLayers or 2;      p.imgEmbedSize = params.imgEmbedSize or 300
     p.dropout = params.dropout or 0.5
     -- device: VD_DEVICE wins (lets the UNCHANGED train.lua run with `-gpuid -1`, i.e. without its

@@ -10,6 +10,10 @@
 #define VD_ERR_HIP -2
 #define VD_ERR_STATE -3
 #define VD_FLAG_BF16 1  // see include/visdial_hip.h
+#define VD_FLAG_SPLIT9 2
+#define VD_FLAG_SPLIT6 4
+#define VD_FLAG_SPLIT3 8
+#define VD_FLAG_SPLIT (VD_FLAG_SPLIT9 | VD_FLAG_SPLIT6 | VD_FLAG_SPLIT3)
 
 // thread-local message returned by vd_last_error()
 void vd_set_error(const char* fmt, ...);

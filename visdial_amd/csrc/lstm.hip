@@ -12,6 +12,7 @@
 // the gate columns interleaved so each wave strip holds i,f,o,g of 32 hidden units,
 // and the whole cell update (+ mask) runs in the epilogue on the accumulator registers.
 #include "gemm_core.h"
+#include "split_core.h"
 
 // defined in gemm_ops.hip (declared in include/visdial_hip.h)
 extern "C" int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
@@ -513,9 +514,16 @@ static int lstm_step_fwd(const float* h_prev, const float* Wh, int N, int H, int
 static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, int K, const float* dh_a,
                          const float* dh_b, float* gates, const float* c_t, const float* c_prev, float* dc,
                          int dc_first, hipStream_t s, int flags = 0, vd_bf16_bits* da16 = nullptr,
-                         const vd_bf16_bits* da16_next = nullptr, const vd_bf16_bits* Wh16 = nullptr) {
+                         const vd_bf16_bits* da16_next = nullptr, const vd_bf16_bits* Wh16 = nullptr,
+                         const vd_bf16_bits* W3 = nullptr) {
   SrcRow a{da_next, 4L * H};
   SrcRow b{Wh, 4L * H};  // B[k][n] = Wh[n][k]
+  if (W3 && K > 0 && !(dh_a && dh_b)) {   // exact-operand split: da_{t+1} stays fp32 in memory, Wh as three bf16 planes
+    EpiLstmBwd<2, 2, false> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
+    if (flags & VD_FLAG_SPLIT9) return launch_gemm_split<2, 9>(N, H, K, da_next, 4L * H, W3, 4L * H, 4L * H * H, e, s);
+    if (flags & VD_FLAG_SPLIT6) return launch_gemm_split<2, 6>(N, H, K, da_next, 4L * H, W3, 4L * H, 4L * H * H, e, s);
+    return launch_gemm_split<2, 3>(N, H, K, da_next, 4L * H, W3, 4L * H, 4L * H * H, e, s);
+  }
   if ((flags & VD_FLAG_BF16) && N >= 2048 && K > 0) {
     EpiLstmBwd<2> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H, da16};
     // shadows on: da_{t+1} and Wh are read as the bf16 rows their producers wrote (half the operand bytes, no conversion
@@ -710,13 +718,21 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
   const long NH = (long)N * H;
   float* WhT = nullptr;
   const bool bf16 = (flags & VD_FLAG_BF16) && N >= 2048 && H % 32 == 0;
+  // exact-operand split (split_core.h): the throughput shapes of the fp32 LDS-DMA pipeline only
+  const int split = (!bf16 && (flags & VD_FLAG_SPLIT) && use_glds_fwd(N, H) && T > 1)
+                        ? ((flags & VD_FLAG_SPLIT9) ? 9 : (flags & VD_FLAG_SPLIT6) ? 6 : 3) : 0;
   const bool glds = (use_glds_fwd(N, H) || bf16) && T > 1;   // both paths multiply by the transposed copy
   VdStreamScratch scr;
+  vd_bf16_bits* W3 = nullptr;
   if (glds) {
-    if (int rc0 = vd_stream_scratch(s, (size_t)4 * H * H * (bf16 ? 6 : 4), 0, &scr)) return rc0;
+    if (int rc0 = vd_stream_scratch(s, (size_t)4 * H * H * (split ? 10 : bf16 ? 6 : 4), 0, &scr)) return rc0;
     WhT = scr.wht;
     hipLaunchKernelGGL(wh_gate_transpose_kernel, dim3(4 * H / 32, H / 32), dim3(256), 0, s, Wh, WhT, H);
     VD_LAUNCH_CHECK();
+    if (split) {   // the transposed weights as three bf16 planes (hi / mid / lo), once per pass
+      W3 = reinterpret_cast<vd_bf16_bits*>(scr.wht + (size_t)4 * H * H);
+      if (int rc0 = weights_to_bf16x3(WhT, W3, 4L * H * H, s)) return rc0;
+    }
   }
   // bf16 pass: the step kernels also write a bf16 copy of h (the operand of the dWh contraction of the same pass) ...
   vd_bf16_bits* h16 = nullptr;
@@ -751,6 +767,12 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
                                               reinterpret_cast<const float*>(WhT16), (long)H / 2, e, s);
     else if (bf16 && hp)
       rc = launch_gemm<CfgFbf16>(N, 4 * H, H, 1, SrcRow{hp, H}, SrcRow{WhT, H}, e, s);
+    else if (split == 9 && hp)
+      rc = launch_gemm_split<4, 9>(N, 4 * H, H, hp, (long)H, W3, (long)H, 4L * H * H, e, s);
+    else if (split == 6 && hp)
+      rc = launch_gemm_split<4, 6>(N, 4 * H, H, hp, (long)H, W3, (long)H, 4L * H * H, e, s);
+    else if (split == 3 && hp)
+      rc = launch_gemm_split<4, 3>(N, 4 * H, H, hp, (long)H, W3, (long)H, 4L * H * H, e, s);
     else if (glds && hp)
       rc = launch_gemm_glds<CfgF9, false>(N, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e, s);
     else
@@ -784,17 +806,25 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
   } else {
     vd_bf16_shadow_invalidate(gates, (size_t)T * 4 * NH);
   }
+  const vd_bf16_bits* W3 = nullptr;
+  if (!(flags & VD_FLAG_BF16) && (flags & VD_FLAG_SPLIT) && use_glds_bwd(N, H) && T > 1 && (4 * H) % 32 == 0) {
+    VdStreamScratch wscr;
+    if (int rc0 = vd_stream_scratch(s, (size_t)4 * H * H * 10, 0, &wscr)) return rc0;
+    vd_bf16_bits* w3 = reinterpret_cast<vd_bf16_bits*>(wscr.wht + (size_t)4 * H * H);    // (behind the forward pass's transposed copy)
+    if (int rc0 = weights_to_bf16x3(Wh, w3, 4L * H * H, s)) return rc0;
+    W3 = w3;
+  }
   for (int t = T - 1; t >= 0; --t) {
     const bool last = (t == T - 1);
     const float* da_next = last ? nullptr : gates + (long)(t + 1) * 4 * NH;
     const int rc = lstm_step_bwd(da_next, Wh, N, H, last ? 0 : 4 * H, dh_seq ? dh_seq + t * NH : nullptr, (last && dh_last) ? dh_last : nullptr,
                                  gates + (long)t * 4 * NH, c + t * NH, t ? c + (t - 1) * NH : c0, dc_work, (last && !dc_last) ? 1 : 0, s, flags,
-                                 da16 ? da16 + (long)t * 4 * NH : nullptr, (da16 && !last) ? da16 + (long)(t + 1) * 4 * NH : nullptr, Wh16);
+                                 da16 ? da16 + (long)t * 4 * NH : nullptr, (da16 && !last) ? da16 + (long)(t + 1) * 4 * NH : nullptr, Wh16, W3);
     if (rc) return rc;
   }
   int rc = VD_OK;
   if (dWh_acc && T > 1) {   // recurrent weight gradient dWh += sum_{t>=1} h_{t-1}^T da_t: one contraction over all (T-1)*N rows
-    rc = vd_gemm_tn_acc(h_seq, H, gates + 4 * NH, 4L * H, dWh_acc, 4L * H, H, 4 * H, (T - 1) * N, flags, s);
+    rc = vd_gemm_tn_acc(h_seq, H, gates + 4 * NH, 4L * H, dWh_acc, 4L * H, H, 4 * H, (T - 1) * N, flags & VD_FLAG_BF16, s);
     if (rc) return rc;
   }
   if (dh0) {

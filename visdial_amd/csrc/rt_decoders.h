@@ -66,7 +66,8 @@ struct Disc : Decoder {
     VD_TRY(ws_get(m, "opt.scores", (size_t)N * O, &scores));
     VD_TRY(ws_get(m, "crit.loss_rows", (size_t)N, &loss_rows));
     float* Wopt = Wp(m, "opt.W");
-    const int flags = m->p.lstmBf16 ? VD_FLAG_BF16 : 0;
+    const int flags = m->p.lstmBf16 == 1 ? VD_FLAG_BF16 : m->p.lstmBf16 == 9 ? VD_FLAG_SPLIT9 : m->p.lstmBf16 == 6 ? VD_FLAG_SPLIT6
+                      : m->p.lstmBf16 == 3 ? VD_FLAG_SPLIT3 : 0;
     VD_TRY(fork_stream(m, s, se));
     float* enc_out = nullptr;
     VD_TRY(vd_gemm_nn(Wp(m, "embed"), E, Wopt, 4 * H, Wp(m, "opt.b"), table, 4 * H, (int)V + 1, (int)(4 * H), (int)E, 0, s));
@@ -112,7 +113,7 @@ struct Disc : Decoder {
     // (the encoder chain is that step's critical path: 12.34 -> 12.02 ms, profiles/r03_experiments.txt section 21); in fp32 the step
     // is work-conserving on the matrix pipe and it stays on the encoder stream.  Never joined into `se`: a wait there would be a
     // barrier packet in front of the table-gradient chain.
-    m->wg_active = m->streams && m->s_wg && flags != 0;
+    m->wg_active = m->streams && m->s_wg && (flags & VD_FLAG_BF16) != 0;
     m->wg_used = false;
     auto enc_bwd = [&]() -> int {
       VD_TRY(m->enc->backward(m, se, b, d_enc));
@@ -135,7 +136,7 @@ struct Disc : Decoder {
     VD_TRY(vd_gemm_tn_acc(Wp(m, "embed"), E, dtab, 4 * H, Gp(m, "opt.W"), 4 * H, (int)E, (int)(4 * H), (int)V + 1, 0, st));
     VD_HIP(hipEventRecord(m->ev_prof[4], s));
     if (To > 1)
-      VD_TRY(vd_gemm_tn_acc(h, H, gates + (long)NO * 4 * H, 4 * H, Gp(m, "opt.W") + E * 4 * H, 4 * H, (int)H, (int)(4 * H), (To - 1) * NO, flags,
+      VD_TRY(vd_gemm_tn_acc(h, H, gates + (long)NO * 4 * H, 4 * H, Gp(m, "opt.W") + E * 4 * H, 4 * H, (int)H, (int)(4 * H), (To - 1) * NO, flags & VD_FLAG_BF16,
                             s));
     VD_HIP(hipEventRecord(m->ev_prof[5], s));
     // dEmb += dTable * Wx^T on the table stream, with float atomics: the SHARED embedding gradient has concurrent atomic

@@ -29,7 +29,7 @@ class Decoder(object):
         self.dWx, self.dWh, self.db = dW[:self.E], dW[self.E:], fp.g['opt.b']
         self.streams = StreamPool(ws.device, enabled=False)     # Model attaches its own pool
         # opt-in reduced precision of the option recurrence (BASELINE.json configs[4]); default = exact fp32
-        self.flags = ops.FLAG_BF16 if params.get('lstmPrecision', 'fp32') == 'bf16' else 0
+        self.flags = ops.PRECISION_FLAGS[params.get('lstmPrecision', 'fp32')]
 
     def forward(self, inputs):
         """inputs = {options [To x N*O] int32 time-major, encOut [N x H]} -> scores [N x O]"""

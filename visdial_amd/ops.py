@@ -79,6 +79,9 @@ def gemm_nn(A, B, C_out, bias=None, accumulate=False, M=None, N=None, K=None, ld
 
 
 FLAG_BF16 = 1      # VD_FLAG_BF16: bf16 operands / fp32 accumulation (opt-in, BASELINE configs[4])
+FLAG_SPLIT9, FLAG_SPLIT6, FLAG_SPLIT3 = 2, 4, 8   # exact three-way bf16 split of both operands: 9 products = fp32-grade (opt-in)
+PRECISION_FLAGS = {'fp32': 0, 'bf16': FLAG_BF16, 'split9': FLAG_SPLIT9, 'split6': FLAG_SPLIT6, 'split3': FLAG_SPLIT3}
+PRECISION_CODES = {'fp32': 0, 'bf16': 1, 'split9': 9, 'split6': 6, 'split3': 3}        # vd_model_params.lstmBf16
 
 
 def gemm_tn_acc(A, B, C_acc, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, flags=0):
