@@ -455,3 +455,33 @@ def test_duplicate_options_are_encoded_once_and_exactly(gpu, host):
     assert not bad, bad
     if host == 'native':
         model.close()
+
+
+@pytest.mark.parametrize("size", ['h128', 'h512'])
+def test_native_bf16_compact_state_within_the_stated_bound(gpu, size):
+    """BASELINE.json configs[4] through the model-level runtime: bf16 operands AND compact bf16 state in the option recurrence (saved
+    gates / da, projection-table rows and h as bf16, c and the last state fp32 -- csrc/common.h `vd_lstm_forward_c16`).  The config's own
+    stated bound (tests/test_model_gpu.py::test_bf16_option_lstm_step): |loss diff| < 1e-3, score rel-L2 < 1e-2, gradient rel-L2 < 2e-2
+    per tensor, >= 90 % of the ground-truth ranks identical to the fp64 oracle's."""
+    from visdial_amd.native import NativeModel
+    kw = dict(vocabSize=300, embedSize=64, rnnHiddenSize=128, imgFeatureSize=2048, imgSpatialSize=7,
+              commonEmbeddingSize=128, maxQuesCount=10, batchSize=3, numOptions=100, maxQuesLen=10, maxAnsLen=20)
+    if size == 'h512':
+        kw.update(embedSize=300, rnnHiddenSize=512, commonEmbeddingSize=512, maxQuesLen=20, maxHistoryLenPerRound=40)
+    p = derive(small_params(lstmPrecision='bf16', **kw))         # N * O = 3000 rows: the throughput kernels run
+    batch = SyntheticDataloader(p, seed=41).getTrainBatch(p)
+    model = NativeModel(p, init_seed=2)
+    model.training(False)
+    P0 = {k: v.astype(np.float64) for k, v in model.get_parameters_dict().items()}
+    loss = model.forwardBackward(batch)
+    g = model.get_gradients_dict()
+    N, O = batch['options'].shape[0], batch['options'].shape[1]
+    scores = model.scores(N, O)
+    ref = vo.forward_backward(p['encoder'], p['decoder'], P0, p, batch, None)
+    errs = {k: rel(g[k], ref['grads'][k]) for k in ref['grads'] if np.abs(ref['grads'][k]).max() > 1e-6}
+    agree = (vo.compute_ranks(scores, batch['answer_ind'] - 1) == vo.compute_ranks(ref['scores'], batch['answer_ind'] - 1)).mean()
+    print("bf16 compact state (dloss, score rel, max grad rel, rank agreement):", abs(loss - ref['loss']), rel(scores, ref['scores']),
+          max(errs.items(), key=lambda kv: kv[1]), agree)
+    assert abs(loss - ref['loss']) < 1e-3 and rel(scores, ref['scores']) < 1e-2 and max(errs.values()) < 2e-2 and agree >= 0.9
+    assert rel(scores, ref['scores']) > 1e-5          # the switch really changes the arithmetic
+    model.close()

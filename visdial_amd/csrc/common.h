@@ -61,13 +61,25 @@ struct VdZeroSet {
 };
 int vd_zero_inactive_multi(const VdZeroSet& z, const int32_t* nact_dev, int T, int N, hipStream_t stream);
 
+typedef unsigned short vd_bf16_bits;
+// ---- compact bf16 state of the option recurrence (model-level runtime, lstmBf16 = 1: BASELINE configs[4]) --------------------
+// The saved gates / da live ONLY as bf16 [T x N x 4H], the projection table as bf16 rows, h as bf16 (+ the last step's fp32 h):
+// 291 / 414 instead of 496 / 660 MB of epilogue traffic per forward / backward launch at the headline shape (lstm.hip).
+int vd_lstm_forward_c16(const vd_bf16_bits* table16, int64_t tab_ld, const int32_t* tok_gather, const float* Wh, vd_bf16_bits* gates16,
+                        vd_bf16_bits* h16, float* h_last, float* c, int T, int N, int H, hipStream_t stream);
+int vd_lstm_backward_c16(const float* Wh, vd_bf16_bits* gates16, const float* c, const float* dh_last, float* dc_work, int T, int N, int H,
+                         hipStream_t stream);
+int vd_f32_to_bf16(const float* src, vd_bf16_bits* dst, int64_t n, hipStream_t stream);
+int vd_gemm_tn_acc_bf16(const vd_bf16_bits* A16, const vd_bf16_bits* B16, float* C, int64_t ldc, int M, int N, int K, hipStream_t stream);
+int vd_segment_rowsum_acc_bf16(const vd_bf16_bits* X16, int64_t ldx, const int32_t* tok, const int32_t* perm, int64_t n, int ncol,
+                               float* out, int64_t ldo, hipStream_t stream);
+
 // bf16 shadows of fp32 activations (opt-in bf16 option recurrence, VD_FLAG_BF16; api.hip).  The producing kernels of a
 // bf16 pass (LSTM forward: h; LSTM backward: da) also write a bf16 copy of what they store, into a library-owned buffer
 // registered against the fp32 tensor's address range; the weight-gradient contraction of the same pass finds the two
 // shadows by address and multiplies them directly (LDS-DMA + transpose reads, no fp32 -> bf16 conversion while staging).
 // slot 0 = hidden states, slot 1 = gate gradients.  A shadow is valid until the next producer call on the same slot, or
 // until an fp32 producer overwrites its range (vd_bf16_shadow_invalidate).
-typedef unsigned short vd_bf16_bits;
 int vd_bf16_shadow_get(int slot, const float* base, size_t floats, vd_bf16_bits** out);
 const vd_bf16_bits* vd_bf16_shadow_find(const float* p, size_t floats);
 void vd_bf16_shadow_invalidate(const float* p, size_t floats);
@@ -143,6 +155,13 @@ __device__ __forceinline__ void vd_buf_st4_bf16(__amdgpu_buffer_rsrc_t r, unsign
   typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
   const bf4 t = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(vd_u32x2, t), r, voff, soff, 0);
+}
+
+// 4 consecutive bf16 (one 8-byte buffer load) -> float4
+__device__ __forceinline__ float4 vd_buf_ld4_bf16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const vd_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
 }
 
 // 4 consecutive fp32 -> 4 bf16 (RNE, v_cvt_pk_bf16_f32), one 8-byte store

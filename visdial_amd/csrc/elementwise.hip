@@ -217,7 +217,8 @@ __global__ void tok_fill_kernel(const int* __restrict__ tok, long n, int* __rest
 // token.  Each block walks CHUNK consecutive sorted rows, keeps the running sum of the current
 // token in registers (one float4 per thread per 1024 columns) and flushes with atomics when the
 // token changes, so a long run (the pad token) is split over many blocks.
-template <int CHUNK>
+// X16 = true: X holds bf16 rows (the compact da of a bf16 pass; ldx in bf16 elements), sums still fp32
+template <int CHUNK, bool X16 = false>
 __global__ void __launch_bounds__(256)
 segment_rowsum_kernel(const float* __restrict__ X, long ldx, const int* __restrict__ tok,
                       const int* __restrict__ perm, long n, int ncol, float* __restrict__ out, long ldo) {
@@ -244,7 +245,13 @@ segment_rowsum_kernel(const float* __restrict__ X, long ldx, const int* __restri
       for (int u = 0; u < 4; ++u) {
         const int jj = min(j + u, cnt - 1);
         t[u] = stok[jj];
-        v[u] = *reinterpret_cast<const float4*>(X + (long)srow[jj] * ldx + c);
+        if constexpr (X16) {
+          const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const vd_bf16_bits*>(X) + (long)srow[jj] * ldx + c);
+          v[u] = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                             __uint_as_float(w.y & 0xffff0000u));
+        } else {
+          v[u] = *reinterpret_cast<const float4*>(X + (long)srow[jj] * ldx + c);
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -448,22 +455,8 @@ int vd_segment_rowsum_acc(const float* X, int64_t ldx, const int32_t* tok, const
   VD_CHECK_ARG(X && tok && perm && out && n >= 0 && ncol > 0 && ncol % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0,
                "vd_segment_rowsum_acc: bad args");
   if (n == 0) return VD_OK;
-  static const int chunk_env = 256;
-  if (chunk_env == 128) {
-    hipLaunchKernelGGL(segment_rowsum_kernel<128>, grid1d(n, 128), dim3(256), 0, (hipStream_t)stream, X,
-                       (long)ldx, tok, perm, (long)n, ncol, out, (long)ldo);
-    VD_LAUNCH_CHECK();
-    return VD_OK;
-  }
-  if (chunk_env == 256) {
-    hipLaunchKernelGGL(segment_rowsum_kernel<256>, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, X,
-                       (long)ldx, tok, perm, (long)n, ncol, out, (long)ldo);
-    VD_LAUNCH_CHECK();
-    return VD_OK;
-  }
-  constexpr int CHUNK = 32;
-  hipLaunchKernelGGL(segment_rowsum_kernel<CHUNK>, grid1d(n, CHUNK), dim3(256), 0, (hipStream_t)stream, X,
-                     (long)ldx, tok, perm, (long)n, ncol, out, (long)ldo);
+  hipLaunchKernelGGL(segment_rowsum_kernel<256>, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, X, (long)ldx, tok, perm, (long)n, ncol,
+                     out, (long)ldo);
   VD_LAUNCH_CHECK();
   return VD_OK;
 }
@@ -481,3 +474,14 @@ int vd_clamp_adam(float* w, float* g, float* m, float* v, int64_t n, float gscal
 }
 
 }  // extern "C"
+
+// internal (common.h): the same segmented row sum over bf16 rows (the compact da of a bf16 pass)
+int vd_segment_rowsum_acc_bf16(const vd_bf16_bits* X16, int64_t ldx, const int32_t* tok, const int32_t* perm, int64_t n, int ncol,
+                               float* out, int64_t ldo, hipStream_t stream) {
+  VD_CHECK_ARG(X16 && tok && perm && out && n >= 0 && ncol % 4 == 0 && ldx % 4 == 0, "vd_segment_rowsum_acc_bf16: bad args");
+  if (n == 0) return VD_OK;
+  hipLaunchKernelGGL((segment_rowsum_kernel<256, true>), grid1d(n, 256), dim3(256), 0, stream, reinterpret_cast<const float*>(X16), (long)ldx,
+                     tok, perm, (long)n, ncol, out, (long)ldo);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}

@@ -299,3 +299,27 @@ int vd_colsum_acc(const float* X, int64_t ld, int M, int N, float* out, void* st
 }
 
 }  // extern "C"
+
+// internal (common.h): C[M x N] += A16[K x M]^T * B16[K x N], both operands bf16 rows (the compact h / da of a bf16 pass)
+__global__ void __launch_bounds__(256) bf16_tn_tail_kernel(const vd_bf16_bits* __restrict__ A, const vd_bf16_bits* __restrict__ B, float* __restrict__ C,
+                                                           long ldc, int M, int N, int K) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)M * N) return;
+  const int m = (int)(i / N), n = (int)(i % N);
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k)
+    acc += __uint_as_float((unsigned)A[(long)k * M + m] << 16) * __uint_as_float((unsigned)B[(long)k * N + n] << 16);
+  unsafeAtomicAdd(C + (long)m * ldc + n, acc);
+}
+int vd_gemm_tn_acc_bf16(const vd_bf16_bits* A16, const vd_bf16_bits* B16, float* C, int64_t ldc, int M, int N, int K, hipStream_t stream) {
+  VD_CHECK_ARG(A16 && B16 && C && M % 128 == 0 && N % 128 == 0 && K >= 0, "vd_gemm_tn_acc_bf16: M, N must be multiples of 128");
+  const int K1 = K & ~31;
+  if (K1 > 0)
+    if (int rc = launch_gemm_bf16_tn_tr(A16, B16, C, ldc, M, N, K1, stream)) return rc;
+  if (K1 < K) {   // the last < 32 rows
+    hipLaunchKernelGGL(bf16_tn_tail_kernel, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, stream, A16 + (long)K1 * M, B16 + (long)K1 * N,
+                       C, (long)ldc, M, N, K - K1);
+    VD_LAUNCH_CHECK();
+  }
+  return VD_OK;
+}

@@ -21,7 +21,10 @@ extern "C" int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64
 // ---------------------------------------------------------------------------
 // forward epilogue: acc[g] = (h_prev*Wh)[row, g*H + j]
 // ---------------------------------------------------------------------------
-template <int SEQ>
+// C16 (bf16 pass of the model-level runtime, configs[4]): COMPACT state -- `xproj` is a bf16 projection table (xld in bf16
+// elements), `gates` a bf16 buffer [N x 4H], `h_out` may be null (only the last step's fp32 h has a reader; the recurrence and the
+// weight gradient read the bf16 copy h16): 291 instead of 496 MB of epilogue traffic per launch at the headline shape
+template <int SEQ, bool C16 = false>
 struct EpiLstmFwdT {
   const float* xproj;  // dense: [N x 4H] rows (ld = xld); table mode: table base [V+1 x 4H]
   long xld;
@@ -184,11 +187,19 @@ struct EpiLstmFwdT {
     const unsigned uH4 = (unsigned)H * 4u, uj4 = (unsigned)j * 4u, uxld4 = (unsigned)xld * 4u;
     const unsigned vrow = ((unsigned)(row0 + rl)) * uH4 + uj4;          // byte offset of (row0 + rl, j) in an [M x H] tensor
     auto issue = [&](int p) {
-      const unsigned xo = (unsigned)tk[p] * uxld4 + uj4;
-      x[0] = vd_buf_ld4(rx, xo, 0);
-      x[1] = vd_buf_ld4(rx, xo, uH4);
-      x[2] = vd_buf_ld4(rx, xo, 2 * uH4);
-      x[3] = vd_buf_ld4(rx, xo, 3 * uH4);
+      if constexpr (C16) {
+        const unsigned xo = ((unsigned)tk[p] * uxld4 + uj4) >> 1;
+        x[0] = vd_buf_ld4_bf16(rx, xo, 0);
+        x[1] = vd_buf_ld4_bf16(rx, xo, uH4 >> 1);
+        x[2] = vd_buf_ld4_bf16(rx, xo, uH4);
+        x[3] = vd_buf_ld4_bf16(rx, xo, 3 * (uH4 >> 1));
+      } else {
+        const unsigned xo = (unsigned)tk[p] * uxld4 + uj4;
+        x[0] = vd_buf_ld4(rx, xo, 0);
+        x[1] = vd_buf_ld4(rx, xo, uH4);
+        x[2] = vd_buf_ld4(rx, xo, 2 * uH4);
+        x[3] = vd_buf_ld4(rx, xo, 3 * uH4);
+      }
       cp = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c_prev) cp = vd_buf_ld4(rc, (unsigned)rowc[p] * uH4 + uj4, 0);
     };
@@ -232,6 +243,20 @@ struct EpiLstmFwdT {
 #if VD_EPI_BUF & 1
         const unsigned sp = (unsigned)p * 8u * uH4;                  // row-group stride (uniform)
         const unsigned vg = 4u * vrow - 3u * uj4;                    // (row0 + rl, j) in the [M x 4H] gates tensor
+        if constexpr (C16) {                                           // compact state: bf16 gates, fp32 c, bf16 h (+ fp32 h at the last step)
+          // a sigmoid gate s > 1/2 is stored as s - 1 = -(1 - s): the backward pass needs s AND 1 - s, and near saturation bf16
+          // keeps only one of them (spacing 2^-8 below 1); the sign says which one was stored, both come back to 2^-9 relative
+#define VD_ENC(v) v.x = v.x > 0.5f ? v.x - 1.f : v.x; v.y = v.y > 0.5f ? v.y - 1.f : v.y; v.z = v.z > 0.5f ? v.z - 1.f : v.z; v.w = v.w > 0.5f ? v.w - 1.f : v.w;
+          VD_ENC(gi) VD_ENC(gf) VD_ENC(go)
+#undef VD_ENC
+          vd_buf_st4_bf16(rg, vg >> 1, 2u * sp, gi);
+          vd_buf_st4_bf16(rg, vg >> 1, 2u * sp + (uH4 >> 1), gf);
+          vd_buf_st4_bf16(rg, vg >> 1, 2u * sp + uH4, go);
+          vd_buf_st4_bf16(rg, vg >> 1, 2u * sp + 3 * (uH4 >> 1), gg);
+          vd_buf_st4(rco, vrow, sp, c);
+          if (h_out) vd_buf_st4(rh, vrow, sp, h);
+          vd_buf_st4_bf16(rh16, vrow >> 1, sp >> 1, h);
+        } else {
         vd_buf_st4(rg, vg, 4u * sp, gi);                              // saved for the backward pass
         vd_buf_st4(rg, vg, 4u * sp + uH4, gf);
         vd_buf_st4(rg, vg, 4u * sp + 2 * uH4, go);
@@ -239,6 +264,7 @@ struct EpiLstmFwdT {
         vd_buf_st4(rco, vrow, sp, c);
         vd_buf_st4(rh, vrow, sp, h);
         if (h16) vd_buf_st4_bf16(rh16, vrow >> 1, sp >> 1, h);
+        }
 #else
         float* gr = gates + (long)row * 4 * H + j;
         vd_st4_stream(gr, gi);           // saved for the backward pass: written once, read ~10 ms later
@@ -273,7 +299,9 @@ using EpiLstmFwd = EpiLstmFwdT<0>;
 // TWO = false: the caller guarantees at most ONE incoming-gradient operand (dh_b == nullptr: every step but the last of a
 // recurrence).  The second operand is fetched inside the consume phase, and the s_waitcnt behind that (uniformly skipped) load
 // drains the previous slot's stores even when the load is never executed.
-template <int NT, int BATCH = (NT == 1 ? 2 : 1), bool TWO = true>
+// C16: compact bf16 state (see EpiLstmFwdT): `gates` is a bf16 buffer [N x 4H]; da_t overwrites it in place AS bf16 -- the only copy
+// (operand of the next step's product, of the weight gradient and of the table gradient)
+template <int NT, int BATCH = (NT == 1 ? 2 : 1), bool TWO = true, bool C16 = false>
 struct EpiLstmBwd {
   const float* dh_a;  // nullable [N x H]
   const float* dh_b;  // nullable [N x H]
@@ -316,10 +344,17 @@ struct EpiLstmBwd {
     __amdgpu_buffer_rsrc_t g, ct, cp, dc, dh1, dh2, g16;
   };
   __device__ __forceinline__ void load_slot_buf(Slot& L, const Rsrc& R, unsigned o4, unsigned og4, unsigned uH4) const {
+    if constexpr (C16) {
+      L.g[0] = vd_buf_ld4_bf16(R.g, og4 >> 1, 0);
+      L.g[1] = vd_buf_ld4_bf16(R.g, og4 >> 1, uH4 >> 1);
+      L.g[2] = vd_buf_ld4_bf16(R.g, og4 >> 1, uH4);
+      L.g[3] = vd_buf_ld4_bf16(R.g, og4 >> 1, 3 * (uH4 >> 1));
+    } else {
     L.g[0] = vd_buf_ld4(R.g, og4, 0);          // saved gates: read exactly once
     L.g[1] = vd_buf_ld4(R.g, og4, uH4);
     L.g[2] = vd_buf_ld4(R.g, og4, 2 * uH4);
     L.g[3] = vd_buf_ld4(R.g, og4, 3 * uH4);
+    }
     L.ct = vd_buf_ld4(R.ct, o4, 0);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     L.cp = c_prev ? vd_buf_ld4(R.cp, o4, 0) : z;
@@ -388,25 +423,39 @@ struct EpiLstmBwd {
           float4 ai, af, ao, ag, dn;
 #define VD_CELLB(E)                                                       \
           {                                                               \
+            float gi_ = C.g[0].E, gf_ = C.g[1].E, go_ = C.g[2].E;         \
+            float pi_ = gi_ * (1.f - gi_), pf_ = gf_ * (1.f - gf_), po_ = go_ * (1.f - go_);   \
+            if constexpr (C16) {   /* stored s <= 1/2 as s, s > 1/2 as s - 1 (see the forward epilogue) */   \
+              pi_ = gi_ < 0.f ? (1.f + gi_) * -gi_ : pi_;  gi_ = gi_ < 0.f ? 1.f + gi_ : gi_;   \
+              pf_ = gf_ < 0.f ? (1.f + gf_) * -gf_ : pf_;  gf_ = gf_ < 0.f ? 1.f + gf_ : gf_;   \
+              po_ = go_ < 0.f ? (1.f + go_) * -go_ : po_;  go_ = go_ < 0.f ? 1.f + go_ : go_;   \
+            }                                                             \
             const float tc = vd_tanh(C.ct.E);                             \
-            const float d = C.dcv.E + dh.E * C.g[2].E * (1.f - tc * tc);  \
-            ai.E = d * C.g[3].E * C.g[0].E * (1.f - C.g[0].E);            \
-            af.E = d * C.cp.E * C.g[1].E * (1.f - C.g[1].E);              \
-            ao.E = dh.E * tc * C.g[2].E * (1.f - C.g[2].E);               \
-            ag.E = d * C.g[0].E * (1.f - C.g[3].E * C.g[3].E);            \
-            dn.E = d * C.g[1].E;                                          \
+            const float d = C.dcv.E + dh.E * go_ * (1.f - tc * tc);       \
+            ai.E = d * C.g[3].E * pi_;                                    \
+            af.E = d * C.cp.E * pf_;                                      \
+            ao.E = dh.E * tc * po_;                                       \
+            ag.E = d * gi_ * (1.f - C.g[3].E * C.g[3].E);                 \
+            dn.E = d * gf_;                                               \
           }
           VD_CELLB(x) VD_CELLB(y) VD_CELLB(z) VD_CELLB(w)
 #undef VD_CELLB
           if (row < M && j < N) {
 #if VD_EPI_BUF & 4
             // (row < M and j < N here: the clamped offsets of the loads are the true ones)
+            if constexpr (C16) {
+              vd_buf_st4_bf16(R.g, og4[q] >> 1, 0, ai);
+              vd_buf_st4_bf16(R.g, og4[q] >> 1, uH4 >> 1, af);
+              vd_buf_st4_bf16(R.g, og4[q] >> 1, uH4, ao);
+              vd_buf_st4_bf16(R.g, og4[q] >> 1, 3 * (uH4 >> 1), ag);
+            } else {
             vd_buf_st4(R.g, og4[q], 0, ai);
             vd_buf_st4(R.g, og4[q], uH4, af);
             vd_buf_st4(R.g, og4[q], 2 * uH4, ao);
             vd_buf_st4(R.g, og4[q], 3 * uH4, ag);
+            }
             vd_buf_st4(R.dc, o4[q], 0, dn);
-            if (da16) {
+            if (!C16 && da16) {
               vd_buf_st4_bf16(R.g16, og4[q] >> 1, 0, ai);
               vd_buf_st4_bf16(R.g16, og4[q] >> 1, uH4 >> 1, af);
               vd_buf_st4_bf16(R.g16, og4[q] >> 1, uH4, ao);
@@ -905,6 +954,65 @@ int vd_lstm2_backward(const vd_lstm2_bwd_t* st, int nstacks, int H, void* stream
 }
 
 }  // extern "C"
+
+// ---- compact bf16 state (common.h): the option recurrence of a bf16 pass, model-level runtime --------------------------------------
+int vd_f32_to_bf16(const float* src, vd_bf16_bits* dst, int64_t n, hipStream_t stream) { return weights_to_bf16(src, dst, n, stream); }
+
+int vd_lstm_forward_c16(const vd_bf16_bits* table16, int64_t tab_ld, const int32_t* tok_gather, const float* Wh, vd_bf16_bits* gates16,
+                        vd_bf16_bits* h16, float* h_last, float* c, int T, int N, int H, hipStream_t s) {
+  VD_CHECK_ARG(table16 && tok_gather && Wh && gates16 && h16 && h_last && c && T >= 1 && N >= 2048 && H % 128 == 0 && tab_ld % 4 == 0,
+               "vd_lstm_forward_c16: throughput shapes only (N >= 2048, H %% 128 == 0)");
+  VD_CHECK_ARG((long)N * 4 * H * 4 < (1L << 32), "vd_lstm_forward_c16: N x 4H exceeds 4 GB per step");
+  const long NH = (long)N * H;
+  VdStreamScratch scr;
+  if (int rc = vd_stream_scratch(s, (size_t)4 * H * H * 6, 0, &scr)) return rc;
+  float* WhT = scr.wht;
+  vd_bf16_bits* WhT16 = reinterpret_cast<vd_bf16_bits*>(scr.wht + (size_t)4 * H * H);
+  hipLaunchKernelGGL(wh_gate_transpose_kernel, dim3(4 * H / 32, H / 32), dim3(256), 0, s, Wh, WhT, H);
+  VD_LAUNCH_CHECK();
+  if (int rc = weights_to_bf16(WhT, WhT16, 4L * H * H, s)) return rc;
+  for (int t = 0; t < T; ++t) {
+    EpiLstmFwdT<0, true> e;
+    e.xproj = reinterpret_cast<const float*>(table16);
+    e.xld = tab_ld;
+    e.tok_gather = tok_gather + (long)t * N;
+    e.tok_mask = nullptr;
+    e.c_prev = t ? c + (t - 1) * NH : nullptr;
+    e.gates = reinterpret_cast<float*>(gates16 + (long)t * 4 * NH);
+    e.c_out = c + t * NH;
+    e.h_out = t == T - 1 ? h_last : nullptr;
+    e.H = H;
+    e.h16 = h16 + t * NH;
+    int rc;
+    if (t == 0) rc = launch_gemm<CfgF9>(N, 4 * H, 0, 1, SrcRow{nullptr, H}, SrcKGate4{Wh, 4L * H, H}, e, s);   // no recurrent product yet
+    else rc = launch_gemm_glds<CfgF9bf16, false>(N, 4 * H, H / 2, 1, reinterpret_cast<const float*>(h16 + (t - 1) * NH), (long)H / 2,
+                                                 reinterpret_cast<const float*>(WhT16), (long)H / 2, e, s);
+    if (rc) return rc;
+  }
+  return VD_OK;
+}
+
+int vd_lstm_backward_c16(const float* Wh, vd_bf16_bits* gates16, const float* c, const float* dh_last, float* dc_work, int T, int N, int H,
+                         hipStream_t s) {
+  VD_CHECK_ARG(Wh && gates16 && c && dh_last && dc_work && T >= 1 && N >= 2048 && H % 128 == 0, "vd_lstm_backward_c16: throughput shapes only");
+  const long NH = (long)N * H;
+  VdStreamScratch wscr;
+  if (int rc = vd_stream_scratch(s, (size_t)4 * H * H * 6, 0, &wscr)) return rc;
+  vd_bf16_bits* Wh16 = reinterpret_cast<vd_bf16_bits*>(wscr.wht + (size_t)4 * H * H);
+  if (int rc = weights_to_bf16(Wh, Wh16, 4L * H * H, s)) return rc;
+  for (int t = T - 1; t >= 0; --t) {
+    const bool last = t == T - 1;
+    EpiLstmBwd<2, 1, true, true> e{nullptr, last ? dh_last : nullptr, reinterpret_cast<float*>(gates16 + (long)t * 4 * NH), c + t * NH,
+                                    t ? c + (t - 1) * NH : nullptr, dc_work, last ? 1 : 0, H};
+    int rc;
+    if (last) rc = launch_gemm<CfgB11>(N, H, 0, 1, SrcRow{nullptr, 4L * H}, SrcRow{Wh, 4L * H}, e, s);
+    else rc = launch_gemm_glds<CfgB11bf16, false>(N, H, 4 * H / 2, 1, reinterpret_cast<const float*>(gates16 + (long)(t + 1) * 4 * NH), 2L * H,
+                                                  reinterpret_cast<const float*>(Wh16), 2L * H, e, s);
+    if (rc) return rc;
+  }
+  return VD_OK;
+}
+
 
 #ifdef VD_TIMING
 // diagnostic build only: copy the per-workgroup phase stamps of the last launches to the host

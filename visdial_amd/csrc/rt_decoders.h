@@ -71,13 +71,26 @@ struct Disc : Decoder {
     VD_TRY(fork_stream(m, s, se));
     float* enc_out = nullptr;
     VD_TRY(vd_gemm_nn(Wp(m, "embed"), E, Wopt, 4 * H, Wp(m, "opt.b"), table, 4 * H, (int)V + 1, (int)(4 * H), (int)E, 0, s));
+    // bf16 pass at a throughput shape: COMPACT state (common.h) -- gates / da only as bf16 (in the first half of `gates`), the
+    // projection table as bf16 rows, h as bf16 plus the last step's fp32 state; c stays fp32
+    const bool c16 = (flags & VD_FLAG_BF16) && NO >= 2048 && H % 128 == 0;
+    vd_bf16_bits *gates16 = reinterpret_cast<vd_bf16_bits*>(gates), *h16 = reinterpret_cast<vd_bf16_bits*>(h), *table16 = nullptr;
+    float* h_last = nullptr;
+    if (c16) {
+      float* t16;
+      VD_TRY(ws_get(m, "opt.table16", (size_t)(V + 1) * 2 * H, &t16));
+      VD_TRY(ws_get(m, "opt.h_last", (size_t)NO * H, &h_last));
+      table16 = reinterpret_cast<vd_bf16_bits*>(t16);
+      VD_TRY(vd_f32_to_bf16(table, table16, (V + 1) * 4 * H, s));
+    }
     VD_HIP(hipEventRecord(m->ev_prof[0], s));
-    VD_TRY(vd_lstm_forward(table, 0, 4 * H, b.opt.tok, nullptr, Wopt + E * 4 * H, nullptr, nullptr, gates, h, c, To, NO, (int)H, flags, s));
+    if (c16) VD_TRY(vd_lstm_forward_c16(table16, 4 * H, b.opt.tok, Wopt + E * 4 * H, gates16, h16, h_last, c, To, NO, (int)H, s));
+    else VD_TRY(vd_lstm_forward(table, 0, 4 * H, b.opt.tok, nullptr, Wopt + E * 4 * H, nullptr, nullptr, gates, h, c, To, NO, (int)H, flags, s));
     VD_HIP(hipEventRecord(m->ev_prof[1], s));
     VD_TRY(m->enc->forward(m, se, b, &enc_out));                                   // model.lua:297
     VD_TRY(join_stream(m, se, s));
     // criterion (+ nn.MM backward) in one kernel (model.lua:330-335)
-    const float* optH = h + (long)(To - 1) * NO * H;
+    const float* optH = c16 ? h_last : h + (long)(To - 1) * NO * H;
     float *d_optH = nullptr, *d_enc = nullptr, *d_optH_full = nullptr;
     if (dedup) {   // candidate (n, o) reads the state of its distinct row
       float* full;
@@ -126,16 +139,20 @@ struct Disc : Decoder {
       m->enc_grads_recorded = true;
       return VD_OK;
     };
-    VD_TRY(vd_lstm_backward(Wopt + E * 4 * H, gates, c, nullptr, nullptr, d_optH, nullptr, dc, nullptr, nullptr, nullptr, To, NO, (int)H, flags, s));
+    if (c16) VD_TRY(vd_lstm_backward_c16(Wopt + E * 4 * H, gates16, c, d_optH, dc, To, NO, (int)H, s));
+    else VD_TRY(vd_lstm_backward(Wopt + E * 4 * H, gates, c, nullptr, nullptr, d_optH, nullptr, dc, nullptr, nullptr, nullptr, To, NO, (int)H, flags, s));
     VD_HIP(hipEventRecord(m->ev_prof[3], s));
     VD_TRY(enc_bwd());       // enqueued behind the option recurrence: it runs beside it on the encoder stream
     // table gradient + its consumers beside the dWh contraction
     VD_TRY(fork_stream(m, s, st));
-    VD_TRY(vd_segment_rowsum_acc(gates, 4 * H, b.opt.tok, perm, (long)To * NO, (int)(4 * H), dtab, 4 * H, st));
+    if (c16) VD_TRY(vd_segment_rowsum_acc_bf16(gates16, 4 * H, b.opt.tok, perm, (long)To * NO, (int)(4 * H), dtab, 4 * H, st));
+    else VD_TRY(vd_segment_rowsum_acc(gates, 4 * H, b.opt.tok, perm, (long)To * NO, (int)(4 * H), dtab, 4 * H, st));
     VD_TRY(vd_colsum_acc(dtab, 4 * H, (int)V + 1, (int)(4 * H), Gp(m, "opt.b"), st));
     VD_TRY(vd_gemm_tn_acc(Wp(m, "embed"), E, dtab, 4 * H, Gp(m, "opt.W"), 4 * H, (int)E, (int)(4 * H), (int)V + 1, 0, st));
     VD_HIP(hipEventRecord(m->ev_prof[4], s));
-    if (To > 1)
+    if (To > 1 && c16)
+      VD_TRY(vd_gemm_tn_acc_bf16(h16, gates16 + (long)NO * 4 * H, Gp(m, "opt.W") + E * 4 * H, 4 * H, (int)H, (int)(4 * H), (To - 1) * NO, s));
+    else if (To > 1)
       VD_TRY(vd_gemm_tn_acc(h, H, gates + (long)NO * 4 * H, 4 * H, Gp(m, "opt.W") + E * 4 * H, 4 * H, (int)H, (int)(4 * H), (To - 1) * NO, flags & VD_FLAG_BF16,
                             s));
     VD_HIP(hipEventRecord(m->ev_prof[5], s));
