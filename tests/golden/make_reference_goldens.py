@@ -1,0 +1,261 @@
+#!/usr/bin/env python
+"""EXECUTES THE REFERENCE'S OWN LUA (model.lua, encoders/*.lua, decoders/*.lua, model_utils/*.lua, utils.lua) inside tests/luavm and
+records what it computes, as fixtures under tests/golden/ref__<encoder>__<decoder>.npz.  Runs in the BUILD CONTAINER only
+(/root/reference does not travel); the fixtures and this script are what is committed.
+
+What runs: the reference's files, unmodified, read in place from /root/reference: class Model (model.lua:8-106: construction through
+the plug-in files, wrapper / getParameters, forwardBackward, trainIteration with clamp + optim_updates.lua's adam, retrieveBatch +
+utils.computeRanks).  What stands in for Torch7: tests/luavm (the Lua evaluator), tests/luavm/torch7.py (tensors) and
+tests/luavm/nn7.py (nn / nngraph / rnn module semantics restated from their published behaviour, independent of the oracle).
+
+What is recorded per pair:
+  * the parameters the reference's constructors drew (by module), the batch, the Dropout keep-masks its forward pass drew;
+  * loss and every gradient tensor of Model:forwardBackward in evaluate() and in training() mode;
+  * the parameters after one Model:trainIteration (zeroGradParameters, forwardBackward, clamp(-5, 5), adam, lr decay) + runningLoss + lr;
+  * the GT ranks / all ranks Model:retrieveBatch produces through the reference's utils.computeRanks;
+  * the ORDER of the tensors in `wrapper:getParameters()` -- for the four nngraph encoders this is nngraph's forward-node order, which
+    visdial_amd/t7.py needs to load reference checkpoints (tests/golden/reference_param_order.json).
+The oracle is NOT an input of this script: it is compared with these fixtures by tests/test_reference_goldens.py, and below (a
+cross-check at generation time, so that a disagreement is seen before a fixture is written).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+REF = '/root/reference'
+
+from conftest import small_params  # noqa: E402
+from luavm import new_vm, to_lua, to_py  # noqa: E402
+from luavm import nn7  # noqa: E402
+from luavm.interp import LuaTable, call, first, index  # noqa: E402
+from oracle import visdial_oracle as vo  # noqa: E402
+from visdial_amd.dataloader import SyntheticDataloader  # noqa: E402
+from visdial_amd.opts import derive  # noqa: E402
+
+ALL_ENC = ['lf-ques', 'lf-ques-im', 'lf-ques-hist', 'lf-ques-im-hist', 'lf-att-ques-im-hist', 'hre-ques-hist',
+           'hre-ques-im-hist', 'hrea-ques-im-hist', 'mn-ques-hist', 'mn-ques-im-hist', 'mn-att-ques-im-hist']
+PAIRS = [(e, 'disc') for e in ALL_ENC] + [('lf-ques', 'gen'), ('lf-ques-im-hist', 'gen'), ('mn-att-ques-im-hist', 'gen')]
+# Dropout nodes in the order the encoder files CONSTRUCT them -> the site names of this repo (visdial_amd/dataloader.py)
+DROP_SITES = {'mn-att-ques-im-hist': ['q_emb', 'h_emb', 'hatt', 'img_tr', 'iqc', 'u'], 'mn-ques-hist': ['q_emb', 'h_emb', 'hatt'],
+              'mn-ques-im-hist': ['q_emb', 'h_emb', 'hatt'], 'lf-att-ques-im-hist': ['q_emb', 'h_emb', 'img_tr', 'iqc', 'u'],
+              'hrea-ques-im-hist': ['img'], 'hre-ques-hist': [], 'hre-ques-im-hist': []}
+# module names in the order the encoder FILE constructs them, where that differs from this repo's declaration order
+# (encoders/hre-ques-hist.lua:12-36 builds the question LSTMs before the history LSTMs)
+CREATION_ORDER = {'hre-ques-hist': ['embed', 'ques1', 'ques2', 'hist1', 'hist2', 'dialog']}
+BATCH_TYPES = {'ques_fwd': 'Long', 'hist': 'Long', 'options': 'Long', 'answer_in': 'Long', 'answer_out': 'Long', 'answer_ind': 'Long',
+               'img_feat': 'Double', 'option_in': 'Long', 'option_out': 'Long'}
+
+
+def reference_vm(seed):
+    vm = new_vm(search=[REF, os.path.join(ROOT, 'tests', 'lua_ref_stubs')], stdout=open(os.devnull, 'w'))
+    NN = nn7.install(vm, seed=seed)
+    cj = LuaTable()
+    cj.set('decode', lambda s, *_: to_lua(vm, json.loads(s)))
+    cj.set('encode', lambda t, *_: json.dumps(to_py(t)))
+    vm.preload.set('cjson', lambda *_: cj)
+    vm.preload.set('hdf5', lambda *_: LuaTable())
+    vm.globals.set('runningLoss', 0)
+    vm.dostring("require 'model'")
+    return vm, NN
+
+
+def param_modules(mod, out=None, seen=None):
+    """the DISTINCT parameterised nn7 modules under `mod` (shared clones once, by storage), with their creation index"""
+    out, seen = ([] if out is None else out), (set() if seen is None else seen)
+    ps = mod.params()
+    key = ps[0][0].a.__array_interface__['data'][0] if ps else None       # (after getParameters() every tensor is a view of ONE storage)
+    if ps and key not in seen:
+        seen.add(key)
+        out.append(mod)
+    for c in mod.children():
+        if isinstance(c, nn7.Module):
+            param_modules(c, out, seen)
+    return out
+
+
+def dropouts(mod, out=None):
+    out = [] if out is None else out
+    if isinstance(mod, nn7.Dropout):
+        out.append(mod)
+    for c in mod.children():
+        if isinstance(c, nn7.Module):
+            dropouts(c, out)
+    return out
+
+
+def run_pair(enc, dec, seed=7):
+    # maxQuesCount = 10 and 100 options are hard-coded in the reference (model.lua:281, decoders/disc.lua:10); everything else small.
+    # E = 40 where Dropout(0.5) follows the embedding: a row it zeroes ENTIRELY reads as padding to SeqLSTM:maskZero() (2^-40 per row here,
+    # 2^-300 at the real E = 300) -- the one place where "mask by token id" (this repo) and "mask by zero vector" (rnn) could differ
+    graph = enc.startswith('mn') or enc.startswith('lf-att')
+    p = derive(small_params(encoder=enc, decoder=dec, maxQuesCount=10, numOptions=100, batchSize=2, vocabSize=30, rnnHiddenSize=16,
+                            commonEmbeddingSize=12, maxQuesLen=5, maxHistoryLenPerRound=7, maxAnsLen=4, imgSpatialSize=3, imgFeatureSize=8,
+                            imgEmbedSize=6, embedSize=40 if graph else 10))
+    vm, NN = reference_vm(seed)
+    lp = dict({k: v for k, v in p.items() if isinstance(v, (int, float, str, bool))}, gpuid=-1, weightInit='xavier', ansHiddenSize=0)
+    model = first(call(vm.globals.get('Model'), [to_lua(vm, lp)]))
+    wrapper = index(model, 'wrapper')
+    inv = lambda obj, name, *a: call(index(obj, name), [obj] + list(a))
+
+    # ---- names: the parameterised modules in the order the Lua files construct them == this repo's declaration order
+    spec = vo.param_spec(enc, dec, p)
+    groups, cur = [], None
+    for name, shape, _ in spec:
+        base = name.rsplit('.', 1)[0] if '.' in name else name
+        if base != cur:
+            groups.append([])
+            cur = base
+        groups[-1].append((name, tuple(shape)))
+    if enc in CREATION_ORDER:       # this file constructs its modules in another order than this repo declares them
+        by = {g[0][0].rsplit('.', 1)[0] if '.' in g[0][0] else g[0][0]: g for g in groups}
+        dec_groups = [g for g in groups if (g[0][0].split('.')[0] if '.' in g[0][0] else g[0][0]) not in CREATION_ORDER[enc]]
+        groups = [by[n] for n in CREATION_ORDER[enc]] + dec_groups
+    mods = sorted(param_modules(wrapper), key=lambda m: m.created)
+    assert len(mods) == len(groups), (enc, dec, len(mods), len(groups))
+    flat_W, flat_dW = index(model, 'wrapperW'), index(model, 'wrapperdW')
+    base = flat_W.st.base.__array_interface__['data'][0]
+    order = []
+    for m, g in zip(mods, groups):
+        ps = m.params()
+        assert len(ps) == len(g), (enc, [x[0] for x in g])
+        for (w, dw), (name, shape) in zip(ps, g):
+            assert tuple(w.a.shape) == shape, (enc, dec, name, w.a.shape, shape)
+            order.append(((w.a.__array_interface__['data'][0] - base) // 8, w, name))      # where getParameters() put it
+    order.sort(key=lambda e: e[0])
+    off = 0
+    for o, w, name in order:
+        assert o == off, (enc, dec, name, o, off)           # back to back, every tensor once
+        off += w.a.size
+    assert off == flat_W.a.size
+    order = [(w, name) for _, w, name in order]
+    names_in_flat_order = [n for _, n in order]
+
+    def named(flat):
+        out, o = {}, 0
+        for w, n in order:
+            out[n] = np.array(flat.a[o:o + w.a.size].reshape(w.a.shape), dtype=np.float64)
+            o += w.a.size
+        return out
+
+    P = named(flat_W)
+    dl = SyntheticDataloader(p, seed=11)
+    batch = dl.getTrainBatch(p)
+    lua_batch = lambda: to_lua(vm, {k: v for k, v in batch.items() if isinstance(v, np.ndarray)}, BATCH_TYPES)
+    rec = {'param.' + k: v for k, v in P.items()}
+    rec.update({'batch.' + k: v for k, v in batch.items() if isinstance(v, np.ndarray)})
+    rec['opt.json'] = np.array(json.dumps({k: v for k, v in p.items() if isinstance(v, (int, float, str, bool))}))
+    rec['order.json'] = np.array(json.dumps(names_in_flat_order))
+
+    # ---- evaluate(): dropout off
+    inv(wrapper, 'evaluate')
+    inv(wrapper, 'zeroGradParameters')
+    loss_ev = first(inv(model, 'forwardBackward', lua_batch()))
+    g_ev = named(flat_dW)
+    P = named(flat_W)                 # (nn.LookupTableMaskZero re-zeroes its pad row on every forward: the parameters as the step saw them)
+    rec.update({'param.' + k: v for k, v in P.items()})
+    rec['flat.param'] = np.array(flat_W.a, dtype=np.float64).reshape(-1)          # wrapper:getParameters() itself, in the reference's order
+    ref = vo.forward_backward(enc, dec, P, p, batch, None)
+    worst = max(float(np.linalg.norm(g_ev[k] - ref['grads'][k]) / max(np.linalg.norm(ref['grads'][k]), 1e-30)) for k in g_ev
+                if np.abs(ref['grads'][k]).max() > 1e-12)
+    assert abs(loss_ev - ref['loss']) < 1e-9 * max(1, abs(ref['loss'])) and worst < 1e-8, (enc, dec, 'evaluate', loss_ev, ref['loss'], worst)
+    rec['eval.loss'] = np.float64(loss_ev)
+    rec.update({'eval.grad.' + k: v for k, v in g_ev.items()})
+    report = ['evaluate: |dloss| %.1e worst grad %.1e' % (abs(loss_ev - ref['loss']), worst)]
+
+    # ---- training(): the Dropout nodes draw their own noise; record it by site
+    inv(wrapper, 'training')
+    inv(wrapper, 'zeroGradParameters')
+    NN.dropout_log = []
+    loss_tr = first(inv(model, 'forwardBackward', lua_batch()))
+    g_tr = named(flat_dW)
+    drops = sorted(dropouts(wrapper), key=lambda m: m.created)
+    sites = DROP_SITES.get(enc, ['fuse'] if p.get('dropout', 0.5) > 0 else [])
+    assert len(drops) == len(sites), (enc, len(drops), sites)
+    masks = {s: d.noise for s, d in zip(sites, drops) if d.noise is not None}
+    ref_t = vo.forward_backward(enc, dec, P, p, batch, {k: v.astype(np.float64) for k, v in masks.items()} if masks else None)
+    worst_t = max(float(np.linalg.norm(g_tr[k] - ref_t['grads'][k]) / max(np.linalg.norm(ref_t['grads'][k]), 1e-30)) for k in g_tr
+                  if np.abs(ref_t['grads'][k]).max() > 1e-12)
+    assert abs(loss_tr - ref_t['loss']) < 1e-9 * max(1, abs(ref_t['loss'])) and worst_t < 1e-8, (enc, dec, 'training', loss_tr, ref_t['loss'], worst_t)
+    rec['train.loss'] = np.float64(loss_tr)
+    rec.update({'train.grad.' + k: v for k, v in g_tr.items()})
+    rec.update({'mask.' + k: v.astype(np.uint8) for k, v in masks.items()})
+    report.append('training (%d dropout sites): |dloss| %.1e worst grad %.1e' % (len(masks), abs(loss_tr - ref_t['loss']), worst_t))
+
+    # ---- Model:trainIteration (model.lua:66-106) on a dataloader that serves this batch; dropout off so the step is reproducible
+    inv(wrapper, 'evaluate')
+
+    class OneBatch(object):
+        lua_type = 'table'
+
+        def lua_index(self, k):
+            if k == 'getTrainBatch':
+                return lambda *_a: lua_batch()
+            return None
+    orig_training = index(wrapper, 'training')
+    vm.globals.set('runningLoss', 0)
+    inv(model, 'trainIteration', OneBatch())
+    W1 = named(flat_W)
+    rec.update({'step.param.' + k: v for k, v in W1.items()})
+    rec['step.runningLoss'] = np.float64(vm.globals.get('runningLoss'))
+    rec['step.learningRate'] = np.float64(index(index(model, 'optims'), 'learningRate'))
+    worst_w = 0.0
+    for k in P:
+        w2, _ = vo.clamp_adam(P[k].reshape(-1), g_ev[k].reshape(-1), {}, p['learningRate'])
+        worst_w = max(worst_w, float(np.abs(W1[k].reshape(-1) - w2).max()))
+    assert worst_w < 1e-12, (enc, dec, 'adam', worst_w)
+    want_rl = ref['loss'] / max(int((batch['answer_out'] > 0).sum()), 1) if dec == 'gen' else ref['loss']
+    assert abs(rec['step.runningLoss'] - want_rl) < 1e-9 * max(1, abs(want_rl))
+    assert abs(rec['step.learningRate'] - p['learningRate'] * p['lrDecayRate']) < 1e-15
+    report.append('trainIteration: max |dW - adam(oracle)| %.1e, runningLoss, lr ok' % worst_w)
+
+    # ---- Model:retrieveBatch + utils.computeRanks on the UPDATED parameters (disc)
+    if dec == 'disc':
+        P1 = {k: v for k, v in W1.items()}
+        ev = vo.forward_backward(enc, dec, P1, p, batch, None, only_forward=True)
+        index(model, 'params').set('useGt', True)
+        gt = to_py(first(inv(model, 'retrieveBatch', lua_batch())))
+        index(model, 'params').set('useGt', False)
+        allr = to_py(first(inv(model, 'retrieveBatch', lua_batch())))
+        ref_scores = np.array(index(index(model, 'decoder'), 'output').a, dtype=np.float64)      # the reference decoder's own scores
+        assert np.abs(ref_scores - ev['scores']).max() < 1e-12
+        # utils.computeRanks on the reference's scores == the oracle's rule on the same scores, exactly; on the ORACLE's scores the ranks may
+        # differ only where two candidates tie (duplicate options: equal to the last bit in one implementation, 1 ulp apart in the other)
+        assert (np.asarray(allr).reshape(ref_scores.shape) == vo.compute_ranks(ref_scores)).all()
+        assert (np.asarray(gt).reshape(-1) == vo.compute_ranks(ref_scores, batch['answer_ind'].reshape(-1) - 1)).all()
+        from conftest import unexplained_rank_flips
+        flipped, bad = unexplained_rank_flips(ev['scores'], ref_scores, tol=1e-9)
+        assert not bad, bad[:5]
+        rec['rank.scores'] = ref_scores
+        rec['rank.gt'] = np.asarray(gt, dtype=np.int64).reshape(-1)
+        rec['rank.all'] = np.asarray(allr, dtype=np.int64).reshape(ref_scores.shape)
+        report.append('retrieveBatch / utils.computeRanks: gt + all ranks equal')
+    return p, rec, names_in_flat_order, report
+
+
+def main():
+    orders = {}
+    for enc, dec in PAIRS:
+        p, rec, order, report = run_pair(enc, dec)
+        orders.setdefault(enc, {})[dec] = order
+        print('%-22s + %-4s  %s' % (enc, dec, ' | '.join(report)), flush=True)
+        print('    getParameters() order:', ' '.join(order), flush=True)
+        np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'ref__%s__%s.npz' % (enc, dec)), **rec)
+    enc_orders = {}
+    for enc, d in orders.items():
+        o = d['disc']
+        enc_orders[enc] = [n for n in o if not n.startswith('opt.')]
+    json.dump({'_comment': "Order of the tensors in wrapper:getParameters() as produced by EXECUTING the reference's encoder / decoder files under "
+                           "tests/luavm + tests/luavm/nn7.py (tests/golden/make_reference_goldens.py).  For the four nngraph encoders this is nngraph's "
+                           "forward-node order (depth-first post-order from the output node) with shared storages at their first occurrence.  "
+                           "DERIVED by running the reference's sources on a restated nngraph, not verified against a Torch7-written file.",
+               'encoder': enc_orders, 'decoder': {'disc': ['opt.W', 'opt.b'], 'gen': [n for n in orders['lf-ques']['gen'] if n.startswith(('dec', 'vocab'))]}},
+              open(os.path.join(ROOT, 'tests', 'golden', 'reference_param_order.json'), 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()

@@ -175,6 +175,10 @@ class Tensor(object):
 
     def lua_index(self, k):
         if k.__class__ is str:
+            if k == 'THNN':
+                return THNN
+            if k == 'new':                              # x.new(sizes) and x:new(sizes): a tensor of x's type
+                return lambda *a: TensorCtor(self.T, self.tn).lua_call([v for v in (a[1:] if a and a[0] is self else a)])
             m = getattr(Tensor, 'm_' + k, None)
             if m is None:
                 raise LuaError("luavm-torch: %s has no method '%s'" % (self.typename(), k))
@@ -641,6 +645,28 @@ class Tensor(object):
     def m_totable(self, *_):
         return self.T.totable(self)
 
+    def m_cdata(self, *_):
+        return self                                  # (the THNN stub below takes the tensors themselves)
+
+    def m_new(self, *sizes):
+        return TensorCtor(self.T, self.tn).lua_call(list(sizes))
+
+    def m_addcmul(self, v, a, b=None, *_):
+        if b is None:
+            v, a, b = 1, v, a
+        return self._inplace(self.a + v * a.a.reshape(self.a.shape) * b.a.reshape(self.a.shape))
+
+    def m_addcdiv(self, v, a, b=None, *_):
+        if b is None:
+            v, a, b = 1, v, a
+        return self._inplace(self.a + v * a.a.reshape(self.a.shape) / b.a.reshape(self.a.shape))
+
+    def m_isSameSizeAs(self, o, *_):
+        return self.a.shape == o.a.shape
+
+    def m_storage(self, *_):
+        return self.st
+
     def m_apply(self, fn, *_):
         flat = self.a.reshape(-1) if self.a.flags.c_contiguous else None
         it = np.nditer(self.a, op_flags=['readwrite'])
@@ -650,6 +676,30 @@ class Tensor(object):
                 x[...] = r
         del flat
         return self
+
+
+class _THNN(object):
+    """`tensor.THNN.<fn>(tensor:cdata(), ...)`: the two THNN entry points model_utils/MaskSoftMax.lua calls through the FFI"""
+    lua_type = 'table'
+
+    def lua_index(self, k):
+        return getattr(self, k, None)
+
+    @staticmethod
+    def SoftMax_updateOutput(inp, out, *_):
+        x = inp.a.astype(np.float64)
+        e = np.exp(x - x.max(-1, keepdims=True))
+        Tensor.m_resizeAs(out, inp)
+        out.a[...] = e / e.sum(-1, keepdims=True)
+
+    @staticmethod
+    def SoftMax_updateGradInput(inp, gout, gin, out, *_):
+        y, g = out.a.astype(np.float64), gout.a.astype(np.float64)
+        Tensor.m_resizeAs(gin, out)
+        gin.a[...] = y * (g - (g * y).sum(-1, keepdims=True))
+
+
+THNN = _THNN()
 
 
 class TensorCtor(object):
@@ -698,7 +748,8 @@ class Torch(object):
                      'sqrt', 'median', 'cmul', 'cdiv', 'le', 'lt', 'ge', 'gt', 'eq', 'ne', 'manualSeed', 'setdefaulttensortype',
                      'getdefaulttensortype', 'type', 'typename', 'isTensor', 'class', 'random', 'randperm', 'rand', 'randn', 'uniform',
                      'sort', 'abs', 'exp', 'log', 'add', 'mul', 'div', 'dot', 'norm', 'cumsum', 'setnumthreads', 'getnumthreads',
-                     'save', 'load', 'isTypeOf', 'setmetatable', 'getmetatable', 'squeeze', 'floor', 'clamp', 'pow', 'seed'):
+                     'save', 'load', 'isTypeOf', 'setmetatable', 'getmetatable', 'squeeze', 'floor', 'clamp', 'pow', 'seed', 'triu', 'tril',
+                     'pointer'):
             t.set(name, getattr(self, 'f_' + name.replace('class', 'class_')))
         vm.globals.set('torch', t)
         vm.loaded.set('torch', t)
@@ -798,6 +849,15 @@ class Torch(object):
     def f_floor(self, a, *_):
         return a.new_like(np.floor(a.a))
 
+    def f_triu(self, a, k=0, *_):
+        return a.new_like(np.triu(a.a, int(k)))
+
+    def f_tril(self, a, k=0, *_):
+        return a.new_like(np.tril(a.a, int(k)))
+
+    def f_pointer(self, o, *_):
+        return id(o)
+
     def f_manualSeed(self, s=0, *_):
         self.rng = np.random.RandomState(int(s) % (2 ** 32))
 
@@ -886,6 +946,13 @@ class Torch(object):
             holder.set('__index', pmt)
             mt.meta = holder
         self.classes[name] = mt
+
+        def forward_call(obj, *args):
+            f = lua_index_fn(obj, '__call__')
+            if f is None:
+                raise LuaError("attempt to call an instance of class '%s'" % name)
+            return call(f, [obj] + list(args))
+        mt.set('__call', forward_call)
         ctor = LuaTable()
         cm = LuaTable()
 
