@@ -28,8 +28,6 @@ def main():
     ap.add_argument('-saveRankPath', '--saveRankPath', default='logs/ranks.json')
     ap.add_argument('-perplexity', '--perplexity', type=int, default=0, help='also run Model:evaluate (model.lua:109-139)')
     ap.add_argument('--numThreads', type=int, default=100, help='synthetic fallback only')
-    ap.add_argument('-allowUnverifiedOrder', '--allowUnverifiedOrder', type=int, default=0,
-                    help='1 = accept a Torch7-written .t7 for the nngraph encoders assuming declaration order')
     ap.add_argument('-host', '--host', default='python', choices=['python', 'native'],
                     help="'native' drives the model-level C ABI (what lua/model.lua calls)")
     a = ap.parse_args()
@@ -50,7 +48,7 @@ def main():
         model = NativeModel(p)
     else:
         model = Model(p)
-    restore_weights(model, saved, allow_unverified=bool(a.allowUnverifiedOrder))          # evaluate.lua:91
+    restore_weights(model, saved)          # evaluate.lua:91
     print('Evaluating..')
     if a.perplexity:
         model.evaluate(dl, a.split)

@@ -27,8 +27,6 @@ def main():
     ap.add_argument('-temperature', '--temperature', type=float, default=1.0)
     ap.add_argument('-maxThreads', '--maxThreads', type=int, default=50)
     ap.add_argument('-gpuid', '--gpuid', type=int, default=0)
-    ap.add_argument('-allowUnverifiedOrder', '--allowUnverifiedOrder', type=int, default=0,
-                    help='1 = accept a Torch7-written .t7 for the nngraph encoders assuming declaration order')
     ap.add_argument('-host', '--host', default='python', choices=['python', 'native'],
                     help="'native' drives the model-level C ABI (what lua/model.lua calls)")
     a = vars(ap.parse_args())
@@ -44,7 +42,7 @@ def main():
         model = NativeModel(p)
     else:
         model = Model(p)
-    restore_weights(model, saved, allow_unverified=bool(a['allowUnverifiedOrder']))
+    restore_weights(model, saved)
     answers = model.generateAnswers(dl, 'val', dict(beamSize=a['beamSize'], beamLen=a['beamLen'],
                                                     maxThreads=a['maxThreads'], sampleWords=a['sampleWords'],
                                                     temperature=a['temperature']))

@@ -342,29 +342,76 @@ function Model:generateAnswers(dataloader, dtype, params)
 end
 
 -- The library's tensors in the order of the REFERENCE's `wrapper:getParameters()` flat vector, so that `modelW` of a checkpoint
--- written by the reference's train.lua loads tensor for tensor (and one written through this host loads in the reference):
--- the library declares embed | encoder | decoder in module order, which IS the reference's order for the Sequential-built
--- lf-* encoders; the hre-* files put the image Linear of their ConcatTable BEFORE the history branch
--- (encoders/hre-ques-im-hist.lua:56-60) while the library declares it after -- moved here, exactly like
--- visdial_amd/t7.py:reference_order.  (The four nngraph encoders: order derived from nngraph's node order, t7.py.)
+-- written by the reference's train.lua loads tensor for tensor (and one written through this host loads in the reference and in
+-- the Python hosts).  The table is the same one as visdial_amd/t7.py:_STEMS -- obtained by EXECUTING the reference's encoder
+-- files and reading where getParameters() put every tensor (tests/golden/reference_param_order.json; tests/test_luavm_cpu.py
+-- keeps the two tables equal).  'x*' = x1 .. xN (LSTM layers); for the four nngraph encoders the order is nngraph's forward-node
+-- order (DERIVED, not verified on a Torch7-written file): mn-att reaches the hop-L img_common first, the (ques_common, att)
+-- pairs follow in hop order.
+local STEMS = {
+    ['lf-ques'] = {'embed', 'ques*', 'fuse'},
+    ['lf-ques-im'] = {'embed', 'ques*', 'fuse'},
+    ['lf-ques-hist'] = {'embed', 'ques*', 'hist*', 'fuse'},
+    ['lf-ques-im-hist'] = {'embed', 'ques*', 'hist*', 'fuse'},
+    ['lf-att-ques-im-hist'] = {'img_proj', 'img_common', 'embed', 'ques*', 'hist*', 'qh', 'ques_common', 'att', 'out'},
+    ['hre-ques-hist'] = {'embed', 'ques*', 'hist*', 'dialog'},
+    ['hre-ques-im-hist'] = {'embed', 'img_embed', 'hist*', 'ques*', 'dialog'},
+    ['hrea-ques-im-hist'] = {'embed', 'img_embed', 'hist*', 'ques*', 'att_q', 'att_h', 'dialog'},
+    ['mn-ques-hist'] = {'embed', 'ques*', 'hist*', 'mn1', 'mn2'},
+    ['mn-ques-im-hist'] = {'embed', 'ques*', 'qi', 'hist*', 'mn1', 'mn2'},
+    ['mn-att-ques-im-hist'] = {'img_proj', 'img_common#rev', 'embed', 'ques*', 'hist*', 'mn1', 'mn2', 'ques_common+att#', 'out'},
+}
+
 function Model:tensors()
-    local out, name = {}, ffi.new('char[64]')
+    local declared, name = {}, ffi.new('char[64]')
     local off, rows, cols = ffi.new('int64_t[1]'), ffi.new('int64_t[1]'), ffi.new('int64_t[1]')
+    local byStem, stems = {}, {}
     for i = 0, tonumber(C.vd_model_num_tensors(self.h)) - 1 do
         vd.call('vd_model_tensor_info', self.h, i, name, off, rows, cols)
-        table.insert(out, {name = ffi.string(name), numel = tonumber(rows[0] * cols[0])})
+        local t = {name = ffi.string(name), numel = tonumber(rows[0] * cols[0])}
+        local stem = string.match(t.name, '^(.-)%.[Wb]$') or t.name
+        if not byStem[stem] then byStem[stem] = {}; stems[#stems + 1] = stem end
+        table.insert(byStem[stem], t)
+        declared[#declared + 1] = t
     end
-    if string.match(self.params.encoder, '^hre') then
-        local img, rest = {}, {}
-        for _, t in ipairs(out) do
-            if string.match(t.name, '^img_embed%.') then img[#img + 1] = t else rest[#rest + 1] = t end
+    local function layered(pre)                 -- pre1 .. preN that the model declares, by N
+        local out = {}
+        for _, s in ipairs(stems) do
+            local n = string.match(s, '^' .. pre .. '(%d+)$')
+            if n then out[#out + 1] = {tonumber(n), s} end
         end
-        out = {}
-        for i, t in ipairs(rest) do
-            out[#out + 1] = t
-            if i == 1 then for _, u in ipairs(img) do out[#out + 1] = u end end       -- right behind the shared embedding
+        table.sort(out, function(a, b) return a[1] < b[1] end)
+        for i, e in ipairs(out) do out[i] = e[2] end
+        return out
+    end
+    local function hops(pre)                    -- hop 1 has no suffix, hop i > 1 is <name><i>
+        local out = layered(pre)
+        table.insert(out, 1, pre)
+        return out
+    end
+    local want = {}
+    for _, t in ipairs(assert(STEMS[self.params.encoder], 'Model:tensors: unknown encoder ' .. tostring(self.params.encoder))) do
+        if string.sub(t, -1) == '*' then
+            for _, s in ipairs(layered(string.sub(t, 1, -2))) do want[#want + 1] = s end
+        elseif t == 'img_common#rev' then
+            local h = hops('img_common')
+            for i = #h, 1, -1 do want[#want + 1] = h[i] end
+        elseif t == 'ques_common+att#' then
+            local q, a = hops('ques_common'), hops('att')
+            for i = 1, #q do want[#want + 1] = q[i]; want[#want + 1] = a[i] end
+        else
+            want[#want + 1] = t
         end
     end
+    local out, placed = {}, {}
+    for _, s in ipairs(want) do
+        for _, t in ipairs(assert(byStem[s], 'Model:tensors: the library declares no tensor ' .. s)) do out[#out + 1] = t end
+        placed[s] = true
+    end
+    for _, s in ipairs(stems) do                -- the decoder, in declaration order (decoders/disc.lua, decoders/gen.lua)
+        if not placed[s] then for _, t in ipairs(byStem[s]) do out[#out + 1] = t end end
+    end
+    assert(#out == #declared)
     return out
 end
 

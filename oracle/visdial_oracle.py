@@ -192,8 +192,12 @@ def clamp_adam(w, g, state, lr, clip=5.0, beta1=0.9, beta2=0.999, eps=1e-8):
 
 
 # ----------------------------------------------------------------------------- parameters
-def hop_suffixes(p):
+def hop_suffixes(p, encoder=None):
+    """attention hops: opts.lua:26 `numAttentionLayers` for mn-att (mn-att-ques-im-hist.lua:71); lf-att hard-codes ONE hop
+    (lf-att-ques-im-hist.lua:49, `local num_attention_layer = 1`) whatever the option says"""
     L = int(p.get('numAttentionLayers', 1) or 1)
+    if (encoder or p.get('encoder')) == 'lf-att-ques-im-hist':
+        L = 1
     return [''] + [str(i) for i in range(2, L + 1)]
 
 
@@ -217,7 +221,7 @@ def param_spec(encoder, decoder, p):
         <name><i>"""
         C, K = p['imgFeatureSize'], p.get('commonEmbeddingSize', 512)
         lin('img_proj', C, H)
-        for sfx in hop_suffixes(p):
+        for sfx in hop_suffixes(p, encoder):
             lin('img_common' + sfx, H, K); lin('ques_common' + sfx, H, K); lin('att' + sfx, K, 1)
         lin('out', H, H)
 
@@ -446,7 +450,7 @@ def graph_encoder_forward(encoder, P, p, batch, drop):
             query = st['qi_proj']
         u, st['mn'] = _mn_block_fwd(P, query, h3, B, R, d)
     if 'att' in encoder:
-        out, st['san'] = _san_block_fwd(P, p, batch, u, R, d)
+        out, st['san'] = _san_block_fwd(P, dict(p, encoder=encoder), batch, u, R, d)
     else:
         out = u
     st['enc_out'] = out

@@ -46,7 +46,7 @@ DROP_SITES = {'mn-att-ques-im-hist': ['q_emb', 'h_emb', 'hatt', 'img_tr', 'iqc',
               'hrea-ques-im-hist': ['img'], 'hre-ques-hist': [], 'hre-ques-im-hist': []}
 # module names in the order the encoder FILE constructs them, where that differs from this repo's declaration order
 # (encoders/hre-ques-hist.lua:12-36 builds the question LSTMs before the history LSTMs)
-CREATION_ORDER = {'hre-ques-hist': ['embed', 'ques1', 'ques2', 'hist1', 'hist2', 'dialog']}
+CREATION_ORDER = {'hre-ques-hist': ['embed', 'ques*', 'hist*', 'dialog']}
 BATCH_TYPES = {'ques_fwd': 'Long', 'hist': 'Long', 'options': 'Long', 'answer_in': 'Long', 'answer_out': 'Long', 'answer_ind': 'Long',
                'img_feat': 'Double', 'option_in': 'Long', 'option_out': 'Long'}
 
@@ -88,14 +88,14 @@ def dropouts(mod, out=None):
     return out
 
 
-def run_pair(enc, dec, seed=7):
+def run_pair(enc, dec, seed=7, extra=None, order_only=False):
     # maxQuesCount = 10 and 100 options are hard-coded in the reference (model.lua:281, decoders/disc.lua:10); everything else small.
-    # E = 40 where Dropout(0.5) follows the embedding: a row it zeroes ENTIRELY reads as padding to SeqLSTM:maskZero() (2^-40 per row here,
+    # E = 24 where Dropout(0.5) follows the embedding: a row it zeroes ENTIRELY reads as padding to SeqLSTM:maskZero() (2^-24 per row here,
     # 2^-300 at the real E = 300) -- the one place where "mask by token id" (this repo) and "mask by zero vector" (rnn) could differ
     graph = enc.startswith('mn') or enc.startswith('lf-att')
-    p = derive(small_params(encoder=enc, decoder=dec, maxQuesCount=10, numOptions=100, batchSize=2, vocabSize=30, rnnHiddenSize=16,
+    p = derive(small_params(encoder=enc, decoder=dec, maxQuesCount=10, numOptions=100, batchSize=2, vocabSize=30, rnnHiddenSize=32,
                             commonEmbeddingSize=12, maxQuesLen=5, maxHistoryLenPerRound=7, maxAnsLen=4, imgSpatialSize=3, imgFeatureSize=8,
-                            imgEmbedSize=6, embedSize=40 if graph else 10))
+                            imgEmbedSize=8, embedSize=24 if graph else 12, **(extra or {})))         # (sizes the HIP path accepts: H % 32, E % 4, ...)
     vm, NN = reference_vm(seed)
     lp = dict({k: v for k, v in p.items() if isinstance(v, (int, float, str, bool))}, gpuid=-1, weightInit='xavier', ansHiddenSize=0)
     model = first(call(vm.globals.get('Model'), [to_lua(vm, lp)]))
@@ -113,8 +113,9 @@ def run_pair(enc, dec, seed=7):
         groups[-1].append((name, tuple(shape)))
     if enc in CREATION_ORDER:       # this file constructs its modules in another order than this repo declares them
         by = {g[0][0].rsplit('.', 1)[0] if '.' in g[0][0] else g[0][0]: g for g in groups}
-        dec_groups = [g for g in groups if (g[0][0].split('.')[0] if '.' in g[0][0] else g[0][0]) not in CREATION_ORDER[enc]]
-        groups = [by[n] for n in CREATION_ORDER[enc]] + dec_groups
+        names = [n for t in CREATION_ORDER[enc] for n in ([t] if not t.endswith('*') else ['%s%d' % (t[:-1], l + 1) for l in range(p['numLayers'])])]
+        dec_groups = [g for g in groups if (g[0][0].split('.')[0] if '.' in g[0][0] else g[0][0]) not in names]
+        groups = [by[n] for n in names] + dec_groups
     mods = sorted(param_modules(wrapper), key=lambda m: m.created)
     assert len(mods) == len(groups), (enc, dec, len(mods), len(groups))
     flat_W, flat_dW = index(model, 'wrapperW'), index(model, 'wrapperdW')
@@ -142,11 +143,14 @@ def run_pair(enc, dec, seed=7):
             o += w.a.size
         return out
 
+    flat_W.a[...] = flat_W.a.astype(np.float32).astype(np.float64)      # fp32-representable parameters: the HIP path gets exactly the same ones
+    if order_only:
+        return p, None, names_in_flat_order, []
     P = named(flat_W)
     dl = SyntheticDataloader(p, seed=11)
     batch = dl.getTrainBatch(p)
     lua_batch = lambda: to_lua(vm, {k: v for k, v in batch.items() if isinstance(v, np.ndarray)}, BATCH_TYPES)
-    rec = {'param.' + k: v for k, v in P.items()}
+    rec = {}
     rec.update({'batch.' + k: v for k, v in batch.items() if isinstance(v, np.ndarray)})
     rec['opt.json'] = np.array(json.dumps({k: v for k, v in p.items() if isinstance(v, (int, float, str, bool))}))
     rec['order.json'] = np.array(json.dumps(names_in_flat_order))
@@ -157,8 +161,8 @@ def run_pair(enc, dec, seed=7):
     loss_ev = first(inv(model, 'forwardBackward', lua_batch()))
     g_ev = named(flat_dW)
     P = named(flat_W)                 # (nn.LookupTableMaskZero re-zeroes its pad row on every forward: the parameters as the step saw them)
-    rec.update({'param.' + k: v for k, v in P.items()})
-    rec['flat.param'] = np.array(flat_W.a, dtype=np.float64).reshape(-1)          # wrapper:getParameters() itself, in the reference's order
+    rec.update({'param.' + k: v.astype(np.float32) for k, v in P.items()})
+    assert all((rec['param.' + k].astype(np.float64) == v).all() for k, v in P.items())
     ref = vo.forward_backward(enc, dec, P, p, batch, None)
     worst = max(float(np.linalg.norm(g_ev[k] - ref['grads'][k]) / max(np.linalg.norm(ref['grads'][k]), 1e-30)) for k in g_ev
                 if np.abs(ref['grads'][k]).max() > 1e-12)
@@ -182,7 +186,7 @@ def run_pair(enc, dec, seed=7):
                   if np.abs(ref_t['grads'][k]).max() > 1e-12)
     assert abs(loss_tr - ref_t['loss']) < 1e-9 * max(1, abs(ref_t['loss'])) and worst_t < 1e-8, (enc, dec, 'training', loss_tr, ref_t['loss'], worst_t)
     rec['train.loss'] = np.float64(loss_tr)
-    rec.update({'train.grad.' + k: v for k, v in g_tr.items()})
+    rec.update({'train.grad.' + k: v.astype(np.float32) for k, v in g_tr.items()})         # (fp32 storage; the 1e-15 agreement is in the log)
     rec.update({'mask.' + k: v.astype(np.uint8) for k, v in masks.items()})
     report.append('training (%d dropout sites): |dloss| %.1e worst grad %.1e' % (len(masks), abs(loss_tr - ref_t['loss']), worst_t))
 
@@ -200,7 +204,7 @@ def run_pair(enc, dec, seed=7):
     vm.globals.set('runningLoss', 0)
     inv(model, 'trainIteration', OneBatch())
     W1 = named(flat_W)
-    rec.update({'step.param.' + k: v for k, v in W1.items()})
+    rec.update({'step.delta.' + k: (W1[k] - P[k]).astype(np.float32) for k in W1})        # the Adam step itself (|delta| ~ lr: 1e-10 absolute in fp32)
     rec['step.runningLoss'] = np.float64(vm.globals.get('runningLoss'))
     rec['step.learningRate'] = np.float64(index(index(model, 'optims'), 'learningRate'))
     worst_w = 0.0
@@ -237,7 +241,24 @@ def run_pair(enc, dec, seed=7):
     return p, rec, names_in_flat_order, report
 
 
+VARIANTS = [('mn-att-ques-im-hist', 'disc', {'numAttentionLayers': 3}), ('lf-att-ques-im-hist', 'disc', {'numAttentionLayers': 3}),
+            ('hrea-ques-im-hist', 'gen', {'numLayers': 3}), ('hre-ques-hist', 'gen', {'numLayers': 1}), ('lf-ques-im-hist', 'gen', {'numLayers': 1}),
+            ('mn-ques-im-hist', 'gen', {'numLayers': 3})]
+
+
+def variant_orders():
+    """getParameters() order at other numLayers / numAttentionLayers (construction only, no step)"""
+    return [{'encoder': enc, 'decoder': dec, 'params': extra, 'order': run_pair(enc, dec, extra=extra, order_only=True)[2]}
+            for enc, dec, extra in VARIANTS]
+
+
 def main():
+    path = os.path.join(ROOT, 'tests', 'golden', 'reference_param_order.json')
+    if '--variants-only' in sys.argv:
+        d = json.load(open(path))
+        d['variants'] = variant_orders()
+        json.dump(d, open(path, 'w'), indent=1)
+        return
     orders = {}
     for enc, dec in PAIRS:
         p, rec, order, report = run_pair(enc, dec)
@@ -253,8 +274,9 @@ def main():
                            "tests/luavm + tests/luavm/nn7.py (tests/golden/make_reference_goldens.py).  For the four nngraph encoders this is nngraph's "
                            "forward-node order (depth-first post-order from the output node) with shared storages at their first occurrence.  "
                            "DERIVED by running the reference's sources on a restated nngraph, not verified against a Torch7-written file.",
-               'encoder': enc_orders, 'decoder': {'disc': ['opt.W', 'opt.b'], 'gen': [n for n in orders['lf-ques']['gen'] if n.startswith(('dec', 'vocab'))]}},
-              open(os.path.join(ROOT, 'tests', 'golden', 'reference_param_order.json'), 'w'), indent=1)
+               'encoder': enc_orders, 'decoder': {'disc': ['opt.W', 'opt.b'], 'gen': [n for n in orders['lf-ques']['gen'] if n.startswith(('dec', 'vocab'))]},
+               'variants': variant_orders()},
+              open(path, 'w'), indent=1)
 
 
 if __name__ == '__main__':

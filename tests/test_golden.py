@@ -13,7 +13,7 @@ from oracle import visdial_oracle as vo
 from visdial_amd.opts import derive
 
 FILES = sorted(f for f in glob.glob(os.path.join(ROOT, 'tests', 'golden', '*__*.npz'))     # <encoder>__<decoder>.npz
-               if not os.path.basename(f).startswith('full__'))           # (the full-size fixture: test_full_size_golden.py)
+               if not os.path.basename(f).startswith(('full__', 'ref__')))     # (full-size: test_full_size_golden.py; executed reference: test_reference_goldens.py)
 KW = {'lf-ques': dict(dropout=0.5, imgNorm=1, batchSize=2), 'lf-ques-im-hist': dict(dropout=0.5, imgNorm=1, batchSize=2),
       'hre-ques-im-hist': dict(imgNorm=1, batchSize=2), 'mn-att-ques-im-hist': dict(batchSize=2)}
 
@@ -76,8 +76,13 @@ def test_hip_path_matches_golden(path):
         assert not unexplained, unexplained[:10]
         assert (np.asarray(ranks) != z['eval.ranks']).sum() <= 2 * flipped
         p['useGt'] = True
-        gt = model.retrieveBatch(batch)
+        gt = np.asarray(model.retrieveBatch(batch)).reshape(-1)
+        # the GT rank is the oracle's rule on the DEVICE scores, exactly; against the golden ranks it may move only by the near-tie flips above
+        np.testing.assert_array_equal(gt, vo.compute_ranks(dev_scores, batch['answer_ind'].reshape(-1) - 1))
+        assert np.abs(gt - z['eval.gt_ranks'].reshape(-1)).sum() <= flipped
         m = utils.processRanks(gt, verbose=False)
-        if (gt == z['eval.gt_ranks']).all():
-            np.testing.assert_allclose([m[k] for k in ('r@1', 'r@5', 'r@10', 'medianR', 'meanR', 'meanRR')],
-                                       z['eval.metrics'], atol=1e-12)
+        want = vo.process_ranks(gt, dev_scores.shape[1])         # utils.lua:131-160 restated, on the same ranks
+        np.testing.assert_allclose([m[k] for k in ('r@1', 'r@5', 'r@10', 'medianR', 'meanR', 'meanRR')],
+                                   [want[k] for k in ('r@1', 'r@5', 'r@10', 'medianR', 'meanR', 'meanRR')], atol=1e-12)
+        if flipped == 0:
+            np.testing.assert_allclose([m[k] for k in ('r@1', 'r@5', 'r@10', 'medianR', 'meanR', 'meanRR')], z['eval.metrics'], atol=1e-12)

@@ -74,7 +74,7 @@ def test_lua_model_step_equals_library_and_oracle(gpu, enc, dec, train_mode):
     host = LuaHost(p)
     m = host.model()
     # model.wrapperW:copy(savedModel.modelW) (train.lua:79): a flat vector in the REFERENCE's getParameters() order
-    flat = t7.named_to_flat(P, nat._entries(), enc if enc in t7.VERIFIED_ORDER else None)
+    flat = t7.named_to_flat(P, nat._entries(), enc)
     w = host.get(m, 'wrapperW')
     assert w.tn == 'Float' and w.a.shape == (flat.size,)
     host.invoke(w, 'copy', host.tensor(flat, 'Float'))
@@ -148,7 +148,7 @@ def test_lua_hosts_match_the_golden_fixtures(gpu, path, which):
         from visdial_amd import t7
         m = host.model()
         spec = vo.param_spec(enc, dec, p)
-        flat = t7.named_to_flat(P, spec, enc if enc in t7.VERIFIED_ORDER else None)
+        flat = t7.named_to_flat(P, spec, enc)
         host.invoke(host.get(m, 'wrapperW'), 'copy', host.tensor(flat, 'Float'))
         if masks:
             host.invoke(m, 'setDropoutMasks', lua_masks)
@@ -286,7 +286,7 @@ def test_lua_retrieve_batch_equals_library(gpu, enc, dec):
     host = LuaHost(p)
     m = host.model()
     from visdial_amd import t7
-    flat = t7.named_to_flat(P, nat._entries(), enc if enc in t7.VERIFIED_ORDER else None)
+    flat = t7.named_to_flat(P, nat._entries(), enc)
     host.invoke(m, 'setFlatParameters', host.tensor(flat, 'Float'))
     host.invoke(m, 'setMode', False)
     R = p['maxQuesCount']

@@ -465,6 +465,29 @@ def test_the_model_level_lua_host_executes_every_method(enc, dec):
     assert not dry.models                                           # ffi.gc(handle, vd_model_destroy) ran
 
 
+@pytest.mark.parametrize("enc", ALL_ENC)
+def test_lua_flat_vector_is_in_the_executed_reference_s_order(enc):
+    """lua/model.lua:Model:tensors() -- the order behind model.wrapperW / torch.save(modelW) -- equals the order
+    wrapper:getParameters() produced when the reference's files were executed (tests/golden/reference_param_order.json) and
+    visdial_amd/t7.py:reference_order, so a .t7 written by either host loads in the other (and in Torch7, as far as derived)."""
+    import json
+    from oracle import visdial_oracle as vo
+    from visdial_amd import t7
+    d = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'reference_param_order.json')))
+    cases = [('disc', {})] + [(v['decoder'], v['params']) for v in d['variants'] if v['encoder'] == enc]
+    for dec, extra in cases:
+        p = derive(small_params(encoder=enc, decoder=dec, **extra))
+        host = LuaHost(p, dry=True)
+        m = host.model()
+        names = [t['name'] for t in to_py(first(host.invoke(m, 'tensors')))]
+        want = d['encoder'][enc] + d['decoder'][dec] if not extra else [v['order'] for v in d['variants']
+                                                                         if v['encoder'] == enc and v['params'] == extra][0]
+        assert names == want
+        assert names == [n for n, _, _ in t7.reference_order(enc, vo.param_spec(enc, dec, p))]
+        flat = first(host.invoke(m, 'getFlatParameters'))                  # ... and the flat vector has every tensor exactly once
+        assert flat.a.size == sum(int(np.prod(s)) for _, s, _ in vo.param_spec(enc, dec, p))
+
+
 def test_lua_generate_answers_runs_beam_search_and_sampling():
     from test_dataloader_cpu import raw_dataset
     from visdial_amd.dataloader import Dataloader

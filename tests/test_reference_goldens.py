@@ -1,0 +1,151 @@
+"""Fixtures made by EXECUTING the reference's own Lua (model.lua, encoders/*.lua, decoders/*.lua, model_utils/*.lua, utils.lua) in
+this container -- tests/golden/make_reference_goldens.py: the reference's sources on tests/luavm (Lua 5.1 evaluator + Torch7 tensor
+stub) over tests/luavm/nn7.py (numpy restatement of the nn / nngraph / rnn modules the reference composes; those packages are
+third-party and absent from /root/reference).  tests/golden/ref__<encoder>__<decoder>.npz hold, per pair: the parameters the
+reference initialised (rounded to fp32), one synthetic batch, and what the reference computed from them --
+
+  eval.*    Model:forwardBackward in evaluate() mode: loss + every gradient tensor (fp64)
+  train.*   the same in training() mode, with the noise every nn.Dropout drew recorded under mask.<site>
+  step.*    Model:trainIteration: the Adam update of every tensor, runningLoss (the global), the decayed learning rate
+  rank.*    Model:retrieveBatch -> utils.computeRanks: the decoder's scores, the GT ranks and all ranks        (disc)
+
+CPU: oracle/visdial_oracle.py reproduces all of it (this is what pins the oracle to the reference).
+GPU: the HIP path, fed the same parameters / batch / masks through the C ABI, matches within the fp32 tolerance (1e-4).
+Nothing here reads /root/reference."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, grad_mismatches, unexplained_rank_flips
+from oracle import visdial_oracle as vo
+from visdial_amd.opts import derive
+
+FILES = sorted(glob.glob(os.path.join(ROOT, 'tests', 'golden', 'ref__*__*.npz')))
+IDS = [os.path.basename(f)[5:-4] for f in FILES]
+
+
+def load(path):
+    z = np.load(path)
+    get = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
+    p = derive(json.loads(str(z['opt.json'])))
+    return p['encoder'], p['decoder'], p, z, get('param.'), get('batch.'), get('mask.')
+
+
+def test_fixture_set_is_complete():
+    assert len(FILES) == 14
+    encs = {i.split('__')[0] for i in IDS}
+    assert len(encs) == 11 and sum(i.endswith('__gen') for i in IDS) == 3          # every encoder with disc, three with gen
+
+
+@pytest.mark.parametrize("path", FILES, ids=IDS)
+def test_oracle_reproduces_the_executed_reference(path):
+    enc, dec, p, z, P, batch, masks = load(path)
+    get = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    assert [n for n, _, _ in vo.param_spec(enc, dec, p)] and set(P64) == {n for n, _, _ in vo.param_spec(enc, dec, p)}
+    for n, shape, _ in vo.param_spec(enc, dec, p):                      # the reference's modules have the shapes the oracle declares
+        assert P64[n].shape == tuple(shape), n
+
+    # evaluate(): loss and every gradient, fp64 against fp64
+    r = vo.forward_backward(enc, dec, P64, p, batch, None)
+    assert abs(r['loss'] - float(z['eval.loss'])) < 1e-10 * max(1.0, abs(float(z['eval.loss'])))
+    assert not grad_mismatches(r['grads'], get('eval.grad.'), tol=1e-9)
+
+    # training(): with the noise the reference's Dropout nodes drew (gradients stored in fp32)
+    drop = {k: v.astype(np.float64) for k, v in masks.items()} if masks else None
+    rt = vo.forward_backward(enc, dec, P64, p, batch, drop)
+    assert abs(rt['loss'] - float(z['train.loss'])) < 1e-10 * max(1.0, abs(float(z['train.loss'])))
+    assert not grad_mismatches(rt['grads'], get('train.grad.'), tol=1e-6)
+    if masks:
+        assert abs(float(z['train.loss']) - float(z['eval.loss'])) > 1e-6          # (the masks did something)
+
+    # trainIteration (model.lua:66-106): clamp + adam + runningLoss + lr decay
+    delta = get('step.delta.')
+    for k in P64:
+        w2, _ = vo.clamp_adam(P64[k].reshape(-1), r['grads'][k].reshape(-1), {}, p['learningRate'])
+        assert np.abs((w2 - P64[k].reshape(-1)) - delta[k].reshape(-1)).max() < 1e-9, k
+    want_rl = r['loss'] / max(int((batch['answer_out'] > 0).sum()), 1) if dec == 'gen' else r['loss']
+    assert abs(float(z['step.runningLoss']) - want_rl) < 1e-10 * max(1.0, abs(want_rl))
+    assert abs(float(z['step.learningRate']) - p['learningRate'] * p['lrDecayRate']) < 1e-15
+
+    # retrieveBatch + utils.computeRanks on the updated parameters
+    if dec == 'disc':
+        P1 = {k: P64[k] + delta[k].astype(np.float64) for k in P64}
+        ev = vo.forward_backward(enc, dec, P1, p, batch, None, only_forward=True)
+        assert np.abs(ev['scores'] - z['rank.scores']).max() < 1e-8
+        np.testing.assert_array_equal(vo.compute_ranks(z['rank.scores']), z['rank.all'])          # the rule itself, exactly
+        np.testing.assert_array_equal(vo.compute_ranks(z['rank.scores'], batch['answer_ind'].reshape(-1) - 1), z['rank.gt'])
+        flipped, bad = unexplained_rank_flips(ev['scores'], z['rank.scores'], tol=1e-6)           # on the oracle's own scores: up to ties
+        assert not bad, bad[:5]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FILES, ids=IDS)
+def test_hip_path_matches_the_executed_reference(path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from visdial_amd.model import Model
+    enc, dec, p, z, P, batch, masks = load(path)
+    get = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
+    model = Model(p)
+    model.set_parameters_dict(P)
+
+    model.wrapper.evaluate()
+    model.wrapper.zeroGradParameters()
+    loss = model.forwardBackward(batch)
+    ref = float(z['eval.loss'])
+    assert abs(loss - ref) < 1e-4 * max(1.0, abs(ref))
+    bad = grad_mismatches(model.get_gradients_dict(), get('eval.grad.'))
+    assert not bad, bad
+
+    if masks:
+        model.wrapper.training()
+        model.set_dropout_masks(masks)
+        model.wrapper.zeroGradParameters()
+        loss = model.forwardBackward(batch)
+        ref = float(z['train.loss'])
+        assert abs(loss - ref) < 1e-4 * max(1.0, abs(ref))
+        bad = grad_mismatches(model.get_gradients_dict(), get('train.grad.'))
+        assert not bad, bad
+        model.set_dropout_masks(None)
+
+    # Model:trainIteration on a dataloader that serves this batch, dropout off like the fixture's step
+    class OneBatch(object):
+        def getTrainBatch(self, params):
+            return batch
+    model.wrapper.evaluate()
+    model.runningLoss = 0
+    model.trainIteration(OneBatch())
+    W1 = model.get_parameters_dict()
+    delta = get('step.delta.')
+    for k in P:
+        # Adam's first step is lr * g / (|g| + eps): where |g| ~ eps = 1e-8 the fp32 gradient decides the step, so compare through
+        # the fp64 gradient's margin: elements with |g| > 1e-6 must move by the reference's step within 1e-4 relative
+        g = z['eval.grad.' + k].reshape(-1)
+        big = np.abs(g) > 1e-6
+        got = (W1[k].astype(np.float64) - P[k].astype(np.float64)).reshape(-1)
+        assert np.abs(got[big] - delta[k].reshape(-1)[big]).max(initial=0.0) < 1e-4 * p['learningRate'] + 2e-7 * np.abs(P[k]).max(), k
+        assert np.abs(got).max(initial=0.0) <= p['learningRate'] * 1.0001 + 2e-7 * np.abs(P[k]).max()
+    want_rl = float(z['step.runningLoss'])
+    assert abs(model.runningLoss - want_rl) < 1e-4 * max(1.0, abs(want_rl))
+    assert abs(model.optims['learningRate'] - float(z['step.learningRate'])) < 1e-12
+
+    if dec == 'disc':
+        # ranks from the fixture's UPDATED parameters (not this run's, whose near-zero-gradient elements may have stepped differently)
+        model.set_parameters_dict({k: (P[k].astype(np.float64) + delta[k]).astype(np.float32) for k in P})
+        model.wrapper.evaluate()
+        p['useGt'] = False
+        ranks = np.asarray(model.retrieveBatch(batch))
+        dev_scores = model.decoder.output.cpu().numpy()
+        assert np.abs(dev_scores - z['rank.scores']).max() < 1e-4
+        np.testing.assert_array_equal(ranks.reshape(dev_scores.shape), vo.compute_ranks(dev_scores))
+        flipped, bad = unexplained_rank_flips(dev_scores, z['rank.scores'])
+        assert not bad, bad[:10]
+        assert (ranks.reshape(dev_scores.shape) != z['rank.all']).sum() <= 2 * flipped
+        p['useGt'] = True
+        gt = np.asarray(model.retrieveBatch(batch)).reshape(-1)
+        assert np.abs(gt - z['rank.gt']).sum() <= flipped

@@ -3,6 +3,7 @@ train.lua:99-102: {modelW = tensor, optims = {learningRate, t, m, v}, modelParam
 import struct
 
 import numpy as np
+import pytest
 
 from visdial_amd import t7
 from visdial_amd.params import ParamSpec
@@ -70,48 +71,53 @@ def test_flat_vector_mapping():
         np.testing.assert_array_equal(back[n], named[n])
 
 
-def test_reference_parameter_order_per_encoder_family():
-    """getParameters() order of a reference checkpoint: lf-* = declaration order; hre-* puts the
-    image Linear BEFORE the history LSTMs (concat = wordBranch, imageBranch, histBranch: hre-ques-im-hist.lua:56-60);
-    nngraph encoders (mn-*, lf-att) are refused because their order cannot be derived."""
-    import pytest
+def _spec_for(enc, dec, **kw):
     from visdial_amd import encoders, decoders
     from visdial_amd.opts import default_params
+    p = default_params(encoder=enc, decoder=dec, vocabSize=20, embedSize=8, rnnHiddenSize=32, imgFeatureSize=12,
+                       imgEmbedSize=8, imgSpatialSize=2, commonEmbeddingSize=16, **kw)
+    spec = ParamSpec()
+    spec.embed('embed', p['vocabSize'] + 1, p['embedSize'])
+    encoders.load(enc).declare(p, spec)
+    decoders.load(dec).declare(p, spec)
+    return spec.entries
 
-    def spec_for(enc, dec):
-        p = default_params(encoder=enc, decoder=dec, vocabSize=20, embedSize=8, rnnHiddenSize=32, imgFeatureSize=12,
-                           imgEmbedSize=8, imgSpatialSize=2, commonEmbeddingSize=16)
-        spec = ParamSpec()
-        spec.embed('embed', p['vocabSize'] + 1, p['embedSize'])
-        encoders.load(enc).declare(p, spec)
-        decoders.load(dec).declare(p, spec)
-        return spec.entries
 
+def _derived_orders():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'reference_param_order.json')))
+
+
+def test_reference_parameter_order_equals_the_executed_reference():
+    """t7.reference_order == the order wrapper:getParameters() produced when the reference's encoder / decoder files were
+    EXECUTED (tests/golden/make_reference_goldens.py -> reference_param_order.json), for all 11 encoders x both decoders
+    and for the numLayers / numAttentionLayers variants recorded there."""
+    d = _derived_orders()
     names = lambda entries: [e[0] for e in entries]
-    e = spec_for('lf-ques-im-hist', 'gen')
-    assert names(t7.reference_order('lf-ques-im-hist', e)) == names(e)
-    assert names(e)[:3] == ['embed', 'ques1.W', 'ques1.b'] and 'fuse.W' in names(e)
-    for enc in ('hre-ques-im-hist', 'hrea-ques-im-hist'):
-        e = spec_for(enc, 'disc')
-        ref = names(t7.reference_order(enc, e))
-        assert ref[:3] == ['embed', 'img_embed.W', 'img_embed.b'] and ref[3] == 'hist1.W'
-        assert sorted(ref) == sorted(names(e)) and ref.index('ques1.W') > ref.index('hist2.b')
-        # a flat vector written in reference order comes back tensor by tensor
-        named = {n: np.random.RandomState(len(n)).randn(*s).astype(np.float32) for n, s, _ in e}
-        flat = t7.named_to_flat(named, e, enc)
-        back = t7.flat_to_named(flat, e, enc)
-        for n in named:
-            np.testing.assert_array_equal(back[n], named[n])
-        # ... and differs from declaration order exactly where the image Linear moved
-        assert not np.array_equal(flat, t7.named_to_flat(named, e))
-    e = spec_for('hre-ques-hist', 'disc')
-    assert names(t7.reference_order('hre-ques-hist', e)) == names(e)
-    for enc in ('mn-att-ques-im-hist', 'mn-ques-hist', 'lf-att-ques-im-hist'):
-        e = spec_for(enc, 'disc')
-        flat = np.zeros(sum(int(np.prod(s)) for _, s, _ in e), np.float32)
-        with pytest.raises(ValueError):
-            t7.flat_to_named(flat, e, enc)
-        t7.flat_to_named(flat, e, enc, allow_unverified=True)
+    for enc, order in d['encoder'].items():
+        for dec in ('disc', 'gen'):
+            e = _spec_for(enc, dec)
+            ref = names(t7.reference_order(enc, e))
+            assert ref == order + d['decoder'][dec], (enc, dec)
+            assert sorted(ref) == sorted(names(e))
+            # a flat vector written in reference order comes back tensor by tensor
+            named = {n: np.random.RandomState(len(n)).randn(*s).astype(np.float32) for n, s, _ in e}
+            back = t7.flat_to_named(t7.named_to_flat(named, e, enc), e, enc)
+            for n in named:
+                np.testing.assert_array_equal(back[n], named[n])
+    assert len(d['encoder']) == 11 and len(d['variants']) >= 5
+    for v in d['variants']:
+        e = _spec_for(v['encoder'], v['decoder'], **v['params'])
+        assert names(t7.reference_order(v['encoder'], e)) == v['order'], v
+    # the documented landmarks: hre*-im puts the image Linear right behind the embedding, hre-ques-hist runs the QUESTION LSTMs
+    # first, the nngraph att encoders start with the image tower
+    assert d['encoder']['hre-ques-im-hist'][:3] == ['embed', 'img_embed.W', 'img_embed.b']
+    assert d['encoder']['hre-ques-hist'][1] == 'ques1.W' and d['encoder']['mn-att-ques-im-hist'][0] == 'img_proj.W'
+    assert t7.order_status('mn-att-ques-im-hist') == 'derived' and t7.order_status('hre-ques-hist') == 'source'
+    with pytest.raises(ValueError):                       # the element count is always checked
+        e = _spec_for('mn-att-ques-im-hist', 'disc')
+        t7.flat_to_named(np.zeros(sum(int(np.prod(s)) for _, s, _ in e) + 1, np.float32), e, 'mn-att-ques-im-hist')
 
 
 class _FakeModel(object):
@@ -131,33 +137,86 @@ class _FakeModel(object):
     def set_parameters_dict(self, d):
         self.named = {k: np.array(v) for k, v in d.items()}
 
-    def load_flat_parameters(self, w, allow_unverified=False):
-        self.set_parameters_dict(t7.flat_to_named(w, self._entries(), self.params['encoder'], allow_unverified))
+    def load_flat_parameters(self, w):
+        self.set_parameters_dict(t7.flat_to_named(w, self._entries(), self.params['encoder']))
 
 
-def test_cli_checkpoint_t7_roundtrip_marks_unverified_layouts(tmp_path):
-    """train.py's model_epoch_%d.t7 / model_final.t7 (train.lua:99-102,120-121): Sequential encoders are written in the
-    reference's getParameters() order; nngraph encoders in this library's declaration order WITH a marker, and
-    restore_weights follows the marker instead of guessing (a Torch7-written file without it stays refused)."""
-    import pytest
-    from visdial_amd import checkpoint
+def _fake_named(enc, dec='disc'):
     rng = np.random.RandomState(3)
-    named = {'embed': rng.randn(5, 4).astype(np.float32), 'hist1.W': rng.randn(6, 8).astype(np.float32),
-             'img_embed.W': rng.randn(3, 4).astype(np.float32), 'ques1.W': rng.randn(6, 8).astype(np.float32)}
-    for enc, marked in (('hre-ques-im-hist', False), ('mn-att-ques-im-hist', True)):
+    return {n: rng.randn(*s).astype(np.float32) for n, s, _ in _spec_for(enc, dec)}
+
+
+def test_cli_checkpoint_t7_roundtrip_in_reference_order(tmp_path, capsys):
+    """train.py's model_epoch_%d.t7 / model_final.t7 (train.lua:99-102,120-121): the flat vector is in the reference's
+    getParameters() order for EVERY encoder (t7.reference_order); loading an nngraph encoder says the order is derived."""
+    from visdial_amd import checkpoint
+    for enc in ('hre-ques-im-hist', 'hre-ques-hist', 'mn-att-ques-im-hist'):
+        named = _fake_named(enc)
         m = _FakeModel(enc, dict(named))
         p = str(tmp_path / (enc + '.t7'))
-        checkpoint.save_t7(p, m, {'encoder': enc, 'decoder': 'disc', 'rnnHiddenSize': 8})
+        checkpoint.save_t7(p, m, {'encoder': enc, 'decoder': 'disc', 'rnnHiddenSize': 32})
         ck = checkpoint.load_checkpoint(p)
-        assert ('vdLayout' in ck) == marked and abs(ck['optims']['learningRate'] - 7e-4) < 1e-12
-        if not marked:     # reference order: the image Linear sits between embed and the history LSTM
-            np.testing.assert_array_equal(ck['modelW'][20:32], named['img_embed.W'].reshape(-1))
+        assert 'vdLayout' not in ck and abs(ck['optims']['learningRate'] - 7e-4) < 1e-12
+        first = {'hre-ques-im-hist': ('embed', 'img_embed.W'), 'hre-ques-hist': ('embed', 'ques1.W'),
+                 'mn-att-ques-im-hist': ('img_proj.W', 'img_proj.b')}[enc]
+        o = 0
+        for n in first:
+            np.testing.assert_array_equal(ck['modelW'][o:o + named[n].size], named[n].reshape(-1))
+            o += named[n].size
         m2 = _FakeModel(enc, {k: np.zeros_like(v) for k, v in named.items()})
+        capsys.readouterr()
         checkpoint.restore_weights(m2, ck)
+        assert ('derived' in capsys.readouterr().err) == (enc == 'mn-att-ques-im-hist')
         for k in named:
             np.testing.assert_array_equal(m2.named[k], named[k])
-    # the same vector WITHOUT the marker is what Torch7 would have written: refused unless the caller insists
-    ck.pop('vdLayout')
-    with pytest.raises(ValueError):
-        checkpoint.restore_weights(m2, ck)
-    checkpoint.restore_weights(m2, ck, allow_unverified=True)
+    # a file an EARLIER version of this repo wrote for an nngraph encoder (declaration order + marker) still loads
+    ck['modelW'] = t7.named_to_flat(named, m._entries(), None)
+    ck['vdLayout'] = 'declaration'
+    m3 = _FakeModel(enc, {k: np.zeros_like(v) for k, v in named.items()})
+    checkpoint.restore_weights(m3, ck)
+    for k in named:
+        np.testing.assert_array_equal(m3.named[k], named[k])
+
+
+def test_hand_assembled_torch7_checkpoint(tmp_path):
+    """A checkpoint assembled BYTE BY BYTE here, the way Torch7's File:writeObject lays out what train.lua:99-102 saves on a GPU
+    ({modelW = CudaTensor viewing a storage, optims = {learningRate}, modelParams = {...}}; torch7/File.lua, binary mode) --
+    independent of t7.save.  It loads through checkpoint.load_checkpoint / restore_weights into the named tensors in the
+    reference's getParameters() order."""
+    from visdial_amd import checkpoint
+    enc = 'mn-ques-im-hist'
+    named = _fake_named(enc)
+    order = _derived_orders()['encoder'][enc] + ['opt.W', 'opt.b']
+    flat = np.concatenate([named[n].reshape(-1) for n in order]).astype(np.float32)
+    p = str(tmp_path / 'hand.t7')
+    with open(p, 'wb') as f:
+        w = lambda fmt, *v: f.write(struct.pack('<' + fmt, *v))
+
+        def st(x):
+            w('i', 2); w('i', len(x)); f.write(x.encode())
+
+        def raw(x):
+            w('i', len(x)); f.write(x.encode())
+        w('i', 3); w('i', 1); w('i', 3)                                   # table, ref 1, three pairs
+        st('modelW')
+        w('i', 4); w('i', 2); raw('V 1'); raw('torch.CudaTensor')         # torch object, ref 2
+        w('i', 1); w('q', flat.size); w('q', 1); w('q', 1)                # nDim, size, stride, storageOffset (1-based)
+        w('i', 4); w('i', 3); raw('V 1'); raw('torch.CudaStorage'); w('q', flat.size); f.write(flat.tobytes())
+        st('optims')
+        w('i', 3); w('i', 4); w('i', 1); st('learningRate'); w('i', 1); w('d', 2.5e-4)
+        st('modelParams')
+        w('i', 3); w('i', 5); w('i', 3)
+        st('encoder'); st(enc)
+        st('rnnHiddenSize'); w('i', 1); w('d', 32.0)
+        st('useIm'); w('i', 5); w('i', 1)
+    ck = checkpoint.load_checkpoint(p)
+    assert ck['modelParams'] == {'encoder': enc, 'rnnHiddenSize': 32, 'useIm': True} and ck['optims']['learningRate'] == 2.5e-4
+    m = _FakeModel(enc, {k: np.zeros_like(v) for k, v in named.items()})
+    checkpoint.restore_weights(m, ck)
+    for k in named:
+        np.testing.assert_array_equal(m.named[k], named[k])
+    # the same bytes come out of t7.save for the same object (so a file this repo writes is laid out like the hand-assembled one)
+    q = str(tmp_path / 'saved.t7')
+    t7.save(q, {'modelW': flat, 'optims': {'learningRate': 2.5e-4}, 'modelParams': {'encoder': enc, 'rnnHiddenSize': 32, 'useIm': True}},
+            float_tensor_class='Cuda')
+    assert open(q, 'rb').read() == open(p, 'rb').read()

@@ -46,7 +46,7 @@ def main():
         mp['gpuid'], mp['batchSize'] = opt['gpuid'], opt['batchSize']
         # run control and runtime (non-architectural) choices stay with the command line
         for k in ('numEpochs', 'maxIters', 'savePath', 'saveIter', 'host', 'lstmPrecision', 'saveFormat',
-                  'allowUnverifiedOrder', 'synthetic'):
+                  'synthetic'):
             mp[k] = opt.get(k)
     # the dataloader is built from the CURRENT command line (train.lua:47-48), never from paths stored in a checkpoint
     have = lambda p: os.path.exists(p) or os.path.exists(p[:-3] + '.npz')
@@ -72,7 +72,7 @@ def main():
     else:
         model = Model(opt)
     if saved is not None:                                        # train.lua:78-81
-        restore_weights(model, saved, allow_unverified=bool(opt.get('allowUnverifiedOrder')))
+        restore_weights(model, saved)
         model.optims['learningRate'] = saved['optims']['learningRate']
     print('Training..')
     total = opt['numEpochs'] * opt['numIterPerEpoch']

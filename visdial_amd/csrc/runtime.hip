@@ -132,7 +132,7 @@ int vd_model_create(const vd_model_params* p, const char* encoder, const char* d
   VD_CHECK_ARG(p->dropout >= 0.f && p->dropout < 1.f, "vd_model_create: dropout must lie in [0, 1)");
   vd_model* m = new vd_model();
   m->p = *p;
-  if (m->p.numAttentionLayers < 1) m->p.numAttentionLayers = 1;
+  if (m->p.numAttentionLayers < 1 || has(en, "lf-att")) m->p.numAttentionLayers = 1;   // (lf-att-ques-im-hist.lua:49 hard-codes one hop)
   if (m->p.numLayers < 1) m->p.numLayers = 2;        // opts.lua:27
   m->enc_name = encoder;
   m->dec_name = decoder;

@@ -183,7 +183,8 @@ def dropout_mask_shapes(params, batch):
         if 'att' in enc:
             S2, K = params['imgSpatialSize'] ** 2, params.get('commonEmbeddingSize', 512)
             shp.update(img_tr=(N, S2, H), iqc=(N, S2, K), u=(N, H))
-            for i in range(2, int(params.get('numAttentionLayers', 1) or 1) + 1):     # one Dropout per attention hop
+            hops = 1 if enc.startswith('lf-att') else int(params.get('numAttentionLayers', 1) or 1)     # (lf-att-ques-im-hist.lua:49: always 1)
+            for i in range(2, hops + 1):     # one Dropout per attention hop
                 shp['iqc%d' % i] = (N, S2, K)
     return shp
 

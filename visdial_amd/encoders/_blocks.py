@@ -134,6 +134,8 @@ class SANBlock(object):
     @staticmethod
     def hop_names(params):
         L = int(params.get('numAttentionLayers', 1) or 1)
+        if params.get('encoder') == 'lf-att-ques-im-hist':          # lf-att-ques-im-hist.lua:49 hard-codes one hop
+            L = 1
         return [('img_common' + s, 'ques_common' + s, 'att' + s) for s in [''] + [str(i) for i in range(2, L + 1)]]
 
     @staticmethod

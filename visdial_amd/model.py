@@ -364,13 +364,12 @@ class Model(SplitEval):
     def set_parameters_dict(self, d):
         self.fp.load_host(d)
 
-    def load_flat_parameters(self, modelW, allow_unverified=False):
+    def load_flat_parameters(self, modelW):
         """`model.wrapperW:copy(savedModel.modelW)` (train.lua:79, evaluate.lua:91) for a flat vector in the
         reference's getParameters() layout (no alignment padding, Torch7 module order) -- e.g. `modelW` of a .t7
-        checkpoint.  Raises for the nngraph encoders, whose order is not derivable (t7.VERIFIED_ORDER)."""
+        checkpoint."""
         from . import t7
-        self.set_parameters_dict(t7.flat_to_named(np.asarray(modelW), self.fp.spec.entries, self.params['encoder'],
-                                                  allow_unverified))
+        self.set_parameters_dict(t7.flat_to_named(np.asarray(modelW), self.fp.spec.entries, self.params['encoder']))
 
     def flat_parameters(self):
         """the parameters as the reference's flat `modelW` (Torch7 module order for this encoder)"""

@@ -137,12 +137,11 @@ class NativeModel(SplitEval):
             ('_w' if n.endswith('.W') else '_b')
         return [(n, self._shape(n, r, c), kind(n)) for n, _, r, c in self.tensors]
 
-    def load_flat_parameters(self, modelW, allow_unverified=False):
+    def load_flat_parameters(self, modelW):
         """`model.wrapperW:copy(savedModel.modelW)` for a flat vector in the REFERENCE's getParameters() layout
         (see visdial_amd.model.Model.load_flat_parameters)"""
         from . import t7
-        self.set_parameters_dict(t7.flat_to_named(np.asarray(modelW), self._entries(), self.params['encoder'],
-                                                  allow_unverified))
+        self.set_parameters_dict(t7.flat_to_named(np.asarray(modelW), self._entries(), self.params['encoder']))
 
     def flat_parameters(self):
         from . import t7

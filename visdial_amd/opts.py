@@ -37,8 +37,6 @@ OPTIONS = [
     ('lstmPrecision', 'fp32', "arithmetic of the option-LSTM recurrence GEMMs: 'fp32' (default, v_mfma_f32) | 'split9' (exact 3-way bf16 split of both operands, 9 bf16 MFMAs per fp32 one: fp32-grade) | 'bf16' (bf16 operands, fp32 accumulation) | 'split6' / 'split3' (fewer products: data only)"),
     ('saveFormat', 't7', "checkpoint files: 't7' = model_epoch_%d.t7 / model_final.t7 in the Torch7 binary format "
                          "(train.lua:99-102,120-121) | 'pt' = torch.save of the same three fields"),
-    ('allowUnverifiedOrder', 0, "1 = accept a Torch7-written .t7 for the nngraph encoders (mn-*, lf-att-*), assuming "
-                                "their getParameters() order equals this library's declaration order (unverifiable offline)"),
     ('host', 'python', "which host drives the library: 'python' (operator-level C ABI, visdial_amd/model.py) | 'native' "
                        "(model-level C ABI, the calls lua/model.lua makes; visdial_amd/native.py)"),
 ]

@@ -11,6 +11,7 @@ validated by round trips only and is UNPINNED against real Torch7 output:
   Tensor   := int32 nDim ; int64 size[nDim] ; int64 stride[nDim] ; int64 storageOffset(1-based) ; storage object
   Storage  := int64 n ; n raw elements
 Lua tables with keys 1..n come back as Python lists, everything else as dicts."""
+import re
 import struct
 
 import numpy as np
@@ -170,46 +171,88 @@ def save(path, obj, float_tensor_class=None):
 
 # ---------------------------------------------------------------------------------------------------------
 # flat parameter vector <-> named tensors
-# Torch7's getParameters() flattens parameter storages in depth-first module order.  For the
-# encoders built from nn.Sequential / nn.ConcatTable that order can be read off the reference file:
-#   lf-*    : wordBranch(embed, ques LSTMs) | [image: no parameters] | histBranch(hist LSTMs) | fuse Linear
-#             (encoders/lf-ques-im-hist.lua:12-58) -- equals this repo's declaration order;
-#   hre-*   : concat = wordBranch(embed), imageBranch(Linear F->imgEmbed), histBranch(hist LSTMs)
-#             (encoders/hre-ques-im-hist.lua:56-60), then the question LSTMs (:72-80), [hrea: the two Linear(H,1),
-#             hrea-ques-im-hist.lua:88-95], then the dialog LSTM (:92) -- the image Linear comes BEFORE the history
-#             LSTMs, unlike this repo's declaration order (hist, img_embed, ques, ...).
-# The nngraph encoders (mn-*, lf-att-*) are flattened in nngraph's internal node order, which cannot be derived
-# without nngraph: UNVERIFIED, refused unless the caller insists.
-VERIFIED_ORDER = ('lf-ques', 'lf-ques-im', 'lf-ques-hist', 'lf-ques-im-hist', 'hre-ques-hist', 'hre-ques-im-hist',
-                  'hrea-ques-im-hist')
+# Torch7's getParameters() flattens the parameter storages in module order, every shared storage at its first
+# occurrence.  The orders below were obtained by EXECUTING the reference's encoder / decoder files
+# (tests/golden/make_reference_goldens.py: the reference's Lua on tests/luavm + a numpy restatement of nn / nngraph /
+# rnn) and reading the offsets of every tensor in wrapper:getParameters(); tests/golden/reference_param_order.json
+# holds the result and tests/test_reference_goldens.py keeps this table equal to it.
+#   lf-*    : wordBranch(embed, ques LSTMs) | histBranch(hist LSTMs) | fuse Linear        (lf-ques-im-hist.lua:12-58)
+#   hre-ques-hist : embed, ques LSTMs, hist LSTMs, dialog LSTM                                (hre-ques-hist.lua)
+#   hre(a)-ques-im-hist : embed, image Linear, hist LSTMs (hre-ques-im-hist.lua:56-60), ques LSTMs (:72-80),
+#             [hrea: the two Linear(H,1), hrea-ques-im-hist.lua:88-95], dialog LSTM (:92)
+#   mn-* / lf-att-* (nngraph): gModule keeps its modules in forward-node order = depth-first post-order from the
+#             output node over each node's inputs in declaration order.  mn-att with L attention hops: the hop-L
+#             img_common is reached FIRST (img_common<L> .. img_common2, img_common), the (ques_common, att)
+#             pairs follow in hop order.
+# STATUS: for the Sequential/ConcatTable encoders the order can also be read off the source.  For the four nngraph
+# encoders it rests on the restated nngraph (graph.topsort of the reversed graph) -- DERIVED, NOT VERIFIED against a
+# Torch7-written checkpoint (none exists offline); loaders say so (order_status) and the element count is checked.
+NNGRAPH_ENCODERS = ('lf-att-ques-im-hist', 'mn-ques-hist', 'mn-ques-im-hist', 'mn-att-ques-im-hist')
+_STEMS = {
+    'lf-ques': ('embed', 'ques*', 'fuse'),
+    'lf-ques-im': ('embed', 'ques*', 'fuse'),
+    'lf-ques-hist': ('embed', 'ques*', 'hist*', 'fuse'),
+    'lf-ques-im-hist': ('embed', 'ques*', 'hist*', 'fuse'),
+    'lf-att-ques-im-hist': ('img_proj', 'img_common', 'embed', 'ques*', 'hist*', 'qh', 'ques_common', 'att', 'out'),
+    'hre-ques-hist': ('embed', 'ques*', 'hist*', 'dialog'),
+    'hre-ques-im-hist': ('embed', 'img_embed', 'hist*', 'ques*', 'dialog'),
+    'hrea-ques-im-hist': ('embed', 'img_embed', 'hist*', 'ques*', 'att_q', 'att_h', 'dialog'),
+    'mn-ques-hist': ('embed', 'ques*', 'hist*', 'mn1', 'mn2'),
+    'mn-ques-im-hist': ('embed', 'ques*', 'qi', 'hist*', 'mn1', 'mn2'),
+    'mn-att-ques-im-hist': ('img_proj', 'img_common#rev', 'embed', 'ques*', 'hist*', 'mn1', 'mn2', 'ques_common+att#', 'out'),
+}
+
+
+def order_status(encoder):
+    """'source' (order readable off the Sequential/ConcatTable source and reproduced by executing it) or 'derived'
+    (nngraph encoders: obtained by executing the reference file on a restated nngraph, not verified on a Torch7 file)"""
+    return 'derived' if encoder in NNGRAPH_ENCODERS else 'source'
 
 
 def reference_order(encoder, spec_entries):
-    """spec entries re-ordered to the reference's getParameters() order for `encoder`"""
+    """spec entries re-ordered to the reference's getParameters() order for `encoder`; the decoder's tensors (everything
+    the encoder table does not name) follow in declaration order (decoders/disc.lua, decoders/gen.lua)"""
     entries = list(spec_entries)
-    if encoder is not None and encoder.startswith('hre'):
-        img = [e for e in entries if e[0].startswith('img_embed.')]
-        rest = [e for e in entries if not e[0].startswith('img_embed.')]
-        at = 1 if rest and rest[0][0] == 'embed' else 0
-        entries = rest[:at] + img + rest[at:]
-    return entries
+    if encoder is None:
+        return entries
+    stem = lambda n: n.rsplit('.', 1)[0]
+    stems = []
+    for e in entries:
+        if stem(e[0]) not in stems:
+            stems.append(stem(e[0]))
+    layered = lambda pre: sorted((s for s in stems if re.fullmatch(pre + r'\d+', s)), key=lambda s: int(s[len(pre):]))
+    hops = lambda pre: [pre] + layered(pre)                   # hop 1 has no suffix, hop i > 1 is <name><i>
+    want = []
+    for t in _STEMS[encoder]:
+        if t.endswith('*'):
+            want += layered(t[:-1])
+        elif t == 'img_common#rev':
+            want += list(reversed(hops('img_common')))
+        elif t == 'ques_common+att#':
+            for q, a in zip(hops('ques_common'), hops('att')):
+                want += [q, a]
+        else:
+            want.append(t)
+    missing = [s for s in want if s not in stems]
+    if missing:
+        raise ValueError("reference_order(%s): the model declares no tensor named %s" % (encoder, missing))
+    want += [s for s in stems if s not in want]              # the decoder
+    return [e for s in want for e in entries if stem(e[0]) == s]
 
 
-def flat_to_named(modelW, spec_entries, encoder=None, allow_unverified=False):
+def flat_to_named(modelW, spec_entries, encoder=None):
     """Split a reference-style flat vector (getParameters(): tensors back to back, NO alignment padding) into
     this repo's named tensors, using the reference's parameter order for `encoder` (reference_order).  encoder=None
-    keeps this repo's own declaration order (checkpoints written by this repo's named_to_flat with encoder=None)."""
-    if encoder is not None and encoder not in VERIFIED_ORDER and not allow_unverified:
-        raise ValueError("the getParameters() order of the nngraph encoder '%s' cannot be derived without nngraph "
-                         "(SURVEY.md App. A7): refusing to load a reference flat vector (it would load silently "
-                         "scrambled); pass allow_unverified=True to assume declaration order" % encoder)
+    keeps this repo's own declaration order (files written with vdLayout = 'declaration')."""
     out, o = {}, 0
-    for name, shape, _ in reference_order(encoder, spec_entries):
+    order = reference_order(encoder, spec_entries)
+    total = sum(int(np.prod(shape)) for _, shape, _ in order)
+    if total != len(modelW):
+        raise ValueError('checkpoint holds %d parameters, the model declares %d' % (len(modelW), total))
+    for name, shape, _ in order:
         n = int(np.prod(shape))
         out[name] = np.asarray(modelW[o:o + n], np.float32).reshape(shape)
         o += n
-    if o != len(modelW):
-        raise ValueError('checkpoint holds %d parameters, the model declares %d' % (len(modelW), o))
     return out
 
 
