@@ -255,6 +255,25 @@ def cpu_baseline(seconds_budget=30.0, batch=20):
                          dt, threads, os.cpu_count() or 0, ("%.0f CPUs" % quota) if quota else "none")}
 
 
+def comm_self_check(model, collective, lib_comm, local):
+    """what this rank's gradient exchange looked like in the warm-up steps"""
+    import torch
+    from visdial_amd.parallel import library_comm_available, library_comm_stats
+    out = {'device': torch.cuda.get_device_name(local), 'collective': collective}
+    if lib_comm:
+        out['rccl_version_code'] = library_comm_available()[1]
+        out.update(library_comm_stats())
+        out['bucket1_MB'] = round(out['bucket1_floats'] * 4 / 1e6, 2)
+        out['bucket2_MB'] = round(out['bucket2_floats'] * 4 / 1e6, 2)
+    else:
+        out['rccl_version_code'] = '.'.join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, 'nccl') else None
+        sl = getattr(model, '_enc_slice', None)
+        n = int(model.wrapperdW.numel()) if hasattr(model, 'wrapperdW') else None
+        if sl and n:
+            out.update(bucket1_floats=sl[1] - sl[0], bucket2_floats=n - (sl[1] - sl[0]), overlapped=True)
+    return out
+
+
 def respawn_under_torchrun(args):
     """`python bench.py --gpus N` with N > 1 and no rendezvous environment: become N ranks."""
     port = 29500 + (os.getpid() % 2000)
@@ -310,26 +329,13 @@ def main():
             # rendezvous token, the barriers and the max-over-ranks of the wall time.
             dist.init_process_group(backend='gloo')
             group = dist.group.WORLD
-            from visdial_amd.parallel import init_library_comm_over
-            ok = 1
-            try:
-                from visdial_amd import _lib
-                _lib.call("vd_set_device", local)
-                init_library_comm_over(group)
-            except Exception as exc:     # agree on the outcome: either every rank uses the library or none does
-                print('rank %d: library communicator failed (%s); falling back to torch.distributed nccl' % (rank, exc),
-                      file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            lib_comm = bool(flag.item())
+            from visdial_amd.parallel import join_library_comm
+            # agreed phases (RCCL loadable? -> token -> init): every rank joins or none does, nobody is left inside a collective
+            lib_comm, join_report = join_library_comm(group, device=local)
+            for line in join_report:
+                print('[rank %d] library communicator: %s' % (rank, line), file=sys.stderr, flush=True)
             collective = 'library RCCL (vd_model_allreduce_grads; 2 buckets, library comm stream)'
             if not lib_comm:
-                from visdial_amd.parallel import destroy_library_comm
-                try:
-                    destroy_library_comm()
-                except Exception:
-                    pass
                 group = dist.new_group(backend='nccl', device_id=torch.device('cuda', local))
                 collective = 'torch.distributed nccl (fallback: library communicator failed)'
         else:
@@ -363,6 +369,9 @@ def main():
         loss = model.trainIteration(dl)
     torch.cuda.synchronize()
     if group is not None:
+        # per-rank self-check, so that a first multi-GPU run is diagnosable from its log: which collective, which RCCL, what the
+        # two buckets hold and whether the encoder bucket really went out early (under the decoder's backward)
+        print('[rank %d] %s' % (rank, json.dumps(comm_self_check(model, collective, lib_comm, local))), file=sys.stderr, flush=True)
         dist.barrier(group=group)
     torch.cuda.synchronize()
     ops.PROFILE = {}

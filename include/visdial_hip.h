@@ -292,6 +292,12 @@ int vd_comm_unique_id(void* out128);                      /* ncclGetUniqueId: 12
 int vd_comm_init(int rank, int world, const void* id128); /* ncclCommInitRank on the current device (collective) */
 int vd_comm_info(int* rank, int* world);                  /* world = 0: no communicator */
 int vd_comm_destroy(void);
+/* no collective, no device: can this process load RCCL?  version = NCCL_VERSION_CODE of the loaded library (0 = unknown).
+ * Hosts exchange the answer over their own channel before any rank enters vd_comm_unique_id / vd_comm_init. */
+int vd_comm_available(int* version);
+/* the last vd_model_allreduce_grads: floats in bucket 1 (encoder tensors, reduced under the decoder's backward) and bucket 2
+ * (embedding + decoder), whether bucket 1 was issued early, calls since vd_comm_init */
+int vd_comm_stats(int64_t* bucket1_floats, int64_t* bucket2_floats, int* overlapped, int64_t* calls);
 int vd_model_allreduce_grads(vd_model* m);                /* enqueue only; every rank, once per step */
 int vd_model_init_params(vd_model* m, uint64_t seed);     /* library-default init */
 int vd_model_set_tensor(vd_model* m, const char* name, const float* host, int64_t n);   /* wrapperW:copy(...) */

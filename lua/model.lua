@@ -84,6 +84,22 @@ function Model.commUniqueId()
     return ffi.string(id, 128)
 end
 
+-- no collective, no device: can this process load RCCL?  Exchange the answer BEFORE commUniqueId / initComm, so that a rank
+-- without a usable librccl cannot strand its peers inside the collective ncclCommInitRank.  -> ok, NCCL_VERSION_CODE
+function Model.commAvailable()
+    local v = ffi.new('int[1]')
+    local rc = C.vd_comm_available(v)
+    return rc == 0, tonumber(v[0])
+end
+
+-- the last gradient all-reduce of this process: floats in the early (encoder) bucket and in the late one, whether the early one
+-- was issued under the decoder's backward, calls since initComm -- what a first multi-GPU run prints to be diagnosable
+function Model.commStats()
+    local b1, b2, ov, n = ffi.new('int64_t[1]'), ffi.new('int64_t[1]'), ffi.new('int[1]'), ffi.new('int64_t[1]')
+    vd.call('vd_comm_stats', b1, b2, ov, n)
+    return {bucket1 = tonumber(b1[0]), bucket2 = tonumber(b2[0]), overlapped = ov[0] ~= 0, calls = tonumber(n[0])}
+end
+
 function Model:initComm(rank, world, id)
     assert(#id == 128, 'initComm: the rendezvous token is 128 bytes')
     vd.call('vd_comm_init', rank, world, ffi.cast('const void*', id))

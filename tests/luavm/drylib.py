@@ -155,6 +155,19 @@ class DryLib(object):
         self.comm = (rank, world)
         return 0
 
+    def c_vd_comm_available(self, version):
+        if version:
+            ctypes.cast(version, ctypes.POINTER(ctypes.c_int))[0] = 22203
+        return 0
+
+    def c_vd_comm_stats(self, b1, b2, ov, n):
+        calls = getattr(self, 'comm_calls', 0)
+        for ptr, ty, v in ((b1, ctypes.c_int64, 100 if calls else 0), (b2, ctypes.c_int64, 50 if calls else 0), (ov, ctypes.c_int, 1 if calls else 0),
+                           (n, ctypes.c_int64, calls)):
+            if ptr:
+                ctypes.cast(ptr, ctypes.POINTER(ty))[0] = v
+        return 0
+
     # ---- model level
     def _params_of(self, addr):
         st = self.ffi.structs.get('vd_model_params') or self.ffi.typedefs['vd_model_params']
@@ -320,7 +333,10 @@ class DryLib(object):
         return 0
 
     def c_vd_model_allreduce_grads(self, h):
-        return 0 if self.comm else self.fail('vd_model_allreduce_grads: no communicator (vd_comm_init)')
+        if not self.comm:
+            return self.fail('vd_model_allreduce_grads: no communicator (vd_comm_init)')
+        self.comm_calls = getattr(self, 'comm_calls', 0) + 1
+        return 0
 
 
 def _as_py(v):

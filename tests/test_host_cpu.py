@@ -197,6 +197,62 @@ def test_data_parallel_step_equals_big_batch_step_gloo(tmp_path):
     assert "DP_OK" in outs[0]
 
 
+COMM_WORKER = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from visdial_amd import _lib
+from visdial_amd.parallel import join_library_comm, library_comm_available, library_comm_stats, library_comm_world
+rank = int(sys.argv[1])
+if rank == 1 and sys.argv[2] == 'broken':
+    os.environ['VD_RCCL_LIB'] = '/nonexistent/librccl.so.1'     # ... and no other candidate either:
+    import visdial_amd.parallel as par
+    par.library_comm_available = lambda: (False, 0, 'cannot load librccl.so.1 (test)')
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=rank, world_size=2)
+lib = _lib.load()
+# argument / ordering errors, the same on both ranks and never a collective:
+tok = C.create_string_buffer(128)
+assert lib.vd_comm_init(2, 2, tok) != 0 and b'bad rank 2 / world 2' in lib.vd_last_error()          # rank outside the world
+assert lib.vd_comm_init(-1, 2, tok) != 0 and lib.vd_comm_init(0, 0, tok) != 0 and lib.vd_comm_init(0, 2, None) != 0
+assert lib.vd_model_allreduce_grads(None) != 0                                                       # reduce before init
+assert library_comm_world() == 0 and library_comm_stats()['calls'] == 0
+assert lib.vd_comm_destroy() == 0                                                                    # destroy before init: no-op
+# the agreed three-phase join: here (no GPU) phase 3 fails on every rank -- or phase 1 on the 'broken' rank -- and BOTH ranks
+# come back with the same answer instead of one of them hanging in a collective
+ok, report = join_library_comm(dist.group.WORLD)
+assert ok is False and library_comm_world() == 0, report
+if sys.argv[2] == 'broken':
+    assert any('no rank joins' in r for r in report), report                   # stopped after phase 1, before any token / init
+    assert not any('vd_comm_init' in r for r in report), report
+else:
+    assert any('vd_comm_init failed' in r for r in report) and any('abandoned on every rank' in r for r in report), report
+assert lib.vd_comm_destroy() == 0                                             # nothing half-built is left behind ...
+assert lib.vd_comm_init(3, 2, tok) != 0 and b'bad rank' in lib.vd_last_error()   # ... and the entry points still answer
+dist.barrier()
+print("COMM_OK", rank, report)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("mode", ['healthy', 'broken'])
+def test_library_comm_world2_argument_and_ordering_errors_gloo(tmp_path, mode):
+    """csrc/comm.hip at world 2 without hardware: argument and ordering errors of vd_comm_* / vd_model_allreduce_grads, and
+    parallel.join_library_comm's agreed phases (RCCL loadable? -> token -> init) -- both ranks always leave with the SAME
+    outcome and a clean state, also when one rank cannot load RCCL at all ('broken')."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "comm_worker.py"
+    script.write_text(COMM_WORKER % dict(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("COMM_OK" in o for o in outs), outs
+
+
 def test_library_comm_surface_without_a_gpu():
     """csrc/comm.hip: the communicator entry points exist, report "no communicator" (world 0) before vd_comm_init, refuse
     to reduce without one -- and the library carries no link-time dependency on RCCL (it is dlopen'ed on first use, so a

@@ -452,9 +452,13 @@ def test_the_model_level_lua_host_executes_every_method(enc, dec):
         pred = to_py(first(host.invoke(m, 'predict', D, 'val')))
         assert pred[0]['ranks'] == [float(i) for i in range(1, p['numOptions'] + 1)]
     first(host.invoke(m, 'evaluate', host.dataloader(SyntheticDataloader(p, seed=5, num_threads=5)), 'val'))
+    avail = host.vm.call(host.get(m, 'commAvailable'))
+    assert avail[0] is True and avail[1] == 22203
+    assert to_py(first(host.vm.call(host.get(m, 'commStats'))))['calls'] == 0
     token = first(host.vm.call(host.get(m, 'commUniqueId')))
     host.invoke(m, 'initComm', 1, 2, token)
     host.invoke(m, 'trainIteration', D)
+    assert to_py(first(host.vm.call(host.get(m, 'commStats')))) == {'bucket1': 100, 'bucket2': 50, 'overlapped': True, 'calls': 1}
     assert [c[0] for c in dry.calls[-8:]].count('vd_model_allreduce_grads') == 1 and dry.comm == (1, 2)
     upd = [c for c in dry.calls if c[0] == 'vd_model_update'][-1]
     assert upd[1][1] == 0.5                                         # the 1 / world average goes into clamp + adam

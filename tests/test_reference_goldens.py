@@ -121,15 +121,25 @@ def test_hip_path_matches_the_executed_reference(path):
     model.runningLoss = 0
     model.trainIteration(OneBatch())
     W1 = model.get_parameters_dict()
+    G1 = model.get_gradients_dict()          # (the fused clamp + adam kernel leaves the clamped gradient it used in wrapperdW)
+    assert not grad_mismatches(G1, get('eval.grad.'))
     delta = get('step.delta.')
+    eps1 = 1e-8 / np.sqrt(1 - 0.999)
     for k in P:
-        # Adam's first step is lr * g / (|g| + eps): where |g| ~ eps = 1e-8 the fp32 gradient decides the step, so compare through
-        # the fp64 gradient's margin: elements with |g| > 1e-6 must move by the reference's step within 1e-4 relative
-        g = z['eval.grad.' + k].reshape(-1)
-        big = np.abs(g) > 1e-6
         got = (W1[k].astype(np.float64) - P[k].astype(np.float64)).reshape(-1)
-        assert np.abs(got[big] - delta[k].reshape(-1)[big]).max(initial=0.0) < 1e-4 * p['learningRate'] + 2e-7 * np.abs(P[k]).max(), k
-        assert np.abs(got).max(initial=0.0) <= p['learningRate'] * 1.0001 + 2e-7 * np.abs(P[k]).max()
+        ulp = 2e-7 * max(float(np.abs(P[k]).max()), p['learningRate'])
+        # (1) the update rule itself, element by element on the DEVICE's own gradient: clamp + adam of model.lua:96-99 /
+        #     optim_updates.lua:62-91 in fp32
+        w2, _ = vo.clamp_adam(P[k].astype(np.float64).reshape(-1), G1[k].astype(np.float64).reshape(-1), {}, p['learningRate'])
+        assert np.abs(got - (w2 - P[k].astype(np.float64).reshape(-1))).max(initial=0.0) < 1e-5 * p['learningRate'] + ulp, k
+        # (2) against the reference's step.  Adam's first step is lr * g / (|g| + eps'), eps' = 1e-8 / sqrt(1 - beta2) = 3.2e-7: a
+        #     gradient that is off by dg moves it by lr * eps' * dg / (|g| + eps')^2 -- nothing for |g| >> eps', everything for
+        #     |g| ~ eps'.  dg: 1e-3 of the tensor's largest element (fp32 accumulation over thousands of cancelling rows; the
+        #     tensor-level bound on the gradient is the 1e-4 relative L2 checked above).
+        g = np.abs(z['eval.grad.' + k].reshape(-1))
+        tol = p['learningRate'] * (eps1 * 1e-3 * g.max(initial=0.0) / (g + eps1) ** 2 + 1e-4) + ulp
+        worst = np.abs(got - delta[k].reshape(-1)) / tol
+        assert worst.max(initial=0.0) < 1.0, (k, float(worst.max()), int(worst.argmax()))
     want_rl = float(z['step.runningLoss'])
     assert abs(model.runningLoss - want_rl) < 1e-4 * max(1.0, abs(want_rl))
     assert abs(model.optims['learningRate'] - float(z['step.learningRate'])) < 1e-12

@@ -29,6 +29,7 @@ struct Rccl {
   NcclResult (*GroupStart)() = nullptr;
   NcclResult (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(NcclResult) = nullptr;
+  NcclResult (*GetVersion)(int*) = nullptr;      // optional
 };
 
 struct CommState {
@@ -38,6 +39,9 @@ struct CommState {
   hipStream_t stream = nullptr;      // library-owned communication stream
   hipEvent_t ev_tail = nullptr;      // main stream -> comm stream: "the whole backward has been enqueued up to here"
   hipEvent_t ev_done = nullptr;      // comm stream -> main stream: "both buckets are reduced"
+  // the last vd_model_allreduce_grads, for vd_comm_stats
+  int64_t calls = 0, bucket1 = 0, bucket2 = 0;
+  int overlapped = 0;
 };
 CommState g;
 
@@ -69,8 +73,21 @@ int load_rccl() {
   VD_SYM(GroupEnd, "ncclGroupEnd")
   VD_SYM(GetErrorString, "ncclGetErrorString")
 #undef VD_SYM
+  *(void**)(&a.GetVersion) = dlsym(lib, "ncclGetVersion");
   g.api = a;
   return VD_OK;
+}
+
+// stream + events of this process (not the communicator)
+void release_local() {
+  if (g.ev_tail) (void)hipEventDestroy(g.ev_tail);
+  if (g.ev_done) (void)hipEventDestroy(g.ev_done);
+  if (g.stream) (void)hipStreamDestroy(g.stream);
+  g.ev_tail = g.ev_done = nullptr;
+  g.stream = nullptr;
+  g.comm = nullptr;
+  g.world = 1;
+  g.rank = 0;
 }
 
 }  // namespace
@@ -107,14 +124,45 @@ int vd_comm_init(int rank, int world, const void* id128) {
   NcclUniqueId id;
   memcpy(id.internal, id128, sizeof(id.internal));
   VD_HIP(hipGetDevice(&g.device));
-  VD_NCCL(g.api.CommInitRank(&g.comm, world, id, rank));
-  g.rank = rank;
-  g.world = world;
+  // the stream and events first: nothing below the collective CommInitRank can fail and leave a half-built communicator
   int least = 0, greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-  VD_HIP(hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, greatest));
-  VD_HIP(hipEventCreateWithFlags(&g.ev_tail, hipEventDisableTiming));
-  VD_HIP(hipEventCreateWithFlags(&g.ev_done, hipEventDisableTiming));
+  hipError_t e = hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, greatest);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&g.ev_tail, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&g.ev_done, hipEventDisableTiming);
+  NcclResult r = 0;
+  if (e == hipSuccess) r = g.api.CommInitRank(&g.comm, world, id, rank);
+  if (e != hipSuccess || r != 0) {
+    if (e != hipSuccess) vd_set_error("vd_comm_init: %s", hipGetErrorString(e));
+    else vd_set_error("vd_comm_init: ncclCommInitRank(rank %d of %d) -> %s", rank, world, g.api.GetErrorString(r));
+    release_local();
+    return VD_ERR_HIP;
+  }
+  g.rank = rank;
+  g.world = world;
+  g.calls = 0;
+  return VD_OK;
+}
+
+// no collective, no device: can this process load RCCL at all?  A host exchanges the answer over its own channel BEFORE any
+// rank enters vd_comm_unique_id / vd_comm_init, so that a rank without a usable librccl cannot strand its peers inside
+// the collective ncclCommInitRank.  version = NCCL_VERSION_CODE of the loaded library (0 if it does not say).
+int vd_comm_available(int* version) {
+  if (version) *version = 0;
+  int rc = load_rccl();
+  if (rc != VD_OK) return rc;
+  if (version && g.api.GetVersion) (void)g.api.GetVersion(version);
+  return VD_OK;
+}
+
+// the last vd_model_allreduce_grads of this process: floats in bucket 1 (encoder tensors, reduced underneath the decoder's
+// backward) and bucket 2 (embedding + decoder), whether bucket 1 was issued early (the model had recorded "encoder
+// gradients final" on its side stream), and the number of calls since vd_comm_init
+int vd_comm_stats(int64_t* bucket1_floats, int64_t* bucket2_floats, int* overlapped, int64_t* calls) {
+  if (bucket1_floats) *bucket1_floats = g.bucket1;
+  if (bucket2_floats) *bucket2_floats = g.bucket2;
+  if (overlapped) *overlapped = g.overlapped;
+  if (calls) *calls = g.calls;
   return VD_OK;
 }
 
@@ -126,15 +174,13 @@ int vd_comm_info(int* rank, int* world) {
 
 int vd_comm_destroy(void) {
   if (!g.comm) return VD_OK;
-  (void)hipStreamSynchronize(g.stream);
-  VD_NCCL(g.api.CommDestroy(g.comm));
-  g.comm = nullptr;
-  (void)hipEventDestroy(g.ev_tail);
-  (void)hipEventDestroy(g.ev_done);
-  (void)hipStreamDestroy(g.stream);
-  g.stream = nullptr;
-  g.world = 1;
-  g.rank = 0;
+  if (g.stream) (void)hipStreamSynchronize(g.stream);
+  NcclResult r = g.api.CommDestroy(g.comm);
+  release_local();                       // whatever RCCL said, this process no longer has a communicator
+  if (r != 0) {
+    vd_set_error("vd_comm_destroy: ncclCommDestroy -> %s", g.api.GetErrorString(r));
+    return VD_ERR_HIP;
+  }
   return VD_OK;
 }
 
@@ -164,15 +210,24 @@ int vd_model_allreduce_grads(vd_model* m) {
   VD_HIP(hipStreamWaitEvent(g.stream, g.ev_tail, 0));
   if (split) {
     VD_NCCL(g.api.GroupStart());
-    if (lo > 0) VD_NCCL(g.api.AllReduce(m->G, m->G, (size_t)lo, kNcclFloat32, kNcclSum, g.comm, g.stream));
-    if (m->numel > hi)
-      VD_NCCL(g.api.AllReduce(m->G + hi, m->G + hi, (size_t)(m->numel - hi), kNcclFloat32, kNcclSum, g.comm, g.stream));
-    VD_NCCL(g.api.GroupEnd());
+    NcclResult r = 0;                     // a failure inside the group still closes it
+    if (lo > 0) r = g.api.AllReduce(m->G, m->G, (size_t)lo, kNcclFloat32, kNcclSum, g.comm, g.stream);
+    if (r == 0 && m->numel > hi)
+      r = g.api.AllReduce(m->G + hi, m->G + hi, (size_t)(m->numel - hi), kNcclFloat32, kNcclSum, g.comm, g.stream);
+    NcclResult rend = g.api.GroupEnd();
+    if (r != 0 || rend != 0) {
+      vd_set_error("vd_model_allreduce_grads: bucket 2 -> %s", g.api.GetErrorString(r != 0 ? r : rend));
+      return VD_ERR_HIP;
+    }
   } else {
     VD_NCCL(g.api.AllReduce(m->G, m->G, (size_t)m->numel, kNcclFloat32, kNcclSum, g.comm, g.stream));
   }
   VD_HIP(hipEventRecord(g.ev_done, g.stream));
   VD_HIP(hipStreamWaitEvent(m->s_main, g.ev_done, 0));
+  g.calls++;
+  g.overlapped = split ? 1 : 0;
+  g.bucket1 = split ? hi - lo : 0;
+  g.bucket2 = split ? m->numel - (hi - lo) : m->numel;
   return VD_OK;
 }
 

@@ -91,3 +91,73 @@ def init_library_comm_over(group=None):
 def destroy_library_comm():
     from . import _lib
     _lib.call("vd_comm_destroy")
+
+
+def library_comm_available():
+    """(ok, NCCL_VERSION_CODE, error text): can THIS process load RCCL (no collective, no device needed)"""
+    from . import _lib
+    v = C.c_int(0)
+    rc = _lib.load().vd_comm_available(C.byref(v))
+    return rc == 0, int(v.value), ('' if rc == 0 else _lib.load().vd_last_error().decode('utf-8', 'replace'))
+
+
+def library_comm_stats():
+    """the last vd_model_allreduce_grads of this process: dict(bucket1_floats, bucket2_floats, overlapped, calls)"""
+    from . import _lib
+    b1, b2, ov, n = C.c_int64(), C.c_int64(), C.c_int(), C.c_int64()
+    _lib.call("vd_comm_stats", C.byref(b1), C.byref(b2), C.byref(ov), C.byref(n))
+    return dict(bucket1_floats=int(b1.value), bucket2_floats=int(b2.value), overlapped=bool(ov.value), calls=int(n.value))
+
+
+def join_library_comm(group, device=None):
+    """Every rank of `group` (any backend; gloo is enough -- it only carries flags and the 128-byte token) joins the
+    library's RCCL communicator, or none does.  Three agreed phases, so that no rank can strand its peers inside a collective:
+      1. each rank checks that it can load RCCL (vd_comm_available: no collective)      -> MIN over ranks, stop if 0
+      2. rank 0 makes the token (vd_comm_unique_id)                                      -> broadcast (None = failed), stop if None
+      3. vd_comm_init on every rank (collective inside RCCL)                            -> MIN over ranks; a rank that joined
+         while another failed destroys its communicator again
+    Returns (ok, report): report = one line per phase for this rank's log."""
+    from . import _lib
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    agree = lambda ok: bool(_min_flag(ok, group))
+    report = []
+    if device is not None:
+        try:
+            _lib.call("vd_set_device", int(device))
+        except Exception as exc:
+            report.append('vd_set_device(%s) failed: %s' % (device, exc))
+    ok, version, err = library_comm_available()
+    report.append('librccl: %s' % ('NCCL_VERSION_CODE %d' % version if ok else 'NOT loadable (%s)' % err))
+    if not agree(ok and not any('vd_set_device' in r for r in report)):
+        report.append('a rank cannot load RCCL or select its device: no rank joins')
+        return False, report
+    token = None
+    if rank == 0:
+        buf = C.create_string_buffer(128)
+        if _lib.load().vd_comm_unique_id(buf) == 0:
+            token = bytes(buf.raw)
+        else:
+            report.append('vd_comm_unique_id failed: %s' % _lib.load().vd_last_error().decode('utf-8', 'replace'))
+    box = [token]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if box[0] is None:
+        report.append('rank 0 could not create the rendezvous token: no rank joins')
+        return False, report
+    rc = _lib.load().vd_comm_init(int(rank), int(world), C.create_string_buffer(bytes(box[0]), 128))
+    if rc != 0:
+        report.append('vd_comm_init failed: %s' % _lib.load().vd_last_error().decode('utf-8', 'replace'))
+    if not agree(rc == 0):
+        if rc == 0:
+            destroy_library_comm()
+        report.append('a rank failed to join: communicator abandoned on every rank')
+        return False, report
+    report.append('joined: rank %d of %d' % (rank, world))
+    return True, report
+
+
+def _min_flag(ok, group):
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend(group) == 'nccl':
+        flag = flag.cuda()
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag.item())
