@@ -1,5 +1,5 @@
 """The option recurrence alone at the headline shape (T = 20, N = 20 000, H = 512), per arithmetic: ms per direction and the
-fp32-equivalent TFLOP/s of the recurrent products.   python scripts/mb_recurrence.py [T N H]"""
+fp32-equivalent TFLOP/s of the recurrent products.   python scripts/mb_recurrence.py [T N H [fp32,bf16,...]]"""
 import os
 import sys
 
@@ -20,7 +20,10 @@ c = torch.empty(T, N, H, device='cuda')
 dc = torch.empty(N, H, device='cuda')
 dh_last = torch.randn(N, H, device='cuda', generator=g) * 0.01
 flop = 2.0 * N * H * 4 * H * (T - 1)
+ONLY = sys.argv[4].split(',') if len(sys.argv) > 4 else None
 for name, flags in (('fp32', 0), ('split9', ops.FLAG_SPLIT9), ('split6', ops.FLAG_SPLIT6), ('split3', ops.FLAG_SPLIT3), ('bf16', ops.FLAG_BF16)):
+    if ONLY and name not in ONLY:
+        continue
     res = []
     for fn in (lambda: ops.lstm_forward(tab, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok, flags=flags),
                lambda: ops.lstm_backward(Wh, gates, c, dc, T, N, H, dh_last=dh_last, flags=flags)):

@@ -121,8 +121,10 @@ def test_hip_path_matches_the_executed_reference(path):
     model.runningLoss = 0
     model.trainIteration(OneBatch())
     W1 = model.get_parameters_dict()
-    G1 = model.get_gradients_dict()          # (the fused clamp + adam kernel leaves the clamped gradient it used in wrapperdW)
-    assert not grad_mismatches(G1, get('eval.grad.'))
+    G1 = model.get_gradients_dict()          # (the fused clamp + adam kernel leaves the CLAMPED gradient it used in wrapperdW)
+    assert not grad_mismatches(G1, {k: np.clip(v, -5.0, 5.0) for k, v in get('eval.grad.').items()})
+    if dec == 'gen':
+        assert max(np.abs(v).max() for v in get('eval.grad.').values()) > 5.0          # (the summed gen loss does reach the clamp)
     delta = get('step.delta.')
     eps1 = 1e-8 / np.sqrt(1 - 0.999)
     for k in P:
@@ -135,9 +137,11 @@ def test_hip_path_matches_the_executed_reference(path):
         # (2) against the reference's step.  Adam's first step is lr * g / (|g| + eps'), eps' = 1e-8 / sqrt(1 - beta2) = 3.2e-7: a
         #     gradient that is off by dg moves it by lr * eps' * dg / (|g| + eps')^2 -- nothing for |g| >> eps', everything for
         #     |g| ~ eps'.  dg: 1e-3 of the tensor's largest element (fp32 accumulation over thousands of cancelling rows; the
-        #     tensor-level bound on the gradient is the 1e-4 relative L2 checked above).
+        #     tensor-level bound on the gradient is the 1e-4 relative L2 checked above), at least the 1e-6 absolute floor that
+        #     grad_mismatches grants a tensor whose exact gradient is zero (att.b, att_q.b: a bias in front of a softmax -- its fp32
+        #     gradient is rounding noise around eps', so its first Adam step is noise too, here and in the reference's own fp32).
         g = np.abs(z['eval.grad.' + k].reshape(-1))
-        tol = p['learningRate'] * (eps1 * 1e-3 * g.max(initial=0.0) / (g + eps1) ** 2 + 1e-4) + ulp
+        tol = p['learningRate'] * (eps1 * max(1e-3 * g.max(initial=0.0), 1e-6) / (g + eps1) ** 2 + 1e-4) + ulp
         worst = np.abs(got - delta[k].reshape(-1)) / tol
         assert worst.max(initial=0.0) < 1.0, (k, float(worst.max()), int(worst.argmax()))
     want_rl = float(z['step.runningLoss'])
