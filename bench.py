@@ -132,15 +132,22 @@ def option_families(p, N, prof, steps_for_prof):
     return fams
 
 
-def bf16_option_roofline(fams, dom):
-    # bf16 operands make the matrix work 16x cheaper: the recurrence is priced by its bytes
-    alg = {'opt_lstm_fwd': 19 * 496e6 + 410e6, 'opt_lstm_bwd': 19 * 660e6 + 250e6, 'opt_lstm_dWh': 3.9e9}[dom]
-    gbs = alg / (fams[dom]['ms_total_per_step'] * 1e-3) / 1e9      # bytes of the whole family / its event time
+def bf16_option_roofline(fams, dom, rows=20000, H=512, To=20):
+    """bf16 operands make the matrix work 16x cheaper: the recurrence is priced by its bytes.  ALGORITHMIC bytes per timestep launch over
+    the COMPACT state of round 4: forward = bf16 table rows + bf16 gates written + bf16 h read and written + fp32 c
+    read and written; backward = gates[t] read + da[t+1] read + da[t] written (bf16, in place) + c[t], c[t-1] read + dc read and written
+    (fp32); dWh = the bf16 h and da streams once."""
+    g16, h16, c32 = rows * 4 * H * 2, rows * H * 2, rows * H * 4
+    per_launch = {'opt_lstm_fwd': 2 * g16 + 2 * h16 + 2 * c32, 'opt_lstm_bwd': 3 * g16 + 4 * c32, 'opt_lstm_dWh': (To - 1) * (g16 + h16)}[dom]
+    launches = 1 if dom == 'opt_lstm_dWh' else To
+    gbs = per_launch * launches / (fams[dom]['ms_total_per_step'] * 1e-3) / 1e9      # bytes of the whole family / its event time
     return {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(gbs / 8000.0, 4), "traffic": None, "avg_launch_ms": round(fams[dom]['avg_launch_ms'], 4),
-            "note": "bf16 operands / fp32 accumulation in the option recurrence: bound by HBM bytes (gates, h, c, "
-                    "table gather), algorithmic bytes per direction / HIP-event time; MFMA side: %.0f TFLOP/s of the "
-                    "2 500 TFLOP/s dense bf16 peak" % fams[dom]['tflops_executed'],
+            "algorithmic_MB_per_launch": round(per_launch / 1e6, 1),
+            "note": "bf16 operands / fp32 accumulation in the option recurrence over the compact bf16 state: priced by HBM bytes "
+                    "(algorithmic bytes of the family / its HIP-event time); MFMA side: %.0f TFLOP/s of the 2 500 TFLOP/s dense bf16 "
+                    "peak.  Neither bound is near: the K loop is LDS-bandwidth-bound (profiles/r04_experiments.txt section 2)"
+                    % fams[dom]['tflops_executed'],
             "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
 
 
@@ -182,7 +189,7 @@ def other_config(cfg, steps=10, warmup=3):
         fams = option_families(p, N, {'opt_lstm_fwd': (f[0], 1), 'opt_lstm_bwd': (f[1], 1), 'opt_lstm_dWh': (f[2], 1)}, 1)
         dom = max(fams, key=lambda k: fams[k]['ms_total_per_step'])
         if cfg == 4:
-            out["roofline"] = bf16_option_roofline(fams, dom)
+            out["roofline"] = bf16_option_roofline(fams, dom, rows=N * p['numOptions'], H=H, To=p['maxAnsLen'])
         else:
             a = fams[dom]['tflops_executed']
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(a, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -423,7 +430,7 @@ def main():
                 traffic = None
         roof = None
         if dom and args.config == 4:
-            roof = bf16_option_roofline(fams, dom)
+            roof = bf16_option_roofline(fams, dom, rows=N * p['numOptions'], H=p['rnnHiddenSize'], To=p['maxAnsLen'])
         elif dom and args.recurrence != 'fp32':
             nprod = 9 if args.recurrence == 'split9' else 6
             step_fam = max(('opt_lstm_fwd', 'opt_lstm_bwd'), key=lambda k: fams[k]['ms_total_per_step'])    # (dWh stays on the fp32 MFMA)

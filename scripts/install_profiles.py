@@ -42,7 +42,7 @@ for f in (TAG + '_stream_timeline_bench.txt', TAG + '_hbm_kernels.txt'):
 
 txt = open(G + TAG + '_pmc_option_lstm_kernels.txt').read()
 S3 = 'SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES'
-K = {'fwd': 'false, EpiLstmFwdT<0>', 'bwd': 'false, EpiLstmBwd<2,', 'dWh': 'true, EpiAtomic<4> >'}
+K = {'fwd': 'false, EpiLstmFwdT<0', 'bwd': 'false, EpiLstmBwd<2,', 'dWh': 'true, EpiAtomic<4>'}
 ALG = {'fwd': 496, 'bwd': 660, 'dWh': 3900}
 
 

@@ -14,7 +14,7 @@ python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.er
 python bench.py --steps 50 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_bench_50steps.json 2>> $OUT/${TAG}_bench_default.err
 python bench.py --config 4 --steps 30 --warmup 8 --no-cpu-baseline > $OUT/${TAG}_bench_config4.json 2>> $OUT/${TAG}_bench_default.err
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d $OUT/${TAG}_trace -o run -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
+rocprofv3 --kernel-trace -d $OUT/${TAG}_trace -o run -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
 DB=$(ls $OUT/${TAG}_trace/*.db | head -1)
 python $ROOT/scripts/rocpd_stats.py $DB --steps-only > $OUT/${TAG}_kernel_stats_bench.txt
 python $ROOT/scripts/rocpd_timeline.py $DB > $OUT/${TAG}_stream_timeline_bench.txt
