@@ -146,7 +146,7 @@ def bf16_option_roofline(fams, dom, rows=20000, H=512, To=20):
             "algorithmic_MB_per_launch": round(per_launch / 1e6, 1),
             "note": "bf16 operands / fp32 accumulation in the option recurrence over the compact bf16 state: priced by HBM bytes "
                     "(algorithmic bytes of the family / its HIP-event time); MFMA side: %.0f TFLOP/s of the 2 500 TFLOP/s dense bf16 "
-                    "peak.  Neither bound is near: the K loop is LDS-bandwidth-bound (profiles/r04_experiments.txt section 2)"
+                    "peak.  Neither bound is near: the cell update's VALU work and the CU's load path set the time (profiles/r04_experiments.txt section 2)"
                     % fams[dom]['tflops_executed'],
             "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
 

@@ -51,8 +51,13 @@ def phases(label):
     lib.vd_debug_timing(buf, SL * NB)
     a = np.frombuffer(buf, dtype=np.uint64).reshape(NB, SL).astype(np.int64)
     a = a[a[:, 6] > 0]
+    a = a[a[:, 6] >= a[:, 6].max() - 100000]          # the last launch only (stale rows of earlier, larger grids dropped): within 1 ms
     t0 = a[:, 6].min()
     fill, kloop, epi = (a[:, 8] - a[:, 6]) / 100.0, (a[:, 9] - a[:, 8]) / 100.0, (a[:, 7] - a[:, 9]) / 100.0
+    if a[:, 3].max() > 0 and (a[:, 3] > a[:, 0]).all():        # the wave-asynchronous kernel stamps wave 0's first block
+        print("  %s wave 0, first block, us: operand requests %.1f | K loop %.1f | epilogue %.1f | second block ends at %.1f after the first began" % (
+            label, np.median(a[:, 1] - a[:, 0]) / 100.0, np.median(a[:, 2] - a[:, 1]) / 100.0, np.median(a[:, 3] - a[:, 2]) / 100.0,
+            np.median(a[:, 4] - a[:, 0]) / 100.0), flush=True)
     print("  %s last launch, %d workgroups, us: fill %.1f | K loop %.1f | epilogue %.1f (medians); launch span %.1f; starts p50 %.1f p90 %.1f" % (
         label, len(a), np.median(fill), np.median(kloop), np.median(epi), (a[:, 7].max() - t0) / 100.0,
         np.median(a[:, 6] - t0) / 100.0, np.percentile(a[:, 6] - t0, 90) / 100.0), flush=True)

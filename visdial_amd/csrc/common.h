@@ -157,11 +157,14 @@ __device__ __forceinline__ void vd_buf_st4_bf16(__amdgpu_buffer_rsrc_t r, unsign
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(vd_u32x2, t), r, voff, soff, 0);
 }
 
-// 4 consecutive bf16 (one 8-byte buffer load) -> float4
-__device__ __forceinline__ float4 vd_buf_ld4_bf16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  const vd_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+// 4 packed bf16 -> float4
+__device__ __forceinline__ float4 vd_bf16x4_unpack(const vd_u32x2 v) {
   return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
                      __uint_as_float(v.y & 0xffff0000u));
+}
+// 4 consecutive bf16 (one 8-byte buffer load) -> float4
+__device__ __forceinline__ float4 vd_buf_ld4_bf16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return vd_bf16x4_unpack(__builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
 
 // 4 consecutive fp32 -> 4 bf16 (RNE, v_cvt_pk_bf16_f32), one 8-byte store

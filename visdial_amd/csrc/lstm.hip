@@ -173,11 +173,6 @@ struct EpiLstmFwdT {
     }
     __builtin_amdgcn_sched_barrier(0);
     float4 a[4][4];  // [gate][p]
-    tile_to_rows(acc[0], scr, lane, a[0]);
-    tile_to_rows(acc[1], scr, lane, a[1]);
-    tile_to_rows(acc[2], scr, lane, a[2]);
-    tile_to_rows(acc[3], scr, lane, a[3]);
-    VD_T(3);
     float4 x[4], cp;
 #if VD_EPI_BUF & 1
     // descriptors (SGPRs) + 32-bit byte offsets: per row group one multiply-add for the gathered projection row and one for the
@@ -186,22 +181,43 @@ struct EpiLstmFwdT {
                                  rh = vd_rsrc(h_out), rh16 = vd_rsrc(h16);
     const unsigned uH4 = (unsigned)H * 4u, uj4 = (unsigned)j * 4u, uxld4 = (unsigned)xld * 4u;
     const unsigned vrow = ((unsigned)(row0 + rl)) * uH4 + uj4;          // byte offset of (row0 + rl, j) in an [M x H] tensor
+    // C16: the projection rows are bf16 -- 12 VGPRs per row group while in flight (4 x 8 bytes packed + c) -- so TWO row groups are
+    // kept in flight: groups 0 and 1 are requested before the LDS transposes, group p + 2 when group p has been folded
+    vd_u32x2 xs[2][4];
+    float4 cs[2];
+    auto issue16 = [&](int p, int st) {
+      const unsigned xo = ((unsigned)tk[p] * uxld4 + uj4) >> 1;
+      xs[st][0] = __builtin_amdgcn_raw_buffer_load_b64(rx, xo, 0, 0);
+      xs[st][1] = __builtin_amdgcn_raw_buffer_load_b64(rx, xo, uH4 >> 1, 0);
+      xs[st][2] = __builtin_amdgcn_raw_buffer_load_b64(rx, xo, uH4, 0);
+      xs[st][3] = __builtin_amdgcn_raw_buffer_load_b64(rx, xo, 3 * (uH4 >> 1), 0);
+      cs[st] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c_prev) cs[st] = vd_buf_ld4(rc, (unsigned)rowc[p] * uH4 + uj4, 0);
+    };
+    if constexpr (C16) {
+      issue16(0, 0);
+      issue16(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+    tile_to_rows(acc[0], scr, lane, a[0]);
+    tile_to_rows(acc[1], scr, lane, a[1]);
+    tile_to_rows(acc[2], scr, lane, a[2]);
+    tile_to_rows(acc[3], scr, lane, a[3]);
+    VD_T(3);
+#if VD_EPI_BUF & 1
     auto issue = [&](int p) {
       if constexpr (C16) {
-        const unsigned xo = ((unsigned)tk[p] * uxld4 + uj4) >> 1;
-        x[0] = vd_buf_ld4_bf16(rx, xo, 0);
-        x[1] = vd_buf_ld4_bf16(rx, xo, uH4 >> 1);
-        x[2] = vd_buf_ld4_bf16(rx, xo, uH4);
-        x[3] = vd_buf_ld4_bf16(rx, xo, 3 * (uH4 >> 1));
+        issue16(p, p & 1);
       } else {
         const unsigned xo = (unsigned)tk[p] * uxld4 + uj4;
         x[0] = vd_buf_ld4(rx, xo, 0);
         x[1] = vd_buf_ld4(rx, xo, uH4);
         x[2] = vd_buf_ld4(rx, xo, 2 * uH4);
         x[3] = vd_buf_ld4(rx, xo, 3 * uH4);
+        cp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c_prev) cp = vd_buf_ld4(rc, (unsigned)rowc[p] * uH4 + uj4, 0);
       }
-      cp = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c_prev) cp = vd_buf_ld4(rc, (unsigned)rowc[p] * uH4 + uj4, 0);
     };
 #else
     auto issue = [&](int p) {
@@ -214,18 +230,27 @@ struct EpiLstmFwdT {
       if (c_prev) cp = *reinterpret_cast<const float4*>(c_prev + (long)rowc[p] * H + j);
     };
 #endif
-    issue(0);
+    if constexpr (!C16) issue(0);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       // fold the loaded values into the pre-activations; x / cp are dead afterwards
       float4 pi = a[0][p], pf = a[1][p], po = a[2][p], pg = a[3][p];
+      if constexpr (C16) {
+#pragma unroll
+        for (int gk = 0; gk < 4; ++gk) x[gk] = vd_bf16x4_unpack(xs[p & 1][gk]);
+        cp = cs[p & 1];
+      }
       pi.x += x[0].x; pi.y += x[0].y; pi.z += x[0].z; pi.w += x[0].w;
       pf.x += x[1].x; pf.y += x[1].y; pf.z += x[1].z; pf.w += x[1].w;
       po.x += x[2].x; po.y += x[2].y; po.z += x[2].z; po.w += x[2].w;
       pg.x += x[3].x; pg.y += x[3].y; pg.z += x[3].z; pg.w += x[3].w;
       const float4 cq = cp;
       __builtin_amdgcn_sched_barrier(0);
-      if (p + 1 < 4) issue(p + 1);  // in flight under the math and stores below
+      if constexpr (C16) {
+        if (p + 2 < 4) issue(p + 2);  // two groups ahead: in flight under the math and stores of p AND p + 1
+      } else {
+        if (p + 1 < 4) issue(p + 1);  // in flight under the math and stores below
+      }
       __builtin_amdgcn_sched_barrier(0);
       const float km = keep[p] != 0 ? 1.f : 0.f;  // maskZero(): h = c = gates = 0 for pad rows
       float4 gi, gf, go, gg, c, h;
@@ -323,6 +348,8 @@ struct EpiLstmBwd {
   // BATCH = 2; the single-tile latency shapes (NT = 1) fit BATCH = 2 inside 128.
   struct Slot {
     float4 g[4], ct, cp, dcv, dhx;
+    vd_u32x2 g16[4];   // C16: the saved gates as loaded (packed bf16), unpacked when the slot is consumed -- NOT in the load phase, where the
+                       // unpacking would sit in front of the scheduling barrier and wait for every load of the slot
   };
   __device__ __forceinline__ void load_slot(Slot& L, int rc, int jc) const {
     const long o = (long)rc * H + jc;
@@ -345,10 +372,10 @@ struct EpiLstmBwd {
   };
   __device__ __forceinline__ void load_slot_buf(Slot& L, const Rsrc& R, unsigned o4, unsigned og4, unsigned uH4) const {
     if constexpr (C16) {
-      L.g[0] = vd_buf_ld4_bf16(R.g, og4 >> 1, 0);
-      L.g[1] = vd_buf_ld4_bf16(R.g, og4 >> 1, uH4 >> 1);
-      L.g[2] = vd_buf_ld4_bf16(R.g, og4 >> 1, uH4);
-      L.g[3] = vd_buf_ld4_bf16(R.g, og4 >> 1, 3 * (uH4 >> 1));
+      L.g16[0] = __builtin_amdgcn_raw_buffer_load_b64(R.g, og4 >> 1, 0, 0);
+      L.g16[1] = __builtin_amdgcn_raw_buffer_load_b64(R.g, og4 >> 1, uH4 >> 1, 0);
+      L.g16[2] = __builtin_amdgcn_raw_buffer_load_b64(R.g, og4 >> 1, uH4, 0);
+      L.g16[3] = __builtin_amdgcn_raw_buffer_load_b64(R.g, og4 >> 1, 3 * (uH4 >> 1), 0);
     } else {
     L.g[0] = vd_buf_ld4(R.g, og4, 0);          // saved gates: read exactly once
     L.g[1] = vd_buf_ld4(R.g, og4, uH4);
@@ -402,7 +429,11 @@ struct EpiLstmBwd {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < BATCH; ++q) {
-          const Slot& C = L[q];
+          Slot& C = L[q];
+          if constexpr (C16) {
+#pragma unroll
+            for (int gk = 0; gk < 4; ++gk) C.g[gk] = vd_bf16x4_unpack(C.g16[gk]);
+          }
           float4 dh = d4[pp + q];
           dh.x += C.dhx.x; dh.y += C.dhx.y; dh.z += C.dhx.z; dh.w += C.dhx.w;
           const int row = row0 + (pp + q) * 8 + rl;
@@ -1002,7 +1033,7 @@ int vd_lstm_backward_c16(const float* Wh, vd_bf16_bits* gates16, const float* c,
   if (int rc = weights_to_bf16(Wh, Wh16, 4L * H * H, s)) return rc;
   for (int t = T - 1; t >= 0; --t) {
     const bool last = t == T - 1;
-    EpiLstmBwd<2, 1, true, true> e{nullptr, last ? dh_last : nullptr, reinterpret_cast<float*>(gates16 + (long)t * 4 * NH), c + t * NH,
+    EpiLstmBwd<2, 2, false, true> e{nullptr, last ? dh_last : nullptr, reinterpret_cast<float*>(gates16 + (long)t * 4 * NH), c + t * NH,
                                     t ? c + (t - 1) * NH : nullptr, dc_work, last ? 1 : 0, H};
     int rc;
     if (last) rc = launch_gemm<CfgB11>(N, H, 0, 1, SrcRow{nullptr, 4L * H}, SrcRow{Wh, 4L * H}, e, s);
