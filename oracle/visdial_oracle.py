@@ -803,6 +803,11 @@ def generate_beam(encoder, P, p, batch, beam_size, beam_len, START, END):
             logits = x[0] @ P['vocab.W'].T + P['vocab.b']
             m = logits.max(-1, keepdims=True)
             logp = logits - (m + np.log(np.exp(logits - m).sum(-1, keepdims=True)))
+            # decoders/gen.lua:23-24: Sequencer(MaskZero(Linear)), Sequencer(MaskZero(LogSoftMax)) -- a hypothesis whose last token is 0
+            # (a beam slot that was never filled: fewer than beamSize unfinished candidates so far, model.lua:560) has h = c = 0 from
+            # maskZero AND an all-ZERO row of "log-probabilities": its children cost nothing.  torch.topk over that constant row is
+            # implementation-defined in Torch7; here (and in every host of this repo) ties go to the lower index.
+            logp[tok[0] == 0] = 0.0
             cands = []
             for w in range(explore):
                 for cid in np.argsort(-logp[w], kind='stable')[:beam_size]:

@@ -238,6 +238,87 @@ def run_pair(enc, dec, seed=7, extra=None, order_only=False):
         rec['rank.gt'] = np.asarray(gt, dtype=np.int64).reshape(-1)
         rec['rank.all'] = np.asarray(allr, dtype=np.int64).reshape(ref_scores.shape)
         report.append('retrieveBatch / utils.computeRanks: gt + all ranks equal')
+    # ---- Model:retrieveBatch, gen branch (model.lua:392-420): forwardConnect + decoder forward + utils.computeLhood per candidate, then
+    #      utils.computeRanks, on the UPDATED parameters
+    if dec == 'gen':
+        P1 = {k: v for k, v in W1.items()}
+        rb = {k: v for k, v in batch.items() if isinstance(v, np.ndarray)}
+        dl.add_gen_options(rb, rb['ques_fwd'].shape[0])
+        types = dict(BATCH_TYPES)
+        lua_rb = lambda: to_lua(vm, rb, types)
+        scores = vo.retrieve(enc, dec, P1, p, rb)                     # [N, O] summed token log-likelihoods
+        index(model, 'params').set('useGt', True)
+        gt = to_py(first(inv(model, 'retrieveBatch', lua_rb())))
+        index(model, 'params').set('useGt', False)
+        allr = np.asarray(to_py(first(inv(model, 'retrieveBatch', lua_rb())))).reshape(scores.shape)
+        want = vo.compute_ranks(scores)
+        flipped = int((allr != want).sum())
+        if flipped:           # only where two candidates' likelihoods tie to the last bits (duplicate candidates)
+            from conftest import unexplained_rank_flips
+            order = np.argsort(allr, axis=1)                                  # the reference's order, as pseudo-scores
+            pseudo = np.empty_like(scores)
+            pseudo[np.arange(scores.shape[0])[:, None], order] = -np.arange(scores.shape[1], dtype=np.float64)[None, :]
+            _, bad = unexplained_rank_flips(pseudo, scores, tol=1e-9)
+            assert not bad, bad[:5]
+        assert np.abs(np.asarray(gt).reshape(-1) - vo.compute_ranks(scores, rb['answer_ind'].reshape(-1) - 1)).sum() <= flipped
+        rec.update({'rbatch.option_in': rb['option_in'], 'rbatch.option_out': rb['option_out'], 'rbatch.answer_ind': rb['answer_ind'],
+                    'rank.scores': scores, 'rank.gt': np.asarray(gt, dtype=np.int64).reshape(-1), 'rank.all': allr.astype(np.int64)})
+        report.append('retrieveBatch (gen: computeLhood x %d candidates) / computeRanks: equal (%d tie flips)' % (scores.shape[1], flipped))
+    # ---- Model:generateAnswers, beam search (model.lua:432-573), one dialog, on the UPDATED parameters: token-exact against the oracle
+    if dec == 'gen':
+        START, END = p['vocabSize'] - 1, p['vocabSize']
+        words = {i: 'w%d' % i for i in range(1, p['vocabSize'] + 1)}
+        words[START], words[END] = '<START>', '<END>'
+        gbatch = {k: v[:1] for k, v in batch.items() if isinstance(v, np.ndarray) and k in ('ques_fwd', 'hist', 'img_feat')}
+        gbatch.update({k: batch[k][:1] for k in ('answer_in', 'answer_out')})
+
+        class GenLoader(object):
+            lua_type = 'table'
+
+            def __init__(self):
+                self.f = {'word2ind': to_lua(vm, {'<START>': START, '<END>': END}), 'ind2word': to_lua(vm, words),
+                          'numThreads': to_lua(vm, {'val': 1}), 'unique_img_val': to_lua(vm, [4711])}
+
+            def lua_index(self, k):
+                if k == 'getIndexData':
+                    return lambda *_a: to_lua(vm, gbatch, BATCH_TYPES)
+                return self.f.get(k)
+        beam_size, beam_len = 5, 12
+        # model.lua:577 indexes finishBeams[1]: every round must finish a beam, as it does with a trained model.  A freshly initialised
+        # head ranks the words almost identically at every step, so <END> is nudged into contention (a parameter like any other: the
+        # oracle gets the same vector)
+        W1 = named(flat_W)
+        for bias in (0.04, 0.06, 0.08, 0.1, 0.13, 0.16, 0.2, 0.3):         # the smallest nudge with which every round finishes a beam
+            trial = dict(W1)
+            trial['vocab.b'] = W1['vocab.b'].copy()
+            trial['vocab.b'][END - 1] += bias
+            got = vo.generate_beam(enc, trial, p, gbatch, beam_size, beam_len, START, END)
+            if all(END in toks for toks, _ in got):
+                break
+        else:
+            raise AssertionError('no <END> bias finishes every round')
+        for w, name in order:
+            if name == 'vocab.b':
+                w.a[END - 1] += bias
+        W1 = named(flat_W)
+        rec['beam.vocab_b'] = W1['vocab.b'].copy()
+        ans = to_py(first(inv(model, 'generateAnswers', GenLoader(), 'val', to_lua(vm, {'beamSize': beam_size, 'beamLen': beam_len, 'maxThreads': 1}))))
+        assert len(ans) == 1 and ans[0]['image_id'] == 4711 and len(ans[0]['dialog']) == 10
+        want = vo.generate_beam(enc, W1, p, gbatch, beam_size, beam_len, START, END)
+        texts = []
+        for r, (toks, score) in enumerate(want):
+            sent = ''
+            for t in toks:                       # utils.idToWords (utils.lua:48-63)
+                if t > 0:
+                    sent += ' ' + words[int(t)]
+                    if words[int(t)] == '<END>':
+                        break
+            assert ans[0]['dialog'][r]['answer'] == sent, (enc, r, ans[0]['dialog'][r]['answer'], sent)
+            texts.append(sent)
+        rec['beam.tokens'] = np.array([t for t, _ in want], dtype=np.int64)
+        rec['beam.scores'] = np.array([sc for _, sc in want], dtype=np.float64)
+        rec['beam.params'] = np.array([beam_size, beam_len, START, END], dtype=np.int64)
+        report.append('generateAnswers (beam %d x %d): 10 rounds token-exact' % (beam_size, beam_len))
     return p, rec, names_in_flat_order, report
 
 

@@ -514,6 +514,17 @@ class Tensor(object):
             order = np.argsort(self.a, axis=ax, kind='stable')
         return (self.new_like(np.take_along_axis(self.a, order, axis=ax)), self.new_like(order + 1, 'Long'))
 
+    def m_topk(self, k=1, *args):
+        """torch.topk(x, k [, dim] [, dir] [, sort]): dir = true -> the k LARGEST.  Torch7 leaves their order unspecified unless sort is
+        given; here they come sorted (descending for dir = true), which is one of the orders Torch7 may produce."""
+        dim = [a for a in args if a.__class__ is not bool and a is not None]
+        flags = [a for a in args if a.__class__ is bool]
+        largest = bool(flags[0]) if flags else False
+        ax = self.a.ndim - 1 if not dim else self._dim(dim[0])
+        key = -self.a.astype(np.float64) if largest else self.a.astype(np.float64)
+        order = np.take(np.argsort(key, axis=ax, kind='stable'), np.arange(int(k)), axis=ax)
+        return (self.new_like(np.take_along_axis(self.a, order, axis=ax)), self.new_like(order + 1, 'Long'))
+
     def m_norm(self, p=2, *_):
         return float(np.linalg.norm(self.a.reshape(-1).astype(np.float64), p))
 
@@ -747,7 +758,7 @@ class Torch(object):
         for name in ('Tensor', 'zeros', 'ones', 'range', 'repeatTensor', 'totable', 'multinomial', 'cat', 'sum', 'mean', 'max', 'min',
                      'sqrt', 'median', 'cmul', 'cdiv', 'le', 'lt', 'ge', 'gt', 'eq', 'ne', 'manualSeed', 'setdefaulttensortype',
                      'getdefaulttensortype', 'type', 'typename', 'isTensor', 'class', 'random', 'randperm', 'rand', 'randn', 'uniform',
-                     'sort', 'abs', 'exp', 'log', 'add', 'mul', 'div', 'dot', 'norm', 'cumsum', 'setnumthreads', 'getnumthreads',
+                     'sort', 'topk', 'abs', 'exp', 'log', 'add', 'mul', 'div', 'dot', 'norm', 'cumsum', 'setnumthreads', 'getnumthreads',
                      'save', 'load', 'isTypeOf', 'setmetatable', 'getmetatable', 'squeeze', 'floor', 'clamp', 'pow', 'seed', 'triu', 'tril',
                      'pointer'):
             t.set(name, getattr(self, 'f_' + name.replace('class', 'class_')))
@@ -826,7 +837,7 @@ class Torch(object):
             return getattr(Tensor, 'm_' + name)(t.new_like(t.a.copy()) if name in Torch._COPYING else t, *args)
         return f
     _COPYING = ('sqrt', 'abs', 'exp', 'log', 'cumsum', 'clamp', 'pow')
-    for _n in ('sum', 'mean', 'max', 'min', 'median', 'le', 'lt', 'ge', 'gt', 'eq', 'ne', 'sort', 'sqrt', 'abs', 'exp', 'log', 'dot',
+    for _n in ('sum', 'mean', 'max', 'min', 'median', 'le', 'lt', 'ge', 'gt', 'eq', 'ne', 'sort', 'topk', 'sqrt', 'abs', 'exp', 'log', 'dot',
                'norm', 'cumsum', 'squeeze', 'clamp', 'pow'):
         locals()['f_' + _n] = _fn(_n)
     del _fn, _n

@@ -7,7 +7,9 @@ reference initialised (rounded to fp32), one synthetic batch, and what the refer
   eval.*    Model:forwardBackward in evaluate() mode: loss + every gradient tensor (fp64)
   train.*   the same in training() mode, with the noise every nn.Dropout drew recorded under mask.<site>
   step.*    Model:trainIteration: the Adam update of every tensor, runningLoss (the global), the decayed learning rate
-  rank.*    Model:retrieveBatch -> utils.computeRanks: the decoder's scores, the GT ranks and all ranks        (disc)
+  rank.*    Model:retrieveBatch -> utils.computeRanks: the decoder's scores, the GT ranks and all ranks (disc); for gen the 100
+            candidates of rbatch.* scored by forwardConnect + decoder forward + utils.computeLhood (model.lua:392-420)
+  beam.*    Model:generateAnswers, beam search (model.lua:432-573), one dialog x 10 rounds: the winning token vectors         (gen)
 
 CPU: oracle/visdial_oracle.py reproduces all of it (this is what pins the oracle to the reference).
 GPU: the HIP path, fed the same parameters / batch / masks through the C ABI, matches within the fp32 tolerance (1e-4).
@@ -81,6 +83,23 @@ def test_oracle_reproduces_the_executed_reference(path):
         np.testing.assert_array_equal(vo.compute_ranks(z['rank.scores'], batch['answer_ind'].reshape(-1) - 1), z['rank.gt'])
         flipped, bad = unexplained_rank_flips(ev['scores'], z['rank.scores'], tol=1e-6)           # on the oracle's own scores: up to ties
         assert not bad, bad[:5]
+    else:
+        P1 = {k: P64[k] + delta[k].astype(np.float64) for k in P64}
+        rb = dict(batch, option_in=z['rbatch.option_in'], option_out=z['rbatch.option_out'], answer_ind=z['rbatch.answer_ind'])
+        scores = vo.retrieve(enc, dec, P1, p, rb)
+        assert np.abs(scores - z['rank.scores']).max() < 1e-8
+        np.testing.assert_array_equal(vo.compute_ranks(z['rank.scores']), z['rank.all'])             # what the reference returned
+        np.testing.assert_array_equal(vo.compute_ranks(z['rank.scores'], rb['answer_ind'].reshape(-1) - 1), z['rank.gt'])
+        # generateAnswers: the reference's winning beams, token for token (incl. the never-filled-slot corner: a beam whose last
+        # token is 0 gets an all-zero log-probability row from MaskZero, decoders/gen.lua:23-24)
+        bs, bl, START, END = (int(v) for v in z['beam.params'])
+        Pb = dict(P1)
+        Pb['vocab.b'] = z['beam.vocab_b'].astype(np.float64)
+        gb = {k: v[:1] for k, v in batch.items()}
+        got = vo.generate_beam(enc, Pb, p, gb, bs, bl, START, END)
+        np.testing.assert_array_equal(np.array([t for t, _ in got]), z['beam.tokens'])
+        np.testing.assert_allclose([sc for _, sc in got], z['beam.scores'], atol=1e-9)
+        assert (z['beam.tokens'] == END).any(axis=1).all()                        # every round finished a beam
 
 
 @pytest.mark.gpu
@@ -163,3 +182,46 @@ def test_hip_path_matches_the_executed_reference(path):
         p['useGt'] = True
         gt = np.asarray(model.retrieveBatch(batch)).reshape(-1)
         assert np.abs(gt - z['rank.gt']).sum() <= flipped
+    else:
+        # gen retrieval (model.lua:392-420) and beam search (model.lua:432-573) from the fixture's updated parameters, both hosts
+        from visdial_amd.native import NativeModel
+        P1 = {k: (P[k].astype(np.float64) + delta[k]).astype(np.float32) for k in P}
+        rb = dict(batch, option_in=z['rbatch.option_in'], option_out=z['rbatch.option_out'], answer_ind=z['rbatch.answer_ind'])
+        bs, bl, START, END = (int(v) for v in z['beam.params'])
+        words = {i: 'w%d' % i for i in range(1, p['vocabSize'] + 1)}
+        words[START], words[END] = '<START>', '<END>'
+        gb = {k: v[:1] for k, v in batch.items()}
+
+        class GenLoader(object):
+            word2ind, ind2word, numThreads, unique_img_val = {'<START>': START, '<END>': END}, words, {'val': 1}, [4711]
+
+            def getIndexData(self, inds, params, dtype):
+                return gb
+        want_txt = []
+        for toks in z['beam.tokens']:
+            sent = ''
+            for t in toks:
+                if t > 0:
+                    sent += ' ' + words[int(t)]
+                    if words[int(t)] == '<END>':
+                        break
+            want_txt.append(sent)
+        for host in (model, NativeModel(p)):
+            host.set_parameters_dict(P1)
+            (host.wrapper.evaluate if hasattr(host, 'wrapper') else (lambda: host.training(False)))()
+            p['useGt'] = False
+            ranks = np.asarray(host.retrieveBatch(rb)).reshape(z['rank.all'].shape)
+            dev = (host.scores.cpu().numpy() if hasattr(host, 'wrapper') else host.scores(*z['rank.all'].shape)).astype(np.float64)
+            p['useGt'] = True
+            gt = np.asarray(host.retrieveBatch(rb)).reshape(-1)
+            assert np.abs(dev - z['rank.scores']).max() < 1e-4 * max(1.0, np.abs(z['rank.scores']).max())
+            np.testing.assert_array_equal(ranks, vo.compute_ranks(dev))
+            flipped, bad = unexplained_rank_flips(dev, z['rank.scores'])
+            assert not bad, bad[:10]
+            assert (ranks != z['rank.all']).sum() <= 2 * flipped and np.abs(gt - z['rank.gt']).sum() <= flipped
+            Pb = dict(P1)
+            Pb['vocab.b'] = z['beam.vocab_b'].astype(np.float32)
+            host.set_parameters_dict(Pb)
+            out = host.generateAnswers(GenLoader(), 'val', dict(beamSize=bs, beamLen=bl, maxThreads=1))
+            assert out[0]['image_id'] == 4711
+            assert [d['answer'] for d in out[0]['dialog']] == want_txt, (type(host).__name__, [d['answer'] for d in out[0]['dialog']], want_txt)

@@ -387,6 +387,10 @@ inline int Gen_step(Gen* g, vd_model* m, const int32_t* tokens, float* host_logp
   }
   VD_HIP(hipMemcpy2DAsync(host_logp, (size_t)V * 4, logits, (size_t)Vp * 4, (size_t)V * 4, (size_t)n, hipMemcpyDeviceToHost, s));
   VD_HIP(hipStreamSynchronize(s));
+  // Sequencer(MaskZero(Linear)) + Sequencer(MaskZero(LogSoftMax)) (decoders/gen.lua:23-24): the row of a hypothesis whose token is 0 -- a
+  // beam slot that was never filled (model.lua:560) -- is all ZEROS, not log_softmax(bias); its state is already zero (maskZero)
+  for (int i = 0; i < n; ++i)
+    if (tokens[i] == 0) memset(host_logp + (size_t)i * V, 0, (size_t)V * 4);
   return VD_OK;
 }
 // model.lua:560-575: hypothesis i continues from the stepped state of hypothesis src[i]; slots >= n_keep keep theirs

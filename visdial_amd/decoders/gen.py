@@ -72,7 +72,9 @@ class Decoder(object):
         ops.gemm_nt(h, self.Wv, logits, bias=self.bv, M=K, N=V, K=H, ldc=Vp)
         ops.log_softmax_rows(logits, V)
         new_hidden = [(l.output[0].clone(), l.cell[0].clone()) for l in self.rnnLayers]
-        return logits[:, :V].cpu().numpy(), new_hidden
+        logp = logits[:, :V].cpu().numpy()
+        logp[tok[0].cpu().numpy() == 0] = 0.0        # MaskZero(Linear) + MaskZero(LogSoftMax) (gen.lua:23-24): a pad token's row is all zeros
+        return logp, new_hidden
 
     def retrieve_lhood(self, model, option_in, option_out, encOut, seqLen):
         """Model:retrieveBatch gen branch (model.lua:392-420) + utils.computeLhood (utils.lua:86-102).
