@@ -27,7 +27,7 @@ def load(path):
 
 
 def test_fixture_set():
-    assert IDS == ['lf-ques', 'lf-ques-im-hist', 'mn-att-concat']
+    assert sorted(IDS) == ['lf-ques', 'lf-ques-im-hist', 'mn-att-concat']
 
 
 @pytest.mark.parametrize("path", FILES, ids=IDS)
