@@ -329,8 +329,9 @@ int vd_model_decode_step(vd_model* m, const int32_t* tokens, float* host_logprob
 int vd_model_decode_select(vd_model* m, const int32_t* src, int n_keep);
 int vd_model_scores(vd_model* m, float* host_scores, int64_t n);        /* [N x O] of the last forward / retrieve */
 int vd_model_ranks(vd_model* m, int use_gt, int32_t* host_ranks);       /* utils.computeRanks (utils.lua:106-128) */
-/* decoder disc: rows the option LSTM executes for the current batch vs the N * O candidates they stand for -- the upload
- * encodes every DISTINCT candidate row once (decoders/disc.lua:4-15: the encoding depends on the tokens only) */
+/* decoder disc: rows the option LSTM executed for the batch of the LAST STEP (before any step: of the uploaded batch) vs the N * O
+ * candidates they stand for -- the upload encodes every DISTINCT candidate row once (decoders/disc.lua:4-15: the encoding depends on
+ * the tokens only).  In a pipelined loop this is the batch that was stepped, not the one prefetched behind it. */
 int vd_model_option_rows(vd_model* m, int64_t* executed, int64_t* total);
 int vd_model_family_ms(vd_model* m, float* ms3);          /* device ms of option-LSTM fwd, bwd, dWh in the last step */
 int vd_model_synchronize(vd_model* m);

@@ -153,6 +153,7 @@ int vd_free(void* ptr) {
 }
 
 int vd_memset(void* ptr, int value, int64_t bytes, void* stream) {
+  vd_bf16_shadow_invalidate(static_cast<const float*>(ptr), (size_t)(bytes / 4));     // (a writer of an fp32 range: its bf16 shadow is stale)
   VD_HIP(hipMemsetAsync(ptr, value, (size_t)bytes, (hipStream_t)stream));
   return VD_OK;
 }

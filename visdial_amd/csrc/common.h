@@ -79,7 +79,10 @@ int vd_segment_rowsum_acc_bf16(const vd_bf16_bits* X16, int64_t ldx, const int32
 // registered against the fp32 tensor's address range; the weight-gradient contraction of the same pass finds the two
 // shadows by address and multiplies them directly (LDS-DMA + transpose reads, no fp32 -> bf16 conversion while staging).
 // slot 0 = hidden states, slot 1 = gate gradients.  A shadow is valid until the next producer call on the same slot, or
-// until an fp32 producer overwrites its range (vd_bf16_shadow_invalidate).
+// until an fp32 producer overwrites its range (vd_bf16_shadow_invalidate: the fp32 recurrences, a forward pass over the gates buffer,
+// vd_memset).  The registry is process-global and keyed by address only: VD_FLAG_BF16 on vd_gemm_tn_acc is meant for the contraction that
+// directly follows the bf16 recurrences of the same pass -- a host that writes those ranges by other means (its own kernels, a tensor
+// library) must not pass the flag afterwards.
 int vd_bf16_shadow_get(int slot, const float* base, size_t floats, vd_bf16_bits** out);
 const vd_bf16_bits* vd_bf16_shadow_find(const float* p, size_t floats);
 void vd_bf16_shadow_invalidate(const float* p, size_t floats);

@@ -821,6 +821,7 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
   } else {
     vd_bf16_shadow_invalidate(h, (size_t)T * NH);
   }
+  vd_bf16_shadow_invalidate(gates, (size_t)T * 4 * NH);     // this pass overwrites `gates`: a da shadow registered over it (last backward) is stale
   // ... and READ the shadow of h_{t-1} and a bf16 copy of the transposed weights through the LDS-DMA pipeline
   vd_bf16_bits* WhT16 = nullptr;
   if (h16 && glds) {

@@ -609,9 +609,10 @@ int vd_model_family_ms(vd_model* m, float* ms3) {
   return VD_OK;
 }
 
-// rows the option LSTM of the last uploaded batch executes vs the N * O candidates it stands for (decoder disc)
+// rows the option LSTM executed for the batch of the LAST STEP (vd_model_forward_backward / vd_model_retrieve) vs the N * O candidates
+// they stand for (decoder disc); before any step: of the uploaded batch.  In a pipelined loop that is NOT the prefetched batch.
 int vd_model_option_rows(vd_model* m, int64_t* executed, int64_t* total) {
-  VD_CHECK_ARG(m && executed && total && m->uploaded >= 0, "vd_model_option_rows: no batch uploaded");
+  VD_CHECK_ARG(m && executed && total && (m->cur >= 0 || m->uploaded >= 0), "vd_model_option_rows: no batch uploaded");
   const BatchSlot& b = m->slot[m->cur >= 0 ? m->cur : m->uploaded];
   *executed = b.opt.present ? b.opt.N : 0;
   *total = b.opt.present ? (b.opt_total ? b.opt_total : b.opt.N) : 0;
