@@ -195,10 +195,10 @@ function Model:evaluate(dataloader, dtype)
     local curLoss, count, first = 0, 0, 1
     while first <= total do
         local batch, nxt = dataloader:getTestBatch(first, self.params, dtype)
-        if self.params.decoder == 'gen' then
+        if batch['answer_out'] then                                   -- model.lua:124-127, both decoders (dataloader.lua:398-421)
             count = count + batch['answer_out']:gt(0):sum()            -- non-pad target tokens
-            curLoss = curLoss + self:forwardBackward(batch, true)      -- summed token NLL
-        else
+            curLoss = curLoss + self:forwardBackward(batch, true)      -- gen: summed token NLL; disc: the batch's mean cross-entropy
+        else                                                           -- synthetic disc batches without answers: mean over rounds
             local rounds = batch['answer_ind']:nElement()
             count = count + rounds
             curLoss = curLoss + self:forwardBackward(batch, true) * rounds

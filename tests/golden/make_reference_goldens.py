@@ -20,6 +20,7 @@ cross-check at generation time, so that a disagreement is seen before a fixture 
 """
 import json
 import os
+import re
 import sys
 
 import numpy as np
@@ -51,8 +52,24 @@ BATCH_TYPES = {'ques_fwd': 'Long', 'hist': 'Long', 'options': 'Long', 'answer_in
                'img_feat': 'Double', 'option_in': 'Long', 'option_out': 'Long'}
 
 
+class Capture(object):
+    """the VM's stdout: everything is dropped except while .on is set"""
+
+    def __init__(self):
+        self.on, self.text = False, ''
+
+    def write(self, s):
+        if self.on:
+            self.text += s
+
+    def flush(self):
+        pass
+
+
 def reference_vm(seed):
-    vm = new_vm(search=[REF, os.path.join(ROOT, 'tests', 'lua_ref_stubs')], stdout=open(os.devnull, 'w'))
+    out = Capture()
+    vm = new_vm(search=[REF, os.path.join(ROOT, 'tests', 'lua_ref_stubs')], stdout=out)
+    vm.captured = out
     NN = nn7.install(vm, seed=seed)
     cj = LuaTable()
     cj.set('decode', lambda s, *_: to_lua(vm, json.loads(s)))
@@ -319,9 +336,84 @@ def run_pair(enc, dec, seed=7, extra=None, order_only=False):
         rec['beam.scores'] = np.array([sc for _, sc in want], dtype=np.float64)
         rec['beam.params'] = np.array([beam_size, beam_len, START, END], dtype=np.int64)
         report.append('generateAnswers (beam %d x %d): 10 rounds token-exact' % (beam_size, beam_len))
+    # ---- the split-level loops: Model:evaluate, Model:retrieve (+ utils.processRanks), Model:predict (model.lua:109-246) over a
+    #      3-dialog validation split served as two batches (2 + 1), on the parameters as they are now
+    if (enc, dec) in SPLIT_PAIRS:
+        flat_W.a[...] = flat_W.a.astype(np.float32).astype(np.float64)      # fp32-representable again (the Adam step was taken in fp64)
+        Pn = named(flat_W)
+        p2 = dict(p, decoder='gen')
+        sb = []
+        for nb in (2, 1):
+            b = dl.getTrainBatch(p, batch_size=nb, full_length=False)
+            if 'answer_out' not in b:                          # dataloader.lua:398-421: every batch carries the answers, whatever the decoder
+                g = SyntheticDataloader(p2, seed=100 + nb).getTrainBatch(p2, batch_size=nb)
+                b['answer_in'], b['answer_out'] = g['answer_in'], g['answer_out']
+            if dec == 'gen':
+                dl.add_gen_options(b, nb)
+            sb.append({k: v for k, v in b.items() if isinstance(v, np.ndarray)})
+
+        class SplitLoader(object):
+            lua_type = 'table'
+
+            def __init__(self):
+                self.f = {'numThreads': to_lua(vm, {'val': 3}), 'unique_img_val': to_lua(vm, [11, 12, 13]),
+                          'val_num_rounds': vm.torch.tensor(np.array([10, 9, 10]), 'Long')}
+
+            def lua_index(self, k):
+                if k == 'getTestBatch':
+                    return lambda _self, start, *_a: (to_lua(vm, sb[0 if int(start) == 1 else 1], BATCH_TYPES), 3 if int(start) == 1 else 4)
+                return self.f.get(k)
+        D = SplitLoader()
+        vm.captured.on, vm.captured.text = True, ''
+        inv(model, 'evaluate', D, 'val')
+        m_ev = re.search(r'val\tLoss: ([-0-9.]+)\t Perplexity: ([-0-9.a-z+]+)', vm.captured.text)
+        vm.captured.text = ''
+        index(model, 'params').set('useGt', True)
+        recs = to_py(first(inv(model, 'retrieve', D, 'val')))
+        txt = vm.captured.text
+        vm.captured.text = ''
+        index(model, 'params').set('useGt', False)
+        pred = to_py(first(inv(model, 'predict', D, 'val')))
+        vm.captured.on = False
+        # oracle-side restatement of the three loops
+        tot, ntok, gt_ranks, all_ranks = 0.0, 0, [], []
+        for b in sb:
+            tot += vo.forward_backward(enc, dec, Pn, p, b, None, only_forward=True)['loss']
+            ntok += int((b['answer_out'] > 0).sum())
+            sc = vo.retrieve(enc, dec, Pn, p, b)
+            gt_ranks.append(vo.compute_ranks(sc, b['answer_ind'].reshape(-1) - 1).reshape(-1, 10))
+            all_ranks.append(vo.compute_ranks(sc).reshape(-1, 10, sc.shape[1]))
+        gt_ranks, all_ranks = np.concatenate(gt_ranks), np.concatenate(all_ranks)
+        loss = tot / ntok
+        assert m_ev and abs(float(m_ev.group(1)) - loss) < 1e-6 and abs(float(m_ev.group(2)) - np.exp(loss)) < 1e-5 * np.exp(loss), (vm.captured.text, loss)
+        want = vo.process_ranks(gt_ranks)
+        printed = {k: float(v) for k, v in re.findall(r'\t([a-zA-Z@0-9. ]+): ([-0-9.]+)', txt)}
+        for k in ('r@1', 'r@5', 'r@10', 'medianR', 'meanR', 'meanRR'):
+            assert abs(printed[k] - want[k]) < 1e-6, (k, printed, want)
+        assert int(printed['No. questions']) == 30
+        rounds = [10, 9, 10]
+        exp_recs = [{'image_id': 11 + i, 'round_id': j + 1, 'ranks': float(gt_ranks[i, j])} for i in range(3) for j in range(rounds[i])]
+        # utils.processRanks ends with torch.mean(ranks:cinv()) -- IN PLACE -- on `ranks:double():view(-1)`, which on the CPU path
+        # (-gpuid -1: torch.Tensor is already a DoubleTensor, :double() returns it) is the very tensor Model:retrieve then turns into its
+        # records: they hold 1 / rank there.  With -gpuid >= 0 the tensor is a CudaTensor, :double() copies, and the records hold the
+        # ranks -- the behaviour this repo reproduces.  The run here is the CPU path, so:
+        assert len(recs) == len(exp_recs) and all(a['image_id'] == b['image_id'] and a['round_id'] == b['round_id'] and
+                                                  abs(1.0 / a['ranks'] - b['ranks']) < 1e-9 for a, b in zip(recs, exp_recs))
+        exp_pred = [{'image_id': 11 + i, 'round_id': j + 1, 'ranks': [float(x) for x in all_ranks[i, j]]} for i in range(3) for j in range(rounds[i])]
+        assert pred == exp_pred
+        for i, b in enumerate(sb):
+            rec.update({'split.batch%d.%s' % (i, k): v for k, v in b.items()})
+        rec.update({'split.param.' + k: v.astype(np.float32) for k, v in Pn.items()})
+        assert all((rec['split.param.' + k].astype(np.float64) == v).all() for k, v in Pn.items())
+        rec['split.loss'], rec['split.ppl'] = np.float64(float(m_ev.group(1))), np.float64(float(m_ev.group(2)))
+        rec['split.gt_ranks'], rec['split.all_ranks'] = gt_ranks.astype(np.int64), all_ranks.astype(np.int64)
+        rec['split.metrics'] = np.array([printed[k] for k in ('r@1', 'r@5', 'r@10', 'medianR', 'meanR', 'meanRR')])
+        report.append('evaluate / retrieve (+ processRanks) / predict over a 3-dialog split: loss %.6f, metrics and %d + %d records equal' % (
+            loss, len(recs), len(pred)))
     return p, rec, names_in_flat_order, report
 
 
+SPLIT_PAIRS = [('mn-att-ques-im-hist', 'disc'), ('lf-ques', 'gen'), ('hre-ques-im-hist', 'disc')]
 VARIANTS = [('mn-att-ques-im-hist', 'disc', {'numAttentionLayers': 3}), ('lf-att-ques-im-hist', 'disc', {'numAttentionLayers': 3}),
             ('hrea-ques-im-hist', 'gen', {'numLayers': 3}), ('hre-ques-hist', 'gen', {'numLayers': 1}), ('lf-ques-im-hist', 'gen', {'numLayers': 1}),
             ('mn-ques-im-hist', 'gen', {'numLayers': 3})]

@@ -10,6 +10,8 @@ reference initialised (rounded to fp32), one synthetic batch, and what the refer
   rank.*    Model:retrieveBatch -> utils.computeRanks: the decoder's scores, the GT ranks and all ranks (disc); for gen the 100
             candidates of rbatch.* scored by forwardConnect + decoder forward + utils.computeLhood (model.lua:392-420)
   beam.*    Model:generateAnswers, beam search (model.lua:432-573), one dialog x 10 rounds: the winning token vectors         (gen)
+  split.*   Model:evaluate / retrieve (+ utils.processRanks) / predict (model.lua:109-246) over a 3-dialog split in two batches:
+            the printed loss / perplexity / R@k / MRR, the ground-truth ranks and all ranks          (three pairs)
 
 CPU: oracle/visdial_oracle.py reproduces all of it (this is what pins the oracle to the reference).
 GPU: the HIP path, fed the same parameters / batch / masks through the C ABI, matches within the fp32 tolerance (1e-4).
@@ -225,3 +227,98 @@ def test_hip_path_matches_the_executed_reference(path):
             out = host.generateAnswers(GenLoader(), 'val', dict(beamSize=bs, beamLen=bl, maxThreads=1))
             assert out[0]['image_id'] == 4711
             assert [d['answer'] for d in out[0]['dialog']] == want_txt, (type(host).__name__, [d['answer'] for d in out[0]['dialog']], want_txt)
+
+
+# ---------------------------------------------------------------------------------------------------------------------- split loops
+SPLIT = [f for f in FILES if 'split.loss' in np.load(f).files]
+
+
+class _SplitLoader(object):
+    """what Model:evaluate / retrieve / predict use of a dataloader: the fixture's two batches (2 + 1 dialogs)"""
+    numThreads, unique_img_val, val_num_rounds = {'val': 3}, [11, 12, 13], [10, 9, 10]
+
+    def __init__(self, batches):
+        self.batches = batches
+
+    def getTestBatch(self, start, params, dtype):
+        return (self.batches[0], 3) if start == 1 else (self.batches[1], 4)
+
+
+def _split_fixture(path):
+    z = np.load(path)
+    p = derive(json.loads(str(z['opt.json'])))
+    get = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
+    return z, p, get('split.param.'), [get('split.batch0.'), get('split.batch1.')]
+
+
+def _check_split(host, z, exact):
+    """run the product's three loops (visdial_amd/split_eval.py) on `host` and compare with what the reference printed / returned"""
+    D = _SplitLoader(host._batches)
+    loss, ppl = host.evaluate(D, 'val')
+    tol = 1e-6 if exact else 1e-4
+    assert abs(loss - float(z['split.loss'])) < tol * max(1.0, abs(float(z['split.loss']))) + 1e-6          # (%f: six decimals were printed)
+    assert abs(ppl - float(z['split.ppl'])) < (2e-6 if exact else 2e-4) * float(z['split.ppl']) + 1e-6
+    metrics, recs = host.retrieve(D, 'val')
+    gt = z['split.gt_ranks']
+    rounds = [10, 9, 10]
+    flips = 0
+    assert [(r['image_id'], r['round_id']) for r in recs] == [(11 + i, j + 1) for i in range(3) for j in range(rounds[i])]
+    got = np.array([r['ranks'] for r in recs])
+    want = np.array([gt[i, j] for i in range(3) for j in range(rounds[i])], dtype=np.float64)
+    if exact:
+        np.testing.assert_array_equal(got, want)                  # (the ranks themselves: the reference's GPU path; its CPU path returns 1 / rank)
+        np.testing.assert_allclose([metrics[k] for k in ('r@1', 'r@5', 'r@10', 'medianR', 'meanR', 'meanRR')], z['split.metrics'], atol=1e-6)
+    else:
+        flips = int(np.abs(got - want).sum())
+        assert (got != want).mean() < 0.1 and np.abs(got - want).max() <= 2              # fp32 near ties only
+        assert abs(metrics['meanR'] - z['split.metrics'][4]) <= flips / 30.0 + 1e-6
+    pred = host.predict(D, 'val')
+    allr = z['split.all_ranks']
+    assert [(r['image_id'], r['round_id']) for r in pred] == [(11 + i, j + 1) for i in range(3) for j in range(rounds[i])]
+    got = np.array([r['ranks'] for r in pred])
+    want = np.array([allr[i, j] for i in range(3) for j in range(rounds[i])], dtype=np.float64)
+    if exact:
+        np.testing.assert_array_equal(got, want)
+    else:
+        assert (got != want).mean() < 0.02
+
+
+def test_split_fixtures_present():
+    assert len(SPLIT) == 3
+
+
+@pytest.mark.parametrize("path", SPLIT, ids=[os.path.basename(f)[5:-4] for f in SPLIT])
+def test_split_loops_on_an_oracle_host_reproduce_the_executed_reference(path):
+    """visdial_amd/split_eval.py (the loops both product hosts share) driven by the fp64 oracle instead of the device"""
+    from visdial_amd.split_eval import SplitEval
+    z, p, P, batches = _split_fixture(path)
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    enc, dec = p['encoder'], p['decoder']
+
+    class OracleHost(SplitEval):
+        params, _batches = p, batches
+
+        def _set_training(self, on):
+            pass
+
+        def forwardBackward(self, batch, onlyForward=False):
+            return vo.forward_backward(enc, dec, P64, p, batch, None, only_forward=True)['loss']
+
+        def retrieveBatch(self, batch):
+            sc = vo.retrieve(enc, dec, P64, p, batch)
+            return vo.compute_ranks(sc, batch['answer_ind'].reshape(-1) - 1) if self.params['useGt'] else vo.compute_ranks(sc)
+    _check_split(OracleHost(), z, exact=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", SPLIT, ids=[os.path.basename(f)[5:-4] for f in SPLIT])
+def test_split_loops_on_the_hip_hosts_match_the_executed_reference(path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from visdial_amd.model import Model
+    from visdial_amd.native import NativeModel
+    z, p, P, batches = _split_fixture(path)
+    for host in (Model(dict(p)), NativeModel(dict(p))):
+        host.set_parameters_dict(P)
+        host._batches = batches
+        _check_split(host, z, exact=False)

@@ -13,16 +13,17 @@ from . import utils
 
 class SplitEval(object):
     def evaluate(self, dataloader, dtype):
-        """model.lua:109-139: validation loss / perplexity over a split (generative decoder: summed token NLL over
-        the number of non-pad target tokens; for the discriminative decoder, whose batches carry no answer_out, the
-        reference would fail -- here the mean cross-entropy over rounds is reported instead).  Returns (loss, ppl)."""
+        """model.lua:109-139: validation loss / perplexity over a split: the sum over batches of `forwardBackward(batch, true)` (gen:
+        summed token NLL; disc: the batch's MEAN cross-entropy) divided by the number of non-pad target tokens -- for both decoders,
+        as the reference does (dataloader.lua:398-421 puts answer_out into every batch).  Synthetic disc batches without answer_out:
+        the mean cross-entropy over rounds.  Returns (loss, ppl)."""
         self._set_training(False)
         n = dataloader.numThreads[dtype]
         cur, count, start = 0.0, 0.0, 1
         while start <= n:
             batch, nxt = dataloader.getTestBatch(start, self.params, dtype)
-            if self.params['decoder'] == 'gen':
-                count += float((batch['answer_out'] > 0).sum())
+            if 'answer_out' in batch:
+                count += float((np.asarray(batch['answer_out']) > 0).sum())
                 cur += self.forwardBackward(batch, onlyForward=True)
             else:
                 rounds = float(np.asarray(batch['answer_ind']).size)
