@@ -877,6 +877,11 @@ def train_iteration(encoder, decoder, P, p, batch, drop, opt_state, lr):
     """Model:trainIteration (model.lua:66-106) on explicit batch: fwd/bwd, clamp +-5, adam."""
     spec = param_spec(encoder, decoder, p)
     r = forward_backward(encoder, decoder, P, p, batch, drop)
+    # LookupTableMaskZero zeroes its pad row IN the flat parameter vector on every forward: the update starts from that row = 0 (its
+    # gradient need not be zero: where the embedding is joined with another input before the LSTM, pad steps are not masked)
+    P = dict(P)
+    P['embed'] = P['embed'].copy()
+    P['embed'][0] = 0
     w = flatten(P, spec)
     g = flatten(r['grads'], spec)
     w2, g2 = clamp_adam(w, g, opt_state, lr)

@@ -410,6 +410,42 @@ def run_pair(enc, dec, seed=7, extra=None, order_only=False):
         rec['split.metrics'] = np.array([printed[k] for k in ('r@1', 'r@5', 'r@10', 'medianR', 'meanR', 'meanRR')])
         report.append('evaluate / retrieve (+ processRanks) / predict over a 3-dialog split: loss %.6f, metrics and %d + %d records equal' % (
             loss, len(recs), len(pred)))
+    # ---- two MORE Model:trainIteration calls on fresh batches: Adam's moments and bias correction at t = 2, 3, the learning-rate decay
+    #      and the runningLoss moving average across iterations (model.lua:66-106, optim_updates.lua:62-91)
+    if (enc, dec) in SPLIT_PAIRS:
+        state = {}
+        vo.train_iteration(enc, dec, P, p, batch, None, state, p['learningRate'])          # the oracle's optimiser state after the first call
+        Pc = named(flat_W)                                                                   # (the parameters have been edited since: the state has not)
+        rec.update({'multi.param.' + k: v.astype(np.float32) for k, v in Pc.items()})
+        assert all((rec['multi.param.' + k].astype(np.float64) == v).all() for k, v in Pc.items())
+        lr = float(index(index(model, 'optims'), 'learningRate'))
+        rl = float(vm.globals.get('runningLoss'))
+        rec['multi.start'] = np.array([lr, rl])
+        inv(wrapper, 'evaluate')
+        for it in range(2):
+            b = dl.getTrainBatch(p)
+            cur = {'b': b}
+
+            class NextBatch(object):
+                lua_type = 'table'
+
+                def lua_index(self, k):
+                    return (lambda *_a: to_lua(vm, {kk: v for kk, v in cur['b'].items() if isinstance(v, np.ndarray)}, BATCH_TYPES)) if k == 'getTrainBatch' else None
+            inv(model, 'trainIteration', NextBatch())
+            Pc, r = vo.train_iteration(enc, dec, Pc, p, b, None, state, lr)
+            if lr > p['minLRate']:
+                lr *= p['lrDecayRate']
+            curl = r['loss'] / max(int((b['answer_out'] > 0).sum()), 1) if dec == 'gen' else r['loss']
+            rl = 0.95 * rl + 0.05 * curl if rl > 0 else curl
+            rec.update({'multi.batch%d.%s' % (it, k): v for k, v in b.items() if isinstance(v, np.ndarray)})
+        Wn = named(flat_W)
+        worst = max(float(np.abs(Wn[k] - Pc[k]).max()) for k in Pc)
+        assert worst < 1e-12, (enc, dec, 'three iterations', worst, {k: float(np.abs(Wn[k] - Pc[k]).max()) for k in Pc})
+        assert abs(float(vm.globals.get('runningLoss')) - rl) < 1e-9 * max(1, abs(rl))
+        assert abs(float(index(index(model, 'optims'), 'learningRate')) - lr) < 1e-15
+        rec.update({'multi.delta.' + k: (Wn[k] - rec['multi.param.' + k].astype(np.float64)).astype(np.float32) for k in Wn})
+        rec['multi.end'] = np.array([lr, rl])
+        report.append('trainIteration x 3 (Adam t = 2, 3; lr decay; runningLoss EMA): max |dW| vs oracle %.1e' % worst)
     return p, rec, names_in_flat_order, report
 
 

@@ -10,6 +10,7 @@ reference initialised (rounded to fp32), one synthetic batch, and what the refer
   rank.*    Model:retrieveBatch -> utils.computeRanks: the decoder's scores, the GT ranks and all ranks (disc); for gen the 100
             candidates of rbatch.* scored by forwardConnect + decoder forward + utils.computeLhood (model.lua:392-420)
   beam.*    Model:generateAnswers, beam search (model.lua:432-573), one dialog x 10 rounds: the winning token vectors         (gen)
+  multi.*   two MORE Model:trainIteration calls on fresh batches (Adam at t = 2, 3, lr decay, runningLoss moving average)   (three pairs)
   split.*   Model:evaluate / retrieve (+ utils.processRanks) / predict (model.lua:109-246) over a 3-dialog split in two batches:
             the printed loss / perplexity / R@k / MRR, the ground-truth ranks and all ranks          (three pairs)
 
@@ -322,3 +323,76 @@ def test_split_loops_on_the_hip_hosts_match_the_executed_reference(path):
         host.set_parameters_dict(P)
         host._batches = batches
         _check_split(host, z, exact=False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------- three iterations
+@pytest.mark.parametrize("path", SPLIT, ids=[os.path.basename(f)[5:-4] for f in SPLIT])
+def test_oracle_reproduces_three_reference_iterations(path):
+    enc, dec, p, z, P, batch, masks = load(path)
+    get = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
+    state = {}
+    vo.train_iteration(enc, dec, {k: v.astype(np.float64) for k, v in P.items()}, p, batch, None, state, p['learningRate'])
+    Pc = {k: v.astype(np.float64) for k, v in get('multi.param.').items()}
+    start = {k: v.copy() for k, v in Pc.items()}
+    lr, rl = (float(v) for v in z['multi.start'])
+    for it in range(2):
+        b = get('multi.batch%d.' % it)
+        Pc, r = vo.train_iteration(enc, dec, Pc, p, b, None, state, lr)
+        if lr > p['minLRate']:
+            lr *= p['lrDecayRate']
+        cur = r['loss'] / max(int((b['answer_out'] > 0).sum()), 1) if dec == 'gen' else r['loss']
+        rl = 0.95 * rl + 0.05 * cur if rl > 0 else cur
+    delta = get('multi.delta.')
+    for k in Pc:
+        assert np.abs((Pc[k] - start[k]) - delta[k]).max() < 1e-9, k                 # (deltas stored in fp32: |delta| ~ 3e-3)
+    assert abs(lr - float(z['multi.end'][0])) < 1e-15 and abs(rl - float(z['multi.end'][1])) < 1e-9 * max(1.0, abs(rl))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", SPLIT, ids=[os.path.basename(f)[5:-4] for f in SPLIT])
+def test_hip_hosts_reproduce_three_reference_iterations(path):
+    """Adam's moments / bias correction at t = 2, 3, the lr decay and the runningLoss moving average across calls, through both hosts"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from visdial_amd.model import Model
+    from visdial_amd.native import NativeModel
+    enc, dec, p, z, P, batch, masks = load(path)
+    get = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
+    batches = [batch, get('multi.batch0.'), get('multi.batch1.')]
+    delta = get('multi.delta.')
+    start = get('multi.param.')
+
+    class Loader(object):
+        def __init__(self):
+            self.i = 0
+
+        def getTrainBatch(self, params, **_k):
+            b = batches[min(self.i, 2)]
+            self.i += 1
+            return b
+    for host in (Model(dict(p)), NativeModel(dict(p))):
+        host.set_parameters_dict(P)
+        (host.wrapper.evaluate if hasattr(host, 'wrapper') else (lambda: host.training(False)))()
+        dl = Loader()
+        host.runningLoss = 0
+        host.trainIteration(dl)                                   # t = 1 on the first batch (checked above); then the fixture's edited parameters
+        if hasattr(host, 'synchronize'):
+            host.synchronize()
+        host.set_parameters_dict(start)
+        host.optims['learningRate'], host.runningLoss = float(z['multi.start'][0]), float(z['multi.start'][1])
+        host.trainIteration(dl)                                   # (the pipelined hosts have already prefetched batches[1]: inputs only)
+        host.trainIteration(dl)
+        W = host.get_parameters_dict()
+        eps1 = 1e-8 / np.sqrt(1 - 0.999)
+        for k in start:
+            got = (W[k].astype(np.float64) - start[k].astype(np.float64)).reshape(-1)
+            # two Adam steps of <= lr each; an element's step is sensitive to fp32 gradient noise only where |g| ~ eps' (see above):
+            # bound the worst element by 2 lr for those, and the bulk by 1e-3 of the step
+            err = np.abs(got - delta[k].reshape(-1))
+            assert err.max(initial=0.0) <= 2.0001 * p['learningRate'] + 4e-7 * np.abs(start[k]).max(), k
+            if np.abs(delta[k]).max() < 1e-9:          # the reference did not move it (att.b: exact gradient 0): the fp32 step is rounding noise
+                continue
+            assert np.median(err) < 2e-6 * p['learningRate'] + 4e-7 * max(float(np.abs(start[k]).max()), 1e-3), (k, float(np.median(err)))
+            assert np.linalg.norm(err) <= 0.02 * np.linalg.norm(delta[k]) + 1e-6, (k, float(np.linalg.norm(err)), float(np.linalg.norm(delta[k])))
+        assert abs(host.optims['learningRate'] - float(z['multi.end'][0])) < 1e-7 * p['learningRate']      # (the library keeps it in fp32)
+        assert abs(host.runningLoss - float(z['multi.end'][1])) < 1e-4 * max(1.0, abs(float(z['multi.end'][1])))
