@@ -34,9 +34,9 @@ CASES = {'lf-ques-im-hist': dict(encoder='lf-ques-im-hist', concatHistory=False,
 first = lambda vals: vals[0] if vals else None
 
 
-def two_splits(rng, att):
-    info, raw, img = raw_dataset(rng, n=6, R=4, MQ=6, MA=5, V=30, O=5, nopt=40, F=8, att=att)
-    info2, raw2, img2 = raw_dataset(rng, n=5, R=4, MQ=6, MA=5, V=30, O=5, nopt=40, F=8, att=att)
+def two_splits(rng, att, R=4, O=5):
+    info, raw, img = raw_dataset(rng, n=6, R=R, MQ=6, MA=5, V=30, O=O, nopt=40, F=8, att=att)
+    info2, raw2, img2 = raw_dataset(rng, n=5, R=R, MQ=6, MA=5, V=30, O=O, nopt=40, F=8, att=att)
     raw.update({k.replace('_train', '_val'): v for k, v in raw2.items()})
     img.update({k.replace('_train', '_val'): v for k, v in img2.items()})
     info['unique_img_val'] = ['%012d' % (100 + i) for i in range(5)]

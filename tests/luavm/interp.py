@@ -1393,6 +1393,21 @@ class LuaFile(object):
         return self.f.tell()
 
 
+def _os_date(fmt='%c', t=None, *_):
+    """os.date: '*t' / '!*t' give the broken-down time as a table (year, month, day, hour, min, sec, wday, yday, isdst)"""
+    utc = fmt.startswith('!')
+    if utc:
+        fmt = fmt[1:]
+    tm = (time.gmtime if utc else time.localtime)(t)
+    if fmt == '*t':
+        out = LuaTable()
+        for k, v in (('year', tm.tm_year), ('month', tm.tm_mon), ('day', tm.tm_mday), ('hour', tm.tm_hour), ('min', tm.tm_min),
+                     ('sec', tm.tm_sec), ('wday', (tm.tm_wday + 1) % 7 + 1), ('yday', tm.tm_yday), ('isdst', bool(tm.tm_isdst))):
+            out.set(k, v)
+        return out
+    return time.strftime(fmt, tm)
+
+
 class LuaVM(object):
     """One Lua state.  search = directories that `dofile` / `require` resolve relative paths in (first hit wins)."""
 
@@ -1720,7 +1735,7 @@ class LuaVM(object):
         O.set('getenv', lambda k, *_: os.environ.get(k))
         O.set('time', lambda *_: int(time.time()))
         O.set('clock', lambda *_: time.process_time())
-        O.set('date', lambda fmt='%c', t=None, *_: time.strftime(fmt, time.localtime(t)))
+        O.set('date', _os_date)
         O.set('exit', lambda code=0, *_: (_ for _ in ()).throw(SystemExit(int(code if code.__class__ in (int, float) else 0))))
         O.set('remove', lambda p, *_: (os.remove(p), True)[1])
         G.set('os', O)

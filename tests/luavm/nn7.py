@@ -490,7 +490,7 @@ class Dropout(Module):
             self.noise = None
             return self.out(x)
         self.noise = (self.NN.rng.uniform(size=x.shape) > self.p).astype(np.float64)     # keep-mask
-        self.NN.dropout_log.append(self)
+        self.NN.dropout_log.append((self, self.noise))        # (module, the keep-mask of THIS call), in forward order
         return self.out(x * self.noise / (1 - self.p))
 
     def updateGradInput(self, inp, gout):

@@ -756,7 +756,7 @@ class Torch(object):
             t.set(tn + 'Tensor', TensorCtor(self, tn))
         t.set('LongStorage', lambda *a: LongStorage(_sizes(a) if not (len(a) == 1 and a[0].__class__ in (int, float)) else [0] * int(a[0])))
         for name in ('Tensor', 'zeros', 'ones', 'range', 'repeatTensor', 'totable', 'multinomial', 'cat', 'sum', 'mean', 'max', 'min',
-                     'sqrt', 'median', 'cmul', 'cdiv', 'le', 'lt', 'ge', 'gt', 'eq', 'ne', 'manualSeed', 'setdefaulttensortype',
+                     'sqrt', 'median', 'cmul', 'cdiv', 'le', 'lt', 'ge', 'gt', 'eq', 'ne', 'manualSeed', 'setdefaulttensortype', 'CmdLine',
                      'getdefaulttensortype', 'type', 'typename', 'isTensor', 'class', 'random', 'randperm', 'rand', 'randn', 'uniform',
                      'sort', 'topk', 'abs', 'exp', 'log', 'add', 'mul', 'div', 'dot', 'norm', 'cumsum', 'setnumthreads', 'getnumthreads',
                      'save', 'load', 'isTypeOf', 'setmetatable', 'getmetatable', 'squeeze', 'floor', 'clamp', 'pow', 'seed', 'triu', 'tril',
@@ -989,6 +989,49 @@ class Torch(object):
             scope = nxt
         scope.set(parts[-1], ctor)
         return (mt, pmt) if pmt is not None else mt
+
+    def f_CmdLine(self, *_):
+        """torch.CmdLine(): text / option / parse, as opts.lua uses them (values typed like the option's default)"""
+        T = self
+
+        class CmdLine(object):
+            lua_type = 'table'
+
+            def __init__(self):
+                self.opts = []
+
+            def lua_index(self, k):
+                if k == 'text':
+                    return lambda *_a: None
+                if k == 'option':
+                    return lambda _s, name, default=None, help='', *_a: self.opts.append((name, default))
+                if k == 'parse':
+                    def parse(_s, arg=None, *_a):
+                        out = LuaTable()
+                        for name, default in self.opts:
+                            out.set(name.lstrip('-'), default)
+                        args = []
+                        i = 1
+                        while arg is not None and arg.get(i) is not None:
+                            args.append(arg.get(i))
+                            i += 1
+                        known = dict(self.opts)
+                        i = 0
+                        while i < len(args):
+                            if args[i] not in known:
+                                raise LuaError('CmdLine: unknown option %s' % (args[i],))
+                            d, v = known[args[i]], args[i + 1]
+                            if d.__class__ is bool:
+                                v = v in ('true', True)
+                            elif isinstance(d, (int, float)):
+                                v = float(v)
+                                v = int(v) if v == int(v) else v
+                            out.set(args[i].lstrip('-'), v)
+                            i += 2
+                        return out
+                    return parse
+                return None
+        return CmdLine()
 
     def f_save(self, *_):
         raise LuaError('luavm-torch: torch.save is not available (install a handler on vm.torch.module)')
