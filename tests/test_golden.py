@@ -13,7 +13,7 @@ from oracle import visdial_oracle as vo
 from visdial_amd.opts import derive
 
 FILES = sorted(f for f in glob.glob(os.path.join(ROOT, 'tests', 'golden', '*__*.npz'))     # <encoder>__<decoder>.npz
-               if not os.path.basename(f).startswith(('full__', 'ref__', 'ref_dataloader__')))     # (full-size: test_full_size_golden.py; executed reference: test_reference_goldens.py)
+               if not os.path.basename(f).startswith(('full__', 'ref_')))     # (full-size: test_full_size_golden.py; executed reference: test_reference_goldens.py)
 KW = {'lf-ques': dict(dropout=0.5, imgNorm=1, batchSize=2), 'lf-ques-im-hist': dict(dropout=0.5, imgNorm=1, batchSize=2),
       'hre-ques-im-hist': dict(imgNorm=1, batchSize=2), 'mn-att-ques-im-hist': dict(batchSize=2)}
 
