@@ -56,6 +56,7 @@ def run_case(enc, dec, seed=5):
     NN = nn7.install(vm, seed=7)
     cj = LuaTable()
     cj.set('decode', lambda text, *_: to_lua(vm, json.loads(text)))
+    cj.set('encode', lambda t, *_: json.dumps(to_py(t)))
     vm.preload.set('cjson', lambda *_: cj)
     h5 = LuaTable()
     files = {'ques.h5': raw, 'img.h5': img}
@@ -156,6 +157,47 @@ def run_case(enc, dec, seed=5):
     rec['final.delta'] = (saved[1][1] - captured['W0']).astype(np.float32)
     rec['epoch1.delta'] = (saved[0][1] - captured['W0']).astype(np.float32)
     rec['end'] = np.array([lr, rl])
+
+    # ---- evaluate.lua, unedited, on the epoch-2 checkpoint and the val split: -useGt true (Model:retrieve) and false (Model:predict),
+    #      -saveRanks true (utils.writeJSON).  torch.load hands back what torch.save was given.
+    ck = saved[1]
+    loaded = LuaTable()
+    loaded.set('modelW', vm.torch.tensor(ck[1].copy(), 'Double'))
+    loaded.set('modelParams', ck[3])
+    lo = LuaTable()
+    lo.set('learningRate', ck[2])
+    loaded.set('optims', lo)
+    vm.torch.module.set('load', lambda path, *_a: loaded)
+    Pf = _split64(ck[1], spec, enc)
+    val = Dataloader(seed=1).from_arrays(json.loads(json.dumps(info)), raw, img, opt, ['val'])
+    results = {}
+    for use_gt in (True, False):
+        out_json = os.path.join(tmp, 'ranks_%d.json' % use_gt)
+        vm.globals.set('arg', to_lua(vm, ['-inputJson', jpath, '-inputQues', 'ques.h5', '-inputImg', 'img.h5', '-gpuid', '-1', '-loadPath',
+                                          os.path.join(tmp, 'ck', 'model_epoch_2.t7'), '-split', 'val', '-batchSize', '2',
+                                          '-useGt', 'true' if use_gt else 'false', '-saveRanks', 'true', '-saveRankPath', out_json]))
+        vm.dofile('evaluate.lua')
+        results[use_gt] = json.load(open(out_json))
+    # the oracle's version of the same: batches of 2 + 2 + 1 dialogs from the product loader
+    p_eval = dict(opt, batchSize=2)
+    start, gt_r, all_r = 1, [], []
+    while start <= 5:
+        b, start = val.getTestBatch(start, p_eval, 'val')
+        sc = vo.retrieve(enc, dec, Pf, opt, b)
+        gt_r.append(vo.compute_ranks(sc, np.asarray(b['answer_ind']).reshape(-1) - 1).reshape(-1, 10))
+        all_r.append(vo.compute_ranks(sc).reshape(-1, 10, sc.shape[1]))
+    gt_r, all_r = np.concatenate(gt_r), np.concatenate(all_r)
+    ids = [100 + i for i in range(5)]
+    nr = raw['num_rounds_val'].astype(int)
+    want = [(ids[i], j + 1) for i in range(5) for j in range(nr[i])]
+    assert [(r['image_id'], r['round_id']) for r in results[True]] == want and [(r['image_id'], r['round_id']) for r in results[False]] == want
+    # (-useGt true goes through utils.processRanks, which inverts the tensor in place on this CPU path: the records hold 1 / rank)
+    assert all(abs(1.0 / r['ranks'] - gt_r[i, j]) < 1e-9 for r, (i, j) in zip(results[True], [(i, j) for i in range(5) for j in range(nr[i])]))
+    assert all(r['ranks'] == [float(x) for x in all_r[i, j]] for r, (i, j) in zip(results[False], [(i, j) for i in range(5) for j in range(nr[i])]))
+    rec.update({'raw.' + k: v for k, v in raw.items() if k.endswith('_val')})
+    rec.update({'img.' + k: v for k, v in img.items() if k.endswith('_val')})
+    rec['info.json'] = np.array(json.dumps(info))
+    rec['eval.gt_ranks'], rec['eval.all_ranks'] = gt_r.astype(np.int64), all_r.astype(np.int64)
     return rec, worst
 
 
@@ -182,7 +224,8 @@ def main():
         rec, worst = run_case(enc, dec)
         np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'ref_train__%s__%s.npz' % (enc, dec)), **rec)
         print('%-22s + %-4s  train.lua end to end: opts.lua, dataloader.lua, Model, 4 iterations with dropout, 3 checkpoints; final flat '
-              'vector vs the oracle replay: max |dW| %.1e' % (enc, dec, worst), flush=True)
+              'vector vs the oracle replay: max |dW| %.1e; evaluate.lua on the checkpoint (-useGt true / false, -saveRanks): ranks equal'
+              % (enc, dec, worst), flush=True)
 
 
 if __name__ == '__main__':

@@ -1,5 +1,6 @@
 """Fixtures made by EXECUTING the reference's unedited train.lua END TO END under tests/luavm (tests/golden/make_reference_train_golden.py):
-opts.lua -> dataloader.lua on a small raw dataset -> Model -> four training iterations with dropout on -> torch.save of the checkpoints.
+opts.lua -> dataloader.lua on a small raw dataset -> Model -> four training iterations with dropout on -> torch.save of the checkpoints,
+then the unedited evaluate.lua on the epoch-2 checkpoint and the val split (-useGt true: Model:retrieve, false: Model:predict, -saveRanks).
 Stored: the raw dataset, the initial flat vector (wrapper:getParameters() order), the thread ids and the Dropout noise of every iteration,
 and where the run ended (flat vector after epoch 1 and at the end, learning rate, runningLoss).
 
@@ -27,7 +28,7 @@ def load(path):
     z = np.load(path)
     get = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
     opt = derive(json.loads(str(z['opt.json'])))
-    dl = Dataloader(seed=1).from_arrays(json.loads(str(z['info.json'])), get('raw.'), get('img.'), opt, ['train'])
+    dl = Dataloader(seed=1).from_arrays(json.loads(str(z['info.json'])), get('raw.'), get('img.'), opt, ['train', 'val'])
     spec = vo.param_spec(opt['encoder'], opt['decoder'], opt)
 
     def batch(it):
@@ -39,6 +40,7 @@ def load(path):
             b['answer_ind'] = b['answer_ind'].reshape(-1)
         return b
     masks = lambda it: get('it%d.mask.' % it)
+    batch.loader = dl
     return z, opt, spec, batch, masks
 
 
@@ -77,6 +79,15 @@ def test_oracle_replays_the_executed_train_lua(path):
     assert (np.abs((flat - z['W0']) - z['final.delta']) < 1e-9 + 1e-7 * np.abs(z['final.delta'])).all()     # model_epoch_2.t7 == the final state
     assert abs(lr - float(z['end'][0])) < 1e-15 and abs(rl - float(z['end'][1])) < 1e-9 * max(1.0, abs(rl))
     assert np.abs(z['final.delta']).max() > 1e-3                                     # (four Adam steps did move the weights)
+    # evaluate.lua on that checkpoint: val split in batches of 2 (dataloader.lua:342-375), retrieveBatch + utils.computeRanks
+    val, start, gt_r, all_r = batch.loader, 1, [], []
+    while start <= 5:
+        b, start = val.getTestBatch(start, dict(opt, batchSize=2), 'val')
+        sc = vo.retrieve(enc, dec, P, opt, b)
+        gt_r.append(vo.compute_ranks(sc, np.asarray(b['answer_ind']).reshape(-1) - 1).reshape(-1, 10))
+        all_r.append(vo.compute_ranks(sc).reshape(-1, 10, sc.shape[1]))
+    np.testing.assert_array_equal(np.concatenate(gt_r), z['eval.gt_ranks'])
+    np.testing.assert_array_equal(np.concatenate(all_r), z['eval.all_ranks'])
 
 
 @pytest.mark.gpu
@@ -117,3 +128,27 @@ def test_hip_hosts_replay_the_executed_train_lua(path):
             assert np.linalg.norm(err) <= 0.02 * np.linalg.norm(want[k]) + 1e-6, (k, float(np.linalg.norm(err)), float(np.linalg.norm(want[k])))
         assert abs(host.optims['learningRate'] - float(z['end'][0])) < 1e-7 * opt['learningRate']
         assert abs(host.runningLoss - float(z['end'][1])) < 1e-4 * max(1.0, abs(float(z['end'][1])))
+        # evaluate.lua's two modes on the REFERENCE's final weights, through the product's split loops (visdial_amd/split_eval.py)
+        host.set_parameters_dict({k: (W0[k].astype(np.float64) + want[k]).astype(np.float32) for k in W0})
+        host.set_dropout_masks(None)
+        host.params['batchSize'] = 2
+        # (the 100 candidates of a round are drawn from a 40-entry option list: exact duplicates tie, and fp32 may order a tie group
+        #  differently -- a rank may move by at most the number of candidates whose fp64 score lies within 1e-3 of the candidate's own)
+        Pf = {k: W0[k].astype(np.float64) + want[k] for k in W0}
+        start, sc = 1, []
+        while start <= 5:
+            b, start = batch.loader.getTestBatch(start, dict(opt, batchSize=2), 'val')
+            sc.append(vo.retrieve(enc, opt['decoder'], Pf, opt, b).reshape(-1, 10, 100))
+        sc = np.concatenate(sc)
+        near = (np.abs(sc[..., :, None] - sc[..., None, :]) < 1e-3 * np.maximum(1.0, np.abs(sc[..., :, None]))).sum(-1) - 1      # [5, 10, 100]
+        metrics, recs = host.retrieve(batch.loader, 'val')
+        got = np.array([r['ranks'] for r in recs]).reshape(5, 10)
+        gt_opt = np.argmax(z['eval.all_ranks'] == z['eval.gt_ranks'][..., None], axis=-1)                   # which candidate is the ground truth
+        slack = np.take_along_axis(near, gt_opt[..., None], -1)[..., 0]
+        assert (np.abs(got - z['eval.gt_ranks']) <= slack).all()
+        assert [(r['image_id'], r['round_id']) for r in recs] == [(100 + i, j + 1) for i in range(5) for j in range(10)]
+        pred = host.predict(batch.loader, 'val')
+        got = np.array([r['ranks'] for r in pred]).reshape(5, 10, -1)
+        assert (np.abs(got - z['eval.all_ranks']) <= near).all()
+        assert (got == z['eval.all_ranks']).mean() > 0.5
+        host.params['batchSize'] = opt['batchSize']
