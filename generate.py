@@ -34,7 +34,10 @@ def main():
     p = opts.derive(saved['modelParams'])                      # generate.lua:57-70
     p['gpuid'] = a['gpuid']
     p.update(inputImg=a['inputImg'], inputQues=a['inputQues'], inputJson=a['inputJson'])
-    dl = Dataloader(seed=1234).initialize(p, ['val'])
+    # generate.lua:57-70 derives useHistory / useIm for the dataloader but NOT concatHistory (train.lua and evaluate.lua do): the history
+    # of a generation run is the previous round's question + answer even for the lf-* encoders, with the default maxHistoryLen.
+    # Reproduced as is (found by executing generate.lua: tests/golden/make_reference_train_golden.py).
+    dl = Dataloader(seed=1234).initialize(dict(p, concatHistory=False, maxHistoryLen=60), ['val'])
     for k in ('vocabSize', 'maxQuesCount', 'maxQuesLen', 'maxAnsLen'):
         p[k] = getattr(dl, k)
     if a['host'] == 'native':

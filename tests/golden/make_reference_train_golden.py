@@ -198,6 +198,51 @@ def run_case(enc, dec, seed=5):
     rec.update({'img.' + k: v for k, v in img.items() if k.endswith('_val')})
     rec['info.json'] = np.array(json.dumps(info))
     rec['eval.gt_ranks'], rec['eval.all_ranks'] = gt_r.astype(np.int64), all_r.astype(np.int64)
+
+    # ---- generate.lua, unedited (gen decoder): beam search over the first two val dialogs, results.json.  NOTE generate.lua:57-70 sets
+    #      useHistory / useIm but NOT concatHistory: the dataloader builds per-round history there even for the lf-* encoders.
+    if dec == 'gen':
+        V = int(opt['vocabSize'])
+        START, END = V - 1, V
+        gen_opt = dict(opt, concatHistory=False, maxHistoryLen=60)
+        gval = Dataloader(seed=1).from_arrays(json.loads(json.dumps(info)), raw, img, gen_opt, ['val'])
+        gb = [gval.getIndexData(np.array([c]), gen_opt, 'val') for c in (1, 2)]
+        bs, bl = 5, 10
+        for bias in (0.0, 0.05, 0.1, 0.2, 0.3, 0.5, 0.8):          # (model.lua:577 needs a finished beam in every round: see make_reference_goldens.py)
+            Pg = {k: v.copy() for k, v in Pf.items()}
+            Pg['vocab.b'][END - 1] += bias
+            beams = [vo.generate_beam(enc, Pg, gen_opt, b, bs, bl, START, END) for b in gb]
+            if all(END in toks for conv in beams for toks, _ in conv):
+                break
+        else:
+            raise AssertionError('no <END> bias finishes every round')
+        flatg = np.concatenate([Pg[n].reshape(-1) for n, _, _ in t7.reference_order(enc, spec)])
+        loaded.set('modelW', vm.torch.tensor(flatg.copy(), 'Double'))
+        res_dir = os.path.join(tmp, 'results')
+        os.makedirs(res_dir, exist_ok=True)
+        vm.globals.set('arg', to_lua(vm, ['-inputJson', jpath, '-inputQues', 'ques.h5', '-inputImg', 'img.h5', '-gpuid', '-1', '-loadPath',
+                                          os.path.join(tmp, 'ck', 'model_epoch_2.t7'), '-resultPath', res_dir, '-beamSize', str(bs),
+                                          '-beamLen', str(bl), '-maxThreads', '2']))
+        vm.dofile('generate.lua')
+        out = json.load(open(os.path.join(res_dir, 'results.json')))
+        ind2word = {int(i): w for w, i in info['word2ind'].items()}
+        ind2word[START], ind2word[END] = '<START>', '<END>'
+
+        def words(vec):
+            s_ = ''
+            for t in vec:
+                if t > 0:
+                    s_ += ' ' + ind2word[int(t)]
+                    if ind2word[int(t)] == '<END>':
+                        break
+            return s_
+        assert [d['image_id'] for d in out['data']] == [100, 101]
+        for c in range(2):
+            assert [r['answer'] for r in out['data'][c]['dialog']] == [words(toks) for toks, _ in beams[c]], (c, out['data'][c]['dialog'])
+            assert [r['question'] for r in out['data'][c]['dialog']] == [words(q) for q in gb[c]['ques_fwd'][0]]
+        rec['gen.vocab_b'] = Pg['vocab.b'].copy()
+        rec['gen.tokens'] = np.array([[toks for toks, _ in conv] for conv in beams], dtype=np.int64)
+        rec['gen.params'] = np.array([bs, bl, START, END], dtype=np.int64)
     return rec, worst
 
 
@@ -224,8 +269,8 @@ def main():
         rec, worst = run_case(enc, dec)
         np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'ref_train__%s__%s.npz' % (enc, dec)), **rec)
         print('%-22s + %-4s  train.lua end to end: opts.lua, dataloader.lua, Model, 4 iterations with dropout, 3 checkpoints; final flat '
-              'vector vs the oracle replay: max |dW| %.1e; evaluate.lua on the checkpoint (-useGt true / false, -saveRanks): ranks equal'
-              % (enc, dec, worst), flush=True)
+              'vector vs the oracle replay: max |dW| %.1e; evaluate.lua on the checkpoint (-useGt true / false, -saveRanks): ranks equal%s'
+              % (enc, dec, worst, '; generate.lua (beam search, results.json): answers token-exact' if dec == 'gen' else ''), flush=True)
 
 
 if __name__ == '__main__':

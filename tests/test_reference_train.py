@@ -1,6 +1,7 @@
 """Fixtures made by EXECUTING the reference's unedited train.lua END TO END under tests/luavm (tests/golden/make_reference_train_golden.py):
 opts.lua -> dataloader.lua on a small raw dataset -> Model -> four training iterations with dropout on -> torch.save of the checkpoints,
-then the unedited evaluate.lua on the epoch-2 checkpoint and the val split (-useGt true: Model:retrieve, false: Model:predict, -saveRanks).
+then the unedited evaluate.lua on the epoch-2 checkpoint and the val split (-useGt true: Model:retrieve, false: Model:predict, -saveRanks)
+and, for the gen pair, the unedited generate.lua (beam search over two val dialogs -> results.json).
 Stored: the raw dataset, the initial flat vector (wrapper:getParameters() order), the thread ids and the Dropout noise of every iteration,
 and where the run ended (flat vector after epoch 1 and at the end, learning rate, runningLoss).
 
@@ -42,6 +43,13 @@ def load(path):
     masks = lambda it: get('it%d.mask.' % it)
     batch.loader = dl
     return z, opt, spec, batch, masks
+
+
+def _gen_batches(z, opt):
+    get = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
+    gopt = dict(opt, concatHistory=False, maxHistoryLen=60)
+    dl = Dataloader(seed=1).from_arrays(json.loads(str(z['info.json'])), get('raw.'), get('img.'), gopt, ['val'])
+    return [dl.getIndexData(np.array([c]), gopt, 'val') for c in (1, 2)]
 
 
 def split(flat, spec, enc):
@@ -88,6 +96,13 @@ def test_oracle_replays_the_executed_train_lua(path):
         all_r.append(vo.compute_ranks(sc).reshape(-1, 10, sc.shape[1]))
     np.testing.assert_array_equal(np.concatenate(gt_r), z['eval.gt_ranks'])
     np.testing.assert_array_equal(np.concatenate(all_r), z['eval.all_ranks'])
+    if dec == 'gen':          # generate.lua: per-round history (it never sets concatHistory), beams of the first two val dialogs
+        bs, bl, START, END = (int(v) for v in z['gen.params'])
+        Pg = dict(P)
+        Pg['vocab.b'] = z['gen.vocab_b'].astype(np.float64)
+        for c, gb in enumerate(_gen_batches(z, opt)):
+            got = vo.generate_beam(enc, Pg, dict(opt, concatHistory=False, maxHistoryLen=60), gb, bs, bl, START, END)
+            np.testing.assert_array_equal(np.array([t for t, _ in got]), z['gen.tokens'][c])
 
 
 @pytest.mark.gpu
@@ -152,3 +167,29 @@ def test_hip_hosts_replay_the_executed_train_lua(path):
         assert (np.abs(got - z['eval.all_ranks']) <= near).all()
         assert (got == z['eval.all_ranks']).mean() > 0.5
         host.params['batchSize'] = opt['batchSize']
+        if opt['decoder'] == 'gen':          # generate.lua's beams, through the product's host loop
+            bs, bl, START, END = (int(v) for v in z['gen.params'])
+            Pg = {k: (W0[k].astype(np.float64) + want[k]).astype(np.float32) for k in W0}
+            Pg['vocab.b'] = z['gen.vocab_b'].astype(np.float32)
+            host.set_parameters_dict(Pg)
+            gbs = _gen_batches(z, opt)
+            words = {int(i): w for w, i in json.loads(str(z['info.json']))['word2ind'].items()}
+            words[START], words[END] = '<START>', '<END>'
+
+            class GenLoader(object):
+                word2ind, ind2word, numThreads, unique_img_val = {'<START>': START, '<END>': END}, words, {'val': 2}, [100, 101]
+
+                def getIndexData(self, inds, params, dtype):
+                    return gbs[int(np.asarray(inds).reshape(-1)[0]) - 1]
+            out = host.generateAnswers(GenLoader(), 'val', dict(beamSize=bs, beamLen=bl, maxThreads=2))
+            for c in range(2):
+                want_txt = []
+                for toks in z['gen.tokens'][c]:
+                    s_ = ''
+                    for t in toks:
+                        if t > 0:
+                            s_ += ' ' + words[int(t)]
+                            if words[int(t)] == '<END>':
+                                break
+                    want_txt.append(s_)
+                assert [d['answer'] for d in out[c]['dialog']] == want_txt, (type(host).__name__, c)
