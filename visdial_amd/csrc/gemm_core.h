@@ -25,7 +25,7 @@
 
 // Diagnostic build only (-DVD_TIMING, `make timing`): wave 0 of every workgroup stamps the shader clock
 // (s_memtime) at the phase boundaries of gemm_block and the 100 MHz chip-wide clock (s_memrealtime) at
-// its start and end; scripts/block_timing.py reads the table back.  Never compiled into the product.
+// its start and end; scripts/mb_c16.py reads the table back (vd_debug_timing).  Never compiled into the product.
 #ifdef VD_TIMING
 #define VD_TSLOTS 12
 #define VD_TBLOCKS 8192
