@@ -104,13 +104,17 @@ def test_gemm_tn_rows_acc(ops, M, N, R, K):
     assert relerr(C, ref) < 1e-5
 
 
-def test_colsum(ops):
+@pytest.mark.parametrize("M,N,ld", [(8001, 2048, None), (9800, 512, None), (11323, 2048, None), (63, 2048, None), (4001, 300, 304),
+                                    (777, 11322, 11324), (65, 4, None), (1, 2048, None)])
+def test_colsum(ops, M, N, ld):
+    """bias gradients: the float4 kernel (N % 4 == 0, aligned rows, M >= 64: ragged row counts, a narrowed view with ld > N) and the
+    scalar one (N % 4 != 0, short M)"""
     rng = np.random.RandomState(0)
-    X = f32(rng, 8001, 2048)
-    out0 = f32(rng, 2048)
+    X = f32(rng, M, ld or N)
+    out0 = f32(rng, N)
     out = dev(out0)
-    ops.colsum_acc(dev(X), out)
-    assert relerr(out, out0 + X.astype(np.float64).sum(0)) < 1e-5
+    ops.colsum_acc(dev(X), out, M=M, N=N, ld=ld or N)
+    assert relerr(out, out0 + X[:, :N].astype(np.float64).sum(0)) < 1e-5
 
 
 # N >= 2048 rows take the LDS-DMA pipeline: H = 32 / 64 / 96 give 2, 4 and 6 K tiles in the forward step (fewer
