@@ -55,7 +55,7 @@ int vd_copy_2d(float* dst, int64_t dst_ld, const float* src, int64_t src_ld, int
 /* VD_FLAG_SPLIT9 (vd_lstm_forward / vd_lstm_backward, throughput shapes): the recurrent product h*Wh / da*Wh^T as the EXACT
  * three-way bf16 split of both fp32 operands -- nine bf16 MFMAs with fp32 accumulation per fp32 one, every product exact
  * (csrc/split_core.h): fp32-grade results at 9/16 of the matrix-pipe time.  Opt-in; VD_FLAG_SPLIT6 / VD_FLAG_SPLIT3 drop the
- * smallest products (NOT fp32-grade: they exist for the error table of tests/test_split_gpu.py). */
+ * smallest products (NOT fp32-grade: they exist for the error table of tests/test_ops_gpu.py). */
 #define VD_FLAG_SPLIT9 2
 #define VD_FLAG_SPLIT6 4
 #define VD_FLAG_SPLIT3 8

@@ -487,3 +487,52 @@ def test_lstm2_wavefront_matches_oracle(ops):
     torch.cuda.synchronize()
     for s, r in stacks:
         assert relerr(s['gates2'], r['da2']) < 2e-5 and relerr(s['gates1'], r['da1']) < 2e-5
+
+
+def test_bf16_compact_state_saturated_gates(ops):
+    """configs[4] compact bf16 state (csrc/lstm.hip, EpiLstmFwdT<.., C16>): a sigmoid gate s > 1/2 is stored as s - 1.  A gate that
+    saturates to exactly 1.0f (pre-activation above ~16.6) must not be stored as +0 -- the backward pass would read s = 0 and cut the
+    cell gradient through a saturated forget gate.  Forget-gate pre-activations of +20 / +40 on most rows: dc0 and da
+    against the fp64 recurrence on the same bf16-rounded table and weights."""
+    import ctypes as C
+    from visdial_amd import _lib
+    lib = _lib.load()
+    fwd = getattr(lib, '_Z19vd_lstm_forward_c16PKtlPKiPKfPtS5_PfS6_iiiP12ihipStream_t')
+    bwd = getattr(lib, '_Z20vd_lstm_backward_c16PKfPtS0_S0_PfiiiP12ihipStream_t')
+    p = C.c_void_p
+    fwd.argtypes = [p, C.c_long, p, p, p, p, p, p, C.c_int, C.c_int, C.c_int, p]
+    bwd.argtypes = [p, p, p, p, p, C.c_int, C.c_int, C.c_int, p]
+    T, N, H, V = 4, 2048, 128, 50
+    rng = np.random.RandomState(11)
+    Wh = (f32(rng, H, 4 * H) / np.sqrt(H) * 0.5).astype(np.float32)
+    tab = f32(rng, V + 1, 4 * H) * 0.5
+    tab[1:40, H:2 * H] += 20.0           # forget gate saturates to exactly 1.0f in fp32 ...
+    tab[40:, H:2 * H] += 40.0
+    tab[1:20, 0:H] += 18.0               # ... and so do some input / output gates
+    tab[20:40, 2 * H:3 * H] += 25.0
+    tab16 = dev(tab).to(torch.bfloat16)
+    Wh16 = dev(Wh).to(torch.bfloat16)
+    tok = rng.randint(1, V + 1, size=(T, N)).astype(np.int32)
+    dh_last = f32(rng, N, H)
+    gates16 = torch.empty(T, N, 4 * H, device='cuda', dtype=torch.bfloat16)
+    h16 = torch.empty(T, N, H, device='cuda', dtype=torch.bfloat16)
+    h_last = torch.empty(N, H, device='cuda')
+    c = torch.empty(T, N, H, device='cuda')
+    dc = torch.empty(N, H, device='cuda')
+    Whd, tokd, dhd = dev(Wh), dev(tok), dev(dh_last)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert fwd(tab16.data_ptr(), 4 * H, tokd.data_ptr(), Whd.data_ptr(), gates16.data_ptr(), h16.data_ptr(), h_last.data_ptr(),
+               c.data_ptr(), T, N, H, stream) == 0
+    torch.cuda.synchronize()
+    # fp64 recurrence on the operands the kernel multiplies: bf16 table rows, bf16 weights (h is rounded to bf16 between steps: inside the bound)
+    xw = tab16.float().cpu().numpy().astype(np.float64)[tok]                       # [T, N, 4H] = the gathered projection rows
+    W = np.concatenate([np.eye(4 * H), Wh16.float().cpu().numpy().astype(np.float64)], 0)    # x = the projection itself (Wx = I, b = 0)
+    h_ref, c_ref, g_ref = vo.lstm_forward(xw, W, np.zeros(4 * H))
+    assert (g_ref[:, :, H:2 * H].astype(np.float32) == 1.0).mean() > 0.5           # the case under test is present
+    assert relerr(c, c_ref) < 1e-2 and relerr(h_last, h_ref[-1]) < 1e-2
+    assert bwd(Whd.data_ptr(), gates16.data_ptr(), c.data_ptr(), dhd.data_ptr(), dc.data_ptr(), T, N, H, stream) == 0
+    torch.cuda.synchronize()
+    _, _, _, _, dc0_ref, da_ref = vo.lstm_backward(xw, W, g_ref, h_ref, c_ref, dh_last=dh_last.astype(np.float64), return_da=True)
+    # with the +0 encoding dc0 lost every path through a saturated forget gate (rel-L2 ~ 1); the bf16 bound of the config is 2e-2
+    assert relerr(dc, dc0_ref) < 2e-2, relerr(dc, dc0_ref)
+    assert relerr(gates16.float(), da_ref) < 2e-2, relerr(gates16.float(), da_ref)

@@ -271,9 +271,13 @@ struct EpiLstmFwdT {
         if constexpr (C16) {                                           // compact state: bf16 gates, fp32 c, bf16 h (+ fp32 h at the last step)
           // a sigmoid gate s > 1/2 is stored as s - 1 = -(1 - s): the backward pass needs s AND 1 - s, and near saturation bf16
           // keeps only one of them (spacing 2^-8 below 1); the sign says which one was stored, both come back to 2^-9 relative
-#define VD_ENC(v) v.x = v.x > 0.5f ? v.x - 1.f : v.x; v.y = v.y > 0.5f ? v.y - 1.f : v.y; v.z = v.z > 0.5f ? v.z - 1.f : v.z; v.w = v.w > 0.5f ? v.w - 1.f : v.w;
+          // (a gate that saturates to exactly 1.0f -- pre-activation above ~16.6 -- must not encode as +0 = "s = 0": the stored value of the
+          //  s - 1 case is kept strictly negative; -1e-30 is a bf16 normal and decodes to s = 1, s (1 - s) = 1e-30)
+#define VD_ENC1(x) x = x > 0.5f ? fminf(x - 1.f, -1e-30f) : x;
+#define VD_ENC(v) VD_ENC1(v.x) VD_ENC1(v.y) VD_ENC1(v.z) VD_ENC1(v.w)
           VD_ENC(gi) VD_ENC(gf) VD_ENC(go)
 #undef VD_ENC
+#undef VD_ENC1
           vd_buf_st4_bf16(rg, vg >> 1, 2u * sp, gi);
           vd_buf_st4_bf16(rg, vg >> 1, 2u * sp + (uH4 >> 1), gf);
           vd_buf_st4_bf16(rg, vg >> 1, 2u * sp + uH4, go);
@@ -599,10 +603,10 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
   SrcRow a{da_next, 4L * H};
   SrcRow b{Wh, 4L * H};  // B[k][n] = Wh[n][k]
   if (W3 && K > 0 && !(dh_a && dh_b)) {   // exact-operand split: da_{t+1} stays fp32 in memory, Wh as three bf16 planes
-    EpiLstmBwd<2, 2, false> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
-    if (flags & VD_FLAG_SPLIT9) return launch_gemm_split<2, 9>(N, H, K, da_next, 4L * H, W3, 4L * H, 4L * H * H, e, s);
-    if (flags & VD_FLAG_SPLIT6) return launch_gemm_split<2, 6>(N, H, K, da_next, 4L * H, W3, 4L * H, 4L * H * H, e, s);
-    return launch_gemm_split<2, 3>(N, H, K, da_next, 4L * H, W3, 4L * H, 4L * H * H, e, s);
+    EpiLstmBwd<4, 2, false> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};   // 128 x 128 tiles: half the A re-reads of the fp32 kernel's 128 x 64
+    if (flags & VD_FLAG_SPLIT9) return launch_gemm_split<9>(N, H, K, da_next, 4L * H, W3, 4L * H, 4L * H * H, e, s);
+    if (flags & VD_FLAG_SPLIT6) return launch_gemm_split<6>(N, H, K, da_next, 4L * H, W3, 4L * H, 4L * H * H, e, s);
+    return launch_gemm_split<3>(N, H, K, da_next, 4L * H, W3, 4L * H, 4L * H * H, e, s);
   }
   if ((flags & VD_FLAG_BF16) && N >= 2048 && K > 0) {
     EpiLstmBwd<2> e{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H, da16};
@@ -849,11 +853,11 @@ int vd_lstm_forward(const float* xproj, int64_t x_tstride, int64_t x_ld, const i
     else if (bf16 && hp)
       rc = launch_gemm<CfgFbf16>(N, 4 * H, H, 1, SrcRow{hp, H}, SrcRow{WhT, H}, e, s);
     else if (split == 9 && hp)
-      rc = launch_gemm_split<4, 9>(N, 4 * H, H, hp, (long)H, W3, (long)H, 4L * H * H, e, s);
+      rc = launch_gemm_split<9>(N, 4 * H, H, hp, (long)H, W3, (long)H, 4L * H * H, e, s);
     else if (split == 6 && hp)
-      rc = launch_gemm_split<4, 6>(N, 4 * H, H, hp, (long)H, W3, (long)H, 4L * H * H, e, s);
+      rc = launch_gemm_split<6>(N, 4 * H, H, hp, (long)H, W3, (long)H, 4L * H * H, e, s);
     else if (split == 3 && hp)
-      rc = launch_gemm_split<4, 3>(N, 4 * H, H, hp, (long)H, W3, (long)H, 4L * H * H, e, s);
+      rc = launch_gemm_split<3>(N, 4 * H, H, hp, (long)H, W3, (long)H, 4L * H * H, e, s);
     else if (glds && hp)
       rc = launch_gemm_glds<CfgF9, false>(N, 4 * H, H, 1, hp, (long)H, WhT, (long)H, e, s);
     else

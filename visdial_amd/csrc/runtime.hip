@@ -36,14 +36,18 @@ int upload_tokens(BatchSlot& sl, SeqTok& ss, const std::string& tag, const int32
   VD_TRY(pin_get(sl.pinned, tag + ".stage", total * sizeof(int32_t), (void**)&stage));
   int32_t* tok = stage;
   std::vector<int> len(sorted ? N : 0);
+  // A row's length is counted FROM ITS FIRST NON-ZERO TOKEN: the wavefront skips a row only at the steps before that token, where
+  // maskZero() keeps the state at zero (exact), and applies the per-token mask inside the active span -- so a row that is not the
+  // dataloader's right-aligned layout (left-aligned, interior zeros: reachable through the generic C ABI) is encoded exactly like the
+  // masked per-step stack does.  For right-aligned rows this is the count of non-zero tokens.
   for (int n = 0; n < N; ++n) {
-    int l = 0;
+    int first = T;
     for (int t = 0; t < T; ++t) {
       const int32_t v = rows_major[(size_t)n * T + t];
       tok[(size_t)t * N + n] = v;
-      l += v != 0;
+      if (v != 0 && first == T) first = t;
     }
-    if (sorted) len[n] = l;
+    if (sorted) len[n] = T - first;
   }
   if (sorted) {
     int32_t* tok_sorted = stage + TN;

@@ -5,14 +5,21 @@
 // bf16 values is exact in fp32, so  A * B = sum_{i,j in {hi,mid,lo}} A_i * B_j  -- nine bf16 MFMAs (v_mfma_f32_32x32x16_bf16,
 // fp32 accumulation) per fp32 one, 9/16 of the matrix-pipe time, every product exact.  NPROD selects the products that are
 // issued: 9 = all (fp32-grade), 6 = those with i + j <= 2 (drops terms below 2^-24 of the largest), 3 = i + j <= 1, 1 = plain
-// bf16.  Only 9 is a substitute for fp32; the others exist for the error table (tests/test_split_gpu.py).
+// bf16.  Only 9 is a substitute for fp32; the others exist for the error table (tests/test_ops_gpu.py).
 //
 // Operands: A [M x K] fp32 rows exactly as the fp32 kernels read them -- the activations stay fp32 in memory, a wave splits its
-// fragments into three bf16 planes IN REGISTERS (VALU work that hides under the MFMA burst) -- and B as three precomputed bf16
-// planes Bt_p [N x K] (k contiguous; the recurrent weights, converted once per pass).  Tiles go global -> LDS by DMA with the
-// chunk swizzle of gemm_block_glds; one macro step = 16 k = one fp32 A tile [BM x 16] (64-byte rows) + three bf16 B tiles [BN x 16]
-// (32-byte rows): 20 KB per stage at 128 x 128, two stages = 40 KB, so THREE workgroups share a CU like the fp32 kernels -- the
-// epilogue of one (HBM-bound: gates, c, h, the projection-table gather) runs under the MFMAs of the others.
+// fragments into three bf16 planes IN REGISTERS -- and B as three precomputed bf16 planes Bt_p [N x K] (k contiguous; the recurrent
+// weights, converted once per pass).  Tiles go global -> LDS by DMA; one macro step = 16 k = one fp32 A tile [128 x 16] (64-byte rows,
+// chunk swizzle of gemm_block_glds) + three bf16 B tiles [128 x 16] (32-byte rows, chunk swizzle (row >> 4) & 1: conflict-free for
+// ds_read_b128's lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}, SQ_LDS_BANK_CONFLICT = 0; round 4's (row >> 2) & 1 was two-way
+// conflicted on every B read): 20 KB per stage, two stages = 40 KB, four workgroups per CU -- the epilogue of one (gates, c, h, the
+// projection-table gather) runs under the MFMAs of the others.  Per K step a B plane's four fragments are read once and multiplied
+// with the three A planes, column tile innermost: consecutive MFMAs never share an accumulator.
+//
+// What bounds it (profiles/r05_experiments.txt section 1): POWER.  v_mfma_f32_32x32x16_bf16 on non-zero operands sustains 1.85 PFLOP/s
+// on this chip, not 2.5 (scripts/probes/mfma_bf16_peak.hip: the clock falls to ~1.75 GHz); 9 x 41.9 GFLOP take 204 us at that rate with
+// the pipe 100 % busy.  The K loop alone runs 299 us on random operands and 206 us on zeros (same code, same cycles, higher clock);
+// bigger wave tiles (64 x 128 per wave: half the LDS-DMA bytes and fragment reads per MFMA) do not change it.
 #pragma once
 #include "gemm_core.h"
 
@@ -54,31 +61,49 @@ static int weights_to_bf16x3(const float* src, vd_bf16_bits* dst, long n, hipStr
   return VD_OK;
 }
 
-template <int NT_, int NSTAGE_ = 2>
 struct SplitCfg {
-  static constexpr int NT = NT_, WM = 4, THREADS = 256, NSTAGE = NSTAGE_;
-  static constexpr int BM = 128, BN = NT * 32;
+  static constexpr int NT = 4, WM = 4, THREADS = 256;
+  static constexpr int BM = 128, BN = 128;
   static constexpr int ATILE = BM * 64;                           // [BM rows][16 fp32]      = 64-byte rows
   static constexpr int BTILE = BN * 32;                           // [BN rows][16 bf16]      = 32-byte rows, one per plane
   static constexpr int STAGE = ATILE + 3 * BTILE;                 // one macro step = 16 k
-  static constexpr int LDS_BYTES = (NSTAGE * STAGE > 4 * 4096) ? NSTAGE * STAGE : 4 * 4096;   // (>= the epilogue's 4 KB per wave)
+#ifndef VD_SPLIT_LDS
+#define VD_SPLIT_LDS 41984                                        // as the fp32 step kernels: three workgroups per CU + room for one latency-shape
+#endif                                                            // workgroup of the encoder streams (`make variant DEFS=-DVD_SPLIT_LDS=40960`: four)
+  static constexpr int LDS_BYTES = VD_SPLIT_LDS;
+  static_assert(LDS_BYTES >= 2 * STAGE, "two stages of 20 KB");
 };
 
-template <int NT, int NPROD, int NSTAGE, class Epi>
-__device__ __forceinline__ void gemm_block_split(int M, int N, int K, int row_base, int col_base, const float* A, long lda,
-                                                 const vd_bf16_bits* B, long ldb, long bplane, const Epi& epi, float* smem) {
-  using Cfg = SplitCfg<NT, NSTAGE>;
-  constexpr int WM = Cfg::WM, BM = Cfg::BM;
-  constexpr int NIA = (BM / 16) / WM;                            // 1 KB DMA instructions per wave: A tile = 8
-  // B: one plane tile = BN / 32 instructions (32 rows of 32 bytes each); 3 planes.  NT = 4: 12 instructions, 3 per wave (wave w
-  // takes row group w of every plane).  NT = 2: 6 instructions -> 2 per wave, instruction ids {w, w + 4} mod 6 (two are issued
-  // twice: identical bytes to the identical place) so that every wave has the SAME count and the vmcnt immediates are uniform
-  constexpr int NIB = NT == 4 ? 3 : 2;
-  static_assert(NT == 4 || NT == 2, "split pipeline: 128- or 64-column tiles");
-  constexpr int PER_STEP = NIA + NIB;
+// workgroup id -> tile.  When the column tiles divide over the 8 XCDs, every XCD owns a COLUMN slice of the weight planes (resident
+// in its 4 MB L2: the three planes together are 6 MB) and walks all row tiles (block b runs on XCD b % 8); else XCD-contiguous
+// ranges with the column tile fastest.
+__device__ __forceinline__ void split_tile_of(int bid, int nwg, int tiles_n, int& tile_m, int& tile_n) {
+  if ((tiles_n & 7) == 0) {
+    const int xcd = bid & 7, li = bid >> 3, cpx = tiles_n >> 3;
+    tile_n = xcd * cpx + li % cpx;
+    tile_m = li / cpx;
+    return;
+  }
+  const int wg = xcd_remap(bid, nwg);
+  tile_n = wg % tiles_n;
+  tile_m = wg / tiles_n;
+}
+
+template <int NPROD, class Epi>
+__global__ void __launch_bounds__(256, 3)
+gemm_split_kernel(int M, int N, int K, int tiles_n, const float* A, long lda, const vd_bf16_bits* B, long ldb, long bplane, Epi epi) {
+  using Cfg = SplitCfg;
+  constexpr int NT = Cfg::NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int tile_m, tile_n;
+  split_tile_of((int)blockIdx.x, (int)gridDim.x, tiles_n, tile_m, tile_n);
+  const int row_base = tile_m * Cfg::BM, col_base = tile_n * Cfg::BN;
+  constexpr int NIA = 2;                                         // this wave's own 32 rows = 2 pieces of 16 rows x 64 bytes
+  constexpr int NIB = 3;                                         // row group `wave` (32 rows x 32 bytes) of every plane
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nm = K / 16;                                         // macro steps
+  const int wrow = row_base + wm * 32;                           // first row of this wave
 
   f32x16 acc[NT];
 #pragma unroll
@@ -87,72 +112,46 @@ __device__ __forceinline__ void gemm_block_split(int M, int N, int K, int row_ba
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   typename EpiPreOf<Epi>::type pre;
-  if constexpr (EpiPreOf<Epi>::value) epi.preload(pre, row_base + wm * 32, lane, M);
+  if constexpr (EpiPreOf<Epi>::value) epi.preload(pre, wrow, lane, M);
 
   // per-thread source byte offsets of this wave's DMA instructions (macro step 0); chunk index swizzled on the source side
-  unsigned voffa[NIA], voffb[NIB], ldsb[NIB];
-  long planeb[NIB];
+  unsigned voffa[NIA], voffb[NIB];
 #pragma unroll
   for (int i = 0; i < NIA; ++i) {
-    const int r = (i * WM + wm) * 16 + (lane >> 2);
+    const int r = wm * 32 + i * 16 + (lane >> 2);
     const int c = (lane & 3) ^ ((r >> 2) & 3);
     voffa[i] = (unsigned)(((long)min(row_base + r, M - 1) * lda + c * 4) * 4);
   }
+  {
+    const int r = wm * 32 + (lane >> 1);
+    const int c = (lane & 1) ^ ((r >> 4) & 1);
+    const unsigned v = (unsigned)(((long)min(col_base + r, N - 1) * ldb + c * 8) * 2);
 #pragma unroll
-  for (int i = 0; i < NIB; ++i) {
-    int plane, grp;                                              // which plane, which 32-row group of its tile
-    if constexpr (NT == 4) { plane = i; grp = wm; }
-    else { const int id = (wm + 4 * i) % 6; plane = id >> 1; grp = id & 1; }
-    const int r = grp * 32 + (lane >> 1);
-    const int c = (lane & 1) ^ ((r >> 2) & 1);
-    voffb[i] = (unsigned)(((long)min(col_base + r, N - 1) * ldb + c * 8) * 2);
-    planeb[i] = (long)plane * bplane;
-    ldsb[i] = (unsigned)(Cfg::ATILE + plane * Cfg::BTILE + grp * 1024);
+    for (int i = 0; i < NIB; ++i) voffb[i] = v;
   }
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   auto issue = [&](int m, int st) {
     const unsigned base = lds0 + st * Cfg::STAGE;
 #pragma unroll
-    for (int i = 0; i < NIB; ++i) glds16(voffb[i], reinterpret_cast<const float*>(B + planeb[i] + (long)m * 16), base + ldsb[i]);
+    for (int i = 0; i < NIB; ++i)
+      glds16(voffb[i], reinterpret_cast<const float*>(B + (long)i * bplane + (long)m * 16), base + Cfg::ATILE + i * Cfg::BTILE + wm * 1024);
     const float* ak = A + (long)m * 16;
 #pragma unroll
-    for (int i = 0; i < NIA; ++i) glds16(voffa[i], ak, base + (i * WM + wm) * 1024);
-  };
-  auto wait_vm = [&](int n) {
-    switch (n) {
-      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-      case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
+    for (int i = 0; i < NIA; ++i) glds16(voffa[i], ak, base + (wm * NIA + i) * 1024);
   };
   const int hi = lane >> 5, l31 = lane & 31;
   const int sw = (l31 >> 2) & 3;
+  const int cb = (hi ^ ((l31 >> 4) & 1)) * 16;                   // this lane's 8 bf16 k inside a 32-byte B row
 
   if (nm > 0) {
-#pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-      if (s < nm) issue(s, s);
+    issue(0, 0);
     int st = 0;
     for (int m = 0; m < nm; ++m) {
-      const int ahead = m + NSTAGE - 1;
-      if (ahead < nm) {
-        int sa = st + NSTAGE - 1;
-        if (sa >= NSTAGE) sa -= NSTAGE;
-        issue(ahead, sa);
-        if constexpr (PER_STEP * (NSTAGE - 1) == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else if constexpr (PER_STEP * (NSTAGE - 1) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if constexpr (PER_STEP * (NSTAGE - 1) == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if constexpr (PER_STEP * (NSTAGE - 1) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if constexpr (PER_STEP * (NSTAGE - 1) == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-        else if constexpr (PER_STEP * (NSTAGE - 1) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else static_assert(PER_STEP * (NSTAGE - 1) <= 15, "steady-state vmcnt immediate");
+      if (m + 1 < nm) {
+        issue(m + 1, st ^ 1);
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");          // NIA + NIB requests of step m + 1 may stay in flight
       } else {
-        wait_vm(PER_STEP * (nm - 1 - m));                        // the tail: only the later steps' requests may still fly
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       asm volatile("s_barrier" ::: "memory");                    // every wave's share of macro step m has landed
       const char* sbase = reinterpret_cast<const char*>(smem) + st * Cfg::STAGE;
@@ -161,56 +160,47 @@ __device__ __forceinline__ void gemm_block_split(int M, int N, int K, int row_ba
       const float4 w = *reinterpret_cast<const float4*>(sa + (((hi * 2 + 1) ^ sw) * 4));
       vd_bf16x8 ap[3];
       vd_split3(u, w, ap[0], ap[1], ap[2]);
-      const int cb = (hi ^ (sw & 1)) * 16;                       // byte offset of this lane's 8 bf16 k inside a 32-byte B row
+      // plane p of B against planes i of A, smallest terms first; j innermost
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        vd_bf16x8 bp[3];
+      for (int p = 2; p >= 0; --p) {
+        vd_bf16x8 bp[NT];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int j = 0; j < NT; ++j) {
           const vd_f32x4 t = *reinterpret_cast<const vd_f32x4*>(sbase + Cfg::ATILE + p * Cfg::BTILE + (j * 32 + l31) * 32 + cb);
-          bp[p] = __builtin_bit_cast(vd_bf16x8, t);
+          bp[j] = __builtin_bit_cast(vd_bf16x8, t);
         }
-        // smallest products first
-#define VD_PROD(i, jj) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i], bp[jj], acc[j], 0, 0, 0);
-        if constexpr (NPROD >= 9) { VD_PROD(2, 2) VD_PROD(2, 1) VD_PROD(1, 2) }
-        if constexpr (NPROD >= 6) { VD_PROD(2, 0) VD_PROD(1, 1) VD_PROD(0, 2) }
-        if constexpr (NPROD >= 3) { VD_PROD(1, 0) VD_PROD(0, 1) }
-        VD_PROD(0, 0)
-#undef VD_PROD
+#pragma unroll
+        for (int i = 2; i >= 0; --i) {
+          constexpr int LIM = NPROD >= 9 ? 4 : NPROD >= 6 ? 2 : NPROD >= 3 ? 1 : 0;     // products with i + p <= LIM are issued
+          if (i + p > LIM) continue;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i], bp[j], acc[j], 0, 0, 0);
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage `st` may be refilled
-      if (++st == NSTAGE) st = 0;
+      st ^= 1;
     }
   }
-  if constexpr (EpiPreOf<Epi>::value) epi(acc, row_base + wm * 32, col_base, lane, M, N, smem + wm * 1024, &pre);
-  else epi(acc, row_base + wm * 32, col_base, lane, M, N, smem + wm * 1024);
-}
-
-template <int NT, int NPROD, int NSTAGE, class Epi>
-__global__ void __launch_bounds__(256, 3)
-gemm_split_kernel(int M, int N, int K, int tiles_m, int tiles_n, const float* A, long lda, const vd_bf16_bits* B, long ldb, long bplane, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
-  gemm_block_split<NT, NPROD, NSTAGE>(M, N, K, tile_m * SplitCfg<NT>::BM, tile_n * SplitCfg<NT>::BN, A, lda, B, ldb, bplane, epi, smem);
+  if constexpr (EpiPreOf<Epi>::value) epi(acc, wrow, col_base, lane, M, N, smem + wm * 1024, &pre);
+  else epi(acc, wrow, col_base, lane, M, N, smem + wm * 1024);
 }
 
 // C[M x N] = epi(A[M x K] (fp32 rows) * Bt[N x K]^T), Bt given as three bf16 planes; K % 16 == 0
-template <int NT, int NPROD, class Epi, int NSTAGE = 2>
+template <int NPROD, class Epi>
 static int launch_gemm_split(int M, int N, int K, const float* A, long lda, const vd_bf16_bits* B, long ldb, long bplane, const Epi& e,
                              hipStream_t stream) {
   if (M <= 0 || N <= 0) return VD_OK;
-  using Cfg = SplitCfg<NT, NSTAGE>;
+  using Cfg = SplitCfg;
   VD_CHECK_ARG(K % 16 == 0 && lda % 4 == 0 && ldb % 8 == 0 && (long)M * lda * 4 < (1L << 32) && (long)N * ldb * 2 < (1L << 32),
                "launch_gemm_split: unsupported shape M=%d N=%d K=%d", M, N, K);
   const int tiles_m = vd_cdiv(M, Cfg::BM), tiles_n = vd_cdiv(N, Cfg::BN);
-  auto kern = gemm_split_kernel<NT, NPROD, NSTAGE, Epi>;
+  auto kern = gemm_split_kernel<NPROD, Epi>;
   static bool attr_set = false;
   if (!attr_set) {
     VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Cfg::LDS_BYTES, stream, M, N, K, tiles_m, tiles_n, A, lda, B, ldb, bplane, e);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Cfg::LDS_BYTES, stream, M, N, K, tiles_n, A, lda, B, ldb, bplane, e);
   VD_LAUNCH_CHECK();
   return VD_OK;
 }
