@@ -20,6 +20,7 @@ def main():
     ap.add_argument('-inputQues', '--inputQues', default='data/visdial_data.h5')
     ap.add_argument('-inputJson', '--inputJson', default='data/visdial_params.json')
     ap.add_argument('-loadPath', '--loadPath', required=True)
+    ap.add_argument('-paramOrder', '--paramOrder', default='', help="layout of the .t7 flat vector: '' | declaration | <json> (visdial_amd/t7.py resolve_order)")
     ap.add_argument('-split', '--split', default='val')
     ap.add_argument('-useGt', '--useGt', type=int, default=1)
     ap.add_argument('-batchSize', '--batchSize', type=int, default=20)
@@ -48,7 +49,7 @@ def main():
         model = NativeModel(p)
     else:
         model = Model(p)
-    restore_weights(model, saved)          # evaluate.lua:91
+    restore_weights(model, saved, a.paramOrder or None)          # evaluate.lua:91
     print('Evaluating..')
     if a.perplexity:
         model.evaluate(dl, a.split)

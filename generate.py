@@ -20,6 +20,7 @@ def main():
     ap.add_argument('-inputQues', '--inputQues', default='data/visdial_data.h5')
     ap.add_argument('-inputJson', '--inputJson', default='data/visdial_params.json')
     ap.add_argument('-loadPath', '--loadPath', required=True)
+    ap.add_argument('-paramOrder', '--paramOrder', default='', help="layout of the .t7 flat vector: '' | declaration | <json> (visdial_amd/t7.py resolve_order)")
     ap.add_argument('-resultPath', '--resultPath', default='vis/results')
     ap.add_argument('-beamSize', '--beamSize', type=int, default=5)
     ap.add_argument('-beamLen', '--beamLen', type=int, default=20)
@@ -45,7 +46,7 @@ def main():
         model = NativeModel(p)
     else:
         model = Model(p)
-    restore_weights(model, saved)
+    restore_weights(model, saved, a['paramOrder'] or None)
     answers = model.generateAnswers(dl, 'val', dict(beamSize=a['beamSize'], beamLen=a['beamLen'],
                                                     maxThreads=a['maxThreads'], sampleWords=a['sampleWords'],
                                                     temperature=a['temperature']))

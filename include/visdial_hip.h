@@ -32,6 +32,10 @@ extern "C" {
 
 /* ---- library ------------------------------------------------------------------------- */
 const char* vd_last_error(void);
+/* Bumped whenever an exported symbol is removed or the meaning of an argument changes; hosts compare it with the VD_ABI_VERSION they
+ * were written against right after loading (visdial_amd/_lib.py, lua/visdial_ffi.lua).  2 = round 4's surface: vd_tune_set /
+ * vd_tune_clear / vd_lstm_seq_status removed, vd_model_params.lstmBf16 also takes 3 / 6 / 9 (exact-operand split). */
+#define VD_ABI_VERSION 2
 int vd_abi_version(void);
 int vd_device_count(int* count);
 int vd_set_device(int device);                 /* replaces cutorch.setDevice, train.lua:19 */

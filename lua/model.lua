@@ -378,6 +378,8 @@ local STEMS = {
     ['mn-att-ques-im-hist'] = {'img_proj', 'img_common#rev', 'embed', 'ques*', 'hist*', 'mn1', 'mn2', 'ques_common+att#', 'out'},
 }
 
+-- Escape hatch: `params.paramOrder` = a Lua table of tensor names in flat order (e.g. read off `th lua/dump_param_order.lua <ckpt>`
+-- under a real Torch7) replaces the table above; 'declaration' keeps the library's own declaration order.
 function Model:tensors()
     local declared, name = {}, ffi.new('char[64]')
     local off, rows, cols = ffi.new('int64_t[1]'), ffi.new('int64_t[1]'), ffi.new('int64_t[1]')
@@ -403,6 +405,18 @@ function Model:tensors()
     local function hops(pre)                    -- hop 1 has no suffix, hop i > 1 is <name><i>
         local out = layered(pre)
         table.insert(out, 1, pre)
+        return out
+    end
+    local po = self.params.paramOrder
+    if po == 'declaration' then return declared end
+    if type(po) == 'table' then
+        local byName, out = {}, {}
+        for _, t in ipairs(declared) do byName[t.name] = t end
+        for _, n in ipairs(po) do
+            out[#out + 1] = assert(byName[n], 'Model:tensors: paramOrder names ' .. tostring(n) .. ' twice or the library declares no such tensor')
+            byName[n] = nil
+        end
+        assert(#out == #declared, 'Model:tensors: paramOrder must name every tensor exactly once')
         return out
     end
     local want = {}

@@ -86,7 +86,10 @@ class DryLib(object):
         return ctypes.addressof(self.last_error)
 
     def c_vd_abi_version(self):
-        return 1
+        import os
+        import re
+        hdr = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..', 'include', 'visdial_hip.h')).read()
+        return int(re.search(r'#define\s+VD_ABI_VERSION\s+(\d+)', hdr).group(1))
 
     def c_vd_device_count(self, out):
         ctypes.c_int.from_address(out).value = 1

@@ -1737,7 +1737,15 @@ class LuaVM(object):
         O.set('clock', lambda *_: time.process_time())
         O.set('date', _os_date)
         O.set('exit', lambda code=0, *_: (_ for _ in ()).throw(SystemExit(int(code if code.__class__ in (int, float) else 0))))
-        O.set('remove', lambda p, *_: (os.remove(p), True)[1])
+        def os_remove(p, *_):
+            # the VM also runs the REFERENCE's scripts (untrusted): deletions are confined to the temporary directory
+            import tempfile
+            rp, root = os.path.realpath(str(p)), os.path.realpath(tempfile.gettempdir())
+            if not rp.startswith(root + os.sep):
+                return (None, '%s: os.remove outside %s is disabled in the test VM' % (p, root))
+            os.remove(rp)
+            return True
+        O.set('remove', os_remove)
         G.set('os', O)
         IO = LuaTable()
 
@@ -1746,6 +1754,11 @@ class LuaVM(object):
                 p = path
                 if 'r' in mode and not os.path.isabs(path):
                     p = vm.find_file(path) or path
+                if 'r' not in mode or '+' in mode:      # writes: temporary directory only (see os.remove)
+                    import tempfile
+                    rp, root = os.path.realpath(str(p)), os.path.realpath(tempfile.gettempdir())
+                    if not rp.startswith(root + os.sep):
+                        return (None, '%s: writing outside %s is disabled in the test VM' % (path, root), 13)
                 return LuaFile(open(p, mode.replace('b', ''), encoding='latin-1', newline=''))
             except IOError as e:
                 return (None, '%s: %s' % (path, e.strerror), e.errno)

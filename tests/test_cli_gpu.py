@@ -35,7 +35,7 @@ def test_train_then_evaluate(tmp_path, host):
     from visdial_amd import t7
     ck = t7.load(save + 'model_epoch_10.t7')
     assert set(ck) >= {'modelW', 'optims', 'modelParams'} and ck['optims']['learningRate'] < 1e-3
-    assert 'vdLayout' not in ck                            # every encoder is written in the reference's getParameters() order
+    assert ck.get('vdLayout') == 'reference'                  # every encoder is written in the reference's getParameters() order, and says so
     e = subprocess.run([sys.executable, os.path.join(ROOT, 'evaluate.py'), '-loadPath', save + 'model_final.t7',
                         '-batchSize', '4', '--numThreads', '8', '-saveRanks', '1', '-saveRankPath',
                         str(tmp_path / 'ranks.json'), '-perplexity', '1', '-host', 'native' if host == 'python' else 'python'],

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "library does not export %s" % name
     assert declared == set(_lib.PROTOTYPES), (declared ^ set(_lib.PROTOTYPES))
-    assert lib.vd_abi_version() == 1
+    assert lib.vd_abi_version() == 2 == _lib.ABI_VERSION
     assert isinstance(lib.vd_last_error(), bytes)
 
 

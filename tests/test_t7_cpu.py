@@ -156,7 +156,7 @@ def test_cli_checkpoint_t7_roundtrip_in_reference_order(tmp_path, capsys):
         p = str(tmp_path / (enc + '.t7'))
         checkpoint.save_t7(p, m, {'encoder': enc, 'decoder': 'disc', 'rnnHiddenSize': 32})
         ck = checkpoint.load_checkpoint(p)
-        assert 'vdLayout' not in ck and abs(ck['optims']['learningRate'] - 7e-4) < 1e-12
+        assert ck.get('vdLayout') == 'reference' and abs(ck['optims']['learningRate'] - 7e-4) < 1e-12
         first = {'hre-ques-im-hist': ('embed', 'img_embed.W'), 'hre-ques-hist': ('embed', 'ques1.W'),
                  'mn-att-ques-im-hist': ('img_proj.W', 'img_proj.b')}[enc]
         o = 0
@@ -166,7 +166,8 @@ def test_cli_checkpoint_t7_roundtrip_in_reference_order(tmp_path, capsys):
         m2 = _FakeModel(enc, {k: np.zeros_like(v) for k, v in named.items()})
         capsys.readouterr()
         checkpoint.restore_weights(m2, ck)
-        assert ('derived' in capsys.readouterr().err) == (enc == 'mn-att-ques-im-hist')
+        err = capsys.readouterr().err
+        assert ('derived' in err) == (enc == 'mn-att-ques-im-hist') and 'no vdLayout marker' not in err
         for k in named:
             np.testing.assert_array_equal(m2.named[k], named[k])
     # a file an EARLIER version of this repo wrote for an nngraph encoder (declaration order + marker) still loads
@@ -220,3 +221,72 @@ def test_hand_assembled_torch7_checkpoint(tmp_path):
     t7.save(q, {'modelW': flat, 'optims': {'learningRate': 2.5e-4}, 'modelParams': {'encoder': enc, 'rnnHiddenSize': 32, 'useIm': True}},
             float_tensor_class='Cuda')
     assert open(q, 'rb').read() == open(p, 'rb').read()
+
+
+def test_param_order_escape_hatch(tmp_path, capsys):
+    """-paramOrder: a user with a real Torch7 runs lua/dump_param_order.lua on a checkpoint and hands the JSON to
+    the loaders.  (a) a dump that agrees with this repo's table in every tensor size keeps the table and names the same-size groups it
+    cannot tell apart; (b) a dump that contradicts the table wins; (c) an explicit name list is followed verbatim; (d) a file without a
+    layout marker is announced as such for the encoders whose order changed between rounds; (e) the fresh-initialisation forget-bias
+    pattern is reported."""
+    import json
+    from visdial_amd import checkpoint
+    enc = 'mn-att-ques-im-hist'
+    named = _fake_named(enc)
+    for k in named:                                     # a fresh reference init: forget-gate quarter of every LSTM bias = 1
+        if k.endswith('.b') and named[k[:-2] + '.W'].shape[0] > named[k].size // 4 and named[k[:-2] + '.W'].shape[-1] == named[k].size:
+            named[k][named[k].size // 4:named[k].size // 2] = 1.0
+    m = _FakeModel(enc, dict(named))
+    entries = m._entries()
+    table = t7.reference_order(enc, entries)
+
+    def dump_of(order):                                 # what lua/dump_param_order.lua prints for a flat vector laid out in `order`
+        rows, o = [], 0
+        for i, (n, shape, _) in enumerate(order):
+            rows.append({'module': i + 1, 'type': 'nn.Linear', 'field': 'weight', 'offset': o, 'numel': int(np.prod(shape)), 'rows': int(shape[0])})
+            o += int(np.prod(shape))
+        return {'encoder': enc, 'decoder': 'disc', 'total': o, 'tensors': rows}
+    flat = t7.named_to_flat(named, entries, enc)
+    ck = {'modelW': flat, '_flat_reference_layout': True}
+    # (a) + (d) + (e)
+    pa = str(tmp_path / 'agree.json')
+    json.dump(dump_of(table), open(pa, 'w'))
+    m2 = _FakeModel(enc, {k: np.zeros_like(v) for k, v in named.items()})
+    capsys.readouterr()
+    checkpoint.restore_weights(m2, ck, pa)
+    err = capsys.readouterr().err
+    assert 'agrees with the Torch7 dump' in err and "'ques_common.W'" in err and 'forget-gate-bias-1 pattern' in err
+    for k in named:
+        np.testing.assert_array_equal(m2.named[k], named[k])
+    capsys.readouterr()
+    checkpoint.restore_weights(_FakeModel(enc, dict(named)), ck)
+    assert 'no vdLayout marker' in capsys.readouterr().err
+    # (b) the real order differs from the table: embed first
+    real = [e for e in table if e[0] == 'embed'] + [e for e in table if e[0] != 'embed']
+    flat_real = np.concatenate([named[n].reshape(-1) for n, _, _ in real])
+    pb = str(tmp_path / 'contradict.json')
+    json.dump(dump_of(real), open(pb, 'w'))
+    m3 = _FakeModel(enc, {k: np.zeros_like(v) for k, v in named.items()})
+    capsys.readouterr()
+    checkpoint.restore_weights(m3, {'modelW': flat_real, '_flat_reference_layout': True}, pb)
+    assert 'CONTRADICTS the table from position 0' in capsys.readouterr().err
+    for k in named:
+        np.testing.assert_array_equal(m3.named[k], named[k])
+    # (c) explicit list, including a permutation of two same-size tensors that no dump could express
+    names = [e[0] for e in table]
+    i, j = names.index('ques_common.W'), names.index('att.W') if named['att.W'].size == named['ques_common.W'].size else names.index('mn1.W')
+    names[i], names[j] = names[j], names[i]
+    flat_c = np.concatenate([named[n].reshape(-1) for n in names])
+    pc = str(tmp_path / 'explicit.json')
+    json.dump({'order': names}, open(pc, 'w'))
+    m4 = _FakeModel(enc, {k: np.zeros_like(v) for k, v in named.items()})
+    checkpoint.restore_weights(m4, {'modelW': flat_c, '_flat_reference_layout': True}, pc)
+    for k in named:
+        np.testing.assert_array_equal(m4.named[k], named[k])
+    with pytest.raises(ValueError):
+        t7.resolve_order(entries, enc, {'order': names[:-1]})
+    # a mis-split fresh init is flagged: read a declaration-order vector with the reference table
+    bad = _FakeModel(enc, {k: np.zeros_like(v) for k, v in named.items()})
+    capsys.readouterr()
+    checkpoint.restore_weights(bad, {'modelW': t7.named_to_flat(named, entries, None), '_flat_reference_layout': True, 'vdLayout': 'reference'})
+    assert 'CHECK the parameter order' in capsys.readouterr().err or any((bad.named[k] != named[k]).any() for k in named)

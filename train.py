@@ -72,7 +72,7 @@ def main():
     else:
         model = Model(opt)
     if saved is not None:                                        # train.lua:78-81
-        restore_weights(model, saved)
+        restore_weights(model, saved, opt.get('paramOrder') or None)
         model.optims['learningRate'] = saved['optims']['learningRate']
     print('Training..')
     total = opt['numEpochs'] * opt['numIterPerEpoch']

@@ -9,6 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VD_LIB_PATH") or os.path.join(_HERE, "libvisdial_hip.so")   # override: A/B builds
 
+ABI_VERSION = 2    # include/visdial_hip.h VD_ABI_VERSION this binding was written against
+
 _p = C.c_void_p
 _i = C.c_int
 _l = C.c_int64
@@ -157,6 +159,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, C.c_int)
+    if lib.vd_abi_version() != ABI_VERSION:
+        raise VisdialHipError("%s exports ABI version %d, this binding was written against %d: rebuild the library (make -C visdial_amd/csrc)"
+                              % (LIB_PATH, lib.vd_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -17,24 +17,32 @@ def load_checkpoint(path):
     return torch.load(path, weights_only=True)      # plain tensors and primitives only
 
 
-def restore_weights(model, saved):
-    """`model.wrapperW:copy(savedModel.modelW)` (train.lua:79, evaluate.lua:91, generate.lua:83).  A Torch7-written flat
-    vector is split in the reference's getParameters() order (t7.reference_order); for the four nngraph encoders that
-    order is DERIVED (t7.order_status) and the loader says so on stderr.  The element count is always checked."""
+def restore_weights(model, saved, param_order=None):
+    """`model.wrapperW:copy(savedModel.modelW)` (train.lua:79, evaluate.lua:91, generate.lua:83).  A Torch7-format flat vector is split
+    in the reference's getParameters() order (t7.reference_order); for the four nngraph encoders that order is DERIVED
+    (t7.order_status) and the loader says so on stderr.  `param_order` (-paramOrder) overrides it: 'declaration', 'reference', or a JSON
+    file -- an explicit name list or the output of lua/dump_param_order.lua under a real Torch7 (t7.resolve_order).  The element count
+    is always checked; the forget-bias pattern of a fresh reference initialisation is reported when present."""
     w = saved['modelW']
     if saved.get('_flat_reference_layout'):
-        if saved.get('vdLayout') == 'declaration':
-            # written by an earlier save_t7 of THIS repo for an nngraph encoder: tensors back to back in the library's
-            # own declaration order (vd_model_tensor_info)
-            from . import t7 as _t7
-            entries = model._entries() if hasattr(model, '_entries') else model.fp.spec.entries
-            model.set_parameters_dict(_t7.flat_to_named(np.asarray(w, np.float32), entries, None))
-        else:
-            enc = model.params['encoder']
-            if t7.order_status(enc) == 'derived':
-                sys.stderr.write("note: '%s' is an nngraph encoder; its getParameters() order is derived (reference file executed on "
-                                 "a restated nngraph), not verified against a Torch7-written checkpoint\n" % enc)
-            model.load_flat_parameters(np.asarray(w, np.float32))
+        note = lambda m: sys.stderr.write('note: ' + m + '\n')
+        enc = model.params['encoder']
+        entries = model._entries() if hasattr(model, '_entries') else model.fp.spec.entries
+        marker = saved.get('vdLayout')
+        order = param_order or ('declaration' if marker == 'declaration' else None)
+        if not order and t7.order_status(enc) == 'derived':
+            note("'%s' is an nngraph encoder; its getParameters() order is derived (reference file executed on a restated nngraph), not "
+                 "verified against a Torch7-written checkpoint -- `th lua/dump_param_order.lua <ckpt>` + -paramOrder <json> checks it" % enc)
+        if not order and marker is None and (enc.startswith('hre') or t7.order_status(enc) == 'derived'):
+            note("the file carries no vdLayout marker: read as a Torch7 / reference-order vector.  (A file written through this repo's "
+                 "Lua host BEFORE round 4 is in declaration order: pass -paramOrder declaration.)")
+        named = t7.flat_to_named(np.asarray(w, np.float32), entries, enc, order, note)
+        n, ok = t7.forget_bias_report(named, entries)
+        if n and ok == n:
+            note("all %d LSTM biases carry the forget-gate-bias-1 pattern of a fresh reference initialisation: the split is plausible" % n)
+        elif n and ok:
+            note("%d of %d LSTM biases carry the fresh-initialisation forget-bias pattern, the others do not: CHECK the parameter order" % (ok, n))
+        model.set_parameters_dict(named)
     else:
         model.wrapperW.copy_(w.to(model.wrapperW.device))
         # the copy runs on torch's current stream; the native library's streams are non-blocking and never order
@@ -51,7 +59,7 @@ def save_t7(path, model, params, optims=True):
     enc = params['encoder']
     entries = model._entries() if hasattr(model, '_entries') else model.fp.spec.entries
     named = model.get_parameters_dict()
-    obj = {'modelW': t7.named_to_flat(named, entries, enc), 'modelParams': clean}
+    obj = {'modelW': t7.named_to_flat(named, entries, enc), 'modelParams': clean, 'vdLayout': 'reference'}
     if optims:
         obj['optims'] = {'learningRate': float(model.optims['learningRate'])}
     t7.save(path, obj)

@@ -9,6 +9,7 @@
 #include <utility>
 
 #include "common.h"
+#include "../../include/visdial_hip.h"
 
 static thread_local char g_err[1024] = "";
 
@@ -112,7 +113,7 @@ extern "C" {
 
 const char* vd_last_error(void) { return g_err; }
 
-int vd_abi_version(void) { return 1; }
+int vd_abi_version(void) { return VD_ABI_VERSION; }
 
 int vd_device_count(int* count) {
   VD_CHECK_ARG(count, "vd_device_count: null");

@@ -71,6 +71,9 @@ def parse(argv=None):
     ap.add_argument('--vocabSize', type=int, default=11322)
     ap.add_argument('--numTrainThreads', type=int, default=2000)
     ap.add_argument('--maxIters', type=int, default=0, help='stop after this many iterations (0 = numEpochs)')
+    ap.add_argument('-paramOrder', '--paramOrder', default='',
+                    help="flat-vector layout of a .t7 given to -loadPath: '' (this repo's table of the reference's getParameters() order), "
+                         "'declaration', or a JSON file: {\"order\": [names]} or the output of lua/dump_param_order.lua under Torch7")
     ap.add_argument('-synthetic', '--synthetic', type=int, default=0,
                     help='1 = allow resuming (-loadPath) on synthetic batches when no dataset files exist')
     opt = vars(ap.parse_args(argv))

@@ -240,12 +240,66 @@ def reference_order(encoder, spec_entries):
     return [e for s in want for e in entries if stem(e[0]) == s]
 
 
-def flat_to_named(modelW, spec_entries, encoder=None):
+def resolve_order(spec_entries, encoder=None, param_order=None, log=None):
+    """The flat-vector order to use: this repo's table (reference_order) unless `param_order` overrides it.
+      None / '' / 'reference'   the table (Torch7 files, files written by this repo with vdLayout = 'reference')
+      'declaration'             the library's own declaration order (files with vdLayout = 'declaration': earlier writers of this repo)
+      {'order': [names]}        an explicit list of tensor names in flat order
+      {'tensors': [...]}        the output of lua/dump_param_order.lua run under a real Torch7: offsets, element counts and module types of
+                                every parameter tensor in flat order.  The table's order is CHECKED against it: where the element-count
+                                sequences agree the table stands (tensors of equal size cannot be told apart by a dump: they are reported);
+                                where they differ the dump wins -- every position takes the first unused tensor of the dumped size.
+    `log(str)` receives what was found."""
+    say = log or (lambda m: None)
+    entries = list(spec_entries)
+    if param_order in (None, '', 'reference'):
+        return reference_order(encoder, entries)
+    if param_order == 'declaration':
+        return entries
+    if isinstance(param_order, str):
+        import json
+        with open(param_order) as f:
+            param_order = json.load(f)
+    by_name = {e[0]: e for e in entries}
+    if 'order' in param_order:
+        names = list(param_order['order'])
+        if sorted(names) != sorted(by_name):
+            raise ValueError('paramOrder: the list must name every tensor exactly once; missing %s, unknown %s' % (
+                sorted(set(by_name) - set(names)), sorted(set(names) - set(by_name))))
+        return [by_name[n] for n in names]
+    dump = sorted(param_order['tensors'], key=lambda t: t['offset'])
+    table = reference_order(encoder, entries)
+    numel = lambda e: int(np.prod(e[1]))
+    if len(dump) != len(table) or sum(int(t['numel']) for t in dump) != sum(numel(e) for e in table):
+        raise ValueError('paramOrder: the dump lists %d tensors / %d parameters, the model declares %d / %d (different options?)' % (
+            len(dump), sum(int(t['numel']) for t in dump), len(table), sum(numel(e) for e in table)))
+    if [int(t['numel']) for t in dump] == [numel(e) for e in table]:
+        groups = {}
+        for e in table:
+            groups.setdefault(numel(e), []).append(e[0])
+        amb = [v for v in groups.values() if len(v) > 1]
+        say("paramOrder: the table's order agrees with the Torch7 dump in every tensor size (%d tensors); sizes shared by several tensors, "
+            "which a dump cannot tell apart: %s" % (len(table), amb if amb else 'none'))
+        return table
+    pool, out = list(table), []
+    for i, t in enumerate(dump):
+        j = next((k for k, e in enumerate(pool) if numel(e) == int(t['numel'])), None)
+        if j is None:
+            raise ValueError('paramOrder: no unused tensor of %d elements for dump position %d (%s.%s)' % (t['numel'], i, t.get('type'), t.get('field')))
+        out.append(pool.pop(j))
+    first = next(i for i, (a, b) in enumerate(zip(out, table)) if a[0] != b[0])
+    say("paramOrder: the Torch7 dump CONTRADICTS the table from position %d on (table: %s, dump: %d elements of %s) -- following the dump: %s" % (
+        first, table[first][0], dump[first]['numel'], dump[first].get('type'), [e[0] for e in out]))
+    return out
+
+
+def flat_to_named(modelW, spec_entries, encoder=None, param_order=None, log=None):
     """Split a reference-style flat vector (getParameters(): tensors back to back, NO alignment padding) into
-    this repo's named tensors, using the reference's parameter order for `encoder` (reference_order).  encoder=None
-    keeps this repo's own declaration order (files written with vdLayout = 'declaration')."""
+    this repo's named tensors, using the reference's parameter order for `encoder` (reference_order) or the override
+    `param_order` (resolve_order).  encoder=None keeps this repo's own declaration order (files written with
+    vdLayout = 'declaration')."""
     out, o = {}, 0
-    order = reference_order(encoder, spec_entries)
+    order = resolve_order(spec_entries, encoder, param_order, log)
     total = sum(int(np.prod(shape)) for _, shape, _ in order)
     if total != len(modelW):
         raise ValueError('checkpoint holds %d parameters, the model declares %d' % (len(modelW), total))
@@ -256,6 +310,21 @@ def flat_to_named(modelW, spec_entries, encoder=None):
     return out
 
 
-def named_to_flat(named, spec_entries, encoder=None):
+def named_to_flat(named, spec_entries, encoder=None, param_order=None):
     return np.concatenate([np.asarray(named[n], np.float32).reshape(-1)
-                           for n, _, _ in reference_order(encoder, spec_entries)])
+                           for n, _, _ in resolve_order(spec_entries, encoder, param_order)])
+
+
+def forget_bias_report(named, spec_entries):
+    """Plausibility of a split flat vector (reported, never enforced): nn.SeqLSTM:reset() leaves the forget-gate quarter of every LSTM
+    bias at 1 on a FRESH initialisation (Element-Research rnn SeqLSTM.lua, [UPSTREAM-RECALL]); a mis-ordered split of such a file puts
+    other values there.  -> (n_lstm_biases, n_with_forget_quarter_all_one)"""
+    n = ok = 0
+    for name, shape, _ in spec_entries:
+        if name.endswith('.b') and (name[:-2] + '.W') in named and len(named[name[:-2] + '.W'].shape) == 2:
+            W, b = named[name[:-2] + '.W'], np.asarray(named[name]).reshape(-1)
+            H4 = b.size
+            if H4 % 4 == 0 and W.shape[1] == H4 and W.shape[0] > H4 // 4:       # [(D + H) x 4H] weight: an LSTM layer
+                n += 1
+                ok += bool(np.all(b[H4 // 4:H4 // 2] == 1.0))
+    return n, ok
