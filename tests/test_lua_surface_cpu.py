@@ -155,12 +155,13 @@ def test_lua_files_parse_and_use_no_undeclared_names():
             lua_lint.check(bad)
     assert [n for n, _ in lua_lint.check('local a = 1\nprint(a, bb)\nlocal function g() return cc end')] == ['bb', 'cc']
     files = sorted(glob.glob(os.path.join(ROOT, 'lua', '*.lua')) + glob.glob(os.path.join(ROOT, 'lua', '*', '*.lua')))
-    assert len(files) == 17
+    assert len(files) == 18
     for f in files:
         parser = lua_lint.Parser(open(f).read(), os.path.relpath(f, ROOT), lua_lint.LUA_GLOBALS)
         parser.chunk()                                            # LuaSyntaxError with file:line on any syntax slip
         reads = set(n for n, _ in parser.undeclared if n not in parser.assigned_globals)
-        assert reads <= {'torch'}, (f, sorted(reads))
+        # (dump_param_order.lua runs inside the REFERENCE checkout under Torch7: `Model` is the global class the reference's model.lua defines)
+        assert reads <= ({'torch', 'Model'} if f.endswith('dump_param_order.lua') else {'torch'}), (f, sorted(reads))
         assert parser.assigned_globals <= {'runningLoss'}, (f, sorted(parser.assigned_globals))
 
 
