@@ -11,7 +11,38 @@
 #include "common.h"
 #include "../../include/visdial_hip.h"
 
+#include <dlfcn.h>
+
 static thread_local char g_err[1024] = "";
+
+// ---- ROCTx (common.h) ------------------------------------------------------------------------------------------------------------
+namespace {
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)();
+roctx_push_fn g_roctx_push = nullptr;
+roctx_pop_fn g_roctx_pop = nullptr;
+std::once_flag g_roctx_once;
+void roctx_resolve() {
+  const char* on = getenv("VD_ROCTX");
+  if (!on || on[0] != '1') return;
+  for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+    void* lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) continue;
+    g_roctx_push = (roctx_push_fn)dlsym(lib, "roctxRangePushA");
+    g_roctx_pop = (roctx_pop_fn)dlsym(lib, "roctxRangePop");
+    if (g_roctx_push && g_roctx_pop) return;
+    g_roctx_push = nullptr;
+    g_roctx_pop = nullptr;
+  }
+}
+}  // namespace
+void vd_range_push(const char* name) {
+  std::call_once(g_roctx_once, roctx_resolve);
+  if (g_roctx_push) g_roctx_push(name);
+}
+void vd_range_pop() {
+  if (g_roctx_pop) g_roctx_pop();
+}
 
 void vd_set_error(const char* fmt, ...) {
   va_list ap;
@@ -53,41 +84,63 @@ int vd_stream_scratch(hipStream_t stream, size_t wht_bytes, size_t sync_bytes, V
 }
 
 // ---- bf16 shadows (common.h) -----------------------------------------------------------------------------
+// One entry per registered fp32 range (keyed by device + base address), so that two models -- or two recurrences of one model -- in a
+// process never share a shadow buffer.  At most VD_MAX_SHADOWS live entries; an invalidated entry keeps its buffer and is the first to be
+// re-used, then the least recently registered one is evicted.  (`slot` of the older two-slot registry is accepted and ignored.)
 namespace {
 struct Bf16Shadow {
-  const float* base = nullptr;   // registered fp32 range [base, base + floats)
+  const float* base = nullptr;   // registered fp32 range [base, base + floats); nullptr = free (buffer kept for re-use)
   size_t floats = 0;
   vd_bf16_bits* buf = nullptr;
   size_t cap = 0;                // elements allocated
   int dev = -1;
+  unsigned long stamp = 0;       // registration order (eviction)
 };
-Bf16Shadow g_shadow[2];
+constexpr int VD_MAX_SHADOWS = 8;
+Bf16Shadow g_shadow[VD_MAX_SHADOWS];
+unsigned long g_shadow_clock = 0;
 std::mutex g_shadow_mu;
 }  // namespace
 
-int vd_bf16_shadow_get(int slot, const float* base, size_t floats, vd_bf16_bits** out) {
+int vd_bf16_shadow_get(int /*slot*/, const float* base, size_t floats, vd_bf16_bits** out) {
   std::lock_guard<std::mutex> lk(g_shadow_mu);
-  Bf16Shadow& s = g_shadow[slot & 1];
   int dev = 0;
   VD_HIP(hipGetDevice(&dev));
+  Bf16Shadow* pick = nullptr;
+  for (Bf16Shadow& s : g_shadow)                                   // the same tensor again (every pass of a training loop)
+    if (s.base == base && s.dev == dev) pick = &s;
+  if (!pick)
+    for (Bf16Shadow& s : g_shadow)                                 // a free entry whose buffer already fits
+      if (!s.base && s.dev == dev && s.cap >= floats && (!pick || s.cap < pick->cap)) pick = &s;
+  if (!pick)
+    for (Bf16Shadow& s : g_shadow)                                 // a never-used entry
+      if (!s.base && !s.buf) { pick = &s; break; }
+  if (!pick)
+    for (Bf16Shadow& s : g_shadow)                                 // any free entry, else the least recently registered one
+      if (!pick || (!s.base && pick->base) || ((!s.base) == (!pick->base) && s.stamp < pick->stamp)) pick = &s;
+  Bf16Shadow& s = *pick;
   if (s.cap < floats || s.dev != dev) {
     if (s.buf) VD_HIP(hipFree(s.buf));     // synchronises the device: earlier users are done
     s.buf = nullptr;
     s.cap = 0;
+    s.base = nullptr;
     VD_HIP(hipMalloc((void**)&s.buf, floats * sizeof(vd_bf16_bits)));
     s.cap = floats;
     s.dev = dev;
   }
   s.base = base;
   s.floats = floats;
+  s.stamp = ++g_shadow_clock;
   *out = s.buf;
   return VD_OK;
 }
 
 const vd_bf16_bits* vd_bf16_shadow_find(const float* p, size_t floats) {
   std::lock_guard<std::mutex> lk(g_shadow_mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   for (const Bf16Shadow& s : g_shadow)
-    if (s.base && p >= s.base && p + floats <= s.base + s.floats) return s.buf + (p - s.base);
+    if (s.base && s.dev == dev && p >= s.base && p + floats <= s.base + s.floats) return s.buf + (p - s.base);
   return nullptr;
 }
 

@@ -192,6 +192,7 @@ int vd_comm_destroy(void) {
 // The main stream then waits for both, so the next call -- vd_model_update(m, 1 / world) -- sees the reduced gradient.
 // Every rank must call this once per step, in the same order.
 int vd_model_allreduce_grads(vd_model* m) {
+  VdRange r("vd_model_allreduce_grads");
   VD_CHECK_ARG(m, "vd_model_allreduce_grads: null model");
   VD_CHECK_ARG(g.comm, "vd_model_allreduce_grads: no communicator (vd_comm_init first)");
   VD_CHECK_ARG(m->cur >= 0, "vd_model_allreduce_grads: no backward pass has been enqueued");

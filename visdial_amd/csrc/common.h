@@ -40,6 +40,19 @@ void vd_set_error(const char* fmt, ...);
 
 static inline int vd_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ROCTx ranges around the phases of a step (SURVEY.md section 5 "tracing"): host-side ranges on the enqueuing thread, visible in
+// `rocprofv3 --marker-trace --kernel-trace` next to the kernels dispatched inside them.  librocprofiler-sdk-roctx.so / libroctx64.so is
+// dlopen'ed on first use and ONLY when the environment says VD_ROCTX=1 (scripts/measure_round.sh sets it for the trace pass); otherwise,
+// or when neither library loads, the calls are no-ops.  (api.hip)
+void vd_range_push(const char* name);
+void vd_range_pop();
+struct VdRange {
+  explicit VdRange(const char* name) { vd_range_push(name); }
+  ~VdRange() { vd_range_pop(); }
+  VdRange(const VdRange&) = delete;
+  VdRange& operator=(const VdRange&) = delete;
+};
+
 // Library-owned per-(device, stream) scratch (api.hip): work buffers whose lifetime is one stream-ordered call
 // (the gate-interleaved Wh^T copy and the tile queues / arrival counters of the persistent recurrence kernels).
 // Calls on different streams get different buffers, so they may overlap freely.
@@ -78,7 +91,8 @@ int vd_segment_rowsum_acc_bf16(const vd_bf16_bits* X16, int64_t ldx, const int32
 // bf16 pass (LSTM forward: h; LSTM backward: da) also write a bf16 copy of what they store, into a library-owned buffer
 // registered against the fp32 tensor's address range; the weight-gradient contraction of the same pass finds the two
 // shadows by address and multiplies them directly (LDS-DMA + transpose reads, no fp32 -> bf16 conversion while staging).
-// slot 0 = hidden states, slot 1 = gate gradients.  A shadow is valid until the next producer call on the same slot, or
+// One shadow per registered tensor (keyed by device + base address: two models in a process never share one; the `slot` argument of the
+// older two-slot registry is ignored).  A shadow is valid until the next producer call on the same tensor, or
 // until an fp32 producer overwrites its range (vd_bf16_shadow_invalidate: the fp32 recurrences, a forward pass over the gates buffer,
 // vd_memset).  The registry is process-global and keyed by address only: VD_FLAG_BF16 on vd_gemm_tn_acc is meant for the contraction that
 // directly follows the bf16 recurrences of the same pass -- a host that writes those ranges by other means (its own kernels, a tensor
@@ -132,14 +146,11 @@ __device__ __forceinline__ float4 vd_ld4_stream(const float* p) {
 #endif
 }
 
-// Buffer addressing for the step kernels' epilogues (VD_EPI_BUF): an SGPR descriptor per tensor + a 32-bit VGPR byte offset + an
+// Buffer addressing for the step kernels' epilogues: an SGPR descriptor per tensor + a 32-bit VGPR byte offset + an
 // SGPR byte offset for the uniform part (gate / row-group strides).  buffer_load / buffer_store compute the address in the
 // memory pipeline, so the ~130 64-bit VALU address instructions a tile's epilogue spent on `ptr + (long)row * ld + j` go away --
 // and VALU issue is what the epilogue costs (profiles/r03_experiments.txt section 13c).  The compiler tracks vmcnt for these
 // builtins (unlike inline asm).  No reliance on the hardware range check: the SGPR offset is not part of it on gfx9.
-#ifndef VD_EPI_BUF
-#define VD_EPI_BUF 7   // bit 0: forward step epilogue; bits 1 / 2: backward epilogue loads / stores (with them the TWO-slot backward epilogue fits 128 VGPRs)
-#endif
 typedef unsigned vd_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned vd_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t vd_rsrc(const void* p) {

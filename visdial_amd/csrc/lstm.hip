@@ -174,7 +174,6 @@ struct EpiLstmFwdT {
     __builtin_amdgcn_sched_barrier(0);
     float4 a[4][4];  // [gate][p]
     float4 x[4], cp;
-#if VD_EPI_BUF & 1
     // descriptors (SGPRs) + 32-bit byte offsets: per row group one multiply-add for the gathered projection row and one for the
     // clamped state row; the gate stride and the row-group stride are SGPR offsets
     const __amdgpu_buffer_rsrc_t rx = vd_rsrc(xproj), rc = vd_rsrc(c_prev), rg = vd_rsrc(gates), rco = vd_rsrc(c_out),
@@ -199,13 +198,11 @@ struct EpiLstmFwdT {
       issue16(1, 1);
       __builtin_amdgcn_sched_barrier(0);
     }
-#endif
     tile_to_rows(acc[0], scr, lane, a[0]);
     tile_to_rows(acc[1], scr, lane, a[1]);
     tile_to_rows(acc[2], scr, lane, a[2]);
     tile_to_rows(acc[3], scr, lane, a[3]);
     VD_T(3);
-#if VD_EPI_BUF & 1
     auto issue = [&](int p) {
       if constexpr (C16) {
         issue16(p, p & 1);
@@ -219,17 +216,6 @@ struct EpiLstmFwdT {
         if (c_prev) cp = vd_buf_ld4(rc, (unsigned)rowc[p] * uH4 + uj4, 0);
       }
     };
-#else
-    auto issue = [&](int p) {
-      const float* xr = xproj + (long)tk[p] * xld + j;
-      x[0] = *reinterpret_cast<const float4*>(xr);
-      x[1] = *reinterpret_cast<const float4*>(xr + H);
-      x[2] = *reinterpret_cast<const float4*>(xr + 2 * H);
-      x[3] = *reinterpret_cast<const float4*>(xr + 3 * H);
-      cp = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c_prev) cp = *reinterpret_cast<const float4*>(c_prev + (long)rowc[p] * H + j);
-    };
-#endif
     if constexpr (!C16) issue(0);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -265,7 +251,6 @@ struct EpiLstmFwdT {
 #undef VD_CELL
       const int row = row0 + p * 8 + rl;
       if (row < M) {
-#if VD_EPI_BUF & 1
         const unsigned sp = (unsigned)p * 8u * uH4;                  // row-group stride (uniform)
         const unsigned vg = 4u * vrow - 3u * uj4;                    // (row0 + rl, j) in the [M x 4H] gates tensor
         if constexpr (C16) {                                           // compact state: bf16 gates, fp32 c, bf16 h (+ fp32 h at the last step)
@@ -294,16 +279,6 @@ struct EpiLstmFwdT {
         vd_buf_st4(rh, vrow, sp, h);
         if (h16) vd_buf_st4_bf16(rh16, vrow >> 1, sp >> 1, h);
         }
-#else
-        float* gr = gates + (long)row * 4 * H + j;
-        vd_st4_stream(gr, gi);           // saved for the backward pass: written once, read ~10 ms later
-        vd_st4_stream(gr + H, gf);
-        vd_st4_stream(gr + 2 * H, go);
-        vd_st4_stream(gr + 3 * H, gg);
-        *reinterpret_cast<float4*>(c_out + (long)row * H + j) = c;
-        *reinterpret_cast<float4*>(h_out + (long)row * H + j) = h;
-        if (h16) vd_st4_bf16(h16 + (long)row * H + j, h);
-#endif
       }
     }
   }
@@ -355,21 +330,6 @@ struct EpiLstmBwd {
     vd_u32x2 g16[4];   // C16: the saved gates as loaded (packed bf16), unpacked when the slot is consumed -- NOT in the load phase, where the
                        // unpacking would sit in front of the scheduling barrier and wait for every load of the slot
   };
-  __device__ __forceinline__ void load_slot(Slot& L, int rc, int jc) const {
-    const long o = (long)rc * H + jc;
-    const float* gr = gates + (long)rc * 4 * H + jc;
-    L.g[0] = vd_ld4_stream(gr);          // saved gates: read exactly once
-    L.g[1] = vd_ld4_stream(gr + H);
-    L.g[2] = vd_ld4_stream(gr + 2 * H);
-    L.g[3] = vd_ld4_stream(gr + 3 * H);
-    L.ct = *reinterpret_cast<const float4*>(c_t + o);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    L.cp = c_prev ? *reinterpret_cast<const float4*>(c_prev + o) : z;
-    L.dcv = dc_first ? z : *reinterpret_cast<const float4*>(dc + o);
-    const float* dh1 = dh_a ? dh_a : dh_b;   // the common case has at most one incoming-gradient operand
-    L.dhx = dh1 ? *reinterpret_cast<const float4*>(dh1 + o) : z;
-  }
-#if VD_EPI_BUF & 6
   // buffer addressing (common.h): `o4` = byte offset of (row, j) in an [M x H] tensor; the gates tensor's is 4 * o4 - 12 * j
   struct Rsrc {
     __amdgpu_buffer_rsrc_t g, ct, cp, dc, dh1, dh2, g16;
@@ -392,15 +352,12 @@ struct EpiLstmBwd {
     L.dcv = dc_first ? z : vd_buf_ld4(R.dc, o4, 0);
     L.dhx = (dh_a || dh_b) ? vd_buf_ld4(R.dh1, o4, 0) : z;   // the common case has at most one incoming-gradient operand
   }
-#endif
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[NT], int row0, int col0, int lane, int M,
                                              int N, float* scr) const {
     const int rl = lane >> 3, cl = (lane & 7) * 4;
     const bool two_dh = TWO && dh_a && dh_b;
-#if VD_EPI_BUF & 6
     const Rsrc R{vd_rsrc(gates), vd_rsrc(c_t), vd_rsrc(c_prev), vd_rsrc(dc), vd_rsrc(dh_a ? dh_a : dh_b), vd_rsrc(dh_b), vd_rsrc(da16)};
     const unsigned uH4 = (unsigned)H * 4u;
-#endif
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
       float4 d4[4];
@@ -410,26 +367,14 @@ struct EpiLstmBwd {
 #pragma unroll
       for (int pp = 0; pp < 4; pp += BATCH) {
         Slot L[BATCH];
-#if VD_EPI_BUF & 6
         unsigned o4[BATCH], og4[BATCH];
 #pragma unroll
         for (int q = 0; q < BATCH; ++q) {
           const int row = row0 + (pp + q) * 8 + rl;
           o4[q] = (unsigned)(row < M ? row : M - 1) * uH4 + (unsigned)jc * 4u;
           og4[q] = 4u * o4[q] - 12u * (unsigned)jc;
-#if VD_EPI_BUF & 2
           load_slot_buf(L[q], R, o4[q], og4[q], uH4);
-#else
-          load_slot(L[q], row < M ? row : M - 1, jc);
-#endif
         }
-#else
-#pragma unroll
-        for (int q = 0; q < BATCH; ++q) {
-          const int row = row0 + (pp + q) * 8 + rl;
-          load_slot(L[q], row < M ? row : M - 1, jc);
-        }
-#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < BATCH; ++q) {
@@ -441,20 +386,12 @@ struct EpiLstmBwd {
           float4 dh = d4[pp + q];
           dh.x += C.dhx.x; dh.y += C.dhx.y; dh.z += C.dhx.z; dh.w += C.dhx.w;
           const int row = row0 + (pp + q) * 8 + rl;
-#if VD_EPI_BUF & 6
           if constexpr (TWO) {
             if (two_dh) {
               const float4 t = vd_buf_ld4(R.dh2, o4[q], 0);
               dh.x += t.x; dh.y += t.y; dh.z += t.z; dh.w += t.w;
             }
           }
-#else
-          const long o = (long)(row < M ? row : M - 1) * H + jc;
-          if (two_dh) {
-            const float4 t = *reinterpret_cast<const float4*>(dh_b + o);
-            dh.x += t.x; dh.y += t.y; dh.z += t.z; dh.w += t.w;
-          }
-#endif
           float4 ai, af, ao, ag, dn;
 #define VD_CELLB(E)                                                       \
           {                                                               \
@@ -476,7 +413,6 @@ struct EpiLstmBwd {
           VD_CELLB(x) VD_CELLB(y) VD_CELLB(z) VD_CELLB(w)
 #undef VD_CELLB
           if (row < M && j < N) {
-#if VD_EPI_BUF & 4
             // (row < M and j < N here: the clamped offsets of the loads are the true ones)
             if constexpr (C16) {
               vd_buf_st4_bf16(R.g, og4[q] >> 1, 0, ai);
@@ -496,24 +432,6 @@ struct EpiLstmBwd {
               vd_buf_st4_bf16(R.g16, og4[q] >> 1, uH4, ao);
               vd_buf_st4_bf16(R.g16, og4[q] >> 1, 3 * (uH4 >> 1), ag);
             }
-#else
-#if VD_EPI_BUF & 6
-            const long o = (long)row * H + j;
-#endif
-            float* gr = gates + (long)row * 4 * H + j;
-            *reinterpret_cast<float4*>(gr) = ai;
-            *reinterpret_cast<float4*>(gr + H) = af;
-            *reinterpret_cast<float4*>(gr + 2 * H) = ao;
-            *reinterpret_cast<float4*>(gr + 3 * H) = ag;
-            *reinterpret_cast<float4*>(dc + o) = dn;
-            if (da16) {
-              vd_bf16_bits* g16 = da16 + (long)row * 4 * H + j;
-              vd_st4_bf16(g16, ai);
-              vd_st4_bf16(g16 + H, af);
-              vd_st4_bf16(g16 + 2 * H, ao);
-              vd_st4_bf16(g16 + 3 * H, ag);
-            }
-#endif
           }
         }
       }
@@ -625,8 +543,8 @@ static int lstm_step_bwd(const float* da_next, const float* Wh, int N, int H, in
     if (use_glds_bwd(N, H) && K > 0) {
       // LDS-DMA pipeline: A = da_{t+1} rows, Bt = Wh rows (both contiguous in k = the 4H gate columns).  The two-slot epilogue
       // (loads of two slots in flight before either is consumed: half the serialised round trips) fits the 128-VGPR build with
-      // buffer addressing (-DVD_EPI_BUF & 6); a step with a recurrent product has at most one incoming-gradient operand
-      if ((VD_EPI_BUF & 6) == 6 && !(dh_a && dh_b)) {
+      // buffer addressing; a step with a recurrent product has at most one incoming-gradient operand
+      if (!(dh_a && dh_b)) {
         EpiLstmBwd<2, 2, false> e2c{dh_a, dh_b, gates, c_t, c_prev, dc, dc_first, H};
         return launch_gemm_glds<CfgB11, false>(N, H, K, 1, da_next, 4L * H, Wh, 4L * H, e2c, s);
       }

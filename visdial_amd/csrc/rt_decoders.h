@@ -84,10 +84,16 @@ struct Disc : Decoder {
       VD_TRY(vd_f32_to_bf16(table, table16, (V + 1) * 4 * H, s));
     }
     VD_HIP(hipEventRecord(m->ev_prof[0], s));
-    if (c16) VD_TRY(vd_lstm_forward_c16(table16, 4 * H, b.opt.tok, Wopt + E * 4 * H, gates16, h16, h_last, c, To, NO, (int)H, s));
-    else VD_TRY(vd_lstm_forward(table, 0, 4 * H, b.opt.tok, nullptr, Wopt + E * 4 * H, nullptr, nullptr, gates, h, c, To, NO, (int)H, flags, s));
+    {
+      VdRange r("disc: option LSTM forward");
+      if (c16) VD_TRY(vd_lstm_forward_c16(table16, 4 * H, b.opt.tok, Wopt + E * 4 * H, gates16, h16, h_last, c, To, NO, (int)H, s));
+      else VD_TRY(vd_lstm_forward(table, 0, 4 * H, b.opt.tok, nullptr, Wopt + E * 4 * H, nullptr, nullptr, gates, h, c, To, NO, (int)H, flags, s));
+    }
     VD_HIP(hipEventRecord(m->ev_prof[1], s));
-    VD_TRY(m->enc->forward(m, se, b, &enc_out));                                   // model.lua:297
+    {
+      VdRange r("encoder forward");
+      VD_TRY(m->enc->forward(m, se, b, &enc_out));                                 // model.lua:297
+    }
     VD_TRY(join_stream(m, se, s));
     // criterion (+ nn.MM backward) in one kernel (model.lua:330-335)
     const float* optH = c16 ? h_last : h + (long)(To - 1) * NO * H;
@@ -129,6 +135,7 @@ struct Disc : Decoder {
     m->wg_active = m->streams && m->s_wg && (flags & VD_FLAG_BF16) != 0;
     m->wg_used = false;
     auto enc_bwd = [&]() -> int {
+      VdRange r("encoder backward");
       VD_TRY(m->enc->backward(m, se, b, d_enc));
       if (m->wg_used) {   // encoder tensors final = the chain on `se` AND the gradient work on s_wg
         VD_TRY(fork_stream(m, se, m->s_wg));
@@ -139,11 +146,15 @@ struct Disc : Decoder {
       m->enc_grads_recorded = true;
       return VD_OK;
     };
-    if (c16) VD_TRY(vd_lstm_backward_c16(Wopt + E * 4 * H, gates16, c, d_optH, dc, To, NO, (int)H, s));
-    else VD_TRY(vd_lstm_backward(Wopt + E * 4 * H, gates, c, nullptr, nullptr, d_optH, nullptr, dc, nullptr, nullptr, nullptr, To, NO, (int)H, flags, s));
+    {
+      VdRange r("disc: option LSTM backward");
+      if (c16) VD_TRY(vd_lstm_backward_c16(Wopt + E * 4 * H, gates16, c, d_optH, dc, To, NO, (int)H, s));
+      else VD_TRY(vd_lstm_backward(Wopt + E * 4 * H, gates, c, nullptr, nullptr, d_optH, nullptr, dc, nullptr, nullptr, nullptr, To, NO, (int)H, flags, s));
+    }
     VD_HIP(hipEventRecord(m->ev_prof[3], s));
     VD_TRY(enc_bwd());       // enqueued behind the option recurrence: it runs beside it on the encoder stream
     // table gradient + its consumers beside the dWh contraction
+    VdRange rwg("disc: table gradient + dWh");
     VD_TRY(fork_stream(m, s, st));
     if (c16) VD_TRY(vd_segment_rowsum_acc_bf16(gates16, 4 * H, b.opt.tok, perm, (long)To * NO, (int)(4 * H), dtab, 4 * H, st));
     else VD_TRY(vd_segment_rowsum_acc(gates, 4 * H, b.opt.tok, perm, (long)To * NO, (int)(4 * H), dtab, 4 * H, st));
@@ -238,7 +249,11 @@ struct Gen : Decoder {
     const int N = b.q.N, Ta = b.ain.T;
     const long rows = (long)Ta * N;
     float* encOut;
-    VD_TRY(m->enc->forward(m, s, b, &encOut));                                      // model.lua:297
+    {
+      VdRange r("encoder forward");
+      VD_TRY(m->enc->forward(m, s, b, &encOut));                                    // model.lua:297
+    }
+    VdRange rdec("gen: decoder forward + criterion + backward");
     VD_TRY(forwardConnect(m, s, encOut, m->enc->seqLen(b), nullptr, N));            // model.lua:300
     float *x, *h, *logits, *loss_rows;
     VD_TRY(ws_get(m, "dec.x", (size_t)rows * E, &x));
@@ -264,7 +279,10 @@ struct Gen : Decoder {
     VD_TRY(vd_embed_scatter_acc(Gp(m, "embed"), b.ain.tok, nullptr, dx[0], rows, (int)E, 1.f, s));
     const float* gradDecOut = backwardConnect(m);                                   // model.lua:319
     VD_CHECK_ARG(gradDecOut, "backwardConnect produced no gradient");
-    VD_TRY(m->enc->backward(m, s, b, gradDecOut));                                  // model.lua:322
+    {
+      VdRange r("encoder backward");
+      VD_TRY(m->enc->backward(m, s, b, gradDecOut));                                // model.lua:322
+    }
     VD_HIP(hipEventRecord(m->ev_enc_grads, s));
     m->enc_grads_recorded = true;
     m->prof_valid = m->prof_hist;       // [history branch fwd, history branch bwd, vocabulary family] (vd_model_family_ms)

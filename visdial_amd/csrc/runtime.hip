@@ -368,6 +368,7 @@ int vd_model_upload_batch(vd_model* m, const vd_batch* hb) {
   const bool disc = m->dec_name == "disc";
   VD_CHECK_ARG(!disc || (hb->options && hb->To > 0), "vd_model_upload_batch: decoder 'disc' needs options");
   // (decoder gen: answer_in/answer_out for training, option_in/option_out for retrieval, neither for generation)
+  VdRange r("vd_model_upload_batch");
   BatchSlot& sl = m->slot[m->cur < 0 ? 0 : (m->cur ^ 1)];   // the slot the running step does not read
   hipStream_t s = m->s_copy;
   // the step that last read this slot may still be executing (the host runs ahead of the device)
@@ -493,6 +494,7 @@ static int begin_step(vd_model* m, bool zero_grads, BatchSlot** out) {
 
 // Model:forwardBackward on the uploaded batch (model.lua:249-342).  Enqueues only.
 int vd_model_forward_backward(vd_model* m, int only_forward) {
+  VdRange r(only_forward ? "vd_model_forward" : "vd_model_forward_backward");
   BatchSlot* b = nullptr;
   VD_TRY(begin_step(m, !only_forward, &b));
   const int rc = m->dec->forward_backward(m, *b, only_forward != 0);
@@ -503,6 +505,7 @@ int vd_model_forward_backward(vd_model* m, int only_forward) {
 // Model:retrieveBatch up to the option scores (model.lua:344-425): disc = option scores of a forward pass, gen = the
 // log-likelihood of every candidate under the decoder.  Read them with vd_model_scores / vd_model_ranks.
 int vd_model_retrieve(vd_model* m) {
+  VdRange r("vd_model_retrieve");
   BatchSlot* b = nullptr;
   VD_TRY(begin_step(m, false, &b));
   const int rc = m->dec->retrieve(m, *b);
@@ -552,6 +555,7 @@ int vd_model_loss(vd_model* m, float* loss) {
 // [gradient already reduced by the caller] -> clamp(-5, 5) -> adam -> lr decay (model.lua:96-105; optim_updates.lua:62-91)
 int vd_model_update(vd_model* m, float gscale) {
   VD_CHECK_ARG(m, "vd_model_update: null model");
+  VdRange r("vd_model_update: clamp + adam");
   m->adam_t += 1;
   const double t = m->adam_t;
   const float step = (float)(m->lr * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t)));
