@@ -50,12 +50,51 @@ def _world_arg(argv):
 # resolve inside the command processor and the step is 3-4 % faster (profiles/r02_hw_queues.txt).
 # Must be in the environment before HIP initialises, i.e. before torch touches the device; an explicit setting wins.
 # (The Python operator-level host is slower that way -- 29.0 vs 26.8 ms -- so it keeps the default.)
-# Only for ONE GPU: with peers, RCCL's kernels would share that single hardware queue with the five compute streams --
-# never measured on an 8-GPU node (none is available to the builder), so multi-GPU runs keep HIP's default.
-if _host_arg(sys.argv[1:]) == 'native' and _world_arg(sys.argv[1:]) == 1:
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '1')
+# With peers, RCCL's kernels share the hardware queues with the compute streams and nothing was ever measured on a multi-GPU
+# node: the setting is then CHOSEN BY MEASUREMENT -- every rank runs two short probe children of this script (3 warm-up + 3 timed
+# steps each, the full data-parallel step with the library communicator, on their own rendezvous ports), one with a single
+# hardware queue and one with HIP's default; the faster one (max over ranks, so every rank picks the same) is used and printed.
+QUEUE_CHOICE = None
+
+
+def _probe_hw_queues(world):
+    """-> (choice or None, report).  Runs before HIP is initialised in this process; any failure keeps HIP's default."""
+    import subprocess
+    rank = os.environ.get('RANK', '0')
+    base = int(os.environ.get('MASTER_PORT', '29533'))
+    res = {}
+    for k, setting in enumerate(('1', 'default')):
+        env = dict(os.environ, VD_BENCH_PROBE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(20000 + (base * 7 + 101 * (k + 1)) % 20000))
+        env.pop('TORCHELASTIC_USE_AGENT_STORE', None)          # the probe children rendezvous among themselves (rank 0's child hosts the store)
+        env.pop('GPU_MAX_HW_QUEUES', None)
+        if setting != 'default':
+            env['GPU_MAX_HW_QUEUES'] = setting
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), '--gpus', str(world), '--steps', '3', '--warmup', '3',
+                                  '--no-cpu-baseline', '--no-other-configs'], env=env, capture_output=True, text=True, timeout=180)
+            ms = [float(l.split()[1]) for l in out.stdout.splitlines() if l.startswith('PROBE_MS ')]
+            if out.returncode != 0 or not ms:
+                return None, 'probe with GPU_MAX_HW_QUEUES=%s failed on rank %s (rc %d): %s' % (setting, rank, out.returncode, out.stderr[-300:])
+            res[setting] = ms[-1]
+        except Exception as exc:      # timeout, spawn failure: keep the default
+            return None, 'probe with GPU_MAX_HW_QUEUES=%s failed on rank %s: %r' % (setting, rank, exc)
+    choice = min(res, key=res.get)
+    return choice, 'GPU_MAX_HW_QUEUES A/B (3 + 3 steps each, ms/step max over ranks): %s -> %s' % (res, choice)
+
+
+if os.environ.get('VD_BENCH_PROBE') != '1' and _host_arg(sys.argv[1:]) == 'native' and 'GPU_MAX_HW_QUEUES' not in os.environ:
+    if _world_arg(sys.argv[1:]) == 1 and os.environ.get('VD_BENCH_FORCE_QUEUE_PROBE') != '1':
+        os.environ['GPU_MAX_HW_QUEUES'] = '1'
+    elif 'RANK' in os.environ:          # a rank of a multi-GPU run (under torch.distributed.run): measure, then choose
+        _choice, QUEUE_CHOICE = _probe_hw_queues(_world_arg(sys.argv[1:]))
+        if _choice and _choice != 'default':
+            os.environ['GPU_MAX_HW_QUEUES'] = _choice
+        print('[rank %s] %s' % (os.environ.get('RANK'), QUEUE_CHOICE), file=sys.stderr, flush=True)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+BF16_MFMA_SUSTAINED_TFLOPS = 1862.0    # MEASURED on non-zero operands (scripts/probes/mfma_bf16_peak.hip, profiles/r05_mfma_sustained.txt): the clock
+                                       # follows the power budget (2 482 on zeros, 1 862 on random data; v_mfma_f32_32x32x2_f32 holds 154.6 of 157.3)
 STEP_GFLOP_PER_ROUND = 21.934          # SURVEY.md 8(d): nominal dense math of the reference graph per QA round
 
 
@@ -77,7 +116,7 @@ def headline_params(rank=0, batch=20, config=3):
     return config_params(config, rank=rank, batch=batch)
 
 
-def dominant_kernel_alone(p, N, iters=3):
+def dominant_kernel_alone(p, N, iters=3, recurrence='fp32'):
     """The dominant kernel family (option-LSTM backward, To-1 timestep launches) run by itself on the same shapes, HIP
     events on its stream: the rate the kernel reaches when it does not share the matrix pipe with the encoder."""
     import torch
@@ -89,7 +128,8 @@ def dominant_kernel_alone(p, N, iters=3):
     c = torch.randn(To, NO, H, device='cuda', generator=g) * 0.1
     dcw = torch.empty(NO, H, device='cuda')
     dh_last = torch.randn(NO, H, device='cuda', generator=g) * 0.01
-    run = lambda: ops.lstm_backward(Wh, gates, c, dcw, To, NO, H, dh_last=dh_last)
+    flags = ops.PRECISION_FLAGS[recurrence]
+    run = lambda: ops.lstm_backward(Wh, gates, c, dcw, To, NO, H, dh_last=dh_last, flags=flags)
     run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -101,7 +141,11 @@ def dominant_kernel_alone(p, N, iters=3):
     ms = e0.elapsed_time(e1) / iters / (To - 1)
     tf = 2.0 * NO * H * 4 * H / ms / 1e9
     del gates, c
-    return {"avg_launch_ms": round(ms, 4), "achieved": round(tf, 2), "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+    if recurrence == 'fp32':
+        return {"avg_launch_ms": round(ms, 4), "achieved": round(tf, 2), "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+    nprod = int(recurrence[-1])
+    return {"avg_launch_ms": round(ms, 4), "achieved": round(nprod * tf, 2), "frac": round(nprod * tf / BF16_MFMA_PEAK_TFLOPS, 4),
+            "fp32_equivalent_tflops": round(tf, 2)}
 
 
 def csrc_digest():
@@ -149,6 +193,88 @@ def bf16_option_roofline(fams, dom, rows=20000, H=512, To=20):
                     "peak.  Neither bound is near: the cell update's VALU work and the CU's load path set the time (profiles/r04_experiments.txt section 2)"
                     % fams[dom]['tflops_executed'],
             "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
+
+
+def stored_traffic():
+    """-> (lookup(key) -> HBM-side bytes per launch or None, digest of the build the PMC passes were taken on).  profiles/pmc_summary.json is
+    a STORED rocprofv3 measurement (2 x FETCH_SIZE + WRITE_SIZE per launch); it is reported only while the kernel sources are the ones it
+    was taken on.  Keys: opt_lstm_fwd / _bwd / _dWh = the fp32-MFMA kernels, 'split9:opt_lstm_fwd' / '_bwd' = the split kernels."""
+    pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
+    try:
+        summ = json.load(open(pmc))
+    except Exception:
+        return (lambda key: None), None
+    build = summ.get('csrc_sha256')
+    ok = build == csrc_digest()
+    return (lambda key: (summ.get(key) or {}).get('hbm_bytes_per_launch') if ok else None), build
+
+
+def split_roofline(fams, step_fam, recurrence, traffic=None):
+    """the dominant timestep kernel of a split pass: executed bf16-MFMA FLOPs (nprod x the fp32 product's) against the 2.5 PFLOP/s dense peak"""
+    nprod = int(recurrence[-1])
+    a32 = fams[step_fam]['tflops_executed']
+    return {"bound": "mfma", "kernel": step_fam, "achieved": round(nprod * a32, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(nprod * a32 / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "sustained_peak": BF16_MFMA_SUSTAINED_TFLOPS, "frac_of_sustained_peak": round(nprod * a32 / BF16_MFMA_SUSTAINED_TFLOPS, 4),
+            "fp32_equivalent_tflops": round(a32, 2), "fp32_equivalent_frac_of_fp32_mfma_peak": round(a32 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "avg_launch_ms": round(fams[step_fam]['avg_launch_ms'], 4),
+            "note": "every fp32 recurrent product h*Wh / da*Wh^T issued as %d bf16 MFMAs (v_mfma_f32_32x32x16_bf16, fp32 accumulate) on the exact "
+                    "hi/mid/lo split of BOTH operands (all 24 significand bits); achieved = executed bf16-MFMA FLOPs (%d x the fp32 product's) / "
+                    "HIP-event launch time inside the overlapped step, priced against the 2.5 PFLOP/s dense bf16 peak; sustained_peak = what the "
+                    "matrix pipe holds on non-zero operands under the power budget (measured, profiles/r05_mfma_sustained.txt) -- the bound "
+                    "this kernel actually meets (profiles/r05_experiments.txt section 1); the dWh contraction runs on v_mfma_f32_32x32x2_f32"
+                    % (nprod, nprod),
+            "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
+
+
+def fp32_roofline(fams, dom, value, traffic=None, traffic_build=None):
+    a = fams[dom]['tflops_executed']
+    return {"bound": "mfma", "kernel": dom, "achieved": round(a, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(a / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_build": {"pmc_taken_on_csrc": traffic_build, "this_build_csrc": csrc_digest(),
+                              "note": "traffic is null when the kernel sources changed since the PMC pass"},
+            "achieved_nominal": round(fams[dom]['tflops_nominal'], 2),
+            "avg_launch_ms": round(fams[dom]['avg_launch_ms'], 4),
+            "note": "achieved = EXECUTED FLOPs of the dominant kernel per launch (the recurrent h*Wh / da*Wh^T "
+                    "products actually issued on the matrix pipe) / its HIP-event launch time measured inside "
+                    "the overlapped step; achieved_nominal also counts the x*Wx product of the reference graph "
+                    "that this build replaces by an exact table gather (SURVEY 8d); traffic = HBM-side bytes per launch of the "
+                    "same kernel on the same shapes from the committed rocprofv3 PMC passes (profiles/pmc_summary.json: 2 x "
+                    "FETCH_SIZE + WRITE_SIZE), a stored measurement, not a live counter",
+            "step_tflops_nominal": round(STEP_GFLOP_PER_ROUND * value / 1e3, 2),
+            "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
+
+
+def alt_leg(args, N):
+    """The SAME timed protocol (W warm-up + K steps, a fresh batch every step) with the option recurrence on v_mfma_f32_32x32x2_f32 -- the
+    arithmetic of the headline of rounds 1-4, kept beside the split9 headline in the same JSON line.  Single GPU only."""
+    from visdial_amd.dataloader import SyntheticDataloader
+    from visdial_amd.native import NativeModel
+    p = headline_params(batch=args.batch, config=3)
+    model = NativeModel(p)
+    dl = SyntheticDataloader(p, seed=1234, fast=True)
+    for _ in range(args.warmup):
+        model.trainIteration(dl)
+    model.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = model.trainIteration(dl)
+    model.synchronize()
+    elapsed = time.perf_counter() - t0
+    f = model.family_ms()
+    fams = option_families(p, N, {'opt_lstm_fwd': (f[0], 1), 'opt_lstm_bwd': (f[1], 1), 'opt_lstm_dWh': (f[2], 1)}, 1)
+    dom = max(fams, key=lambda k: fams[k]['ms_total_per_step'])
+    value = N * args.steps / elapsed
+    traffic_of, traffic_build = stored_traffic()
+    roof = fp32_roofline(fams, dom, value, traffic_of(dom), traffic_build)
+    try:
+        roof["alone"] = dominant_kernel_alone(p, N)
+    except Exception as exc:
+        roof["alone"] = {"error": str(exc)[:120]}
+    model.close()
+    return {"dtype": "f32 (v_mfma_f32_32x32x2_f32 in the option recurrence as everywhere else)", "recurrence": "fp32",
+            "value": round(value, 2), "unit": "QA-rounds/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3), "steps": args.steps,
+            "warmup": args.warmup, "loss": round(float(loss), 5), "roofline": roof}
 
 
 def other_config(cfg, steps=10, warmup=3):
@@ -301,10 +427,12 @@ def main():
     ap.add_argument('--no-streams', action='store_true', help='whole step on one HIP stream (A/B only)')
     ap.add_argument('--config', type=int, choices=[3, 4], default=3,
                     help='BASELINE.json configs index: 3 = headline (fp32, 14x14x512); 4 = 7x7x2048 features + bf16 option recurrence')
-    ap.add_argument('--recurrence', choices=['fp32', 'split9', 'split6'], default='fp32',
-                    help='arithmetic of the option recurrence at --config 3: fp32 = v_mfma_f32_32x32x2_f32 (DEFAULT, the headline); '
-                         'split9 = exact 3-way bf16 split of both operands, 9 bf16 MFMAs per fp32 one (opt-in, fp32-grade: '
-                         'tests/test_ops_gpu.py::test_split_error_table); split6 = 6 products (data only)')
+    ap.add_argument('--recurrence', choices=['fp32', 'split9', 'split6'], default='split9',
+                    help='arithmetic of the option recurrence at --config 3: split9 (DEFAULT, the headline) = every fp32 operand as the exact sum '
+                         'of three bf16 values, all 9 bf16 MFMA products, fp32 accumulate -- fp32-grade results (errors <= the fp32 MFMA\'s own: '
+                         'tests/test_ops_gpu.py::test_split_error_table, tests/test_full_size_golden.py); fp32 = v_mfma_f32_32x32x2_f32 (reported '
+                         'beside the headline as `alt`); split6 = 6 products (data only, never a headline)')
+    ap.add_argument('--no-alt', action='store_true', help='skip the `alt` leg (the same steps with the fp32-MFMA recurrence) after the headline')
     ap.add_argument('--collective', choices=['library', 'torch'], default='library',
                     help='native host, N > 1: library = RCCL behind the C ABI (default); torch = host-side torch.distributed')
     ap.add_argument('--host', choices=['python', 'native'], default=os.environ.get('VD_BENCH_HOST', 'native'),
@@ -356,8 +484,9 @@ def main():
     from visdial_amd.model import Model
 
     p = headline_params(rank=rank, batch=args.batch, config=args.config)
-    if args.recurrence != 'fp32':
-        assert args.config == 3, "--recurrence applies to the fp32 headline configuration"
+    if args.config != 3:
+        args.recurrence = 'fp32'                # (--recurrence is the arithmetic of the fp32-grade headline; configs[4] is the bf16 pass)
+    elif args.recurrence != 'fp32':
         p['lstmPrecision'] = args.recurrence
     if args.no_streams:
         p['useStreams'] = 0
@@ -407,6 +536,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(t.item())
 
+    if os.environ.get('VD_BENCH_PROBE') == '1':      # a GPU_MAX_HW_QUEUES probe child (see the top of this file): every rank reports, no JSON line
+        print('PROBE_MS %.4f' % (elapsed / args.steps * 1e3), flush=True)
+        if lib_comm:
+            from visdial_amd.parallel import destroy_library_comm
+            model.synchronize()
+            destroy_library_comm()
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * N * args.steps / elapsed
@@ -418,51 +556,18 @@ def main():
         dom = max(fams, key=lambda k: fams[k]['ms_total_per_step']) if fams else None
         # HBM-side bytes per launch of the dominant kernel: a STORED rocprofv3 PMC measurement, reported only while the kernel
         # sources are the ones it was taken on (profiles/pmc_summary.json carries their digest)
-        traffic, traffic_build = None, None
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
-        if os.path.exists(pmc):
-            try:
-                summ = json.load(open(pmc))
-                traffic_build = summ.get('csrc_sha256')
-                if traffic_build == csrc_digest():
-                    traffic = summ.get(dom, {}).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
+        traffic_of, traffic_build = stored_traffic()
+        traffic = traffic_of(dom)
         roof = None
         if dom and args.config == 4:
             roof = bf16_option_roofline(fams, dom, rows=N * p['numOptions'], H=p['rnnHiddenSize'], To=p['maxAnsLen'])
-        elif dom and args.recurrence != 'fp32':
-            nprod = 9 if args.recurrence == 'split9' else 6
-            step_fam = max(('opt_lstm_fwd', 'opt_lstm_bwd'), key=lambda k: fams[k]['ms_total_per_step'])    # (dWh stays on the fp32 MFMA)
-            a32 = fams[step_fam]['tflops_executed']
-            roof = {"bound": "mfma", "kernel": step_fam, "achieved": round(nprod * a32, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                    "frac": round(nprod * a32 / 2500.0, 4), "traffic": None,
-                    "fp32_equivalent_tflops": round(a32, 2), "fp32_equivalent_frac_of_fp32_mfma_peak": round(a32 / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "avg_launch_ms": round(fams[step_fam]['avg_launch_ms'], 4),
-                    "note": "OPT-IN arithmetic, not the headline: every fp32 recurrent product h*Wh / da*Wh^T issued as %d bf16 MFMAs "
-                            "(v_mfma_f32_32x32x16_bf16) on the exact hi/mid/lo split of both operands; achieved = executed bf16-MFMA FLOPs "
-                            "(%d x the fp32 product's) / HIP-event time, priced against the 2.5 PFLOP/s dense bf16 peak; the dWh contraction "
-                            "still runs on v_mfma_f32_32x32x2_f32" % (nprod, nprod),
-                    "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
+        elif dom and args.recurrence != 'fp32' and dom != 'opt_lstm_dWh':
+            roof = split_roofline(fams, dom, args.recurrence, traffic_of(args.recurrence + ':' + dom))
         elif dom:
-            a = fams[dom]['tflops_executed']
-            roof = {"bound": "mfma", "kernel": dom, "achieved": round(a, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(a / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_build": {"pmc_taken_on_csrc": traffic_build, "this_build_csrc": csrc_digest(),
-                                      "note": "traffic is null when the kernel sources changed since the PMC pass"},
-                    "achieved_nominal": round(fams[dom]['tflops_nominal'], 2),
-                    "avg_launch_ms": round(fams[dom]['avg_launch_ms'], 4),
-                    "note": "achieved = EXECUTED FLOPs of the dominant kernel per launch (the recurrent h*Wh / da*Wh^T "
-                            "products actually issued on the matrix pipe) / its HIP-event launch time measured inside "
-                            "the overlapped step; achieved_nominal also counts the x*Wx product of the reference graph "
-                            "that this build replaces by an exact table gather (SURVEY 8d); traffic = HBM-side bytes per launch of the "
-                            "same kernel on the same shapes from the committed rocprofv3 PMC passes (profiles/pmc_summary.json: 2 x "
-                            "FETCH_SIZE + WRITE_SIZE), a stored measurement, not a live counter",
-                    "step_tflops_nominal": round(STEP_GFLOP_PER_ROUND * value / 1e3, 2),
-                    "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
-        if roof and roof.get("bound") == "mfma" and world == 1 and args.recurrence == 'fp32':
+            roof = fp32_roofline(fams, dom, value, traffic, traffic_build)
+        if roof and roof.get("bound") == "mfma" and world == 1 and args.config == 3:
             try:
-                roof["alone"] = dominant_kernel_alone(p, N)     # same kernel, same shapes, nothing else on the chip
+                roof["alone"] = dominant_kernel_alone(p, N, recurrence=args.recurrence if dom != 'opt_lstm_dWh' else 'fp32')   # same kernel, same shapes, nothing else on the chip
             except Exception as exc:                            # never let the extra figure break the bench line
                 roof["alone"] = {"error": str(exc)[:120]}
         ps = np.array(per_step) * 1e3
@@ -475,8 +580,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if args.recurrence == 'fp32' else
-                      "f32 results from the exact 3-way bf16 split of both operands (%s bf16 MFMA products per fp32 product, f32 accumulate) "
-                      "in the option recurrence, f32 MFMA elsewhere" % args.recurrence[-1]) if args.config == 3
+                      "f32 operands and results; the option recurrence multiplies the EXACT 3-way bf16 split of both operands (%s bf16 MFMA "
+                      "products per fp32 product, f32 accumulate: fp32-grade, errors <= the f32 MFMA's own), f32 MFMA (v_mfma_f32_32x32x2_f32) "
+                      "everywhere else; the all-f32-MFMA line of the same run is under `alt`" % args.recurrence[-1]) if args.config == 3
             else "bf16 operands / f32 accumulate (option recurrence only), f32 elsewhere",
             "data": "synthetic" + (" (one resident batch reused)" if args.same_batch else
                                    " (a fresh batch every step: host generation + length sort + H2D upload inside the timed region, overlapped)"),
@@ -486,14 +592,21 @@ def main():
                        "global_batch_dialogs": world * args.batch, "parallelism": "dp%d" % world,
                        "dropout": "on (device generator)", "loss": round(float(loss), 5), "host": args.host,
                        "GPU_MAX_HW_QUEUES": os.environ.get('GPU_MAX_HW_QUEUES', 'default'),
+                       "GPU_MAX_HW_QUEUES_choice": QUEUE_CHOICE,
                        "collective": collective,
                        "option_rows_executed_of_total": (list(model.option_rows()) if args.host == 'native' else None)},
             "roofline": roof,
         }
-        if world == 1 and args.config == 3 and args.recurrence == 'fp32' and not args.no_other_configs:
+        if world == 1 and args.config == 3 and args.host == 'native':
+            model.close()
+        if world == 1 and args.config == 3 and args.recurrence != 'fp32' and args.host == 'native' and not args.no_alt:
+            try:
+                out["alt"] = alt_leg(args, N)
+            except Exception as exc:
+                out["alt"] = {"recurrence": "fp32", "error": str(exc)[:200]}
+        if world == 1 and args.config == 3 and args.host == 'native' and not args.no_other_configs:
             # the other single-GPU configurations of BASELINE.json, driver-visible (the headline `value` above is unaffected:
             # they run after its timed region, on their own models)
-            model.close() if hasattr(model, 'close') else None
             out["other_configs"] = []
             for cfg in (1, 2, 4):
                 try:

@@ -302,6 +302,9 @@ int vd_comm_available(int* version);
 /* the last vd_model_allreduce_grads: floats in bucket 1 (encoder tensors, reduced under the decoder's backward) and bucket 2
  * (embedding + decoder), whether bucket 1 was issued early, calls since vd_comm_init */
 int vd_comm_stats(int64_t* bucket1_floats, int64_t* bucket2_floats, int* overlapped, int64_t* calls);
+/* the last vd_model_allreduce_grads: ms between "bucket 1 summed over the ranks" (communication stream) and "backward ended" (main
+ * stream); positive = hidden under the decoder's backward with that much to spare, negative = exposed.  Waits for both events. */
+int vd_comm_overlap_ms(float* lead_ms);
 int vd_model_allreduce_grads(vd_model* m);                /* enqueue only; every rank, once per step */
 int vd_model_init_params(vd_model* m, uint64_t seed);     /* library-default init */
 int vd_model_set_tensor(vd_model* m, const char* name, const float* host, int64_t n);   /* wrapperW:copy(...) */

@@ -26,13 +26,15 @@ from visdial_amd.parallel import shard_dialogs
 def main():
     backend = os.environ.get('VD_TEST_BACKEND', 'nccl')
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    torch.cuda.set_device(0)
+    # VD_TEST_DISTINCT_DEVICES=1 (boxes with >= world GPUs): rank r drives cuda:r -- the collective meets a real peer over xGMI
+    dev = int(os.environ.get('LOCAL_RANK', 0)) if os.environ.get('VD_TEST_DISTINCT_DEVICES') == '1' else 0
+    torch.cuda.set_device(dev)
     if backend == 'nccl':
-        dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+        dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
     else:
         dist.init_process_group('gloo')
     per_rank = 2
-    p = derive(small_params(batchSize=per_rank, gpuid=0, rank=0))       # same seed on every rank: replicated parameters
+    p = derive(small_params(batchSize=per_rank, gpuid=dev, rank=0))     # same seed on every rank: replicated parameters
     full = SyntheticDataloader(derive(small_params(batchSize=per_rank * world)), seed=123).getTrainBatch(
         derive(small_params(batchSize=per_rank * world)))
     lo, hi = shard_dialogs(per_rank * world, rank, world)
@@ -49,7 +51,7 @@ def main():
             # the process group (gloo) only carries the 128-byte rendezvous token -- what a Lua host would do by file
             from visdial_amd import _lib
             from visdial_amd.parallel import init_library_comm_over, library_comm_world
-            _lib.call("vd_set_device", 0)
+            _lib.call("vd_set_device", dev)
             init_library_comm_over(dist.group.WORLD)
             assert library_comm_world() == world
             model = NativeModel(p, library_comm=True)
@@ -77,7 +79,7 @@ def main():
     losses = [None] * world
     dist.all_gather_object(losses, float(loss))
     if rank == 0:
-        pb = derive(small_params(batchSize=per_rank * world, gpuid=0, rank=0))
+        pb = derive(small_params(batchSize=per_rank * world, gpuid=dev, rank=0))
         if native:
             big = NativeModel(pb)
             big.training(False)
@@ -102,8 +104,12 @@ def main():
         settled = np.abs(g_big) > 1e-6
         assert np.abs(w_dp - w_big)[settled].max() < 1e-6
         assert np.mean(np.abs(w_dp - w_big) < 1e-6) > 0.999
-        print("DP_GPU_OK world=%d backend=%s host=%s async_encoder_bucket=%s grad_rel_err=%.2e" % (
-            world, backend, host, used_async_bucket, err))
+        stats = ''
+        if host == 'native-lib':
+            from visdial_amd.parallel import library_comm_stats
+            stats = ' comm=%s' % (library_comm_stats(),)
+        print("DP_GPU_OK world=%d backend=%s host=%s devices=%s async_encoder_bucket=%s grad_rel_err=%.2e%s" % (
+            world, backend, host, 'distinct' if os.environ.get('VD_TEST_DISTINCT_DEVICES') == '1' else 'shared', used_async_bucket, err, stats))
     if host == 'native-lib':
         from visdial_amd.parallel import destroy_library_comm
         model.synchronize()

@@ -163,6 +163,10 @@ class DryLib(object):
             ctypes.cast(version, ctypes.POINTER(ctypes.c_int))[0] = 22203
         return 0
 
+    def c_vd_comm_overlap_ms(self, lead):
+        self.fail("vd_comm_overlap_ms: the last all-reduce was not split into an early and a late bucket")
+        return -3
+
     def c_vd_comm_stats(self, b1, b2, ov, n):
         calls = getattr(self, 'comm_calls', 0)
         for ptr, ty, v in ((b1, ctypes.c_int64, 100 if calls else 0), (b2, ctypes.c_int64, 50 if calls else 0), (ov, ctypes.c_int, 1 if calls else 0),

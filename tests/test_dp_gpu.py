@@ -61,3 +61,20 @@ def test_native_host_library_rccl_world1():
     RCCL kernels really run on the gradient buffer and the step must equal the plain single-process step."""
     out = _run(1, 'gloo', dict(VD_FORCE_ALLREDUCE='1', VD_TEST_HOST='native-lib', NCCL_DEBUG='VERSION'))
     assert 'host=native-lib' in out
+
+
+def test_native_host_library_rccl_world2_two_devices(capsys):
+    """the FIRST time a box with two GPUs runs this suite, `vd_model_allreduce_grads` meets a real peer -- rank r on
+    cuda:r, the library's own RCCL communicator over xGMI, both buckets -- and the two-rank step must equal the big-batch step (gradient
+    rel-L2 1e-5, post-Adam parameters).  One-GPU boxes skip, with the reason printed."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    n = torch.cuda.device_count()
+    if n < 2:
+        with capsys.disabled():
+            print("\n[test_dp_gpu] %d GPU visible: the two-device library-RCCL step is NOT exercised on this box "
+                  "(world-2 coverage here = gloo + host staging only)" % n)
+        pytest.skip("needs two GPUs (found %d): vd_model_allreduce_grads has no real peer on this box" % n)
+    out = _run(2, 'gloo', dict(VD_TEST_HOST='native-lib', VD_TEST_DISTINCT_DEVICES='1', NCCL_DEBUG='VERSION'))
+    assert 'world=2' in out and 'host=native-lib' in out and 'devices=distinct' in out
+    assert "'overlapped': True" in out                     # the encoder bucket went out early

@@ -112,6 +112,7 @@ PROTOTYPES = {
     "vd_comm_destroy": [],
     "vd_comm_available": [C.POINTER(C.c_int)],
     "vd_comm_stats": [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64)],
+    "vd_comm_overlap_ms": [C.POINTER(C.c_float)],
     "vd_model_allreduce_grads": [_p],
     "vd_model_init_params": [_p, _u64],
     "vd_model_set_tensor": [_p, C.c_char_p, _p, _l],

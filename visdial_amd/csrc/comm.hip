@@ -39,6 +39,9 @@ struct CommState {
   hipStream_t stream = nullptr;      // library-owned communication stream
   hipEvent_t ev_tail = nullptr;      // main stream -> comm stream: "the whole backward has been enqueued up to here"
   hipEvent_t ev_done = nullptr;      // comm stream -> main stream: "both buckets are reduced"
+  hipEvent_t ev_b1 = nullptr;        // comm stream: bucket 1 reduced        } timed: vd_comm_overlap_ms = how long before the end of the
+  hipEvent_t ev_tail_t = nullptr;    // main stream: the backward has ended   } backward the encoder bucket was already summed
+  bool timed = false;                // both recorded by the last call
   // the last vd_model_allreduce_grads, for vd_comm_stats
   int64_t calls = 0, bucket1 = 0, bucket2 = 0;
   int overlapped = 0;
@@ -82,6 +85,10 @@ int load_rccl() {
 void release_local() {
   if (g.ev_tail) (void)hipEventDestroy(g.ev_tail);
   if (g.ev_done) (void)hipEventDestroy(g.ev_done);
+  if (g.ev_b1) (void)hipEventDestroy(g.ev_b1);
+  if (g.ev_tail_t) (void)hipEventDestroy(g.ev_tail_t);
+  g.ev_b1 = g.ev_tail_t = nullptr;
+  g.timed = false;
   if (g.stream) (void)hipStreamDestroy(g.stream);
   g.ev_tail = g.ev_done = nullptr;
   g.stream = nullptr;
@@ -130,6 +137,8 @@ int vd_comm_init(int rank, int world, const void* id128) {
   hipError_t e = hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, greatest);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&g.ev_tail, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&g.ev_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreate(&g.ev_b1);
+  if (e == hipSuccess) e = hipEventCreate(&g.ev_tail_t);
   NcclResult r = 0;
   if (e == hipSuccess) r = g.api.CommInitRank(&g.comm, world, id, rank);
   if (e != hipSuccess || r != 0) {
@@ -163,6 +172,23 @@ int vd_comm_stats(int64_t* bucket1_floats, int64_t* bucket2_floats, int* overlap
   if (bucket2_floats) *bucket2_floats = g.bucket2;
   if (overlapped) *overlapped = g.overlapped;
   if (calls) *calls = g.calls;
+  return VD_OK;
+}
+
+// The last vd_model_allreduce_grads: milliseconds between "bucket 1 (the encoder's tensors) is summed over the ranks" on the communication
+// stream and "the backward pass has ended" on the main stream.  POSITIVE = the exchange of bucket 1 was hidden under the decoder's backward
+// with that much to spare; negative = it finished that long AFTER the backward (exposed).  Waits for both events.  VD_ERR_STATE when the
+// last call did not split the gradient (no encoder-final event, or no call yet).
+int vd_comm_overlap_ms(float* lead_ms) {
+  VD_CHECK_ARG(lead_ms, "vd_comm_overlap_ms: null");
+  *lead_ms = 0.f;
+  if (!g.comm || !g.timed) {
+    vd_set_error("vd_comm_overlap_ms: the last all-reduce was not split into an early and a late bucket");
+    return VD_ERR_STATE;
+  }
+  VD_HIP(hipEventSynchronize(g.ev_b1));
+  VD_HIP(hipEventSynchronize(g.ev_tail_t));
+  VD_HIP(hipEventElapsedTime(lead_ms, g.ev_b1, g.ev_tail_t));
   return VD_OK;
 }
 
@@ -206,7 +232,10 @@ int vd_model_allreduce_grads(vd_model* m) {
   if (split) {
     VD_HIP(hipStreamWaitEvent(g.stream, m->ev_enc_grads, 0));
     VD_NCCL(g.api.AllReduce(m->G + lo, m->G + lo, (size_t)(hi - lo), kNcclFloat32, kNcclSum, g.comm, g.stream));
+    VD_HIP(hipEventRecord(g.ev_b1, g.stream));
+    VD_HIP(hipEventRecord(g.ev_tail_t, m->s_main));
   }
+  g.timed = split;
   VD_HIP(hipEventRecord(g.ev_tail, m->s_main));
   VD_HIP(hipStreamWaitEvent(g.stream, g.ev_tail, 0));
   if (split) {

@@ -106,7 +106,13 @@ def library_comm_stats():
     from . import _lib
     b1, b2, ov, n = C.c_int64(), C.c_int64(), C.c_int(), C.c_int64()
     _lib.call("vd_comm_stats", C.byref(b1), C.byref(b2), C.byref(ov), C.byref(n))
-    return dict(bucket1_floats=int(b1.value), bucket2_floats=int(b2.value), overlapped=bool(ov.value), calls=int(n.value))
+    out = dict(bucket1_floats=int(b1.value), bucket2_floats=int(b2.value), overlapped=bool(ov.value), calls=int(n.value))
+    if out['overlapped']:
+        # how long before the end of the backward pass the encoder bucket was already summed (negative: exposed)
+        lead = C.c_float()
+        if _lib.load().vd_comm_overlap_ms(C.byref(lead)) == 0:
+            out['bucket1_done_before_backward_end_ms'] = round(float(lead.value), 3)
+    return out
 
 
 def join_library_comm(group, device=None):
