@@ -389,6 +389,7 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
     for (int kt = 0; kt < nk; kt += 2) {
       store_tile_from(0, ra, rb);
       __syncthreads();
+      if (kt == 0) VD_T(1);
       if (kt + 2 < nk) load_tile_into(ktile(kt + 2), ra, rb);
       mfma_tile(0);
       __syncthreads();
@@ -400,6 +401,7 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
         __syncthreads();
       }
     }
+    VD_T(2);
   } else if constexpr (Cfg::DB == 1) {
     // two LDS buffers, one barrier per K tile
     if (nk > 0) {

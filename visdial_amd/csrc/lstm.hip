@@ -362,6 +362,7 @@ struct EpiLstmBwd {
     for (int jt = 0; jt < NT; ++jt) {
       float4 d4[4];
       tile_to_rows(acc[jt], scr, lane, d4);  // row-vectorised: 4 consecutive hidden units per lane
+      if (jt == 0) VD_T(3);
       const int j = col0 + jt * 32 + cl;
       const int jc = j < N ? j : N - 4;      // N = H here; columns past the end load a valid address, never stored
 #pragma unroll
