@@ -2,6 +2,7 @@
 // of the encoders (nn.Linear y = x*W^T + b, weight [out x in]), the
 // hoisted LSTM input projections, and every weight-gradient contraction.
 #include "gemm_core.h"
+#include "split_core.h"
 
 using CfgBigDB = GemmCfg<4, 1, 4, 32>;        // 128 x 128 tile, double-buffered LDS (long K loops: weight grads)
 using CfgBig = GemmCfg<4, 1, 4, 16, 0, 3>;    // 128 x 128 tile, BK = 16, single LDS buffer, 3 workgroups / CU
@@ -266,6 +267,16 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
   // rotation: 133.9 TFLOP/s on the option dWh shape (M=512, N=2048, K=380 000) vs 119.6 for the register-staged
   // kernel at 1024 blocks (profiles/r02_dwh_sweep.txt; with 1024 blocks the ranking was the opposite in round 1:
   // the 1.33-round tail, not the pipeline, decided).
+  // exact-operand split (split_core.h): the big contraction of a split9 pass (dWh of the option recurrence); a ragged row tail (< 16
+  // rows) goes through the fp32-MFMA kernel below
+  if ((flags & VD_FLAG_SPLIT9) && !(flags & VD_FLAG_BF16) && M % SplitTnCfg::BM == 0 && N % SplitTnCfg::BN == 0 && K >= 8192 &&
+      16L * lda * 4 < (1L << 31) && 16L * ldb * 4 < (1L << 31)) {
+    const int K1 = K & ~15;
+    if (int rc = launch_gemm_split_tn<9>(M, N, K1, A, lda, B, ldb, C, ldc, (hipStream_t)stream)) return rc;
+    if (K1 == K) return VD_OK;
+    SrcK a2{A + (long)K1 * lda, lda}, b2{B + (long)K1 * ldb, ldb};
+    return launch_gemm<GemmCfg<4, 1, 4, 16, 0, 4, 41984>>(M, N, K - K1, 1, a2, b2, e, (hipStream_t)stream);
+  }
   const bool kmaj = !(flags & VD_FLAG_BF16) && M % 128 == 0 && N % 128 == 0 && K >= 1024;
   if (kmaj && K % 16 != 0) {
     // the k-major pipeline moves whole 16-row K tiles: contract the first floor(K / 16) * 16 rows with it and the last

@@ -828,7 +828,7 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
   }
   int rc = VD_OK;
   if (dWh_acc && T > 1) {   // recurrent weight gradient dWh += sum_{t>=1} h_{t-1}^T da_t: one contraction over all (T-1)*N rows
-    rc = vd_gemm_tn_acc(h_seq, H, gates + 4 * NH, 4L * H, dWh_acc, 4L * H, H, 4 * H, (T - 1) * N, flags & VD_FLAG_BF16, s);
+    rc = vd_gemm_tn_acc(h_seq, H, gates + 4 * NH, 4L * H, dWh_acc, 4L * H, H, 4 * H, (T - 1) * N, flags & (VD_FLAG_BF16 | VD_FLAG_SPLIT9), s);
     if (rc) return rc;
   }
   if (dh0) {

@@ -164,8 +164,8 @@ struct Disc : Decoder {
     if (To > 1 && c16)
       VD_TRY(vd_gemm_tn_acc_bf16(h16, gates16 + (long)NO * 4 * H, Gp(m, "opt.W") + E * 4 * H, 4 * H, (int)H, (int)(4 * H), (To - 1) * NO, s));
     else if (To > 1)
-      VD_TRY(vd_gemm_tn_acc(h, H, gates + (long)NO * 4 * H, 4 * H, Gp(m, "opt.W") + E * 4 * H, 4 * H, (int)H, (int)(4 * H), (To - 1) * NO, flags & VD_FLAG_BF16,
-                            s));
+      VD_TRY(vd_gemm_tn_acc(h, H, gates + (long)NO * 4 * H, 4 * H, Gp(m, "opt.W") + E * 4 * H, 4 * H, (int)H, (int)(4 * H), (To - 1) * NO,
+                            flags & (VD_FLAG_BF16 | VD_FLAG_SPLIT9), s));
     VD_HIP(hipEventRecord(m->ev_prof[5], s));
     // dEmb += dTable * Wx^T on the table stream, with float atomics: the SHARED embedding gradient has concurrent atomic
     // writers (the encoder's scatters), and the product is off the main stream's critical path this way

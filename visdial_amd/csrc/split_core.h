@@ -40,7 +40,7 @@ __device__ __forceinline__ void vd_split3(const float4& u, const float4& w, vd_b
 }
 
 // fp32 matrix -> three bf16 planes (dst + p * plane), same element order
-__global__ void __launch_bounds__(256) f32_to_bf16x3_kernel(const float* __restrict__ src, vd_bf16_bits* __restrict__ dst, long n4, long plane) {
+static __global__ void __launch_bounds__(256) f32_to_bf16x3_kernel(const float* __restrict__ src, vd_bf16_bits* __restrict__ dst, long n4, long plane) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const float4 v = reinterpret_cast<const float4*>(src)[i];
@@ -160,7 +160,9 @@ gemm_split_kernel(int M, int N, int K, int tiles_n, const float* A, long lda, co
       const float4 w = *reinterpret_cast<const float4*>(sa + (((hi * 2 + 1) ^ sw) * 4));
       vd_bf16x8 ap[3];
       vd_split3(u, w, ap[0], ap[1], ap[2]);
-      // plane p of B against planes i of A, smallest terms first; j innermost
+      // plane p of B against planes i of A, smallest terms first; j innermost.  (Measured and dropped: producing the A planes one at a time,
+      // hi first, with the next plane's VALU instructions interleaved into the MFMAs by sched_group_barrier -- the technique that pays in
+      // the dWh kernel below: 337 / 330 vs 342 / 322 us alone, 23.6 vs 23.4 ms in the step, 158 instead of 124 VGPRs.)
 #pragma unroll
       for (int p = 2; p >= 0; --p) {
         vd_bf16x8 bp[NT];
@@ -201,6 +203,163 @@ static int launch_gemm_split(int M, int N, int K, const float* A, long lda, cons
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Cfg::LDS_BYTES, stream, M, N, K, tiles_n, A, lda, B, ldb, bplane, e);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same exact split for the weight-gradient contraction  C[M x N] += A[K x M]^T * B[K x N]  (dWh = h^T * da over all
+// (timestep, row) pairs: K = 380 000 at the headline shape).  Both operands are fp32 rows contracted over their ROW index, so
+// NEITHER can be converted ahead of time without another pass over 4 GB: tiles go global -> LDS by DMA as [16 k][256 m] and
+// [16 k][128 n] fp32 (k-major, dense: a row of the tile is a row segment of the operand), a wave reads its MFMA fragments with
+// ds_read_b32 (lane = one m or n, 8 consecutive k: conflict-free, lanes 0-31 walk one k row) and splits BOTH in registers.
+// A wave owns 64 m x 128 n (8 accumulator tiles): 48 split values (16 of A, 32 of B) per 72 MFMAs.  Split-K over the rows with
+// float atomics at the end; the splits of one K range run on ONE XCD (block b runs on XCD b % 8), so the 16 column tiles that
+// read the same h rows and the 2 row tiles that read the same da rows share them through that XCD's L2.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct SplitTnCfg {
+  static constexpr int BM = 256, BN = 128, THREADS = 256;
+  static constexpr int ATILE = 16 * BM * 4;                       // [16 k][256 m] fp32
+  static constexpr int BTILE = 16 * BN * 4;                       // [16 k][128 n] fp32
+  static constexpr int STAGE = ATILE + BTILE;                     // 24 KB
+  static constexpr int LDS_BYTES = 2 * STAGE;                     // 48 KB: two workgroups per CU (the registers allow no more)
+};
+
+template <int NPROD>
+__global__ void __launch_bounds__(256, 2)
+gemm_split_tn_kernel(int M, int N, int kchunk, int K, int tiles, int tiles_n, int splits, const float* A, long lda, const float* B, long ldb,
+                     float* C, long ldc) {
+  using Cfg = SplitTnCfg;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // tile / K-range of this workgroup: XCD x takes the K ranges [x * spx, (x + 1) * spx) (spx = splits / 8) and all tiles of each
+  int tile, split;
+  if ((splits & 7) == 0) {
+    const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
+    split = xcd * (splits >> 3) + li / tiles;
+    tile = li % tiles;
+  } else {
+    split = (int)blockIdx.x / tiles;
+    tile = (int)blockIdx.x % tiles;
+  }
+  const int m_base = (tile / tiles_n) * Cfg::BM, n_base = (tile % tiles_n) * Cfg::BN;
+  const int ks = split * kchunk, ke = min(K, ks + kchunk);
+  const int nm = ke > ks ? (ke - ks) / 16 : 0;
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][j][r] = 0.f;
+
+  // DMA: A rows are 1 KB (one instruction per k row: 4 per wave), B rows 512 bytes (two k rows per instruction: 2 per wave)
+  unsigned voffa[4], voffb[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) voffa[i] = (unsigned)(((long)(wm * 4 + i) * lda + m_base + lane * 4) * 4);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) voffb[i] = (unsigned)(((long)((wm * 2 + i) * 2 + (lane >> 5)) * ldb + n_base + (lane & 31) * 4) * 4);
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  auto issue = [&](int m, int st) {
+    const unsigned base = lds0 + st * Cfg::STAGE;
+    const float* ak = A + (long)(ks + m * 16) * lda;
+    const float* bk = B + (long)(ks + m * 16) * ldb;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(voffb[i], bk, base + Cfg::ATILE + (wm * 2 + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(voffa[i], ak, base + (wm * 4 + i) * 1024);
+  };
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  if (nm > 0) {
+    issue(0, 0);
+    int st = 0;
+    for (int m = 0; m < nm; ++m) {
+      if (m + 1 < nm) {
+        issue(m + 1, st ^ 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_barrier" ::: "memory");
+      const float* sA = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + st * Cfg::STAGE) + (hi * 8) * Cfg::BM + wm * 64 + l31;
+      const float* sB = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + st * Cfg::STAGE + Cfg::ATILE) + (hi * 8) * Cfg::BN + l31;
+      // Software pipeline inside the step: the A planes and the B planes of column tile 0 are converted up front; then the 18 MFMAs of column
+      // tile j are issued INTERLEAVED with the fragment reads and the split of column tile j + 1 (sched_group_barrier: one MFMA, four VALU
+      // instructions, ...), so most of the ~240 VALU instructions a step spends on splitting sit in the shadow of the matrix pipe instead of
+      // in front of it (left to itself the compiler hoists every conversion above the first MFMA: 5.91 -> 5.51 ms on the headline dWh).
+      // (Measured and dropped: three LDS stages with one barrier per step and the NEXT step's first conversions under the last column
+      //  tile's MFMAs -- 5.82 ms.)
+      vd_bf16x8 ap[2][3], bp[2][3];
+      auto load_b = [&](int j, vd_bf16x8 (&dst)[3]) {
+        const float* p = sB + j * 32;
+        const float4 u = make_float4(p[0], p[Cfg::BN], p[2 * Cfg::BN], p[3 * Cfg::BN]);
+        const float4 w = make_float4(p[4 * Cfg::BN], p[5 * Cfg::BN], p[6 * Cfg::BN], p[7 * Cfg::BN]);
+        vd_split3(u, w, dst[0], dst[1], dst[2]);
+      };
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const float* p = sA + mb * 32;
+        const float4 u = make_float4(p[0], p[Cfg::BM], p[2 * Cfg::BM], p[3 * Cfg::BM]);
+        const float4 w = make_float4(p[4 * Cfg::BM], p[5 * Cfg::BM], p[6 * Cfg::BM], p[7 * Cfg::BM]);
+        vd_split3(u, w, ap[mb][0], ap[mb][1], ap[mb][2]);
+      }
+      load_b(0, bp[0]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < 4) load_b(j + 1, bp[(j + 1) & 1]);
+#pragma unroll
+        for (int pb = 2; pb >= 0; --pb)
+#pragma unroll
+          for (int pa = 2; pa >= 0; --pa) {
+            constexpr int LIM = NPROD >= 9 ? 4 : NPROD >= 6 ? 2 : NPROD >= 3 ? 1 : 0;
+            if (pa + pb > LIM) continue;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[mb][pa], bp[j & 1][pb], acc[mb][j], 0, 0, 0);
+          }
+        if (j + 1 < 4) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);        // the next tile's fragment reads first (their latency hides under the MFMAs)
+#pragma unroll
+          for (int i = 0; i < 18; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA ...
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // ... four VALU instructions of the next tile's split
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      st ^= 1;
+    }
+  }
+  const EpiAtomic<4> e{C, ldc};
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) e(acc[mb], m_base + wm * 64 + mb * 32, n_base, lane, M, N);
+}
+
+// C[M x N] += A[K x M]^T * B[K x N] on the exact split; M % 256 == 0, N % 128 == 0, K % 16 == 0 (the caller contracts a ragged tail elsewhere)
+template <int NPROD>
+static int launch_gemm_split_tn(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, hipStream_t stream) {
+  using Cfg = SplitTnCfg;
+  VD_CHECK_ARG(M % Cfg::BM == 0 && N % Cfg::BN == 0 && K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && 16L * lda * 4 < (1L << 31) && 16L * ldb * 4 < (1L << 31),
+               "launch_gemm_split_tn: unsupported shape M=%d N=%d K=%d", M, N, K);
+  if (K == 0) return VD_OK;
+  const int tiles_n = N / Cfg::BN, tiles = (M / Cfg::BM) * tiles_n;
+  // one full round of workgroups at two per CU; a multiple of 8 K ranges so that each XCD owns whole ranges
+  int splits = vd_cdiv(2L * vd_num_cus(), tiles);
+  splits = (splits + 7) & ~7;
+  int kchunk = vd_cdiv(vd_cdiv(K, splits), 16) * 16;
+  if (kchunk < 64) kchunk = 64;
+  splits = vd_cdiv(K, kchunk);
+  if (splits >= 8) splits = (splits + 7) & ~7;        // (trailing K ranges past the end are empty workgroups)
+  auto kern = gemm_split_tn_kernel<NPROD>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(256), Cfg::LDS_BYTES, stream, M, N, kchunk, K, tiles, tiles_n, splits, A, lda, B, ldb, C, ldc);
   VD_LAUNCH_CHECK();
   return VD_OK;
 }
