@@ -222,7 +222,8 @@ def split_roofline(fams, step_fam, recurrence, traffic=None):
                     "hi/mid/lo split of BOTH operands (all 24 significand bits); achieved = executed bf16-MFMA FLOPs (%d x the fp32 product's) / "
                     "HIP-event launch time inside the overlapped step, priced against the 2.5 PFLOP/s dense bf16 peak; sustained_peak = what the "
                     "matrix pipe holds on non-zero operands under the power budget (measured, profiles/r05_mfma_sustained.txt) -- the bound "
-                    "this kernel actually meets (profiles/r05_experiments.txt section 1); the dWh contraction runs on v_mfma_f32_32x32x2_f32"
+                    "this kernel actually meets (profiles/r05_experiments.txt section 1); the dWh contraction h^T * da runs on the same split "
+                    "(both operands split in registers: csrc/split_core.h gemm_split_tn_kernel)"
                     % (nprod, nprod),
             "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
 
@@ -561,13 +562,13 @@ def main():
         roof = None
         if dom and args.config == 4:
             roof = bf16_option_roofline(fams, dom, rows=N * p['numOptions'], H=p['rnnHiddenSize'], To=p['maxAnsLen'])
-        elif dom and args.recurrence != 'fp32' and dom != 'opt_lstm_dWh':
+        elif dom and args.recurrence != 'fp32':
             roof = split_roofline(fams, dom, args.recurrence, traffic_of(args.recurrence + ':' + dom))
         elif dom:
             roof = fp32_roofline(fams, dom, value, traffic, traffic_build)
         if roof and roof.get("bound") == "mfma" and world == 1 and args.config == 3:
             try:
-                roof["alone"] = dominant_kernel_alone(p, N, recurrence=args.recurrence if dom != 'opt_lstm_dWh' else 'fp32')   # same kernel, same shapes, nothing else on the chip
+                roof["alone"] = dominant_kernel_alone(p, N, recurrence=args.recurrence)   # same kernel, same shapes, nothing else on the chip
             except Exception as exc:                            # never let the extra figure break the bench line
                 roof["alone"] = {"error": str(exc)[:120]}
         ps = np.array(per_step) * 1e3
@@ -581,8 +582,9 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if args.recurrence == 'fp32' else
                       "f32 operands and results; the option recurrence multiplies the EXACT 3-way bf16 split of both operands (%s bf16 MFMA "
-                      "products per fp32 product, f32 accumulate: fp32-grade, errors <= the f32 MFMA's own), f32 MFMA (v_mfma_f32_32x32x2_f32) "
-                      "everywhere else; the all-f32-MFMA line of the same run is under `alt`" % args.recurrence[-1]) if args.config == 3
+                      "products per fp32 product, f32 accumulate: fp32-grade, errors at the f32 MFMA's own level) -- its two step kernels and its "
+                      "weight-gradient contraction; f32 MFMA (v_mfma_f32_32x32x2_f32) everywhere else; the all-f32-MFMA line of the same run is "
+                      "under `alt`" % args.recurrence[-1]) if args.config == 3
             else "bf16 operands / f32 accumulate (option recurrence only), f32 elsewhere",
             "data": "synthetic" + (" (one resident batch reused)" if args.same_batch else
                                    " (a fresh batch every step: host generation + length sort + H2D upload inside the timed region, overlapped)"),

@@ -31,7 +31,7 @@ hdr = [
     % TAG[1:].lstrip('0'),
     "# scripts/measure_round.sh: native host = model-level C ABI, GPU_MAX_HW_QUEUES=1, 7 training steps traced; summarised from the rocpd database by",
     "# `scripts/rocpd_stats.py <db> --steps-only`, i.e. up to the last optimiser launch -- bench.py's `roofline.alone` leg is excluded).  The option recurrence runs",
-    "# the exact-split kernels (gemm_split_kernel<9, Epi>: csrc/split_core.h), the dWh contraction and everything else v_mfma_f32_32x32x2_f32",
+    "# the exact-split kernels (csrc/split_core.h: gemm_split_kernel<9, Epi> = the step kernels, gemm_split_tn_kernel<9> = dWh), everything else v_mfma_f32_32x32x2_f32",
     "# (gemm_f32<WMxWKxNTxKWxDBxMINWxLDSMINxBF16|A, B, Epi>, gemm_f32_glds = LDS-DMA pipeline kernels, gemm_f32_grouped = encoder ticks).",
     "# Same box, un-profiled: `python bench.py` = %.3f ms/step (%.0f QA-rounds/s), 50 steps: %.3f ms/step; alt (fp32-MFMA recurrence, same run): %s ms/step."
     % (d['ms_per_step'], d['value'], d50['ms_per_step'], alt.get('ms_per_step')),
@@ -49,7 +49,7 @@ txt = open(G + TAG + '_pmc_option_lstm_kernels.txt').read()
 S3 = 'SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES'
 KERN = {('fp32', 'fwd'): r'gemm_f32_glds_kernel<[^\n]*false, EpiLstmFwdT<0', ('fp32', 'bwd'): r'gemm_f32_glds_kernel<[^\n]*false, EpiLstmBwd<2,',
         ('fp32', 'dWh'): r'gemm_f32_glds_kernel<[^\n]*true, EpiAtomic<4>', ('split9', 'fwd'): r'gemm_split_kernel<9, EpiLstmFwdT<0',
-        ('split9', 'bwd'): r'gemm_split_kernel<9, EpiLstmBwd<4,'}
+        ('split9', 'bwd'): r'gemm_split_kernel<9, EpiLstmBwd<4,', ('split9', 'dWh'): r'gemm_split_tn_kernel<9>'}
 ALG = {'fwd': 496, 'bwd': 660, 'dWh': 3900}     # algorithmic MB per launch
 
 
@@ -63,7 +63,7 @@ def grab(mode, section, kern, ctr):
 
 summ = {"_comment": "HBM-side bytes per launch from rocprofv3 PMC passes (profiles/%s_pmc_option_lstm_kernels.txt): (2*FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled "
                     "per MI355X_MICROARCH.md (gfx950 counts wide coalesced reads at half).  opt_lstm_fwd / _bwd = ONE timestep launch of the fp32-MFMA kernels "
-                    "(19 per direction per step), opt_lstm_dWh = the single weight-gradient launch; 'split9:opt_lstm_fwd' / '_bwd' = the exact-split kernels.  "
+                    "(19 per direction per step), opt_lstm_dWh = the single weight-gradient launch; 'split9:opt_lstm_fwd' / '_bwd' / '_dWh' = the exact-split kernels.  "
                     "bench.py copies hbm_bytes_per_launch of the dominant kernel into roofline.traffic while csrc_sha256 matches the build (a committed "
                     "measurement, not a live counter)." % TAG}
 lines = []

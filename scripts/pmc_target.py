@@ -19,6 +19,6 @@ dcw, dh_last, dWh = torch.empty(N, H, device="cuda"), rnd(N, H), torch.zeros(H, 
 for _ in range(3):
     ops.lstm_forward(table, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok, flags=FLAGS)
     ops.lstm_backward(Wh, gates, c, dcw, T, N, H, dh_last=dh_last, flags=FLAGS)
-    ops.gemm_tn_acc(h.view(T * N, H), gates.view(T * N, 4 * H)[N:], dWh, M=H, N=4 * H, K=(T - 1) * N, flags=FLAGS & 1)
+    ops.gemm_tn_acc(h.view(T * N, H), gates.view(T * N, 4 * H)[N:], dWh, M=H, N=4 * H, K=(T - 1) * N, flags=FLAGS & 3)
 torch.cuda.synchronize()
 print("pmc target done")
