@@ -100,12 +100,13 @@ STEP_GFLOP_PER_ROUND = 21.934          # nominal dense math of t
 
 def config_params(config, rank=0, batch=20):
     """BASELINE.json configs[config] at its quoted size (batch 20, V = 11 322, H = 512, E = 300):
-      1 = lf-ques-im-hist + gen, VGG-16 fc7 (4096-d);            2 = hre-ques-im-hist + disc, fc7, 100 options;
+      1 = lf-ques-im-hist + gen, VGG-16 fc7 (4096-d);            2 = hre-ques-im-hist + disc, fc7, 100 options (option recurrence on the exact
+      split, like the headline);
       3 = mn-att-ques-im-hist + disc, 14x14x512 pool5 (HEADLINE); 4 = the same with ResNet-200 7x7x2048 features and bf16 operands
       in the option recurrence (informative, never the default)"""
     from visdial_amd.opts import default_params
     kw = {1: dict(encoder='lf-ques-im-hist', decoder='gen', imgFeatureSize=4096),
-          2: dict(encoder='hre-ques-im-hist', decoder='disc', imgFeatureSize=4096),
+          2: dict(encoder='hre-ques-im-hist', decoder='disc', imgFeatureSize=4096, lstmPrecision='split9'),
           3: dict(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=512, imgSpatialSize=14),
           4: dict(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=2048, imgSpatialSize=7, lstmPrecision='bf16')}[config]
     return default_params(batchSize=batch, vocabSize=11322, gpuid=int(os.environ.get('LOCAL_RANK', 0)), rank=rank,
@@ -309,7 +310,8 @@ def other_config(cfg, steps=10, warmup=3):
     out = {"workload": "BASELINE.json configs[%d]: %s + %s, batch %d, %s" % (
                cfg, p['encoder'], p['decoder'], p['batchSize'],
                {1: "VGG-16 fc7 4096-d features", 2: "fc7 4096-d features, 100 options", 4: "ResNet-200 7x7x2048 features, 100 options"}[cfg]),
-           "dtype": "f32" if cfg != 4 else "bf16 operands / f32 accumulate (option recurrence only), f32 elsewhere",
+           "dtype": {1: "f32", 2: "f32 operands and results; option recurrence on the exact 3-way bf16 split (9 products, f32 accumulate), f32 MFMA elsewhere",
+                     4: "bf16 operands / f32 accumulate (option recurrence only), f32 elsewhere"}[cfg],
            "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3), "qa_rounds_per_s": round(N / ms * 1e3, 1),
            "loss": round(float(loss), 5)}
     if p['decoder'] == 'disc':
@@ -317,6 +319,8 @@ def other_config(cfg, steps=10, warmup=3):
         dom = max(fams, key=lambda k: fams[k]['ms_total_per_step'])
         if cfg == 4:
             out["roofline"] = bf16_option_roofline(fams, dom, rows=N * p['numOptions'], H=H, To=p['maxAnsLen'])
+        elif p.get('lstmPrecision') == 'split9':
+            out["roofline"] = split_roofline(fams, dom, 'split9')
         else:
             a = fams[dom]['tflops_executed']
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(a, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
