@@ -268,3 +268,10 @@ def test_library_comm_surface_without_a_gpu():
     assert lib.vd_comm_destroy() == 0                                        # nothing to destroy is not an error
     needed = subprocess.run(['readelf', '-d', _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert 'rccl' not in needed.lower() and 'torch' not in needed.lower()
+
+
+def test_graft_entry_build_runs():
+    """the driver's "does it build" check: make is a no-op when the library is current, the checker builds, every declared symbol loads and
+    the ABI version matches the binding's (a hard-coded version here once outlived a bump)"""
+    import __graft_entry__
+    __graft_entry__.build()
