@@ -333,6 +333,7 @@ gemm_split_tn_kernel(int M, int N, int kchunk, int K, int tiles, int tiles_n, in
       st ^= 1;
     }
   }
+  if (nm == 0) return;                            // (a K range past the end: the range count is rounded up to a multiple of 8)
   const EpiAtomic<4> e{C, ldc};
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) e(acc[mb], m_base + wm * 64 + mb * 32, n_base, lane, M, N);
