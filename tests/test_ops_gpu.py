@@ -200,7 +200,7 @@ def test_lstm_forward_backward_split9(ops, T, N, H, masked, table):
 def test_split_error_table(ops):
     """rel-L2 error against fp64 of the recurrence outputs at the headline's H = 512, per arithmetic: exact fp32 MFMA, split9 (all
     nine products), split6 (i + j <= 2), split3 (i + j <= 1), bf16.  split9 must sit with fp32; split6 / split3 / bf16 are printed as
-    data (only split9 may stand in for fp32).  The table goes to gpurun_out/r04_split_errors.txt."""
+    data (only split9 may stand in for fp32).  The table goes to gpurun_out/r05_split_errors.txt."""
     import os
     rows = []
     for name, flags in (('fp32 (v_mfma_f32_32x32x2_f32)', 0), ('split9', ops.FLAG_SPLIT9), ('split6', ops.FLAG_SPLIT6),
@@ -216,7 +216,7 @@ def test_split_error_table(ops):
     text = '\n'.join(lines)
     print(text)
     os.makedirs('gpurun_out', exist_ok=True)
-    open('gpurun_out/r04_split_errors.txt', 'w').write(text + '\n')
+    open('gpurun_out/r05_split_errors.txt', 'w').write(text + '\n')
     err = {name: e for name, e in rows}
     f32, s9, s6, s3, b16 = (err[n] for n in ('fp32 (v_mfma_f32_32x32x2_f32)', 'split9', 'split6', 'split3', 'bf16'))
     for k in keys:
