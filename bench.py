@@ -434,7 +434,7 @@ def main():
                     help='BASELINE.json configs index: 3 = headline (fp32, 14x14x512); 4 = 7x7x2048 features + bf16 option recurrence')
     ap.add_argument('--recurrence', choices=['fp32', 'split9', 'split6'], default='split9',
                     help='arithmetic of the option recurrence at --config 3: split9 (DEFAULT, the headline) = every fp32 operand as the exact sum '
-                         'of three bf16 values, all 9 bf16 MFMA products, fp32 accumulate -- fp32-grade results (errors <= the fp32 MFMA\'s own: '
+                         'of three bf16 values, all 9 bf16 MFMA products, fp32 accumulate -- fp32-grade results (errors at the fp32 MFMA\'s own level, 0.5-1.4x per tensor: '
                          'tests/test_ops_gpu.py::test_split_error_table, tests/test_full_size_golden.py); fp32 = v_mfma_f32_32x32x2_f32 (reported '
                          'beside the headline as `alt`); split6 = 6 products (data only, never a headline)')
     ap.add_argument('--no-alt', action='store_true', help='skip the `alt` leg (the same steps with the fp32-MFMA recurrence) after the headline')
