@@ -164,6 +164,17 @@ struct EpiPreOf<Epi, std::void_t<typename Epi::Pre>> {
 };
 #endif
 
+// Epilogue functors of the split-K latency shapes may offer a DISTRIBUTED form (HAS_DIST, DOps, dist_ok / dist_load / dist_store): the four
+// K-slice waves of a 32-row tile each finish one 8-row group instead of wave 0 finishing all four.
+template <class Epi, class = void>
+struct EpiDistOf {
+  static constexpr bool value = false;
+};
+template <class Epi>
+struct EpiDistOf<Epi, std::void_t<typename Epi::DOps>> {
+  static constexpr bool value = Epi::HAS_DIST;
+};
+
 // XCD-aware bijective remap of the flat workgroup id (guide T1).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7;
@@ -431,6 +442,37 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
     VD_T(2);
   }
 
+  if constexpr (Cfg::WK == 4 && Cfg::WM == 1 && NT == 4 && EpiDistOf<Epi>::value) {
+    // distributed epilogue (see EpiLstmFwdT::dist_load): every wave requests the operands of ITS row group, then the four partial tiles of
+    // each gate meet in LDS and every wave sums the 8 rows it finishes
+    if (epi.dist_ok()) {
+      typename Epi::DOps q;
+      float4 a[4];
+      float* red = smem;                       // 4 waves x 32 x 32 floats
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // the operand requests go out once half of the accumulator tiles are dead (register budget: 128 VGPRs beside the throughput
+        // kernels); the round trip hides under the remaining two exchanges
+        if (j == 2) epi.dist_load(q, row_base, col_base, lane, wk, M);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wk * 1024 + mfma_row(r, lane) * 32 + (lane & 31)] = acc[j][r];
+        __syncthreads();
+        const float* src = red + (wk * 8 + (lane >> 3)) * 32 + (lane & 7) * 4;
+        float4 t = *reinterpret_cast<const float4*>(src);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+          const float4 u = *reinterpret_cast<const float4*>(src + w * 1024);
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        a[j] = t;
+      }
+      epi.dist_store(a, q, row_base, col_base, lane, wk, M);
+      VD_T(4);
+      VD_TREAL(7);
+      return;
+    }
+  }
   if constexpr (Cfg::WK > 1) {
     // intra-block split-K: waves wk>0 park their partial sums in LDS one 32x32 tile at a time
     // (keeps the scratch at 4 KB per parked wave), wk==0 adds them.

@@ -96,6 +96,54 @@ struct EpiLstmFwdT {
       if (h16) vd_st4_bf16(h16 + (long)row * H + j, h);
     }
   }
+  // Split-K latency shapes (one 32-row tile, four waves each holding a K slice of it): the cell update DISTRIBUTED over the four waves.
+  // Wave g takes row group g (8 rows x 32 hidden units, one row x 4 units per lane): it requests its operands (mask id, the four projection
+  // pieces, c_{t-1}) right after the K loop -- the round trip hides under the cross-wave reduction through LDS (gemm_block) -- and does
+  // a quarter of the math and of the stores.  With wave 0 alone serving the four row groups one after the other the epilogue of a tick
+  // workgroup was 5.8 of its 22 us (four dependent round trips; scripts/mb_ticks.py MB_PHASES=1).
+  static constexpr bool HAS_DIST = !C16;
+  struct DOps {
+    float4 x[4], cp;
+    int keep;
+  };
+  __device__ __forceinline__ bool dist_ok() const { return true; }
+  __device__ __forceinline__ void dist_load(DOps& q, int row0, int vcol0, int lane, int grp, int M) const {
+    const int j = (vcol0 >> 7) * 32 + (lane & 7) * 4;
+    const int row = row0 + grp * 8 + (lane >> 3);
+    const int rc = row < M ? row : M - 1;
+    q.keep = tok_mask ? (tok_mask[rc] != 0) : 1;
+    const float* xr = xproj + (tok_gather ? (long)tok_gather[rc] : (long)rc) * xld + j;
+    q.x[0] = *reinterpret_cast<const float4*>(xr);
+    q.x[1] = *reinterpret_cast<const float4*>(xr + H);
+    q.x[2] = *reinterpret_cast<const float4*>(xr + 2 * H);
+    q.x[3] = *reinterpret_cast<const float4*>(xr + 3 * H);
+    q.cp = c_prev ? *reinterpret_cast<const float4*>(c_prev + (long)rc * H + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // a[g] = the reduced pre-activation sums of gate g for this lane's (row, 4 hidden units)
+  __device__ __forceinline__ void dist_store(const float4 (&a)[4], const DOps& q, int row0, int vcol0, int lane, int grp, int M) const {
+    const int j = (vcol0 >> 7) * 32 + (lane & 7) * 4;
+    const int row = row0 + grp * 8 + (lane >> 3);
+    if (row >= M || j >= H) return;
+    const float km = q.keep ? 1.f : 0.f;  // maskZero(): h = c = gates = 0 for pad rows
+    float4 gi, gf, go, gg, c, h;
+#define VD_CELLD(E)                                   \
+    gi.E = km * vd_sigmoid(a[0].E + q.x[0].E);        \
+    gf.E = km * vd_sigmoid(a[1].E + q.x[1].E);        \
+    go.E = km * vd_sigmoid(a[2].E + q.x[2].E);        \
+    gg.E = km * vd_tanh(a[3].E + q.x[3].E);           \
+    c.E = gf.E * q.cp.E + gi.E * gg.E;                \
+    h.E = go.E * vd_tanh(c.E);
+    VD_CELLD(x) VD_CELLD(y) VD_CELLD(z) VD_CELLD(w)
+#undef VD_CELLD
+    float* gr = gates + (long)row * 4 * H + j;
+    *reinterpret_cast<float4*>(gr) = gi;
+    *reinterpret_cast<float4*>(gr + H) = gf;
+    *reinterpret_cast<float4*>(gr + 2 * H) = go;
+    *reinterpret_cast<float4*>(gr + 3 * H) = gg;
+    *reinterpret_cast<float4*>(c_out + (long)row * H + j) = c;
+    *reinterpret_cast<float4*>(h_out + (long)row * H + j) = h;
+    if (h16) vd_st4_bf16(h16 + (long)row * H + j, h);
+  }
   // token / mask ids of the lane's 4 rows, fetched before the K loop by the LDS-DMA pipeline (gemm_block_glds): the
   // dependent chain row -> token id -> projection row loses its first round trip (~3 us under load)
   struct Pre {
@@ -598,10 +646,36 @@ struct EpiTickFwd {
   int kind;  // 0 = LSTM cell update, 1 = plain store (+bias)
   EpiLstmFwdTick f;
   EpiStore<4> s;
+  static constexpr bool HAS_DIST = true;      // both kinds finish distributed over the four K-slice waves (gemm_block): no one-wave path is compiled
+  using DOps = EpiLstmFwdTick::DOps;
+  __device__ __forceinline__ bool dist_ok() const { return true; }
+  __device__ __forceinline__ void dist_load(DOps& q, int row0, int vcol0, int lane, int grp, int M) const {
+    if (kind == 0) f.dist_load(q, row0, vcol0, lane, grp, M);
+  }
+  __device__ __forceinline__ void dist_store(const float4 (&a)[4], const DOps& q, int row0, int vcol0, int lane, int grp, int M) const {
+    if (kind == 0) {
+      f.dist_store(a, q, row0, vcol0, lane, grp, M);
+      return;
+    }
+    // plain store (+ bias) of the layer-2 input projection: plain column order, 4 consecutive columns per lane and column tile
+    const int row = row0 + grp * 8 + (lane >> 3);
+    if (row >= M) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = vcol0 + j * 32 + (lane & 7) * 4;
+      float4 v = a[j];
+      if (s.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(s.bias + col);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      *reinterpret_cast<float4*>(s.C + (long)row * s.ldc + col) = v;
+    }
+  }
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], int row0, int col0, int lane, int M,
                                              int N, float* scr) const {
-    if (kind == 0) f(acc, row0, col0, lane, M, N, scr);
-    else s(acc, row0, col0, lane, M, N);
+    // never reached: the split-K forward tick shape always takes the distributed form above (gemm_block); compiling the one-wave
+    // epilogues next to it cost > 100 spilled VGPRs at the 128-register cap
+    __builtin_trap();
   }
 };
 struct TickFwdProb {
