@@ -442,18 +442,18 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
     VD_T(2);
   }
 
-  if constexpr (Cfg::WK == 4 && Cfg::WM == 1 && NT == 4 && EpiDistOf<Epi>::value) {
+  if constexpr (Cfg::WK == 4 && Cfg::WM == 1 && (NT == 4 || NT == 1) && EpiDistOf<Epi>::value) {
     // distributed epilogue (see EpiLstmFwdT::dist_load): every wave requests the operands of ITS row group, then the four partial tiles of
     // each gate meet in LDS and every wave sums the 8 rows it finishes
     if (epi.dist_ok()) {
       typename Epi::DOps q;
-      float4 a[4];
+      float4 a[NT];
       float* red = smem;                       // 4 waves x 32 x 32 floats
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NT; ++j) {
         // the operand requests go out once half of the accumulator tiles are dead (register budget: 128 VGPRs beside the throughput
-        // kernels); the round trip hides under the remaining two exchanges
-        if (j == 2) epi.dist_load(q, row_base, col_base, lane, wk, M);
+        // kernels); the round trip hides under the remaining exchanges
+        if (j == (NT == 4 ? 2 : 0)) epi.dist_load(q, row_base, col_base, lane, wk, M);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wk * 1024 + mfma_row(r, lane) * 32 + (lane & 31)] = acc[j][r];

@@ -373,6 +373,63 @@ struct EpiLstmBwd {
   // throughput shape (it spills at the 128-register cap), so that shape has two builds: <=128 VGPRs with BATCH = 1
   // (a latency-shape workgroup of another stream still fits beside three of these on a SIMD) and <=168 VGPRs with
   // BATCH = 2; the single-tile latency shapes (NT = 1) fit BATCH = 2 inside 128.
+  // split-K latency shape (NT = 1: a 32 x 32 tile, four K-slice waves): the gate gradients DISTRIBUTED over the four waves like the forward
+  // cell update (EpiLstmFwdT::dist_load): wave g finishes rows g*8 .. g*8+7, one (row, 4 hidden units) slot per lane, ONE round trip
+  static constexpr bool HAS_DIST = NT == 1 && !C16;
+  struct DOps {
+    float4 g[4], ct, cp, dcv, dha, dhb;
+  };
+  __device__ __forceinline__ bool dist_ok() const { return true; }
+  __device__ __forceinline__ void dist_load(DOps& q, int row0, int col0, int lane, int grp, int M) const {
+    const int j = col0 + (lane & 7) * 4;
+    const int row = row0 + grp * 8 + (lane >> 3);
+    const int rc = row < M ? row : M - 1;
+    const long o = (long)rc * H + j;
+    const float* gr = gates + (long)rc * 4 * H + j;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    q.g[0] = *reinterpret_cast<const float4*>(gr);
+    q.g[1] = *reinterpret_cast<const float4*>(gr + H);
+    q.g[2] = *reinterpret_cast<const float4*>(gr + 2 * H);
+    q.g[3] = *reinterpret_cast<const float4*>(gr + 3 * H);
+    q.ct = *reinterpret_cast<const float4*>(c_t + o);
+    q.cp = c_prev ? *reinterpret_cast<const float4*>(c_prev + o) : z;
+    q.dcv = dc_first ? z : *reinterpret_cast<const float4*>(dc + o);
+    q.dha = dh_a ? *reinterpret_cast<const float4*>(dh_a + o) : z;
+    q.dhb = dh_b ? *reinterpret_cast<const float4*>(dh_b + o) : z;
+  }
+  __device__ __forceinline__ void dist_store(const float4 (&a)[1], const DOps& q, int row0, int col0, int lane, int grp, int M) const {
+    const int j = col0 + (lane & 7) * 4;
+    const int row = row0 + grp * 8 + (lane >> 3);
+    if (row >= M || j >= H) return;
+    float4 dh = a[0], ai, af, ao, ag, dn;
+    dh.x += q.dha.x + q.dhb.x; dh.y += q.dha.y + q.dhb.y; dh.z += q.dha.z + q.dhb.z; dh.w += q.dha.w + q.dhb.w;
+#define VD_CELLBD(E)                                                      \
+    {                                                                     \
+      const float gi_ = q.g[0].E, gf_ = q.g[1].E, go_ = q.g[2].E;         \
+      const float tc = vd_tanh(q.ct.E);                                   \
+      const float d = q.dcv.E + dh.E * go_ * (1.f - tc * tc);             \
+      ai.E = d * q.g[3].E * gi_ * (1.f - gi_);                            \
+      af.E = d * q.cp.E * gf_ * (1.f - gf_);                              \
+      ao.E = dh.E * tc * go_ * (1.f - go_);                               \
+      ag.E = d * gi_ * (1.f - q.g[3].E * q.g[3].E);                       \
+      dn.E = d * gf_;                                                     \
+    }
+    VD_CELLBD(x) VD_CELLBD(y) VD_CELLBD(z) VD_CELLBD(w)
+#undef VD_CELLBD
+    float* gr = gates + (long)row * 4 * H + j;
+    *reinterpret_cast<float4*>(gr) = ai;
+    *reinterpret_cast<float4*>(gr + H) = af;
+    *reinterpret_cast<float4*>(gr + 2 * H) = ao;
+    *reinterpret_cast<float4*>(gr + 3 * H) = ag;
+    *reinterpret_cast<float4*>(dc + (long)row * H + j) = dn;
+    if (da16) {
+      vd_bf16_bits* g16 = da16 + (long)row * 4 * H + j;
+      vd_st4_bf16(g16, ai);
+      vd_st4_bf16(g16 + H, af);
+      vd_st4_bf16(g16 + 2 * H, ao);
+      vd_st4_bf16(g16 + 3 * H, ag);
+    }
+  }
   struct Slot {
     float4 g[4], ct, cp, dcv, dhx;
     vd_u32x2 g16[4];   // C16: the saved gates as loaded (packed bf16), unpacked when the slot is consumed -- NOT in the load phase, where the
@@ -689,6 +746,20 @@ struct EpiTickBwdT {
   int kind;
   EpiLstmBwd<NT> f;      // (default BATCH: 2 slots in flight for NT = 1, 1 for NT >= 2)
   EpiStore<NT> s;
+  static constexpr bool HAS_DIST = NT == 1;   // 32 x 32 split-K tiles: both kinds finish distributed over the four waves (gemm_block)
+  using DOps = typename EpiLstmBwd<NT>::DOps;
+  __device__ __forceinline__ bool dist_ok() const { return true; }
+  __device__ __forceinline__ void dist_load(DOps& q, int row0, int col0, int lane, int grp, int M) const {
+    if (kind == 0) f.dist_load(q, row0, col0, lane, grp, M);
+  }
+  __device__ __forceinline__ void dist_store(const float4 (&a)[1], const DOps& q, int row0, int col0, int lane, int grp, int M) const {
+    if (kind == 0) {
+      f.dist_store(a, q, row0, col0, lane, grp, M);
+      return;
+    }
+    const int row = row0 + grp * 8 + (lane >> 3), col = col0 + (lane & 7) * 4;      // plain store: dh1[t] = da2[t] * Wx2^T
+    if (row < M) *reinterpret_cast<float4*>(s.C + (long)row * s.ldc + col) = a[0];
+  }
   __device__ __forceinline__ void operator()(const f32x16 (&acc)[NT], int row0, int col0, int lane, int M,
                                              int N, float* scr) const {
     if (kind == 0) f(acc, row0, col0, lane, M, N, scr);
