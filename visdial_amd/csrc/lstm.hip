@@ -1034,6 +1034,8 @@ int vd_lstm2_forward(const vd_lstm2_fwd_t* st, int nstacks, int H, void* stream)
       }
     }
     if (g.nprob == 0) continue;
+    static_assert(CfgFwdSmallC::WK == 4 && CfgFwdSmallC::WM == 1 && CfgFwdSmallC::NT == 4,
+                  "EpiTickFwd finishes only through the distributed epilogue of the 32 x 128 four-wave split-K shape (gemm_block)");
     if (int rc = launch_grouped<CfgFwdSmallC>(g, (hipStream_t)stream)) return rc;
   }
   return VD_OK;
