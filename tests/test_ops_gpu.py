@@ -536,3 +536,27 @@ def test_bf16_compact_state_saturated_gates(ops):
     # with the +0 encoding dc0 lost every path through a saturated forget gate (rel-L2 ~ 1); the bf16 bound of the config is 2e-2
     assert relerr(dc, dc0_ref) < 2e-2, relerr(dc, dc0_ref)
     assert relerr(gates16.float(), da_ref) < 2e-2, relerr(gates16.float(), da_ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 256, 4096 + 7), (256, 512, 8192 + 32 * 5 + 9), (512, 2048, 3000 * 19), (384, 256, 9000)])
+def test_bf16_weight_gradient_contraction(ops, M, N, K):
+    """configs[4] weight-gradient contraction dWh += h16^T * da16 over the compact bf16 state (csrc/gemm_ops.hip `vd_gemm_tn_acc_bf16`):
+    LDS-DMA tiles + transpose reads, 128 x 128 tiles (any M, N % 128 == 0) or 256 x 256 tiles with eight waves (M, N % 256 == 0 and
+    K >= 8192), split-K partial sums by atomics, the last < 32 rows by a tail kernel.  bf16 products are exact in fp32, so the only
+    difference to an fp32 matmul of the same bf16 values is the summation order: 1e-5 relative.  ACCUMULATES into C."""
+    import ctypes as C
+    from visdial_amd import _lib
+    lib = _lib.load()
+    tn = getattr(lib, '_Z19vd_gemm_tn_acc_bf16PKtS0_PfliiiP12ihipStream_t')
+    p = C.c_void_p
+    tn.argtypes = [p, p, p, C.c_long, C.c_int, C.c_int, C.c_int, p]
+    g = torch.Generator(device='cuda').manual_seed(5)
+    a16 = (torch.randn(K, M, device='cuda', generator=g) * 0.3).to(torch.bfloat16)
+    b16 = (torch.randn(K, N, device='cuda', generator=g) * 0.05).to(torch.bfloat16)
+    c0 = torch.randn(M, N, device='cuda', generator=g)
+    c = c0.clone()
+    assert tn(a16.data_ptr(), b16.data_ptr(), c.data_ptr(), N, M, N, K, torch.cuda.current_stream().cuda_stream) == 0, lib.vd_last_error()
+    torch.cuda.synchronize()
+    ref = c0.double() + a16.double().t() @ b16.double()
+    err = ((c.double() - ref).norm() / ref.norm()).item()
+    assert err < 1e-5, err

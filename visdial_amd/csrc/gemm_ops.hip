@@ -187,6 +187,135 @@ gemm_bf16_tn_tr_kernel(const vd_bf16_bits* __restrict__ A, const vd_bf16_bits* _
   }
 }
 
+// 256 x 256 output tiles, eight waves (wave = 64 x 128: 2 x 4 accumulator tiles): the 128 x 128 kernel above moves 16 KB through LDS-DMA and
+// 40 KB through the transpose reads per MFLOP-tile of 8 MFMAs per wave -- LDS-bound 1.75 x over its matrix time.  Here a 32-k tile is
+// 32 KB of DMA + 96 KB of fragment reads for 16 MFMAs per wave (LDS and matrix time balanced), and the L2 -> LDS volume of a contraction
+// halves.  Same block layout ([k-group][m-group] blocks of [4 k][16 m]); a k-group of 256 columns is two DMA instructions.  Three buffers
+// of 32 KB: one workgroup per CU.
+template <int NBUF>
+__global__ void __launch_bounds__(512)
+gemm_bf16_tn_tr256_kernel(const vd_bf16_bits* __restrict__ A, const vd_bf16_bits* __restrict__ B, float* __restrict__ C, long ldc,
+                          int M, int N, int K, int kchunk, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TILE = 16384;                           // bytes per operand tile (32 k x 256 columns); NBUF buffers per operand
+  char* const lds = reinterpret_cast<char*>(smem);     // [NBUF][A tile | B tile]
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = wg % tiles_n, tile_m = (wg / tiles_n) % tiles_m, split = wg / (tiles_n * tiles_m);
+  const int ks = split * kchunk, ke = min(K, ks + kchunk);
+  const int nk = ke > ks ? (ke - ks) / 32 : 0;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wm = w & 3, wn = w >> 2;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // DMA: instruction id = k-group * 2 + column half (16 per operand and tile); this wave issues ids w and w + 8 of both operands
+  const int key = (lane & 7) >> 1, col = (lane >> 3) * 16 + (lane & 1) * 8;
+  unsigned voffa[2], voffb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = i * 8 + w, krow = (id >> 1) * 4 + key, c = (id & 1) * 128 + col;
+    voffa[i] = (unsigned)(((long)krow * M + m0 + c) * 2);
+    voffb[i] = (unsigned)(((long)krow * N + n0 + c) * 2);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)lds;
+  auto issue = [&](int kt, int buf) {
+    const float* ak = reinterpret_cast<const float*>(A + (long)(ks + kt * 32) * M);
+    const float* bk = reinterpret_cast<const float*>(B + (long)(ks + kt * 32) * N);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(voffb[i], bk, lds0 + buf * 2 * TILE + TILE + (i * 8 + w) * 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(voffa[i], ak, lds0 + buf * 2 * TILE + (i * 8 + w) * 1024);
+  };
+  // transpose-read offsets inside a tile: k-group pair by lane half (2 KB per k-group), m-group by lane quarter, 8 bytes per lane
+  const int g = lane >> 4, li = lane & 15;
+  const int frag = ((g >> 1) * 2) * 2048 + (g & 1) * 128 + li * 8;
+  auto rd8 = [&](const char* base, int off) {
+    typedef __attribute__((address_space(3))) vd_s16x4* lds_p;
+    union {
+      vd_s16x4 h[2];
+      vd_bf16x8 v;
+    } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off + 2048));
+    return u.v;
+  };
+
+  if (nk > 0) {
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+      if (i < nk) issue(i, i);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // tile kt has landed when at most the 4 instructions of each of the (up to NBUF - 2) later tiles are still in flight
+      const int later = min(NBUF - 2, nk - 1 - kt);
+      if (later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");   // everybody's share of tile kt is in LDS; tile kt - 1 is fully consumed
+      if (kt + NBUF - 1 < nk) issue(kt + NBUF - 1, buf == 0 ? NBUF - 1 : buf - 1);
+      const char* ta = lds + buf * 2 * TILE;
+      const char* tb = ta + TILE;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {            // two 16-k MFMA steps per 32-k tile (four k-groups = 8 KB each)
+        vd_bf16x8 a8[2], b8[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a8[i] = rd8(ta, frag + st * 8192 + (wm * 4 + i * 2) * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b8[j] = rd8(tb, frag + st * 8192 + (wn * 8 + j * 2) * 128);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+      }
+      buf = buf == NBUF - 1 ? 0 : buf + 1;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = n0 + wn * 128 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + mfma_row(r, lane);
+        unsafeAtomicAdd(C + (long)row * ldc + c, acc[i][j][r]);
+      }
+    }
+}
+
+static int launch_gemm_bf16_tn_tr256(const vd_bf16_bits* A, const vd_bf16_bits* B, float* C, long ldc, int M, int N, int K,
+                                     hipStream_t stream) {
+  const int tiles_m = M / 256, tiles_n = N / 256;
+  long splits = vd_cdiv(256, (long)tiles_m * tiles_n);       // one workgroup per CU: one full round
+  int kchunk = vd_cdiv(vd_cdiv(K, splits), 32) * 32;
+  if (kchunk < 32) kchunk = 32;
+  splits = vd_cdiv(K, kchunk);
+  static bool attr_set = false;
+#ifndef VD_TR256_NBUF
+#define VD_TR256_NBUF 4
+#endif
+  constexpr int NBUF = VD_TR256_NBUF;
+  const int lds = NBUF * 2 * 16384;
+  if (!attr_set) {
+    VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_tn_tr256_kernel<NBUF>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_tn_tr256_kernel<NBUF>, dim3((unsigned)(tiles_m * tiles_n * splits)), dim3(512), lds, stream, A, B, C,
+                     ldc, M, N, K, kchunk, tiles_m, tiles_n);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
 static int launch_gemm_bf16_tn_tr(const vd_bf16_bits* A, const vd_bf16_bits* B, float* C, long ldc, int M, int N, int K,
                                   hipStream_t stream) {
   const int tiles_m = M / 128, tiles_n = N / 128;
@@ -375,8 +504,14 @@ __global__ void __launch_bounds__(256) bf16_tn_tail_kernel(const vd_bf16_bits* _
 int vd_gemm_tn_acc_bf16(const vd_bf16_bits* A16, const vd_bf16_bits* B16, float* C, int64_t ldc, int M, int N, int K, hipStream_t stream) {
   VD_CHECK_ARG(A16 && B16 && C && M % 128 == 0 && N % 128 == 0 && K >= 0, "vd_gemm_tn_acc_bf16: M, N must be multiples of 128");
   const int K1 = K & ~31;
-  if (K1 > 0)
-    if (int rc = launch_gemm_bf16_tn_tr(A16, B16, C, ldc, M, N, K1, stream)) return rc;
+  if (K1 > 0) {
+#ifdef VD_NO_TR256   // (A/B build knob: `make variant NAME=notr256 DEFS=-DVD_NO_TR256`)
+    const bool big = false;
+#else
+    const bool big = M % 256 == 0 && N % 256 == 0 && K1 >= 8192;
+#endif
+    if (int rc = big ? launch_gemm_bf16_tn_tr256(A16, B16, C, ldc, M, N, K1, stream) : launch_gemm_bf16_tn_tr(A16, B16, C, ldc, M, N, K1, stream)) return rc;
+  }
   if (K1 < K) {   // the last < 32 rows
     hipLaunchKernelGGL(bf16_tn_tail_kernel, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, stream, A16 + (long)K1 * M, B16 + (long)K1 * N,
                        C, (long)ldc, M, N, K - K1);

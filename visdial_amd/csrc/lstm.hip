@@ -563,6 +563,13 @@ using CfgB11bf16 = GemmCfg<4, 1, 2, 16, 0, 4, 41984, 1>;
 using CfgFwdSmallA = GemmCfg<1, 4, 4, 8, 0, 3>;   // 32 x (32 j x 4 gates), BK = 32, 23 KB LDS
 using CfgFwdSmallC = GemmCfg<1, 4, 4, 8, 0, 4>;   // as A, <=128 VGPR: fits beside 3 padded throughput workgroups
 using CfgBwdSmallD = GemmCfg<1, 4, 1, 32, 2, 4>;
+#ifdef VD_PROBE_TICK_BF16
+using CfgTickFwd = GemmCfg<1, 4, 4, 16, 0, 3, 0, 1>;
+using CfgTickBwd = GemmCfg<1, 4, 1, 32, 0, 4, 0, 1>;
+#else
+using CfgTickFwd = CfgFwdSmallC;
+using CfgTickBwd = CfgBwdSmallD;
+#endif
 
 // WhT[vc][k] = Wh[k][g*H + jb*32 + jj], vc = jb*128 + g*32 + jj: the recurrent weights as k-contiguous rows
 // in the gate-interleaved column order of the forward step, so that both operands of the LDS-DMA pipeline
@@ -1034,9 +1041,9 @@ int vd_lstm2_forward(const vd_lstm2_fwd_t* st, int nstacks, int H, void* stream)
       }
     }
     if (g.nprob == 0) continue;
-    static_assert(CfgFwdSmallC::WK == 4 && CfgFwdSmallC::WM == 1 && CfgFwdSmallC::NT == 4,
+    static_assert(CfgTickFwd::WK == 4 && CfgTickFwd::WM == 1 && CfgTickFwd::NT == 4,
                   "EpiTickFwd finishes only through the distributed epilogue of the 32 x 128 four-wave split-K shape (gemm_block)");
-    if (int rc = launch_grouped<CfgFwdSmallC>(g, (hipStream_t)stream)) return rc;
+    if (int rc = launch_grouped<CfgTickFwd>(g, (hipStream_t)stream)) return rc;
   }
   return VD_OK;
 }
@@ -1051,7 +1058,7 @@ int vd_lstm2_backward(const vd_lstm2_bwd_t* st, int nstacks, int H, void* stream
                  "vd_lstm2_backward: stack %d has null/empty fields", s);
     Tmax = st[s].T > Tmax ? st[s].T : Tmax;
   }
-  return lstm2_backward_ticks<CfgBwdSmallD, 1>(st, nstacks, H, Tmax, (hipStream_t)stream);   // two register stages
+  return lstm2_backward_ticks<CfgTickBwd, 1>(st, nstacks, H, Tmax, (hipStream_t)stream);   // two register stages
 }
 
 }  // extern "C"
