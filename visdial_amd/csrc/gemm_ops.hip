@@ -190,8 +190,9 @@ gemm_bf16_tn_tr_kernel(const vd_bf16_bits* __restrict__ A, const vd_bf16_bits* _
 // 256 x 256 output tiles, eight waves (wave = 64 x 128: 2 x 4 accumulator tiles): the 128 x 128 kernel above moves 16 KB through LDS-DMA and
 // 40 KB through the transpose reads per MFLOP-tile of 8 MFMAs per wave -- LDS-bound 1.75 x over its matrix time.  Here a 32-k tile is
 // 32 KB of DMA + 96 KB of fragment reads for 16 MFMAs per wave (LDS and matrix time balanced), and the L2 -> LDS volume of a contraction
-// halves.  Same block layout ([k-group][m-group] blocks of [4 k][16 m]); a k-group of 256 columns is two DMA instructions.  Three buffers
-// of 32 KB: one workgroup per CU.
+// halves.  The LDS image is the plain [32 k][256 m] tile (each DMA instruction copies two whole 512-byte rows -- fully coalesced on the
+// memory side, where the block layout above makes every lane pair jump to another row); the transpose reads gather their [4 k][16 m]
+// blocks from four rows, kept on different banks by a 64-byte XOR swizzle.  NBUF buffers of 32 KB: one workgroup per CU.
 template <int NBUF>
 __global__ void __launch_bounds__(512)
 gemm_bf16_tn_tr256_kernel(const vd_bf16_bits* __restrict__ A, const vd_bf16_bits* __restrict__ B, float* __restrict__ C, long ldc,
@@ -216,14 +217,17 @@ gemm_bf16_tn_tr256_kernel(const vd_bf16_bits* __restrict__ A, const vd_bf16_bits
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // DMA: instruction id = k-group * 2 + column half (16 per operand and tile); this wave issues ids w and w + 8 of both operands
-  const int key = (lane & 7) >> 1, col = (lane >> 3) * 16 + (lane & 1) * 8;
+  // DMA: one instruction moves TWO whole k-rows of the tile (2 x 512 B, each contiguous in memory: lanes 0-31 row 2 id, lanes 32-63 row
+  // 2 id + 1), 16 instructions per operand and tile; this wave issues ids w and w + 8 of both operands.  LDS image = plain [32 k][256 m]
+  // rows of 512 B whose 64-byte chunks are XOR-swizzled with k & 3 inside every 256 bytes (the four k-rows one transpose read touches
+  // fall on different banks); the swizzle is applied to the SOURCE column, the LDS position of a lane is fixed by the instruction.
   unsigned voffa[2], voffb[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int id = i * 8 + w, krow = (id >> 1) * 4 + key, c = (id & 1) * 128 + col;
-    voffa[i] = (unsigned)(((long)krow * M + m0 + c) * 2);
-    voffb[i] = (unsigned)(((long)krow * N + n0 + c) * 2);
+    const int krow = (i * 8 + w) * 2 + (lane >> 5);
+    const int cb = ((lane & 31) * 16) ^ ((krow & 3) << 6);          // source column, bytes
+    voffa[i] = (unsigned)(((long)krow * M + m0) * 2 + cb);
+    voffb[i] = (unsigned)(((long)krow * N + n0) * 2 + cb);
   }
   const unsigned lds0 = (unsigned)(uintptr_t)lds;
   auto issue = [&](int kt, int buf) {
@@ -234,9 +238,15 @@ gemm_bf16_tn_tr256_kernel(const vd_bf16_bits* __restrict__ A, const vd_bf16_bits
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16(voffa[i], ak, lds0 + buf * 2 * TILE + (i * 8 + w) * 1024);
   };
-  // transpose-read offsets inside a tile: k-group pair by lane half (2 KB per k-group), m-group by lane quarter, 8 bytes per lane
+  // transpose-read addresses: a 16-lane group fetches [4 k][16 m] (lane li: k-row li / 4, 8 bytes = 4 columns at (li % 4) * 4); lane halves
+  // take the k-groups {0, 1} / {2, 3} of a 16-k step (2 KB per k-group), lane quarters the two 16-row halves of a 32-row fragment
   const int g = lane >> 4, li = lane & 15;
-  const int frag = ((g >> 1) * 2) * 2048 + (g & 1) * 128 + li * 8;
+  const int frag = (g >> 1) * 4096 + (li >> 2) * 512 + (g & 1) * 32 + (li & 3) * 8;
+  int xa[2], xb[4];                                                   // swizzled 64-byte chunk of fragment i / j in this lane's k-row
+#pragma unroll
+  for (int i = 0; i < 2; ++i) xa[i] = frag + (((wm * 2 + i) ^ (li >> 2)) << 6);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xb[j] = frag + (((wn * 4 + j) ^ (li >> 2)) << 6);
   auto rd8 = [&](const char* base, int off) {
     typedef __attribute__((address_space(3))) vd_s16x4* lds_p;
     union {
@@ -248,35 +258,54 @@ gemm_bf16_tn_tr256_kernel(const vd_bf16_bits* __restrict__ A, const vd_bf16_bits
     return u.v;
   };
 
+  // Fragments are read one 16-k step AHEAD of the MFMAs that consume them, across the tile boundary: while the matrix pipe works on step 1
+  // of tile kt the transpose reads of step 0 of tile kt + 1 are in flight, so the barrier sits between two batches of ready MFMAs and the
+  // two waves of a SIMD never wait for LDS at the same time.  One barrier per tile, placed after step 0: it certifies tile kt + 1 (landed,
+  // every wave's share) and that nobody reads tile kt - 1 any more, whose buffer the next DMA overwrites.
+  struct Frags {
+    vd_bf16x8 a[2], b[4];
+  };
+  auto read_step = [&](Frags& f, int buf, int st) {
+    const char* ta = lds + buf * 2 * TILE;
+    const char* tb = ta + TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) f.a[i] = rd8(ta, xa[i] + st * 8192);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f.b[j] = rd8(tb, xb[j] + st * 8192);
+  };
+  auto mfma_step = [&](const Frags& f) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+  };
+  auto wait_tiles_in_flight = [&](int later) {   // DMA instructions of at most `later` tiles (4 each) may still be pending
+    if (later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
   if (nk > 0) {
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i)
       if (i < nk) issue(i, i);
+    wait_tiles_in_flight(min(NBUF - 2, nk - 1));
+    asm volatile("s_barrier" ::: "memory");       // tile 0 is in LDS
+    Frags f0, f1;
+    read_step(f0, 0, 0);
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-      // tile kt has landed when at most the 4 instructions of each of the (up to NBUF - 2) later tiles are still in flight
-      const int later = min(NBUF - 2, nk - 1 - kt);
-      if (later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");   // everybody's share of tile kt is in LDS; tile kt - 1 is fully consumed
-      if (kt + NBUF - 1 < nk) issue(kt + NBUF - 1, buf == 0 ? NBUF - 1 : buf - 1);
-      const char* ta = lds + buf * 2 * TILE;
-      const char* tb = ta + TILE;
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {            // two 16-k MFMA steps per 32-k tile (four k-groups = 8 KB each)
-        vd_bf16x8 a8[2], b8[4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a8[i] = rd8(ta, frag + st * 8192 + (wm * 4 + i * 2) * 128);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b8[j] = rd8(tb, frag + st * 8192 + (wn * 8 + j * 2) * 128);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+      const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
+      read_step(f1, buf, 1);
+      mfma_step(f0);
+      if (kt + 1 < nk) {
+        wait_tiles_in_flight(min(NBUF - 3, nk - 2 - kt));   // tile kt + 1 has landed: only tiles kt + 2 .. kt + NBUF - 2 may be pending
+        asm volatile("s_barrier" ::: "memory");
+        if (kt + NBUF - 1 < nk) issue(kt + NBUF - 1, buf == 0 ? NBUF - 1 : buf - 1);   // into the buffer of tile kt - 1
+        read_step(f0, nbuf, 0);
       }
-      buf = buf == NBUF - 1 ? 0 : buf + 1;
+      mfma_step(f1);
+      buf = nbuf;
     }
   }
 #pragma unroll

@@ -563,13 +563,11 @@ using CfgB11bf16 = GemmCfg<4, 1, 2, 16, 0, 4, 41984, 1>;
 using CfgFwdSmallA = GemmCfg<1, 4, 4, 8, 0, 3>;   // 32 x (32 j x 4 gates), BK = 32, 23 KB LDS
 using CfgFwdSmallC = GemmCfg<1, 4, 4, 8, 0, 4>;   // as A, <=128 VGPR: fits beside 3 padded throughput workgroups
 using CfgBwdSmallD = GemmCfg<1, 4, 1, 32, 2, 4>;
-#ifdef VD_PROBE_TICK_BF16
-using CfgTickFwd = GemmCfg<1, 4, 4, 16, 0, 3, 0, 1>;
-using CfgTickBwd = GemmCfg<1, 4, 1, 32, 0, 4, 0, 1>;
-#else
-using CfgTickFwd = CfgFwdSmallC;
-using CfgTickBwd = CfgBwdSmallD;
-#endif
+// bf16 pass of the model-level runtime (configs[4]: "bf16 LSTM step"): the encoder's ticks round both operands to bf16 while staging them
+// into LDS and multiply on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, fp32 state): an eighth of the matrix time and half of the LDS
+// traffic of a workgroup whose K loop is 45 % MFMA time.  BK = 64 (16 k per wave and MFMA): 156 VGPRs forward, hence three waves per SIMD.
+using CfgTickFwdBf16 = GemmCfg<1, 4, 4, 16, 0, 3, 0, 1>;
+using CfgTickBwdBf16 = GemmCfg<1, 4, 1, 32, 0, 4, 0, 1>;
 
 // WhT[vc][k] = Wh[k][g*H + jb*32 + jj], vc = jb*128 + g*32 + jj: the recurrent weights as k-contiguous rows
 // in the gate-interleaved column order of the forward step, so that both operands of the LDS-DMA pipeline
@@ -993,16 +991,11 @@ int vd_lstm_backward(const float* Wh, float* gates, const float* c, const float*
   return VD_OK;
 }
 
-int vd_lstm2_forward(const vd_lstm2_fwd_t* st, int nstacks, int H, void* stream) {
-  VD_CHECK_ARG(st && nstacks >= 1 && nstacks <= VD_MAX_STACKS && H > 0 && H % 32 == 0,
-               "vd_lstm2_forward: bad args (nstacks=%d, max %d)", nstacks, VD_MAX_STACKS);
-  int Tmax = 0;
-  for (int s = 0; s < nstacks; ++s) {
-    VD_CHECK_ARG(st[s].T >= 1 && st[s].N >= 1 && st[s].Wh1 && st[s].Wx2 && st[s].b2 && st[s].Wh2 && st[s].gates1 &&
-                     st[s].h1 && st[s].c1 && st[s].gates2 && st[s].h2 && st[s].c2,
-                 "vd_lstm2_forward: stack %d has null/empty fields", s);
-    Tmax = st[s].T > Tmax ? st[s].T : Tmax;
-  }
+}  // extern "C"
+
+// the per-tick grouped launches of the forward direction, for one tile configuration
+template <class Cfg>
+static int lstm2_forward_ticks(const vd_lstm2_fwd_t* st, int nstacks, int H, int Tmax, hipStream_t stream) {
   for (int tau = 0; tau < Tmax + 2; ++tau) {
     GroupArgs<TickFwdProb, 3 * VD_MAX_STACKS> g;
     g.nprob = 0;
@@ -1041,14 +1034,28 @@ int vd_lstm2_forward(const vd_lstm2_fwd_t* st, int nstacks, int H, void* stream)
       }
     }
     if (g.nprob == 0) continue;
-    static_assert(CfgTickFwd::WK == 4 && CfgTickFwd::WM == 1 && CfgTickFwd::NT == 4,
+    static_assert(Cfg::WK == 4 && Cfg::WM == 1 && Cfg::NT == 4,
                   "EpiTickFwd finishes only through the distributed epilogue of the 32 x 128 four-wave split-K shape (gemm_block)");
-    if (int rc = launch_grouped<CfgTickFwd>(g, (hipStream_t)stream)) return rc;
+    if (int rc = launch_grouped<Cfg>(g, stream)) return rc;
   }
   return VD_OK;
 }
 
-int vd_lstm2_backward(const vd_lstm2_bwd_t* st, int nstacks, int H, void* stream) {
+int vd_lstm2_forward_p(const vd_lstm2_fwd_t* st, int nstacks, int H, int flags, hipStream_t stream) {
+  VD_CHECK_ARG(st && nstacks >= 1 && nstacks <= VD_MAX_STACKS && H > 0 && H % 32 == 0,
+               "vd_lstm2_forward: bad args (nstacks=%d, max %d)", nstacks, VD_MAX_STACKS);
+  int Tmax = 0;
+  for (int s = 0; s < nstacks; ++s) {
+    VD_CHECK_ARG(st[s].T >= 1 && st[s].N >= 1 && st[s].Wh1 && st[s].Wx2 && st[s].b2 && st[s].Wh2 && st[s].gates1 &&
+                     st[s].h1 && st[s].c1 && st[s].gates2 && st[s].h2 && st[s].c2,
+                 "vd_lstm2_forward: stack %d has null/empty fields", s);
+    Tmax = st[s].T > Tmax ? st[s].T : Tmax;
+  }
+  if ((flags & VD_FLAG_BF16) && H % 64 == 0) return lstm2_forward_ticks<CfgTickFwdBf16>(st, nstacks, H, Tmax, stream);
+  return lstm2_forward_ticks<CfgFwdSmallC>(st, nstacks, H, Tmax, stream);
+}
+
+int vd_lstm2_backward_p(const vd_lstm2_bwd_t* st, int nstacks, int H, int flags, hipStream_t stream) {
   VD_CHECK_ARG(st && nstacks >= 1 && nstacks <= VD_MAX_STACKS && H > 0 && H % 32 == 0,
                "vd_lstm2_backward: bad args (nstacks=%d, max %d)", nstacks, VD_MAX_STACKS);
   int Tmax = 0;
@@ -1058,9 +1065,13 @@ int vd_lstm2_backward(const vd_lstm2_bwd_t* st, int nstacks, int H, void* stream
                  "vd_lstm2_backward: stack %d has null/empty fields", s);
     Tmax = st[s].T > Tmax ? st[s].T : Tmax;
   }
-  return lstm2_backward_ticks<CfgTickBwd, 1>(st, nstacks, H, Tmax, (hipStream_t)stream);   // two register stages
+  if (flags & VD_FLAG_BF16) return lstm2_backward_ticks<CfgTickBwdBf16, 1>(st, nstacks, H, Tmax, stream);   // (BK = 128 divides 4H)
+  return lstm2_backward_ticks<CfgBwdSmallD, 1>(st, nstacks, H, Tmax, stream);   // two register stages
 }
 
+extern "C" {
+int vd_lstm2_forward(const vd_lstm2_fwd_t* st, int nstacks, int H, void* stream) { return vd_lstm2_forward_p(st, nstacks, H, 0, (hipStream_t)stream); }
+int vd_lstm2_backward(const vd_lstm2_bwd_t* st, int nstacks, int H, void* stream) { return vd_lstm2_backward_p(st, nstacks, H, 0, (hipStream_t)stream); }
 }  // extern "C"
 
 // ---- compact bf16 state (common.h): the option recurrence of a bf16 pass, model-level runtime --------------------------------------

@@ -21,6 +21,11 @@
 #include "../../include/visdial_hip.h"
 #include "common.h"
 
+// lstm.hip: the two-layer wavefront with the pass's arithmetic (flags & VD_FLAG_BF16: bf16 operands on the ticks' MFMAs in a bf16 pass;
+// the C-ABI entry points vd_lstm2_forward / vd_lstm2_backward are these with flags = 0)
+int vd_lstm2_forward_p(const vd_lstm2_fwd_t* st, int nstacks, int H, int flags, hipStream_t stream);
+int vd_lstm2_backward_p(const vd_lstm2_bwd_t* st, int nstacks, int H, int flags, hipStream_t stream);
+
 #define VD_TRY(expr)                  \
   do {                                \
     const int rc__ = (expr);          \

@@ -18,6 +18,10 @@ struct Encoder {
   virtual int seqLen(const BatchSlot& b) const { return b.q.T; }
 };
 
+// arithmetic of the encoder's recurrent products: bf16 operands in a bf16 pass (lstmPrecision = 'bf16', BASELINE configs[4] "bf16 LSTM
+// step"), fp32 MFMA otherwise (the exact-split modes of the option recurrence leave the encoder on fp32: it is not on their critical path)
+inline int tick_flags(const vd_model* m) { return m->p.lstmBf16 == 1 ? VD_FLAG_BF16 : 0; }
+
 inline int causal_mask(vd_model* m, int B, int R, uint8_t** out) {
   // model.lua:280-294: mask[i][j] = 0 iff j <= i, tiled over the batch ([N x R] bytes, 1 = hidden)
   const std::string key = "causal." + std::to_string(B);
@@ -103,7 +107,7 @@ struct TextBranches {
     vd_lstm2_fwd_t fw[2];
     fill_fwd(m, b.h, hist1, hist2, &fw[0]);
     fill_fwd(m, b.q, ques1, ques2, &fw[1]);
-    VD_TRY(vd_lstm2_forward(fw, 2, (int)H, s));
+    VD_TRY(vd_lstm2_forward_p(fw, 2, (int)H, tick_flags(m), s));
     float *hl, *ql;
     VD_TRY(ws_get(m, "h.last", (size_t)N * H, &hl));
     VD_TRY(ws_get(m, "q.last", (size_t)N * H, &ql));
@@ -138,7 +142,7 @@ struct TextBranches {
       bw[k].dh1_seq = dhseq; bw[k].dc1 = dc1; bw[k].dc2 = dc2;
       bw[k].nact = ss[k]->nact.data();
     }
-    VD_TRY(vd_lstm2_backward(bw, 2, (int)H, s));
+    VD_TRY(vd_lstm2_backward_p(bw, 2, (int)H, tick_flags(m), s));
     const uint8_t* mk[2] = {m_h, m_q};
     const char* tag[2] = {"h", "q"};
     hipStream_t sw;
@@ -173,7 +177,7 @@ struct HistWave {
     VD_TRY(TextBranches::prepare(m, s, b.h, "h", l1, l2, &mk, &xs, false));
     vd_lstm2_fwd_t fw;
     TextBranches::fill_fwd(m, b.h, l1, l2, &fw);
-    VD_TRY(vd_lstm2_forward(&fw, 1, (int)H, s));
+    VD_TRY(vd_lstm2_forward_p(&fw, 1, (int)H, tick_flags(m), s));
     float* hl;
     VD_TRY(ws_get(m, "h.last", (size_t)N * H, &hl));
     VD_TRY(vd_embed_gather(l2.out_at(b.h.T - 1), b.h.inv, nullptr, hl, N, (int)H, 1.f, s));   // Select(1,-1), back to batch order
@@ -197,7 +201,7 @@ struct HistWave {
     bw.dh_last2 = dls;
     bw.dh1_seq = dhseq; bw.dc1 = dc1; bw.dc2 = dc2;
     bw.nact = b.h.nact.data();
-    VD_TRY(vd_lstm2_backward(&bw, 1, (int)H, s));
+    VD_TRY(vd_lstm2_backward_p(&bw, 1, (int)H, tick_flags(m), s));
     std::vector<float*> dx;
     VD_TRY(l2.param_grads(m, s, {false}, nullptr));
     VD_TRY(l1.param_grads(m, s, {true}, &dx));
