@@ -2,7 +2,7 @@
 idle chip: microseconds per tick at the shapes of BASELINE.json configs[1] (history: T up to 300 concatenated tokens, N = 200 rows, H = 512)
 and of the headline's encoder (T = 40 / 20, N = 200), with all rows active and with a length-sorted ragged batch.
 
-    python scripts/mb_ticks.py [T N H]"""
+    python scripts/mb_ticks.py [T N H [bf16]]      (bf16: the ticks of a bf16 pass, csrc/lstm.hip vd_lstm2_forward_p / _backward_p)"""
 import os
 import sys
 
@@ -11,6 +11,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from visdial_amd import ops  # noqa: E402
+
+
+BF16 = 'bf16' in sys.argv[1:]
+if BF16:
+    sys.argv.remove('bf16')
 
 
 def run(T, N, H, ragged, reps=3):
@@ -34,7 +39,11 @@ def run(T, N, H, ragged, reps=3):
     bw = dict(T=T, N=N, gates1=st['gates1'], c1=st['c1'], gates2=st['gates2'], c2=st['c2'], dh_last2=r(N, H) * 0.01,
               dh1_seq=torch.empty(T, N, H, device='cuda'), dc1=torch.empty(N, H, device='cuda'), dc2=torch.empty(N, H, device='cuda'), nact=nact, **W)
     out = []
-    for name, fn in (('fwd', lambda: ops.lstm2_forward([st], H)), ('bwd', lambda: ops.lstm2_backward([bw], H))):
+    if BF16:
+        fns = (('fwd', lambda: ops.lstm2_pass([st], H, ops.FLAG_BF16)), ('bwd', lambda: ops.lstm2_pass([bw], H, ops.FLAG_BF16, backward=True)))
+    else:
+        fns = (('fwd', lambda: ops.lstm2_forward([st], H)), ('bwd', lambda: ops.lstm2_backward([bw], H)))
+    for name, fn in fns:
         ts = []
         for i in range(reps + 1):
             if name == 'fwd':
@@ -49,7 +58,7 @@ def run(T, N, H, ragged, reps=3):
         ms = float(np.mean(ts[1:]))
         flop = 2.0 * float(nact.sum()) * 3 * H * 4 * H
         out.append("%s %7.3f ms = %5.1f us/tick (%d ticks), %5.1f TFLOP/s executed" % (name, ms, ms / (T + 2) * 1e3, T + 2, flop / ms / 1e9))
-    print("T=%3d N=%3d H=%d %-7s mean active rows %5.1f | %s" % (T, N, H, 'ragged' if ragged else 'full', nact.mean(), ' | '.join(out)), flush=True)
+    print("%sT=%3d N=%3d H=%d %-7s mean active rows %5.1f | %s" % ('bf16 ticks ' if BF16 else '', T, N, H, 'ragged' if ragged else 'full', nact.mean(), ' | '.join(out)), flush=True)
 
 
 if os.environ.get('MB_PHASES') == '1':

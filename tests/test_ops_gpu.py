@@ -447,8 +447,18 @@ def test_error_reporting(ops):
         ops.gemm_nt(A, A, torch.zeros(4, 4, device="cuda"), K=6)       # K % 4 != 0 -> rejected loudly
 
 
-def test_lstm2_wavefront_matches_oracle(ops):
-    """two stacks (T=7 and T=4) x two layers through the grouped skewed-wavefront drivers"""
+@pytest.mark.parametrize("arith", ['fp32', 'bf16'])
+def test_lstm2_wavefront_matches_oracle(ops, arith):
+    """two stacks (T=7 and T=4) x two layers through the grouped skewed-wavefront drivers.  fp32: the C-ABI entry points (fp32 MFMA),
+    1e-5 / 2e-5 against the fp64 oracle.  bf16: the ticks of a bf16 pass of the model-level runtime (configs[4]; csrc/lstm.hip
+    `vd_lstm2_forward_p(flags = VD_FLAG_BF16)`: both operands of every recurrent product rounded to bf16 while staged, fp32 accumulate,
+    fp32 state) within the bf16 bound of the config (1e-2 states, 2e-2 gate gradients) and measurably different from fp32."""
+    if arith == 'bf16':
+        fwd = lambda st, H: ops.lstm2_pass(st, H, ops.FLAG_BF16)
+        bwd = lambda st, H: ops.lstm2_pass(st, H, ops.FLAG_BF16, backward=True)
+        tol_f, tol_b = 1e-2, 2e-2
+    else:
+        fwd, bwd, tol_f, tol_b = ops.lstm2_forward, ops.lstm2_backward, 1e-5, 2e-5
     rng = np.random.RandomState(11)
     H, D, V = 64, 20, 30
     stacks = []
@@ -472,21 +482,22 @@ def test_lstm2_wavefront_matches_oracle(ops):
                       gates1=dev((x.reshape(T * N, D).astype(d) @ W1[:D].astype(d) + b1).astype(np.float32).reshape(T, N, 4 * H)),
                       h1=t(T, N, H), c1=t(T, N, H), gates2=t(T, N, 4 * H), h2=t(T, N, H), c2=t(T, N, H))
         stacks.append((dev_st, dict(h1=h1, h2=h2, c2=c2, g1=g1, g2=g2, da1=da1, da2=da2, dlast=dlast)))
-    ops.lstm2_forward([s for s, _ in stacks], H)
+    fwd([s for s, _ in stacks], H)
     torch.cuda.synchronize()
     for s, r in stacks:
-        assert relerr(s['h1'], r['h1']) < 1e-5 and relerr(s['h2'], r['h2']) < 1e-5
-        assert relerr(s['gates1'], r['g1']) < 1e-5 and relerr(s['gates2'], r['g2']) < 1e-5 and relerr(s['c2'], r['c2']) < 1e-5
+        assert relerr(s['h1'], r['h1']) < tol_f and relerr(s['h2'], r['h2']) < tol_f
+        assert relerr(s['gates1'], r['g1']) < tol_f and relerr(s['gates2'], r['g2']) < tol_f and relerr(s['c2'], r['c2']) < tol_f
+        assert arith == 'fp32' or relerr(s['h2'], r['h2']) > 1e-5       # the switch really changes the arithmetic
     bw = []
     for s, r in stacks:
         T, N = s['T'], s['N']
         bw.append(dict(T=T, N=N, Wh1=s['Wh1'], Wx2=s['Wx2'], Wh2=s['Wh2'], gates1=s['gates1'], c1=s['c1'],
                        gates2=s['gates2'], c2=s['c2'], dh_last2=dev(r['dlast']), dh1_seq=torch.empty(T, N, H, device="cuda"),
                        dc1=torch.empty(N, H, device="cuda"), dc2=torch.empty(N, H, device="cuda")))
-    ops.lstm2_backward(bw, H)
+    bwd(bw, H)
     torch.cuda.synchronize()
     for s, r in stacks:
-        assert relerr(s['gates2'], r['da2']) < 2e-5 and relerr(s['gates1'], r['da1']) < 2e-5
+        assert relerr(s['gates2'], r['da2']) < tol_b and relerr(s['gates1'], r['da1']) < tol_b
 
 
 def test_bf16_compact_state_saturated_gates(ops):

@@ -330,7 +330,7 @@ static int launch_gemm_bf16_tn_tr256(const vd_bf16_bits* A, const vd_bf16_bits* 
   splits = vd_cdiv(K, kchunk);
   static bool attr_set = false;
 #ifndef VD_TR256_NBUF
-#define VD_TR256_NBUF 4
+#define VD_TR256_NBUF 3
 #endif
   constexpr int NBUF = VD_TR256_NBUF;
   const int lds = NBUF * 2 * 16384;

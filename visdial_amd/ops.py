@@ -249,8 +249,7 @@ def copy_2d(dst, dst_ld, src, src_ld, rows, cols, dst_off=0, src_off=0):
     call("vd_copy_2d", dst.data_ptr() + 4 * dst_off, dst_ld, src.data_ptr() + 4 * src_off, src_ld, rows, cols, _stream())
 
 
-def lstm2_forward(stacks, H):
-    """stacks: list of dicts with the vd_lstm2_fwd_t fields (tensors)."""
+def _lstm2_fwd_array(stacks):
     arr = (_lib.Lstm2Fwd * len(stacks))()
     for a, s in zip(arr, stacks):
         a.T, a.N = s['T'], s['N']
@@ -259,11 +258,10 @@ def lstm2_forward(stacks, H):
             setattr(a, k, _p(s[k], F32))
         na = s.get('nact')            # host numpy int32[T] (kept alive by the caller's dict) or None
         a.nact = na.ctypes.data if na is not None else None
-    import ctypes
-    call("vd_lstm2_forward", ctypes.cast(arr, ctypes.c_void_p), len(stacks), H, _stream())
+    return arr
 
 
-def lstm2_backward(stacks, H):
+def _lstm2_bwd_array(stacks):
     arr = (_lib.Lstm2Bwd * len(stacks))()
     for a, s in zip(arr, stacks):
         a.T, a.N = s['T'], s['N']
@@ -271,8 +269,35 @@ def lstm2_backward(stacks, H):
             setattr(a, k, _p(s[k], F32))
         na = s.get('nact')
         a.nact = na.ctypes.data if na is not None else None
+    return arr
+
+
+def lstm2_forward(stacks, H):
+    """stacks: list of dicts with the vd_lstm2_fwd_t fields (tensors)."""
     import ctypes
-    call("vd_lstm2_backward", ctypes.cast(arr, ctypes.c_void_p), len(stacks), H, _stream())
+    call("vd_lstm2_forward", ctypes.cast(_lstm2_fwd_array(stacks), ctypes.c_void_p), len(stacks), H, _stream())
+
+
+def lstm2_backward(stacks, H):
+    import ctypes
+    call("vd_lstm2_backward", ctypes.cast(_lstm2_bwd_array(stacks), ctypes.c_void_p), len(stacks), H, _stream())
+
+
+def lstm2_pass(stacks, H, flags, backward=False):
+    """The wavefront with a pass's arithmetic (flags = FLAG_BF16: the encoder ticks of a bf16 pass of the model-level runtime) through
+    the library-internal entry points csrc/lstm.hip `vd_lstm2_forward_p / vd_lstm2_backward_p` (C++ linkage: the C ABI's
+    vd_lstm2_forward / _backward are these with flags = 0).  Test and microbenchmark access only."""
+    import ctypes
+    lib = _lib.load()
+    name = ('_Z19vd_lstm2_backward_pPK14vd_lstm2_bwd_tiiiP12ihipStream_t' if backward
+            else '_Z18vd_lstm2_forward_pPK14vd_lstm2_fwd_tiiiP12ihipStream_t')
+    fn = getattr(lib, name)
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    fn.restype = ctypes.c_int
+    arr = _lstm2_bwd_array(stacks) if backward else _lstm2_fwd_array(stacks)
+    rc = fn(ctypes.cast(arr, ctypes.c_void_p), len(stacks), H, int(flags), _stream())
+    if rc != 0:
+        raise _lib.VisdialHipError("%s failed (%d): %s" % (name, rc, lib.vd_last_error().decode()))
 
 
 def hrea_attention_forward(sq, sh, Hm, P, att, B, R, H):
