@@ -463,6 +463,17 @@ int vd_gemm_tn_acc(const float* A, int64_t lda, const float* B, int64_t ldb, flo
         return launch_gemm<GemmCfg<4, 1, 4, 32, 0, 3, 0, 1>>(M, N, K - K1, 1, a2, b2, e, (hipStream_t)stream);
       }
     }
+    // fp32 operands in memory (the encoder's saved state in a bf16 pass of the model-level runtime): LDS-DMA tiles of the fp32 rows, both
+    // operands rounded to bf16 in registers, one v_mfma_f32_32x32x16_bf16 per 16 k = the exact-split kernel with its first product
+    // only (split_core.h).  The last < 16 rows through the staging kernel.
+    if (M % SplitTnCfg::BM == 0 && N % SplitTnCfg::BN == 0 && K >= 1024 && lda % 4 == 0 && ldb % 4 == 0 && 16L * lda * 4 < (1L << 31) &&
+        16L * ldb * 4 < (1L << 31)) {
+      const int K1 = K & ~15;
+      if (int rc = launch_gemm_split_tn<1>(M, N, K1, A, lda, B, ldb, C, ldc, (hipStream_t)stream)) return rc;
+      if (K1 == K) return VD_OK;
+      SrcK a2{A + (long)K1 * lda, lda}, b2{B + (long)K1 * ldb, ldb};
+      return launch_gemm<GemmCfg<4, 1, 4, 32, 0, 3, 0, 1>>(M, N, K - K1, 1, a2, b2, e, (hipStream_t)stream);
+    }
     return launch_gemm<GemmCfg<4, 1, 4, 32, 0, 3, 0, 1>>(M, N, K, (int)splits, a, b, e, (hipStream_t)stream);
   }
   if (kmaj)

@@ -419,11 +419,14 @@ struct SeqLSTM {
     // of dependent (row index -> row) loads per K tile whose long-lived workgroups take the third slot of a third of the
     // CUs away from the option-LSTM backward kernels for most of their run.
     auto dense_fits = [&](long Mrows, long K) { return Mrows % 128 == 0 && (4 * H) % 128 == 0 && K >= 1024; };
+    // bf16 pass (lstmPrecision = 'bf16', configs[4]): the dense contractions whose shape the bf16 kernel takes (256-row tiles) round both
+    // fp32 operands to bf16 in registers and multiply on the bf16 MFMA (gemm_ops.hip: 77 vs 167 us at K = 8 000)
+    auto wg_flags = [&](long Mrows) { return m->p.lstmBf16 == 1 && Mrows % 256 == 0 ? VD_FLAG_BF16 : 0; };
     if (by_rows && !(T > 1 && dense_fits(H, (long)(T - 1) * N))) {
       if (rows->n_act1 > 0)
         VD_TRY(vd_gemm_tn_rows_acc(h, H, rows->prev1, gates, 4 * H, rows->act1, dWh, 4 * H, (int)H, (int)(4 * H), rows->n_act1, s));
     } else if (T > 1) {
-      VD_TRY(vd_gemm_tn_acc(h, H, gates + (long)N * 4 * H, 4 * H, dWh, 4 * H, (int)H, (int)(4 * H), (T - 1) * N, 0, s));
+      VD_TRY(vd_gemm_tn_acc(h, H, gates + (long)N * 4 * H, 4 * H, dWh, 4 * H, (int)H, (int)(4 * H), (T - 1) * N, wg_flags(H), s));
     }
     if (h0) VD_TRY(vd_gemm_tn_acc(h0, H, gates, 4 * H, dWh, 4 * H, (int)H, (int)(4 * H), N, 0, s));
     VD_TRY(vd_colsum_acc(gates, 4 * H, (int)TN, (int)(4 * H), Gp(m, name + ".b"), s));
@@ -435,7 +438,7 @@ struct SeqLSTM {
           VD_TRY(vd_gemm_tn_rows_acc(xs[i], parts[i], rows->act, gates, 4 * H, rows->act, dW + roff * 4 * H, 4 * H, (int)parts[i],
                                      (int)(4 * H), rows->n_act, s));
       } else {
-        VD_TRY(vd_gemm_tn_acc(xs[i], parts[i], gates, 4 * H, dW + roff * 4 * H, 4 * H, (int)parts[i], (int)(4 * H), (int)TN, 0, s));
+        VD_TRY(vd_gemm_tn_acc(xs[i], parts[i], gates, 4 * H, dW + roff * 4 * H, 4 * H, (int)parts[i], (int)(4 * H), (int)TN, wg_flags(parts[i]), s));
       }
       if (need_dx.empty() || need_dx[i]) {
         float* dx;

@@ -45,6 +45,17 @@ inline int stage_loss(vd_model* m, const float* loss_rows, long n, bool is_sum, 
 //   * nn.MM + CrossEntropyCriterion (+ their backward) -> vd_score_ce
 // The option LSTM (a handful of big launches) runs on the main stream, the encoder (~200 small ones) beside it.
 // ------------------------------------------------------------------------------------------------------------
+#ifdef VD_PROBE_PHASES
+inline hipEvent_t* probe_events() {
+  static hipEvent_t e[6];
+  static bool made = false;
+  if (!made) { for (auto& x : e) (void)hipEventCreate(&x); made = true; }
+  return e;
+}
+#define VD_PROBE_REC(i, stream) (void)hipEventRecord(probe_events()[i], stream)
+#else
+#define VD_PROBE_REC(i, stream)
+#endif
 struct Disc : Decoder {
   void declare(vd_model* m) override { add_lstm(m, "opt", m->p.embedSize, m->p.rnnHiddenSize); }
   int forward_backward(vd_model* m, BatchSlot& b, bool only_forward) override {
@@ -93,6 +104,7 @@ struct Disc : Decoder {
     {
       VdRange r("encoder forward");
       VD_TRY(m->enc->forward(m, se, b, &enc_out));                                 // model.lua:297
+      VD_PROBE_REC(0, se);
     }
     VD_TRY(join_stream(m, se, s));
     // criterion (+ nn.MM backward) in one kernel (model.lua:330-335)
@@ -137,6 +149,8 @@ struct Disc : Decoder {
     auto enc_bwd = [&]() -> int {
       VdRange r("encoder backward");
       VD_TRY(m->enc->backward(m, se, b, d_enc));
+      VD_PROBE_REC(1, se);
+      if (m->wg_used) VD_PROBE_REC(2, m->s_wg);
       if (m->wg_used) {   // encoder tensors final = the chain on `se` AND the gradient work on s_wg
         VD_TRY(fork_stream(m, se, m->s_wg));
         VD_HIP(hipEventRecord(m->ev_enc_grads, m->s_wg));
@@ -170,10 +184,12 @@ struct Disc : Decoder {
     // dEmb += dTable * Wx^T on the table stream, with float atomics: the SHARED embedding gradient has concurrent atomic
     // writers (the encoder's scatters), and the product is off the main stream's critical path this way
     VD_TRY(vd_gemm_nt(dtab, 4 * H, Wopt, 4 * H, nullptr, Gp(m, "embed"), E, (int)V + 1, (int)E, (int)(4 * H), VD_ACT_NONE, 2, st));
+    VD_PROBE_REC(3, st);
     VD_TRY(join_stream(m, se, s));
     if (m->wg_used) VD_TRY(join_stream(m, m->s_wg, s));
     m->wg_active = m->wg_used = false;
     VD_TRY(join_stream(m, st, s));
+    VD_PROBE_REC(4, s);
     return VD_OK;
   }
   int retrieve(vd_model* m, BatchSlot& b) override { return forward_backward(m, b, true); }   // model.lua:421-425

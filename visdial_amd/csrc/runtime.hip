@@ -614,6 +614,13 @@ int vd_model_family_ms(vd_model* m, float* ms3) {
   VD_HIP(hipEventElapsedTime(&ms3[0], m->ev_prof[0], m->ev_prof[1]));
   VD_HIP(hipEventElapsedTime(&ms3[1], m->ev_prof[2], m->ev_prof[3]));
   VD_HIP(hipEventElapsedTime(&ms3[2], m->ev_prof[4], m->ev_prof[5]));
+#ifdef VD_PROBE_PHASES
+  { float t[12]; hipEvent_t* pe = vdrt::probe_events();
+    for (int i = 1; i < 6; ++i) (void)hipEventElapsedTime(&t[i], m->ev_prof[0], m->ev_prof[i]);
+    for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&t[6 + i], m->ev_prof[0], pe[i]);
+    fprintf(stderr, "PHASES (ms after option-fwd start) main: fwd end %.2f | bwd %.2f -> %.2f | dWh %.2f -> %.2f | all joined %.2f  ||  enc fwd end %.2f | enc bwd chain end %.2f | "
+            "wg chain end %.2f | table chain end %.2f\n", t[1], t[2], t[3], t[4], t[5], t[10], t[6], t[7], t[8], t[9]); }
+#endif
   return VD_OK;
 }
 
