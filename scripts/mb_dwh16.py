@@ -48,3 +48,23 @@ ms = sorted(ts[1:])[len(ts[1:]) // 2]
 flops = 2.0 * H * 4 * H * K
 nbytes = K * (H + 4 * H) * 2
 print("dWh16 M=%d N=%d K=%d: %.3f ms  = %.0f TFLOP/s bf16, %.2f TB/s of its %.2f GB" % (H, 4 * H, K, ms, flops / ms / 1e9, nbytes / ms / 1e9, nbytes / 1e9))
+
+# the projection-table gradient's row sums over the same da16 rows + those of step 0 (T * N rows, token order)
+rs = getattr(lib, '_Z26vd_segment_rowsum_acc_bf16PKtlPKiS2_liPflP12ihipStream_t')
+rs.argtypes = [p, C.c_long, p, p, C.c_long, C.c_int, p, C.c_long, p]
+V1 = 11323
+n = T * N
+da_all = (torch.randn(n, 4 * H, device='cuda', generator=g) * 0.01).to(torch.bfloat16)
+tok = torch.randint(1, V1, (n,), device='cuda', generator=g, dtype=torch.int32)
+perm = torch.argsort(tok.long(), stable=True).to(torch.int32)
+dtab = torch.zeros(V1, 4 * H, device='cuda')
+ts = []
+for i in range(6):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    assert rs(da_all.data_ptr(), 4 * H, tok.data_ptr(), perm.data_ptr(), n, 4 * H, dtab.data_ptr(), 4 * H, stream) == 0
+    e1.record()
+    torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1))
+ms = sorted(ts[1:])[len(ts[1:]) // 2]
+print("segment row sums [%d x %d] bf16 -> [%d x %d]: %.3f ms = %.2f TB/s of its %.2f GB" % (n, 4 * H, V1, 4 * H, ms, n * 4 * H * 2 / ms / 1e9, n * 4 * H * 2 / 1e9))

@@ -571,3 +571,29 @@ def test_bf16_weight_gradient_contraction(ops, M, N, K):
     ref = c0.double() + a16.double().t() @ b16.double()
     err = ((c.double() - ref).norm() / ref.norm()).item()
     assert err < 1e-5, err
+
+
+def test_bf16_segment_rowsum(ops):
+    """configs[4] projection-table gradient: out[token] += sum of the bf16 rows of that token, rows visited in token order (csrc/elementwise.hip
+    `vd_segment_rowsum_acc_bf16`: 16-byte loads, fp32 sums, a run of one token that spans two chunks flushed by float atomics).  Against
+    index_add of the same bf16 values in fp64; ragged chunk at the end, a long run (the most frequent token) and absent tokens."""
+    import ctypes as C
+    from visdial_amd import _lib
+    lib = _lib.load()
+    fn = getattr(lib, '_Z26vd_segment_rowsum_acc_bf16PKtlPKiS2_liPflP12ihipStream_t')
+    p = C.c_void_p
+    fn.argtypes = [p, C.c_long, p, p, C.c_long, C.c_int, p, C.c_long, p]
+    rng = np.random.RandomState(3)
+    n, ncol, V1 = 5000 + 37, 512, 300
+    tok = rng.randint(1, V1, size=n).astype(np.int32)
+    tok[rng.rand(n) < 0.3] = 7                                   # one long run
+    tok[(tok > 100) & (tok < 120)] = 99                           # tokens 101..119 never occur
+    perm = np.argsort(tok, kind='stable').astype(np.int32)
+    x16 = (torch.randn(n, ncol, device='cuda') * 0.1).to(torch.bfloat16)
+    out0 = torch.randn(V1, ncol, device='cuda')
+    out = out0.clone()
+    tok_d, perm_d = dev(tok), dev(perm)
+    assert fn(x16.data_ptr(), ncol, tok_d.data_ptr(), perm_d.data_ptr(), n, ncol, out.data_ptr(), ncol, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    ref = out0.double().index_add(0, torch.from_numpy(tok.astype(np.int64)).cuda(), x16.double())
+    assert float((out.double() - ref).norm() / ref.norm()) < 1e-6

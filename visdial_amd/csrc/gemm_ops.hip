@@ -382,8 +382,17 @@ int vd_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const f
   }
   EpiStore<4> e{C, ldc, bias, act, accumulate};
   // both operands are k-contiguous rows: throughput shapes take the LDS-DMA pipeline (gemm_core.h)
-  if (M >= 1024 && K >= 64 && K % 16 == 0 && (long)M * lda * 4 < (1L << 32) && (long)N * ldw * 4 < (1L << 32))
-    return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 41984>, false>(M, N, K, 1, A, lda, W, ldw, e, s);
+  if (M >= 1024 && K >= 64 && K % 16 == 0 && (long)M * lda * 4 < (1L << 32) && (long)N * ldw * 4 < (1L << 32)) {
+    // atomic accumulation (accumulate == 2, no bias / activation) may split K: a narrow product such as dEmb += dTable * Wx^T
+    // (N = 300: 267 tiles, one workgroup per CU, every K tile an exposed round trip) runs three K slices per tile instead
+    int splits = 1;
+    const long tiles = (long)vd_cdiv(M, 128) * vd_cdiv(N, 128);
+    if (accumulate == 2 && !bias && act == VD_ACT_NONE && tiles < 512 && K >= 1024) {
+      splits = (int)vd_cdiv(768, tiles);
+      if (splits > K / 512) splits = K / 512;
+    }
+    return launch_gemm_glds<GemmCfg<4, 1, 4, 16, 0, 4, 41984>, false>(M, N, K, splits, A, lda, W, ldw, e, s, -1, splits > 1);
+  }
   return launch_gemm<CfgBig>(M, N, K, 1, a, b, e, s);
 }
 
