@@ -183,6 +183,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + li;
 }
 
+// Lane mapping of the k-major staging loads: piece f of a [BK k][D columns] tile -> (group of 4 columns r4, k row kk).  SIXTEEN adjacent
+// lanes take sixteen consecutive k of one column group: the transposing LDS stores (ds_write_b32: two groups of 32 lanes, 32 banks) then
+// write 16 consecutive floats per row group, and the two row groups of a lane group sit 4 * STRIDE = 16 (mod 32) banks apart --
+// conflict-free.  (With runs of eight k the four row groups of a lane group fell on two bank sets: 2-way conflicts, 8 instead of 4 cycles
+// on each of the 64 store instructions of a forward-tick iteration.)   `make variant DEFS=-DVD_KMAJ_OLD` restores runs of eight.
+template <int D, int BK>
+__device__ __forceinline__ void kmaj_piece(int f, int& r4, int& kk) {
+#ifndef VD_KMAJ_OLD
+  if constexpr (BK % 16 == 0) {
+    const int klo = f & 15, g = f >> 4;
+    r4 = g % (D / 4);
+    kk = (g / (D / 4)) * 16 + klo;
+    return;
+  }
+#endif
+  const int klo = f & 7, g = f >> 3;
+  r4 = g % (D / 4);
+  kk = (g / (D / 4)) * 8 + klo;
+}
+
 // One workgroup's tile: C[row_base.., col_base..] over K range [ks, ke).  Shared by the plain and the
 // grouped kernels.
 template <class Cfg, class ASrc, class BSrc, class Epi>
@@ -224,9 +244,9 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
         gr = row_base + f / (BK / 4);
         ka[i] = (f % (BK / 4)) * 4;
       } else {
-        const int g = f >> 3;
-        gr = row_base + (g % (BM / 4)) * 4;
-        ka[i] = (g / (BM / 4)) * 8 + (f & 7);
+        int r4;
+        kmaj_piece<BM, BK>(f, r4, ka[i]);
+        gr = row_base + r4 * 4;
       }
       pa[i] = gr < M ? asrc.ptr(gr, ka[i]) : nullptr;
     }
@@ -240,9 +260,9 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
         gr = col_base + f / (BK / 4);
         kb[i] = (f % (BK / 4)) * 4;
       } else {
-        const int g = f >> 3;
-        gr = col_base + (g % (BN / 4)) * 4;
-        kb[i] = (g / (BN / 4)) * 8 + (f & 7);
+        int r4;
+        kmaj_piece<BN, BK>(f, r4, kb[i]);
+        gr = col_base + r4 * 4;
       }
       pb[i] = gr < N ? bsrc.ptr(gr, kb[i]) : nullptr;
     }
@@ -265,8 +285,8 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
         const int gr = row_base + r, gk = k0 + kq * 4;
         if (gr < M && gk < ke) v = asrc.ld4(gr, gk);
       } else {
-        const int klo = f & 7, g = f >> 3;
-        const int r4 = g % (BM / 4), kk = (g / (BM / 4)) * 8 + klo;
+        int r4, kk;
+        kmaj_piece<BM, BK>(f, r4, kk);
         const int gr = row_base + r4 * 4, gk = k0 + kk;
         if (gr < M && gk < ke) v = asrc.ld4(gr, gk);
       }
@@ -289,8 +309,8 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
         const int gr = col_base + r, gk = k0 + kq * 4;
         if (gr < N && gk < ke) v = bsrc.ld4(gr, gk);
       } else {
-        const int klo = f & 7, g = f >> 3;
-        const int r4 = g % (BN / 4), kk = (g / (BN / 4)) * 8 + klo;
+        int r4, kk;
+        kmaj_piece<BN, BK>(f, r4, kk);
         const int gr = col_base + r4 * 4, gk = k0 + kk;
         if (gr < N && gk < ke) v = bsrc.ld4(gr, gk);
       }
@@ -329,8 +349,8 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
         const int r = f / (BK / 4), kq = f % (BK / 4);
         put_row4(sa + r * STR + kq * 4, ra[i]);
       } else {
-        const int klo = f & 7, g = f >> 3;
-        const int r4 = g % (BM / 4), kk = (g / (BM / 4)) * 8 + klo;
+        int r4, kk;
+        kmaj_piece<BM, BK>(f, r4, kk);
         put_col4(sa + (r4 * 4) * STR + kk, ra[i]);
       }
     }
@@ -341,8 +361,8 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
         const int r = f / (BK / 4), kq = f % (BK / 4);
         put_row4(sb + r * STR + kq * 4, rb[i]);
       } else {
-        const int klo = f & 7, g = f >> 3;
-        const int r4 = g % (BN / 4), kk = (g / (BN / 4)) * 8 + klo;
+        int r4, kk;
+        kmaj_piece<BN, BK>(f, r4, kk);
         put_col4(sb + (r4 * 4) * STR + kk, rb[i]);
       }
     }
