@@ -597,3 +597,24 @@ def test_bf16_segment_rowsum(ops):
     torch.cuda.synchronize()
     ref = out0.double().index_add(0, torch.from_numpy(tok.astype(np.int64)).cuda(), x16.double())
     assert float((out.double() - ref).norm() / ref.norm()) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 2048, 8000), (256, 128, 1024 + 16 * 3 + 5), (512, 256, 4000)])
+def test_bf16_contraction_of_fp32_rows(ops, M, N, K):
+    """The encoder's dense weight gradients in a bf16 pass (csrc/gemm_ops.hip `vd_gemm_tn_acc(flags = VD_FLAG_BF16)` on fp32 operands with
+    no bf16 shadow: M % 256 == 0, N % 128 == 0, K >= 1024 take gemm_split_tn_kernel<1> -- LDS-DMA tiles of the fp32 rows, both operands
+    rounded to bf16 (RNE) in registers, fp32 accumulation; the last K % 16 rows through the staging kernel).  Exact against the fp64 product of
+    the bf16-ROUNDED operands up to summation order (1e-5); against the fp32 operands it is the bf16 pass's error (a few 1e-3)."""
+    g = torch.Generator(device='cuda').manual_seed(9)
+    a = torch.tanh(torch.randn(K, M, device='cuda', generator=g))
+    b = torch.randn(K, N, device='cuda', generator=g) * 0.01
+    c0 = torch.randn(M, N, device='cuda', generator=g) * 0.1
+    c = c0.clone()
+    ops.gemm_tn_acc(a, b, c, M=M, N=N, K=K, flags=ops.FLAG_BF16)
+    torch.cuda.synchronize()
+    ref16 = c0.double() + a.to(torch.bfloat16).double().t() @ b.to(torch.bfloat16).double()
+    ref32 = c0.double() + a.double().t() @ b.double()
+    e16 = float((c.double() - ref16).norm() / ref16.norm())
+    e32 = float((c.double() - ref32).norm() / ref32.norm())
+    assert e16 < 1e-5, e16
+    assert 1e-5 < e32 < 1e-2, e32
