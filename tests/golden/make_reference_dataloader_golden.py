@@ -9,7 +9,11 @@ options, over-long captions, both history modes):
 The hdf5 and cjson rocks are absent: `hdf5.open(...):read(name):all()` is served from the arrays below (tests/luavm stub), the JSON goes
 through a real temporary file and a json-backed cjson stub.  At generation time every array is checked against oracle/dataloader_oracle.py
 and against the product loader (visdial_amd.dataloader.Dataloader); tests/test_reference_dataloader.py keeps both on the stored outputs.
-Output: tests/golden/ref_dataloader__<case>.npz (data only).   python tests/golden/make_reference_dataloader_golden.py"""
+Output: tests/golden/ref_dataloader__<case>.npz (data only).   python tests/golden/make_reference_dataloader_golden.py [case ...]
+
+Case `prepro` feeds dataloader.lua the file the reference's OWN data/prepro.py wrote (tests/golden/prepro/, made by make_prepro_golden.py
+running the real prepro.py): reference writer -> reference reader, with only the hdf5 rock between them stubbed (arrays = the h5py
+read-back of that file, expected.npz).  10 rounds, 100 options, truncated questions / answers / captions, UNK tokens, an empty answer."""
 import json
 import os
 import sys
@@ -30,7 +34,9 @@ from visdial_amd.opts import default_params, derive        # noqa: E402
 
 CASES = {'lf-ques-im-hist': dict(encoder='lf-ques-im-hist', concatHistory=False, att=False),
          'mn-att-concat': dict(encoder='mn-att-ques-im-hist', concatHistory=True, att=True),
-         'lf-ques': dict(encoder='lf-ques', concatHistory=False, att=False)}
+         'lf-ques': dict(encoder='lf-ques', concatHistory=False, att=False),
+         'prepro': dict(encoder='lf-ques-im-hist', concatHistory=False, att=False, prepro=True)}
+PREPRO = os.path.join(ROOT, 'tests', 'golden', 'prepro')
 first = lambda vals: vals[0] if vals else None
 
 
@@ -65,9 +71,18 @@ class H5File(object):
         return None
 
 
+def prepro_source():
+    """what data/prepro.py itself wrote (make_prepro_golden.py): the params JSON as is, the datasets as h5py read them back"""
+    z = np.load(os.path.join(PREPRO, 'expected.npz'))
+    info = json.load(open(os.path.join(PREPRO, 'visdial_params.json')))
+    raw = {k[5:]: z[k] for k in z.files if k.startswith('data.')}
+    img = {k[4:]: z[k] for k in z.files if k.startswith('img.')}
+    return info, raw, img
+
+
 def run_case(name, cfg, seed=3):
     rng = np.random.RandomState(seed)
-    info, raw, img = two_splits(rng, cfg['att'])
+    info, raw, img = prepro_source() if cfg.get('prepro') else two_splits(rng, cfg['att'])
     opt = derive(default_params(encoder=cfg['encoder'], decoder='disc', batchSize=3, concatHistory=cfg['concatHistory']))
     tmp = tempfile.mkdtemp()
     jpath = os.path.join(tmp, 'params.json')
@@ -103,7 +118,9 @@ def run_case(name, cfg, seed=3):
     for k in ('vocabSize', 'maxQuesCount', 'maxQuesLen', 'maxAnsLen', 'numOptions', 'maxHistoryLen'):
         assert int(index(dl, k)) == int(getattr(prod, k)), (name, k, index(dl, k), getattr(prod, k))
     rec['stats'] = np.array([int(index(dl, k)) for k in ('vocabSize', 'maxQuesCount', 'maxQuesLen', 'maxAnsLen', 'numOptions', 'maxHistoryLen')])
-    assert to_py(index(dl, 'unique_img_val')) == [100, 101, 102, 103, 104]          # tonumber(string.match(v, '000%d+'))
+    want_ids = [2001, 2002, 2003, 2004] if cfg.get('prepro') else [100, 101, 102, 103, 104]
+    assert to_py(index(dl, 'unique_img_val')) == want_ids                            # tonumber(string.match(v, '000%d+'))
+    rec['unique_img_val'] = np.array(want_ids)
 
     # ---- batches: getTestBatch (disc, gen), getIndexData, getTrainBatch with the drawn ids
     def batch_arrays(t):
@@ -120,7 +137,7 @@ def run_case(name, cfg, seed=3):
     for dec in ('disc', 'gen'):
         p = dict(params, decoder=dec)
         start = 1
-        for bi in range(2):                                   # 5 val threads, batch 3: a full and a short batch
+        for bi in range(2):                                   # 5 (prepro: 4) val threads, batch 3: a full and a short batch
             res = call(index(dl, 'getTestBatch'), [dl, start, to_lua(vm, p), 'val'])
             b, nxt = batch_arrays(res[0]), int(res[1])
             mine, mynxt = prod.getTestBatch(start, dict(opt, decoder=dec), 'val')
@@ -131,7 +148,7 @@ def run_case(name, cfg, seed=3):
                 rec['test.%s.%d.%s' % (dec, bi, k)] = v.astype(np.float32 if v.dtype.kind == 'f' else np.int64)
             start = nxt
     # getTrainBatch: the thread ids come from torch's generator (inds:random(1, numTrainThreads)); pin them
-    drawn = np.array([4, 1, 6], dtype=np.int64)
+    drawn = np.array([4, 1, 5] if cfg.get('prepro') else [4, 1, 6], dtype=np.int64)
 
     class FixedRng(object):
         def randint(self, lo, hi=None, size=None, **_k):
@@ -160,6 +177,8 @@ def run_case(name, cfg, seed=3):
 
 def main():
     for name, cfg in CASES.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         rec = run_case(name, cfg)
         np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'ref_dataloader__%s.npz' % name), **rec)
         print('%-18s %d arrays: prepareDataset (train, val), getTestBatch disc / gen x 2, getTrainBatch disc / gen == product loader' % (name, len(rec)), flush=True)

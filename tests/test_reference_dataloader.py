@@ -27,7 +27,7 @@ def load(path):
 
 
 def test_fixture_set():
-    assert sorted(IDS) == ['lf-ques', 'lf-ques-im-hist', 'mn-att-concat']
+    assert sorted(IDS) == ['lf-ques', 'lf-ques-im-hist', 'mn-att-concat', 'prepro']
 
 
 @pytest.mark.parametrize("path", FILES, ids=IDS)
@@ -36,7 +36,7 @@ def test_product_loader_reproduces_the_executed_reference(path):
     dl = Dataloader(seed=1).from_arrays(info, raw, img, opt, ['train', 'val'])
     stats = [int(getattr(dl, k)) for k in ('vocabSize', 'maxQuesCount', 'maxQuesLen', 'maxAnsLen', 'numOptions', 'maxHistoryLen')]
     assert stats == z['stats'].tolist()
-    assert list(dl.unique_img_val) == [100, 101, 102, 103, 104]
+    assert list(dl.unique_img_val) == (z['unique_img_val'].tolist() if 'unique_img_val' in z.files else [100, 101, 102, 103, 104])
     n = 0
     for split in ('train', 'val'):
         for f, want in get('prep.%s.' % split).items():
@@ -51,7 +51,7 @@ def test_product_loader_reproduces_the_executed_reference(path):
             assert set(want) == {k for k, v in b.items() if isinstance(v, np.ndarray)}
             for k, v in want.items():
                 np.testing.assert_array_equal(b[k], v, err_msg='getTestBatch %s %d %s' % (dec, bi, k))
-        assert start == 6                                              # numValThreads + 1
+        assert start == raw['ques_val'].shape[0] + 1                   # numValThreads + 1
         inds = z['train.inds']
         b = dl.getIndexData(inds, dict(opt, decoder=dec), 'train')
         if dec == 'disc':                                              # dataloader.lua:330-337
@@ -81,6 +81,8 @@ def test_oracle_reproduces_the_executed_reference(path):
             h, hl, _ = do.process_history(L('cap'), L('cap_length'), L('ques'), L('ques_length'), L('ans'), L('ans_length'),
                                           opt['concatHistory'], END)
             np.testing.assert_array_equal(h, want['hist']); np.testing.assert_array_equal(hl, want['hist_len'])
+    if 'prepro' in path:
+        return
     # the quirks the fixture is built to contain are live: rightAlign's `break` (a zero-length question hides the later ones of the dialog)
     ql = raw['ques_length_train'].astype(np.int64)
     assert (ql[1, 1] == 0) and (ql[1, 2:] > 0).any() and (get('prep.train.')['ques_fwd'][1, 1:] == 0).all()

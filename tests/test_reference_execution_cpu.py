@@ -54,7 +54,7 @@ def test_parameter_order_file_is_reproduced():
         assert g.run_pair(enc, 'disc', order_only=True)[2] == d['encoder'][enc] + d['decoder']['disc']
 
 
-@pytest.mark.parametrize("case", ['lf-ques-im-hist', 'mn-att-concat', 'lf-ques'])
+@pytest.mark.parametrize("case", ['lf-ques-im-hist', 'mn-att-concat', 'lf-ques', 'prepro'])
 def test_dataloader_fixture_is_reproduced(case):
     import make_reference_dataloader_golden as g
     rec = g.run_case(case, g.CASES[case])
