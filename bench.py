@@ -50,46 +50,45 @@ def _world_arg(argv):
 # resolve inside the command processor and the step is 3-4 % faster (profiles/r02_hw_queues.txt).
 # Must be in the environment before HIP initialises, i.e. before torch touches the device; an explicit setting wins.
 # (The Python operator-level host is slower that way -- 29.0 vs 26.8 ms -- so it keeps the default.)
-# With peers, RCCL's kernels share the hardware queues with the compute streams and nothing was ever measured on a multi-GPU
-# node: the setting is then CHOSEN BY MEASUREMENT -- every rank runs two short probe children of this script (3 warm-up + 3 timed
-# steps each, the full data-parallel step with the library communicator, on their own rendezvous ports), one with a single
-# hardware queue and one with HIP's default; the faster one (max over ranks, so every rank picks the same) is used and printed.
+# With peers (world > 1) RCCL's kernels share the hardware queues with the compute streams and the single-queue setting was never
+# measured on a multi-GPU node: HIP's default is kept there (VD_BENCH_HW_QUEUES=<n> overrides, identically on every rank because it is
+# read from the environment torch.distributed.run hands to all of them).  Rounds 4-5 chose by running probe JOBS per rank before the
+# real run (own communicators, own ports); that was the most fragile code in the file and is gone: nothing runs before the timed job
+# any more except its own warm-up, under the wall-clock cap below.
 QUEUE_CHOICE = None
-
-
-def _probe_hw_queues(world):
-    """-> (choice or None, report).  Runs before HIP is initialised in this process; any failure keeps HIP's default."""
-    import subprocess
-    rank = os.environ.get('RANK', '0')
-    base = int(os.environ.get('MASTER_PORT', '29533'))
-    res = {}
-    for k, setting in enumerate(('1', 'default')):
-        env = dict(os.environ, VD_BENCH_PROBE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(20000 + (base * 7 + 101 * (k + 1)) % 20000))
-        env.pop('TORCHELASTIC_USE_AGENT_STORE', None)          # the probe children rendezvous among themselves (rank 0's child hosts the store)
-        env.pop('GPU_MAX_HW_QUEUES', None)
-        if setting != 'default':
-            env['GPU_MAX_HW_QUEUES'] = setting
-        try:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), '--gpus', str(world), '--steps', '3', '--warmup', '3',
-                                  '--no-cpu-baseline', '--no-other-configs'], env=env, capture_output=True, text=True, timeout=180)
-            ms = [float(l.split()[1]) for l in out.stdout.splitlines() if l.startswith('PROBE_MS ')]
-            if out.returncode != 0 or not ms:
-                return None, 'probe with GPU_MAX_HW_QUEUES=%s failed on rank %s (rc %d): %s' % (setting, rank, out.returncode, out.stderr[-300:])
-            res[setting] = ms[-1]
-        except Exception as exc:      # timeout, spawn failure: keep the default
-            return None, 'probe with GPU_MAX_HW_QUEUES=%s failed on rank %s: %r' % (setting, rank, exc)
-    choice = min(res, key=res.get)
-    return choice, 'GPU_MAX_HW_QUEUES A/B (3 + 3 steps each, ms/step max over ranks): %s -> %s' % (res, choice)
-
-
-if os.environ.get('VD_BENCH_PROBE') != '1' and _host_arg(sys.argv[1:]) == 'native' and 'GPU_MAX_HW_QUEUES' not in os.environ:
-    if _world_arg(sys.argv[1:]) == 1 and os.environ.get('VD_BENCH_FORCE_QUEUE_PROBE') != '1':
+if _host_arg(sys.argv[1:]) == 'native' and 'GPU_MAX_HW_QUEUES' not in os.environ:
+    if os.environ.get('VD_BENCH_HW_QUEUES'):
+        os.environ['GPU_MAX_HW_QUEUES'] = os.environ['VD_BENCH_HW_QUEUES']
+        QUEUE_CHOICE = 'VD_BENCH_HW_QUEUES=%s' % os.environ['VD_BENCH_HW_QUEUES']
+    elif _world_arg(sys.argv[1:]) == 1:
         os.environ['GPU_MAX_HW_QUEUES'] = '1'
-    elif 'RANK' in os.environ:          # a rank of a multi-GPU run (under torch.distributed.run): measure, then choose
-        _choice, QUEUE_CHOICE = _probe_hw_queues(_world_arg(sys.argv[1:]))
-        if _choice and _choice != 'default':
-            os.environ['GPU_MAX_HW_QUEUES'] = _choice
-        print('[rank %s] %s' % (os.environ.get('RANK'), QUEUE_CHOICE), file=sys.stderr, flush=True)
+        QUEUE_CHOICE = 'single hardware queue (world 1, measured: profiles/r02_hw_queues.txt)'
+    else:
+        QUEUE_CHOICE = "HIP default (world > 1: never measured with RCCL's kernels on the queue)"
+
+
+class StartupDeadline(object):
+    """Hard wall-clock cap on everything between process start and the timed region (rendezvous, RCCL communicator, model build, warm-up):
+    a rank that is still not timing after `seconds` prints what it was doing and exits with code 3 -- a multi-GPU run can fail, it cannot
+    hang.  (VD_BENCH_STARTUP_CAP_S overrides; the first `import torch` on a fresh box alone can take 1-2 minutes.)"""
+
+    def __init__(self, seconds):
+        import threading
+        self.phase, self.seconds, self.t0 = 'import', seconds, time.time()
+        self._done = threading.Event()
+        t = threading.Thread(target=self._watch, daemon=True)
+        t.start()
+
+    def _watch(self):
+        if not self._done.wait(self.seconds):
+            print('[rank %s] bench.py: startup exceeded %.0f s in phase "%s" -- giving up (exit 3)'
+                  % (os.environ.get('RANK', '0'), self.seconds, self.phase), file=sys.stderr, flush=True)
+            os._exit(3)
+
+    def disarm(self):
+        self._done.set()
+        return time.time() - self.t0
+
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
@@ -100,12 +99,16 @@ STEP_GFLOP_PER_ROUND = 21.934          # nominal dense math of t
 
 def config_params(config, rank=0, batch=20):
     """BASELINE.json configs[config] at its quoted size (batch 20, V = 11 322, H = 512, E = 300):
+      0 = lf-ques + gen, batch 8, no image features (the reference's CPU-runnable plumbing case, run on the GPU here);
       1 = lf-ques-im-hist + gen, VGG-16 fc7 (4096-d);            2 = hre-ques-im-hist + disc, fc7, 100 options (option recurrence on the exact
       split, like the headline);
       3 = mn-att-ques-im-hist + disc, 14x14x512 pool5 (HEADLINE); 4 = the same with ResNet-200 7x7x2048 features and bf16 operands
       in the option recurrence (informative, never the default)"""
     from visdial_amd.opts import default_params
-    kw = {1: dict(encoder='lf-ques-im-hist', decoder='gen', imgFeatureSize=4096),
+    if config == 0:
+        batch = 8                      # `th train.lua -encoder lf-ques -decoder gen -gpuid -1`, batch 8 -- here on the HIP path (there is no CPU product path)
+    kw = {0: dict(encoder='lf-ques', decoder='gen'),
+          1: dict(encoder='lf-ques-im-hist', decoder='gen', imgFeatureSize=4096),
           2: dict(encoder='hre-ques-im-hist', decoder='disc', imgFeatureSize=4096, lstmPrecision='split9'),
           3: dict(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=512, imgSpatialSize=14),
           4: dict(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=2048, imgSpatialSize=7, lstmPrecision='bf16')}[config]
@@ -309,8 +312,9 @@ def other_config(cfg, steps=10, warmup=3):
     N, H = p['batchSize'] * p['maxQuesCount'], p['rnnHiddenSize']
     out = {"workload": "BASELINE.json configs[%d]: %s + %s, batch %d, %s" % (
                cfg, p['encoder'], p['decoder'], p['batchSize'],
-               {1: "VGG-16 fc7 4096-d features", 2: "fc7 4096-d features, 100 options", 4: "ResNet-200 7x7x2048 features, 100 options"}[cfg]),
-           "dtype": {1: "f32", 2: "f32 operands and results; option recurrence on the exact 3-way bf16 split (9 products, f32 accumulate), f32 MFMA elsewhere",
+               {0: "synthetic tokens, no image features (the reference runs this one on CPU: -gpuid -1)", 1: "VGG-16 fc7 4096-d features",
+                2: "fc7 4096-d features, 100 options", 4: "ResNet-200 7x7x2048 features, 100 options"}[cfg]),
+           "dtype": {0: "f32", 1: "f32", 2: "f32 operands and results; option recurrence on the exact 3-way bf16 split (9 products, f32 accumulate), f32 MFMA elsewhere",
                      4: "bf16 operands / f32 accumulate (option recurrence only), f32 elsewhere"}[cfg],
            "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3), "qa_rounds_per_s": round(N / ms * 1e3, 1),
            "loss": round(float(loss), 5)}
@@ -327,6 +331,15 @@ def other_config(cfg, steps=10, warmup=3):
                                "frac": round(a / FP32_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(fams[dom]['avg_launch_ms'], 4),
                                "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in fams.items()}}
         out["option_rows_executed_of_total"] = list(model.option_rows())
+    elif 'hist' not in served[-1]:
+        # configs[0]: 80 rows per step, ~230 launches -- launch- and latency-bound plumbing.  The only sizeable product is the vocabulary
+        # projection with its two gradients; priced against the WHOLE step's time (a lower bound on its rate: no family events here)
+        b = served[-2] if len(served) >= 2 else served[-1]
+        gflop = 3 * 2.0 * np.asarray(b['answer_in']).size * p['vocabSize'] * H / 1e9
+        out["roofline"] = {"bound": "mfma", "kernel": "vocab (projection + 2 gradients) over the whole step's time", "achieved": round(gflop / ms, 2),
+                           "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gflop / ms / FP32_MFMA_PEAK_TFLOPS, 4),
+                           "gflop_executed": round(gflop, 2),
+                           "note": "latency-bound: 80 rows per step; the figure is the vocabulary family's FLOPs / the step time, not a kernel rate"}
     else:
         # gen over a Sequential encoder: the history branch (two-layer length-sorted wavefront, Th + 1 ticks per direction) is the
         # step.  Executed FLOPs of the batch the LAST step trained on: per tick and active row h*Wh1, h1*Wx2, h2*Wh2 (forward; twice
@@ -427,7 +440,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=20, help='dialogs per GPU (headline: 20)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-other-configs', action='store_true', help='skip the configs[1], [2], [4] legs after the headline')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the configs[0], [1], [2], [4] legs after the headline')
     ap.add_argument('--same-batch', action='store_true', help='reuse one resident batch (round-1 behaviour; A/B only)')
     ap.add_argument('--no-streams', action='store_true', help='whole step on one HIP stream (A/B only)')
     ap.add_argument('--config', type=int, choices=[3, 4], default=3,
@@ -443,10 +456,13 @@ def main():
     ap.add_argument('--host', choices=['python', 'native'], default=os.environ.get('VD_BENCH_HOST', 'native'),
                     help='native (default) = the model-level ABI (csrc/runtime.hip: the orchestration a Lua host gets); '
                          'python = visdial_amd.Model composing the operator-level ABI')
+    ap.add_argument('--startup-cap', type=float, default=float(os.environ.get('VD_BENCH_STARTUP_CAP_S', 300)),
+                    help='seconds allowed between process start and the timed region (rendezvous + communicator + warm-up); exit 3 beyond')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
         respawn_under_torchrun(args)
+    deadline = StartupDeadline(args.startup_cap)
 
     import numpy as np
     import torch
@@ -455,6 +471,9 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    deadline.phase = 'rendezvous / communicator'
+    if world > 1:
+        print('[rank %d] hardware queues: %s' % (rank, QUEUE_CHOICE), file=sys.stderr, flush=True)
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs a GPU"
     torch.cuda.set_device(local)
     group = None
@@ -488,6 +507,7 @@ def main():
     from visdial_amd.dataloader import SyntheticDataloader
     from visdial_amd.model import Model
 
+    deadline.phase = 'model build + warm-up'
     p = headline_params(rank=rank, batch=args.batch, config=args.config)
     if args.config != 3:
         args.recurrence = 'fp32'                # (--recurrence is the arithmetic of the fp32-grade headline; configs[4] is the bf16 pass)
@@ -515,6 +535,7 @@ def main():
         print('[rank %d] %s' % (rank, json.dumps(comm_self_check(model, collective, lib_comm, local))), file=sys.stderr, flush=True)
         dist.barrier(group=group)
     torch.cuda.synchronize()
+    startup_s = deadline.disarm()
     ops.PROFILE = {}
     per_step = []
     t0 = time.perf_counter()
@@ -541,15 +562,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(t.item())
 
-    if os.environ.get('VD_BENCH_PROBE') == '1':      # a GPU_MAX_HW_QUEUES probe child (see the top of this file): every rank reports, no JSON line
-        print('PROBE_MS %.4f' % (elapsed / args.steps * 1e3), flush=True)
-        if lib_comm:
-            from visdial_amd.parallel import destroy_library_comm
-            model.synchronize()
-            destroy_library_comm()
-        if dist.is_initialized():
-            dist.destroy_process_group()
-        return
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * N * args.steps / elapsed
@@ -567,6 +579,11 @@ def main():
         if dom and args.config == 4:
             roof = bf16_option_roofline(fams, dom, rows=N * p['numOptions'], H=p['rnnHiddenSize'], To=p['maxAnsLen'])
         elif dom and args.recurrence != 'fp32':
+            # the dWh contraction runs on the split only for split9 at shapes gemm_split_tn_kernel takes (csrc/gemm_ops.hip: M % 256 == 0,
+            # N % 128 == 0, K >= 8192 rows); otherwise it is an fp32-MFMA launch and must not be priced as nprod bf16 products
+            dwh_on_split = args.recurrence == 'split9' and p['rnnHiddenSize'] % 256 == 0 and (p['maxAnsLen'] - 1) * N * p['numOptions'] >= 8192
+            if dom == 'opt_lstm_dWh' and not dwh_on_split:
+                dom = max(('opt_lstm_fwd', 'opt_lstm_bwd'), key=lambda k: fams[k]['ms_total_per_step'])
             roof = split_roofline(fams, dom, args.recurrence, traffic_of(args.recurrence + ':' + dom))
         elif dom:
             roof = fp32_roofline(fams, dom, value, traffic, traffic_build)
@@ -598,7 +615,7 @@ def main():
                        "global_batch_dialogs": world * args.batch, "parallelism": "dp%d" % world,
                        "dropout": "on (device generator)", "loss": round(float(loss), 5), "host": args.host,
                        "GPU_MAX_HW_QUEUES": os.environ.get('GPU_MAX_HW_QUEUES', 'default'),
-                       "GPU_MAX_HW_QUEUES_choice": QUEUE_CHOICE,
+                       "GPU_MAX_HW_QUEUES_choice": QUEUE_CHOICE, "startup_s": round(startup_s, 1),
                        "collective": collective,
                        "option_rows_executed_of_total": (list(model.option_rows()) if args.host == 'native' else None)},
             "roofline": roof,
@@ -614,7 +631,7 @@ def main():
             # the other single-GPU configurations of BASELINE.json, driver-visible (the headline `value` above is unaffected:
             # they run after its timed region, on their own models)
             out["other_configs"] = []
-            for cfg in (1, 2, 4):
+            for cfg in (0, 1, 2, 4):
                 try:
                     out["other_configs"].append(other_config(cfg))
                 except Exception as exc:

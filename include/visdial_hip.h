@@ -144,6 +144,10 @@ typedef struct {
 } vd_lstm2_bwd_t;
 int vd_lstm2_forward(const vd_lstm2_fwd_t* stacks, int nstacks, int H, void* stream);
 int vd_lstm2_backward(const vd_lstm2_bwd_t* stacks, int nstacks, int H, void* stream);
+/* the same wavefront with a pass's arithmetic: flags = 0 (fp32 MFMA, = the two calls above) or VD_FLAG_BF16 (both operands of every
+ * recurrent product rounded to bf16 while staged, fp32 accumulate and state: the encoder ticks of a `lstmPrecision = bf16` pass) */
+int vd_lstm2_forward_flags(const vd_lstm2_fwd_t* stacks, int nstacks, int H, int flags, void* stream);
+int vd_lstm2_backward_flags(const vd_lstm2_bwd_t* stacks, int nstacks, int H, int flags, void* stream);
 
 /* zero rows [nact[t], N) of every time slice of a [T x N x ld] buffer (nact_dev: DEVICE int32[T]) */
 int vd_zero_inactive_rows(float* buf, int64_t tstride, int64_t ld, int ncols, const int32_t* nact_dev, int T,

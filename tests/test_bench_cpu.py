@@ -1,5 +1,5 @@
 """bench.py's bookkeeping without a GPU: the roofline blocks (what `frac` divides by, per arithmetic), the stored-traffic lookup (tied to the
-kernel sources by their digest) and the GPU_MAX_HW_QUEUES probe that multi-GPU runs use (children mocked).  The timed path itself needs a
+kernel sources by their digest), the hardware-queue policy (no probe jobs: fixed per world size, overridable) and the startup deadline.  The timed path itself needs a
 GPU (bench.py asserts it) and is exercised by scripts/measure_round.sh."""
 import json
 import os
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture
 def bench(monkeypatch):
-    monkeypatch.setenv('VD_BENCH_PROBE', '1')          # importing bench.py must not probe or touch the environment's queue setting
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', 'as-found')     # an explicit setting wins: importing bench.py leaves the environment alone
     sys.modules.pop('bench', None)
     monkeypatch.setattr(sys, 'argv', ['bench.py'])
     import bench as b
@@ -62,35 +62,47 @@ def test_stored_traffic_is_reported_only_for_the_build_it_was_measured_on(bench,
     assert lookup('opt_lstm_bwd') is None
 
 
-def test_hw_queue_probe_picks_the_faster_setting_and_survives_failures(bench, monkeypatch):
-    calls = []
+def _import_bench(monkeypatch, argv, **env):
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', 'x')
+    monkeypatch.delenv('GPU_MAX_HW_QUEUES')            # (set-then-delete: monkeypatch restores "absent" afterwards, whatever the import does)
+    for k in ('VD_BENCH_HW_QUEUES', 'WORLD_SIZE', 'RANK'):
+        monkeypatch.setenv(k, 'x')
+        monkeypatch.delenv(k)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sys.modules.pop('bench', None)
+    monkeypatch.setattr(sys, 'argv', ['bench.py'] + argv)
+    import bench as b
+    sys.modules.pop('bench', None)
+    return b
 
-    class R(object):
-        def __init__(self, rc, out, err=''):
-            self.returncode, self.stdout, self.stderr = rc, out, err
 
-    def fake_run(cmd, env=None, **kw):
-        calls.append(env)
-        assert env['VD_BENCH_PROBE'] == '1' and 'TORCHELASTIC_USE_AGENT_STORE' not in env and env['MASTER_PORT'] != os.environ.get('MASTER_PORT')
-        one = env.get('GPU_MAX_HW_QUEUES') == '1'
-        return R(0, 'noise\nPROBE_MS %s\n' % ('23.1' if one else '24.0'))
-    monkeypatch.setenv('RANK', '3')
-    monkeypatch.setenv('MASTER_PORT', '29533')
-    monkeypatch.setenv('TORCHELASTIC_USE_AGENT_STORE', 'True')
-    monkeypatch.setattr(subprocess, 'run', fake_run)
-    choice, report = bench._probe_hw_queues(8)
-    assert choice == '1' and "'1': 23.1" in report and len(calls) == 2
-    assert calls[0]['MASTER_PORT'] != calls[1]['MASTER_PORT'] and 'GPU_MAX_HW_QUEUES' not in calls[1]
-    monkeypatch.setattr(subprocess, 'run', lambda cmd, env=None, **kw: R(0, 'PROBE_MS %s\n' % ('25.0' if env.get('GPU_MAX_HW_QUEUES') == '1' else '24.0')))
-    assert bench._probe_hw_queues(8)[0] == 'default'
-    monkeypatch.setattr(subprocess, 'run', lambda cmd, env=None, **kw: R(1, '', 'boom'))
-    choice, report = bench._probe_hw_queues(8)
-    assert choice is None and 'failed' in report                          # -> the caller keeps HIP's default
+def test_hw_queue_policy_needs_no_probe_jobs(monkeypatch):
+    """world 1: the measured single-queue setting; world > 1: HIP's default (never measured with RCCL on the queue) -- decided from argv /
+    the environment alone, identically on every rank, with nothing launched before the timed job"""
+    b = _import_bench(monkeypatch, [])
+    assert os.environ['GPU_MAX_HW_QUEUES'] == '1' and 'single' in b.QUEUE_CHOICE
+    assert not hasattr(b, '_probe_hw_queues')
+    b = _import_bench(monkeypatch, ['--gpus', '8'], RANK='3', WORLD_SIZE='8')
+    assert 'GPU_MAX_HW_QUEUES' not in os.environ and 'HIP default' in b.QUEUE_CHOICE
+    b = _import_bench(monkeypatch, ['--gpus', '8'], RANK='3', WORLD_SIZE='8', VD_BENCH_HW_QUEUES='2')
+    assert os.environ['GPU_MAX_HW_QUEUES'] == '2' and b.QUEUE_CHOICE == 'VD_BENCH_HW_QUEUES=2'
+    b = _import_bench(monkeypatch, ['--host', 'python'])
+    assert 'GPU_MAX_HW_QUEUES' not in os.environ
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert 'subprocess' not in src                      # no child jobs of any kind
 
-    def raising(cmd, env=None, **kw):
-        raise subprocess.TimeoutExpired(cmd, 180)
-    monkeypatch.setattr(subprocess, 'run', raising)
-    assert bench._probe_hw_queues(8)[0] is None
+
+def test_startup_deadline_exits_instead_of_hanging(tmp_path):
+    """the cap on everything before the timed region: a process stuck in its start-up phase leaves with code 3 and says where it was"""
+    code = ("import sys, time; sys.argv=['bench.py']; sys.path.insert(0, %r); import bench\n"
+            "d = bench.StartupDeadline(0.3); d.phase = 'rendezvous / communicator'; time.sleep(5); print('NOT REACHED')" % ROOT)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and 'rendezvous / communicator' in r.stderr and 'NOT REACHED' not in r.stdout
+    code = ("import sys, time; sys.argv=['bench.py']; sys.path.insert(0, %r); import bench\n"
+            "d = bench.StartupDeadline(0.3); s = d.disarm(); time.sleep(0.6); print('OK', s < 0.3)" % ROOT)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and 'OK True' in r.stdout
 
 
 def test_bench_configs_name_the_baseline_workloads(bench):

@@ -261,20 +261,28 @@ def test_native_ragged_empty_and_max_length_inputs(gpu, train_mode):
     model.close()
 
 
-@pytest.mark.parametrize("config", [1, 2])
+@pytest.mark.parametrize("config", ['1', '2', '2-split9', '4-bf16'])
 def test_native_full_size_other_configs_are_additive_over_dialogs(gpu, config):
     """BASELINE.json configs[1] (lf-ques-im-hist + gen, fc7 4096-d features, batch 20, concatenated history up to 300
-    steps) and configs[2] (hre-ques-im-hist + disc, batch 20 x 10 rounds x 100 options) at their FULL sizes through the
-    model-level ABI.  The oracle is too slow there, so the step is checked through the size-independent property data
-    parallelism relies on: dialogs are independent, hence loss and every gradient of the 20-dialog batch equal the sum
-    (gen: summed NLL) / the mean (disc: mean cross-entropy) over its two 10-dialog halves."""
+    steps), configs[2] (hre-ques-im-hist + disc, batch 20 x 10 rounds x 100 options) and configs[4] (mn-att-ques-im-hist + disc on 7x7x2048
+    features with the bf16 pass) at their FULL sizes through the model-level ABI -- in the arithmetic x host x size `bench.py` times them:
+    '2-split9' = configs[2] with its option recurrence on the exact split (bench.py config_params(2)), '4-bf16' = configs[4] with the COMPACT
+    bf16 state of the native runtime (vd_lstm_forward_c16 / _backward_c16 at 20 000 option rows).  The oracle is too slow there, so the step
+    is checked through the size-independent property data parallelism relies on: dialogs are independent, hence loss and every gradient of
+    the 20-dialog batch equal the sum (gen: summed NLL) / the mean (disc: mean cross-entropy) over its two 10-dialog halves.  For the bf16
+    pass the identity holds to ~1e-3 only: the 10 000-row and 20 000-row recurrences can differ in the last bit of an fp32 state, which can
+    flip the bf16 rounding of an operand (tests/test_model_gpu.py::test_full_size_step_is_additive_over_dialogs)."""
     from visdial_amd.native import NativeModel
     from visdial_amd.opts import default_params
-    kw = (dict(encoder='lf-ques-im-hist', decoder='gen') if config == 1 else dict(encoder='hre-ques-im-hist', decoder='disc'))
-    p = default_params(imgFeatureSize=4096, batchSize=20, vocabSize=11322, gpuid=0, maxHistoryLenPerRound=40, **kw)
+    cfg = int(config[0])
+    kw = {1: dict(encoder='lf-ques-im-hist', decoder='gen', imgFeatureSize=4096),
+          2: dict(encoder='hre-ques-im-hist', decoder='disc', imgFeatureSize=4096),
+          4: dict(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=2048, imgSpatialSize=7)}[cfg]
+    if '-' in config:
+        kw['lstmPrecision'] = config.split('-')[1]
+    p = default_params(batchSize=20, vocabSize=11322, gpuid=0, maxHistoryLenPerRound=40, **kw)
     full = SyntheticDataloader(p, seed=77, fast=True).getTrainBatch(p)
-    R = p['maxQuesCount']
-    if config == 1:
+    if cfg == 1:
         assert full["hist"].shape[2] >= 150           # the concatenated-history recurrence really is long
 
     def part(lo, hi):
@@ -291,12 +299,43 @@ def test_native_full_size_other_configs_are_additive_over_dialogs(gpu, config):
         loss = model.forwardBackward(part(lo, hi))
         g = model.get_gradients_dict()
         out.append((loss, np.concatenate([g[k].reshape(-1) for k in names]).astype(np.float64)))
+        if p['decoder'] == 'disc':
+            assert model.option_rows()[0] == (hi - lo) * p['maxQuesCount'] * p['numOptions']     # every option row ran (no accidental dedup)
     (lf, gf), (l1, g1), (l2, g2) = out
-    w = 1.0 if config == 1 else 0.5
-    assert np.isfinite(lf) and abs(lf - w * (l1 + l2)) < 2e-5 * max(1.0, abs(lf)), (lf, l1, l2)
+    w = 1.0 if cfg == 1 else 0.5
+    tol_l, tol_g = (2e-4, 2e-3) if config == '4-bf16' else (2e-5, 1e-4)
+    assert np.isfinite(lf) and abs(lf - w * (l1 + l2)) < tol_l * max(1.0, abs(lf)), (lf, l1, l2)
     gm = w * (g1 + g2)
     err = float(np.linalg.norm(gf - gm) / np.linalg.norm(gm))
-    assert err < 1e-4, err
+    print("full-size additivity %s: dloss %.2e, gradient rel-L2 %.2e" % (config, abs(lf - w * (l1 + l2)), err))
+    assert err < tol_g, err
+    model.close()
+
+
+def test_native_configs0_lf_ques_gen_at_batch_8_matches_oracle(gpu):
+    """BASELINE.json configs[0] AS WRITTEN -- `-encoder lf-ques -decoder gen`, batch 8, the reference's default sizes (H = 512, E = 300,
+    two LSTM layers, V = 11 322; train.lua:22-24, opts.lua) -- on the HIP path (there is deliberately no CPU product path) against the
+    fp64 oracle: loss (summed NLL over answer tokens) and every gradient tensor within 1e-4; then three trainIteration steps follow
+    the oracle's clamp + Adam."""
+    from visdial_amd.native import NativeModel
+    from visdial_amd.opts import default_params
+    p = derive(default_params(encoder='lf-ques', decoder='gen', batchSize=8, vocabSize=11322, gpuid=0))
+    batch = SyntheticDataloader(p, seed=8, fast=True).getTrainBatch(p)
+    assert batch['ques_fwd'].shape[0] == 8 and 'img_feat' not in batch
+    model = NativeModel(p, init_seed=4)
+    model.training(False)
+    P0 = {k: v.astype(np.float64) for k, v in model.get_parameters_dict().items()}
+    loss = model.forwardBackward(batch)
+    ref = vo.forward_backward('lf-ques', 'gen', P0, p, batch, None)
+    assert abs(loss - ref['loss']) < 1e-4 * max(1.0, abs(ref['loss'])), (loss, ref['loss'])
+    g = model.get_gradients_dict()
+    bad = grad_mismatches(g, ref['grads'])
+    assert not bad, bad
+    model.update()
+    after = model.get_parameters_dict()
+    for k in P0:
+        w2, _ = vo.clamp_adam(P0[k].reshape(-1), g[k].astype(np.float64).reshape(-1), {}, p['learningRate'])
+        assert np.abs(after[k].reshape(-1) - w2).max() < 1e-6, k
     model.close()
 
 
@@ -457,7 +496,7 @@ def test_duplicate_options_are_encoded_once_and_exactly(gpu, host):
         model.close()
 
 
-@pytest.mark.parametrize("size", ['h128', 'h512'])
+@pytest.mark.parametrize("size", ['h128', 'h512', 'h128-rows9000'])
 def test_native_bf16_compact_state_within_the_stated_bound(gpu, size):
     """BASELINE.json configs[4] through the model-level runtime: bf16 operands AND compact bf16 state in the option recurrence (saved
     gates / da, projection-table rows and h as bf16, c and the last state fp32 -- csrc/common.h `vd_lstm_forward_c16`).  The config's own
@@ -468,7 +507,9 @@ def test_native_bf16_compact_state_within_the_stated_bound(gpu, size):
               commonEmbeddingSize=128, maxQuesCount=10, batchSize=3, numOptions=100, maxQuesLen=10, maxAnsLen=20)
     if size == 'h512':
         kw.update(embedSize=300, rnnHiddenSize=512, commonEmbeddingSize=512, maxQuesLen=20, maxHistoryLenPerRound=40)
-    p = derive(small_params(lstmPrecision='bf16', **kw))         # N * O = 3000 rows: the throughput kernels run
+    if size == 'h128-rows9000':
+        kw.update(batchSize=9)                                   # 9 000 option rows (71 row tiles of 128: several rounds of workgroups, ragged last tile)
+    p = derive(small_params(lstmPrecision='bf16', **kw))         # N * O = 3000 rows (9000): the throughput kernels run
     batch = SyntheticDataloader(p, seed=41).getTrainBatch(p)
     model = NativeModel(p, init_seed=2)
     model.training(False)

@@ -250,6 +250,41 @@ def test_bf16_weight_gradient_on_producer_shadows(ops):
     assert float((dWh.double() - ref).norm() / ref.norm()) < 1e-2
 
 
+def test_bf16_shadow_registry_drops_overlapping_entries(ops):
+    """ADVICE r5 (csrc/api.hip): a bf16 pass registers shadows for its h / gates tensors by BASE ADDRESS.  When a second, smaller recurrence
+    lives INSIDE the range of an earlier one (the allocator handing out a sub-block of a freed tensor), the earlier entries must stop matching:
+    the dWh contraction of the second pass has to multiply the second pass's bf16 copies, not the first pass's bytes at the same offset."""
+    H, V = 128, 40
+    rng = np.random.RandomState(9)
+    Wh = dev((f32(rng, H, 4 * H) / np.sqrt(H)).astype(np.float32))
+    tab = dev(f32(rng, V + 1, 4 * H) * 0.5)
+
+    def run(T, N, hbuf, gbuf, off_rows, seed):
+        r = np.random.RandomState(seed)
+        h = hbuf[off_rows * H: off_rows * H + T * N * H].view(T, N, H)
+        gates = gbuf[off_rows * 4 * H: off_rows * 4 * H + T * N * 4 * H].view(T, N, 4 * H)
+        c = torch.empty(T, N, H, device="cuda")
+        dc = torch.empty(N, H, device="cuda")
+        tok = dev(r.randint(0, V + 1, size=(T, N)).astype(np.int32))
+        dh_last = dev(f32(r, N, H))
+        ops.lstm_forward(tab, Wh, gates, h, c, T, N, H, 0, 4 * H, tok_gather=tok, flags=1)
+        ops.lstm_backward(Wh, gates, c, dc, T, N, H, dh_last=dh_last, flags=1)
+        return h, gates
+
+    T1, N1 = 3, 4096
+    hbuf = torch.empty(T1 * N1 * H, device="cuda")
+    gbuf = torch.empty(T1 * N1 * 4 * H, device="cuda")
+    run(T1, N1, hbuf, gbuf, 0, 1)                                # registers [X, X + T1 N1 H) and the gates range
+    T2, N2, off = 3, 2048, 1024                                  # a smaller pass at X + offset, inside both old ranges
+    h, gates = run(T2, N2, hbuf, gbuf, off, 2)
+    dWh = torch.zeros(H, 4 * H, device="cuda")
+    K = (T2 - 1) * N2
+    ops.gemm_tn_acc(h.view(T2 * N2, H), gates.view(T2 * N2, 4 * H)[N2:], dWh, M=H, N=4 * H, K=K, flags=1)
+    torch.cuda.synchronize()
+    ref = h.view(T2 * N2, H)[:K].double().T @ gates.view(T2 * N2, 4 * H)[N2:].double()
+    assert float((dWh.double() - ref).norm() / ref.norm()) < 1e-2
+
+
 def test_embed_gather_scatter(ops):
     rng = np.random.RandomState(1)
     V, E, rows = 40, 300, 1234

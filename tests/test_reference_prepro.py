@@ -118,7 +118,7 @@ def test_train_and_evaluate_on_the_files_prepro_py_wrote(tmp_path):
     save = str(tmp_path / "ckpt") + "/"
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), '-encoder', 'lf-ques-im-hist', '-decoder', 'disc',
                         '-imgFeatureSize', '16', '-rnnHiddenSize', '32', '-embedSize', '16', '-batchSize', '2', '-savePath', save,
-                        '-numEpochs', '60', '-saveIter', '1000', '--maxIters', '180', '-saveFormat', 'pt'] + data,
+                        '-numEpochs', '100', '-saveIter', '1000', '--maxIters', '300', '-saveFormat', 'pt'] + data,
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'using synthetic' not in r.stdout

@@ -74,6 +74,8 @@ PROTOTYPES = {
     "vd_zero_inactive_rows": [_p, _l, _l, _i, _p, _i, _i, _p],
     "vd_lstm2_forward": [_p, _i, _i, _p],
     "vd_lstm2_backward": [_p, _i, _i, _p],
+    "vd_lstm2_forward_flags": [_p, _i, _i, _i, _p],
+    "vd_lstm2_backward_flags": [_p, _i, _i, _i, _p],
     "vd_embed_gather": [_p, _p, _p, _p, _l, _i, _f, _p],
     "vd_embed_scatter_acc": [_p, _p, _p, _p, _l, _i, _f, _p],
     "vd_token_sort": [_p, _l, _i, _p, _p, _p, _p],

@@ -119,6 +119,14 @@ int vd_bf16_shadow_get(int /*slot*/, const float* base, size_t floats, vd_bf16_b
     for (Bf16Shadow& s : g_shadow)                                 // any free entry, else the least recently registered one
       if (!pick || (!s.base && pick->base) || ((!s.base) == (!pick->base) && s.stamp < pick->stamp)) pick = &s;
   Bf16Shadow& s = *pick;
+  // every OTHER live entry that overlaps the new range is stale from now on: the caller is about to (re)write [base, base + floats) and its shadow;
+  // an older entry registered over a larger or shifted range (the allocator handed out a sub-block of a freed tensor) would otherwise still
+  // match vd_bf16_shadow_find() -- in array order, possibly before this one -- and serve bytes nobody maintains
+  for (Bf16Shadow& o : g_shadow)
+    if (&o != &s && o.base && o.dev == dev && base < o.base + o.floats && o.base < base + floats) o.base = nullptr;
+  // evicting a LIVE entry registered for another tensor hands its buffer to a new owner while contractions enqueued on other streams may
+  // still read it: wait for the device once (rare: more than VD_MAX_SHADOWS live tensors)
+  if (s.base && s.base != base) VD_HIP(hipDeviceSynchronize());
   if (s.cap < floats || s.dev != dev) {
     if (s.buf) VD_HIP(hipFree(s.buf));     // synchronises the device: earlier users are done
     s.buf = nullptr;

@@ -469,6 +469,7 @@ __device__ __forceinline__ void gemm_block(int M, int N, int ks, int ke, int row
       typename Epi::DOps q;
       float4 a[NT];
       float* red = smem;                       // 4 waves x 32 x 32 floats
+      static_assert(Cfg::LDS_BYTES >= 4 * 1024 * 4, "the distributed split-K epilogue exchanges 4 x 32 x 32 floats (16 KB) through LDS");
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         // the operand requests go out once half of the accumulator tiles are dead (register budget: 128 VGPRs beside the throughput

@@ -1072,6 +1072,8 @@ int vd_lstm2_backward_p(const vd_lstm2_bwd_t* st, int nstacks, int H, int flags,
 extern "C" {
 int vd_lstm2_forward(const vd_lstm2_fwd_t* st, int nstacks, int H, void* stream) { return vd_lstm2_forward_p(st, nstacks, H, 0, (hipStream_t)stream); }
 int vd_lstm2_backward(const vd_lstm2_bwd_t* st, int nstacks, int H, void* stream) { return vd_lstm2_backward_p(st, nstacks, H, 0, (hipStream_t)stream); }
+int vd_lstm2_forward_flags(const vd_lstm2_fwd_t* st, int nstacks, int H, int flags, void* stream) { return vd_lstm2_forward_p(st, nstacks, H, flags, (hipStream_t)stream); }
+int vd_lstm2_backward_flags(const vd_lstm2_bwd_t* st, int nstacks, int H, int flags, void* stream) { return vd_lstm2_backward_p(st, nstacks, H, flags, (hipStream_t)stream); }
 }  // extern "C"
 
 // ---- compact bf16 state (common.h): the option recurrence of a bf16 pass, model-level runtime --------------------------------------

@@ -28,6 +28,18 @@ typedef float vd_f32x4 __attribute__((ext_vector_type(4)));
 
 // v (8 consecutive k of one row) -> hi / mid / lo planes
 __device__ __forceinline__ void vd_split3(const float4& u, const float4& w, vd_bf16x8& hi, vd_bf16x8& mid, vd_bf16x8& lo) {
+#ifdef VD_PROBE_NOSPLIT
+  // PROBE build only (`make variant NAME=nosplit DEFS=-DVD_PROBE_NOSPLIT`; results are garbage): the operand bits reinterpreted as bf16 planes,
+  // no conversion -- the instruction stream a kernel over PRE-SPLIT planes would run (optimistic: it moves 4 instead of 6 bytes per value)
+  // (exponent fields forced to 0x7E: random signs and mantissas with magnitudes in [0.5, 1) -- bit patterns of ordinary operands, so the
+  //  matrix pipe draws what it draws on real data instead of saturating to NaN; one v_and_or_b32 per register)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 a = (__builtin_bit_cast(u32x4, u) & 0x807F807Fu) | 0x3F003F00u, b = (__builtin_bit_cast(u32x4, w) & 0x807F807Fu) | 0x3F003F00u;
+  hi = __builtin_bit_cast(vd_bf16x8, a);
+  mid = __builtin_bit_cast(vd_bf16x8, b);
+  lo = __builtin_bit_cast(vd_bf16x8, a ^ 0x00150015u);
+  return;
+#endif
   const float v[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -74,19 +86,33 @@ struct SplitCfg {
   static_assert(LDS_BYTES >= 2 * STAGE, "two stages of 20 KB");
 };
 
-// workgroup id -> tile.  When the column tiles divide over the 8 XCDs, every XCD owns a COLUMN slice of the weight planes (resident
-// in its 4 MB L2: the three planes together are 6 MB) and walks all row tiles (block b runs on XCD b % 8); else XCD-contiguous
-// ranges with the column tile fastest.
-__device__ __forceinline__ void split_tile_of(int bid, int nwg, int tiles_n, int& tile_m, int& tile_n) {
-  if ((tiles_n & 7) == 0) {
-    const int xcd = bid & 7, li = bid >> 3, cpx = tiles_n >> 3;
-    tile_n = xcd * cpx + li % cpx;
-    tile_m = li / cpx;
-    return;
+// workgroup id -> tile.  Block b runs on XCD b % 8 (round-robin dispatch), so the map decides which operand bytes each XCD's private L2
+// sees.  When the column tiles divide over VD_SPLIT_CG column groups, the 8 XCDs form a CG x (8 / CG) grid: an XCD owns the weight planes
+// of tiles_n / CG column tiles (resident in its 4 MB L2) and walks 1 / (8 / CG) of the row tiles, column tile fastest (a row tile's A rows
+// are fetched once per XCD that needs them and shared by its column tiles through L2).  CG = 8 (round 5): smallest weight slice, but every
+// XCD fetches ALL of A -- 8 x 41 MB per forward launch, the 1.6 x over-fetch of profiles/r05_pmc_option_lstm_kernels.txt; CG = 2: A is
+// fetched twice, 3 MB of planes per XCD.  Else XCD-contiguous ranges with the column tile fastest (the backward step: 4 column tiles).
+// The grid is padded to 8 x rows-per-group x columns-per-group workgroups; a workgroup whose row tile is past the end leaves at once.
+#ifndef VD_SPLIT_CG
+#define VD_SPLIT_CG 2
+#endif
+__device__ __forceinline__ bool split_tile_of(int bid, int nwg, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+  constexpr int CG = VD_SPLIT_CG, RG = 8 / CG;
+  if ((tiles_n % CG) == 0 && tiles_n >= 8) {
+    const int xcd = bid & 7, li = bid >> 3, cpg = tiles_n / CG, rpg = (tiles_m + RG - 1) / RG;
+    tile_n = (xcd % CG) * cpg + li % cpg;
+    tile_m = (xcd / CG) * rpg + li / cpg;
+    return tile_m < tiles_m && li / cpg < rpg;
   }
   const int wg = xcd_remap(bid, nwg);
   tile_n = wg % tiles_n;
   tile_m = wg / tiles_n;
+  return true;
+}
+static int split_grid(int tiles_m, int tiles_n) {
+  constexpr int CG = VD_SPLIT_CG, RG = 8 / CG;
+  if ((tiles_n % CG) == 0 && tiles_n >= 8) return 8 * ((tiles_m + RG - 1) / RG) * (tiles_n / CG);
+  return tiles_m * tiles_n;
 }
 
 template <int NPROD, class Epi>
@@ -96,7 +122,7 @@ gemm_split_kernel(int M, int N, int K, int tiles_n, const float* A, long lda, co
   constexpr int NT = Cfg::NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int tile_m, tile_n;
-  split_tile_of((int)blockIdx.x, (int)gridDim.x, tiles_n, tile_m, tile_n);
+  if (!split_tile_of((int)blockIdx.x, (int)gridDim.x, (M + Cfg::BM - 1) / Cfg::BM, tiles_n, tile_m, tile_n)) return;
   const int row_base = tile_m * Cfg::BM, col_base = tile_n * Cfg::BN;
   constexpr int NIA = 2;                                         // this wave's own 32 rows = 2 pieces of 16 rows x 64 bytes
   constexpr int NIB = 3;                                         // row group `wave` (32 rows x 32 bytes) of every plane
@@ -202,7 +228,7 @@ static int launch_gemm_split(int M, int N, int K, const float* A, long lda, cons
     VD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Cfg::LDS_BYTES, stream, M, N, K, tiles_n, A, lda, B, ldb, bplane, e);
+  hipLaunchKernelGGL(kern, dim3(split_grid(tiles_m, tiles_n)), dim3(256), Cfg::LDS_BYTES, stream, M, N, K, tiles_n, A, lda, B, ldb, bplane, e);
   VD_LAUNCH_CHECK();
   return VD_OK;
 }

@@ -284,20 +284,12 @@ def lstm2_backward(stacks, H):
 
 
 def lstm2_pass(stacks, H, flags, backward=False):
-    """The wavefront with a pass's arithmetic (flags = FLAG_BF16: the encoder ticks of a bf16 pass of the model-level runtime) through
-    the library-internal entry points csrc/lstm.hip `vd_lstm2_forward_p / vd_lstm2_backward_p` (C++ linkage: the C ABI's
-    vd_lstm2_forward / _backward are these with flags = 0).  Test and microbenchmark access only."""
+    """The wavefront with a pass's arithmetic (flags = FLAG_BF16: the encoder ticks of a bf16 pass of the model-level runtime):
+    `vd_lstm2_forward_flags / vd_lstm2_backward_flags` (the C ABI's vd_lstm2_forward / _backward are these with flags = 0)."""
     import ctypes
-    lib = _lib.load()
-    name = ('_Z19vd_lstm2_backward_pPK14vd_lstm2_bwd_tiiiP12ihipStream_t' if backward
-            else '_Z18vd_lstm2_forward_pPK14vd_lstm2_fwd_tiiiP12ihipStream_t')
-    fn = getattr(lib, name)
-    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-    fn.restype = ctypes.c_int
     arr = _lstm2_bwd_array(stacks) if backward else _lstm2_fwd_array(stacks)
-    rc = fn(ctypes.cast(arr, ctypes.c_void_p), len(stacks), H, int(flags), _stream())
-    if rc != 0:
-        raise _lib.VisdialHipError("%s failed (%d): %s" % (name, rc, lib.vd_last_error().decode()))
+    call("vd_lstm2_backward_flags" if backward else "vd_lstm2_forward_flags", ctypes.cast(arr, ctypes.c_void_p), len(stacks), H, int(flags),
+         _stream())
 
 
 def hrea_attention_forward(sq, sh, Hm, P, att, B, R, H):
