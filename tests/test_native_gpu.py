@@ -496,6 +496,33 @@ def test_duplicate_options_are_encoded_once_and_exactly(gpu, host):
         model.close()
 
 
+def test_native_split9_throughput_shape_matches_oracle(gpu):
+    """The headline's arithmetic through the model-level runtime at a shape that takes every split9 kernel but is small enough for the fp64
+    oracle: 3 000 option rows (>= 2 048: the LDS-DMA step kernels on the exact 3 x bf16 split of both operands), H = 256 and K = 19 x 3 000 rows
+    = 16 x 3 562 + 8 for the weight-gradient contraction (gemm_split_tn_kernel<9> + the ragged tail on the fp32 MFMA).  fp32-grade: loss,
+    scores and every gradient within the fp32 tolerance of the other native tests, the recurrent weight gradient to 2e-6."""
+    from visdial_amd.native import NativeModel
+    kw = dict(vocabSize=300, embedSize=64, rnnHiddenSize=256, imgFeatureSize=64, imgSpatialSize=3, commonEmbeddingSize=128, maxQuesCount=10,
+              batchSize=3, numOptions=100, maxQuesLen=8, maxAnsLen=20, maxHistoryLenPerRound=12)
+    p = derive(small_params(lstmPrecision='split9', **kw))
+    batch = SyntheticDataloader(p, seed=43).getTrainBatch(p)
+    model = NativeModel(p, init_seed=6)
+    model.training(False)
+    P0 = {k: v.astype(np.float64) for k, v in model.get_parameters_dict().items()}
+    loss = model.forwardBackward(batch)
+    g = model.get_gradients_dict()
+    N, O = batch['options'].shape[0], batch['options'].shape[1]
+    assert model.option_rows() == (N * O, N * O) and N * O >= 2048
+    scores = model.scores(N, O)
+    ref = vo.forward_backward(p['encoder'], p['decoder'], P0, p, batch, None)
+    assert abs(loss - ref['loss']) < 1e-4 and rel(scores, ref['scores']) < 1e-4
+    bad = grad_mismatches(g, ref['grads'])
+    assert not bad, bad
+    print("split9 at 3 000 rows: dloss %.2e, opt.W gradient rel-L2 %.2e" % (abs(loss - ref['loss']), rel(g['opt.W'], ref['grads']['opt.W'])))
+    assert rel(g['opt.W'], ref['grads']['opt.W']) < 2e-6      # the recurrent weight gradient is fp32-grade, not merely inside 1e-4
+    model.close()
+
+
 @pytest.mark.parametrize("size", ['h128', 'h512', 'h128-rows9000'])
 def test_native_bf16_compact_state_within_the_stated_bound(gpu, size):
     """BASELINE.json configs[4] through the model-level runtime: bf16 operands AND compact bf16 state in the option recurrence (saved
