@@ -499,10 +499,11 @@ def test_duplicate_options_are_encoded_once_and_exactly(gpu, host):
 def test_native_split9_throughput_shape_matches_oracle(gpu):
     """The headline's arithmetic through the model-level runtime at a shape that takes every split9 kernel but is small enough for the fp64
     oracle: 3 000 option rows (>= 2 048: the LDS-DMA step kernels on the exact 3 x bf16 split of both operands), H = 256 and K = 19 x 3 000 rows
-    = 16 x 3 562 + 8 for the weight-gradient contraction (gemm_split_tn_kernel<9> + the ragged tail on the fp32 MFMA).  fp32-grade: loss,
-    scores and every gradient within the fp32 tolerance of the other native tests, the recurrent weight gradient to 2e-6."""
+    = 16 x 3 562 + 8 for the weight-gradient contraction (gemm_split_tn_kernel<9> + the ragged tail on the fp32 MFMA); the image attention's
+    three dense products on the split too (csrc/attention.hip vd_img_*_p: 30 rounds x 36 regions = 1 080 rows = 16 x 67 + 8, K = Kc = H = 256).
+    fp32-grade: loss, scores and every gradient within the fp32 tolerance of the other native tests, the recurrent weight gradient to 2e-6."""
     from visdial_amd.native import NativeModel
-    kw = dict(vocabSize=300, embedSize=64, rnnHiddenSize=256, imgFeatureSize=64, imgSpatialSize=3, commonEmbeddingSize=128, maxQuesCount=10,
+    kw = dict(vocabSize=300, embedSize=64, rnnHiddenSize=256, imgFeatureSize=64, imgSpatialSize=6, commonEmbeddingSize=256, maxQuesCount=10,
               batchSize=3, numOptions=100, maxQuesLen=8, maxAnsLen=20, maxHistoryLenPerRound=12)
     p = derive(small_params(lstmPrecision='split9', **kw))
     batch = SyntheticDataloader(p, seed=43).getTrainBatch(p)

@@ -11,6 +11,7 @@
 //    (SURVEY.md H4).  img_common + ques_common + tanh + dropout run in the MFMA epilogue;
 //    score/softmax(196)/weighted-sum is one wave-reduction kernel per QA round (K7).
 #include "gemm_core.h"
+#include "split_core.h"
 
 // =====================================================================================
 // Memory-network attention
@@ -679,3 +680,99 @@ int vd_img_common_wgrad(const float* dz, const float* pre, const uint8_t* mask1,
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The three dense [N*S2 x 512 x 512] products of the image attention on the EXACT SPLIT (split_core.h), for a split9 pass of the model-level
+// runtime (every fp32 GEMM with K >= 512 that shares the chip with the option recurrence costs 9/16 of the matrix-pipe
+// time this way).  The split kernels move their operands by LDS-DMA, which cannot apply a dropout mask on the fly, so the per-round image
+// tensor img_tr = dropout(gather(pre)) IS materialised once per step (`xdrop` [N*S2 x H], 80 MB at the headline shape, written by one
+// streaming kernel and read by the forward product and the weight gradient); the weights go through three bf16 planes in the stream's
+// scratch.  Same epilogues as the fp32 kernels (EpiImgCommon, EpiImgTrBwd), same results to fp32 rounding; no LDS bank conflicts (the
+// register-staged BK = 16 kernels they replace carried 18-31 %, profiles/r05_lds_conflicts_bench.txt).
+// ---------------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) img_drop_gather_kernel(const float* __restrict__ pre, const uint8_t* __restrict__ mask, float* __restrict__ out,
+                                                              long n4, int H4, int S2, int R, float scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const long row = i / H4;
+  const int k4 = (int)(i - row * H4);
+  const long n = row / S2, sidx = row - n * S2;
+  float4 v = reinterpret_cast<const float4*>(pre)[((n / R) * S2 + sidx) * H4 + k4];
+  if (mask) {
+    const uint32_t mk = reinterpret_cast<const uint32_t*>(mask)[i];
+    v.x = (mk & 0xff) ? v.x * scale : 0.f;
+    v.y = (mk & 0xff00) ? v.y * scale : 0.f;
+    v.z = (mk & 0xff0000) ? v.z * scale : 0.f;
+    v.w = (mk & 0xff000000u) ? v.w * scale : 0.f;
+  }
+  reinterpret_cast<float4*>(out)[i] = v;
+}
+__global__ void __launch_bounds__(256) transpose32_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+  __shared__ float tile[32][33];      // dst[c][r] = src[r][c]
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + i * 8, c = c0 + tx;
+    tile[ty + i * 8][tx] = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + i * 8, r = r0 + tx;
+    if (c < cols && r < rows) dst[(long)c * rows + r] = tile[tx][ty + i * 8];
+  }
+}
+
+static bool img_split_ok(int flags, long rows, int H, int Kc) {
+  return (flags & VD_FLAG_SPLIT9) && rows >= 128 && H % 16 == 0 && Kc % 16 == 0 && H % 4 == 0 && rows * (long)(H > Kc ? H : Kc) * 4 < (1L << 32);
+}
+
+// xdrop[(n, s), :] = dropout1(pre[(n / R, s), :]) -- once per step, shared by every attention hop's forward product and weight gradient
+int vd_img_drop_gather(const float* pre, const uint8_t* mask1, float* xdrop, int N, int R, int S2, int H, float scale, hipStream_t stream) {
+  VD_CHECK_ARG(pre && xdrop && N >= 0 && R >= 1 && S2 >= 1 && H % 4 == 0, "vd_img_drop_gather: bad args");
+  const long n4 = (long)N * S2 * (H / 4);
+  if (n4 == 0) return VD_OK;
+  hipLaunchKernelGGL(img_drop_gather_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, pre, mask1, xdrop, n4, H / 4, S2, R, scale);
+  VD_LAUNCH_CHECK();
+  return VD_OK;
+}
+
+int vd_img_common_forward_p(const float* pre, const uint8_t* mask1, const float* xdrop, const float* Wc, const float* bc, const float* qc,
+                            const uint8_t* mask2, float* iqc, int N, int R, int S2, int H, int Kc, float scale, int flags, hipStream_t stream) {
+  if (!xdrop || !img_split_ok(flags, (long)N * S2, H, Kc))
+    return vd_img_common_forward(pre, mask1, Wc, bc, qc, mask2, iqc, N, R, S2, H, Kc, scale, stream);
+  VdStreamScratch scr;
+  if (int rc = vd_stream_scratch(stream, (size_t)Kc * H * 6, 0, &scr)) return rc;
+  vd_bf16_bits* W3 = reinterpret_cast<vd_bf16_bits*>(scr.wht);
+  if (int rc = weights_to_bf16x3(Wc, W3, (long)Kc * H, stream)) return rc;                // Wc [Kc x H]: rows are k-contiguous as they lie
+  EpiImgCommon e{iqc, bc, qc, mask2, S2, scale};
+  return launch_gemm_split<9>(N * S2, Kc, H, xdrop, (long)H, W3, (long)H, (long)Kc * H, e, stream);
+}
+
+int vd_img_tr_backward_p(const float* dz, const float* Wc, const float* p, const float* datt, const uint8_t* mask1, float* dpre, int N, int R,
+                         int S2, int H, int Kc, float scale, int flags, hipStream_t stream) {
+  if (!img_split_ok(flags, (long)N * S2, H, Kc)) return vd_img_tr_backward(dz, Wc, p, datt, mask1, dpre, N, R, S2, H, Kc, scale, stream);
+  VdStreamScratch scr;
+  if (int rc = vd_stream_scratch(stream, (size_t)Kc * H * 10, 0, &scr)) return rc;
+  float* WcT = scr.wht;                                                                    // [H x Kc]: B^T of dz * Wc, rows k-contiguous
+  vd_bf16_bits* W3 = reinterpret_cast<vd_bf16_bits*>(scr.wht + (size_t)Kc * H);
+  hipLaunchKernelGGL(transpose32_kernel, dim3(vd_cdiv(H, 32), vd_cdiv(Kc, 32)), dim3(256), 0, stream, Wc, WcT, Kc, H);
+  VD_LAUNCH_CHECK();
+  if (int rc = weights_to_bf16x3(WcT, W3, (long)Kc * H, stream)) return rc;
+  EpiImgTrBwd e{dpre, p, datt, mask1, S2, R, scale};
+  return launch_gemm_split<9>(N * S2, H, Kc, dz, (long)Kc, W3, (long)Kc, (long)Kc * H, e, stream);
+}
+
+int vd_img_common_wgrad_p(const float* dz, const float* pre, const uint8_t* mask1, const float* xdrop, float* dWc, int N, int R, int S2, int H,
+                          int Kc, float scale, int flags, hipStream_t stream) {
+  const long K = (long)N * S2;
+  if (!xdrop || !(flags & VD_FLAG_SPLIT9) || Kc % SplitTnCfg::BM != 0 || H % SplitTnCfg::BN != 0 || K < 1024)
+    return vd_img_common_wgrad(dz, pre, mask1, dWc, N, R, S2, H, Kc, scale, stream);
+  const int K1 = (int)(K & ~15L);
+  if (int rc = launch_gemm_split_tn<9>(Kc, H, K1, dz, (long)Kc, xdrop, (long)H, dWc, (long)H, stream)) return rc;
+  if (K1 == K) return VD_OK;
+  SrcK a{dz + (long)K1 * Kc, Kc}, b{xdrop + (long)K1 * H, H};                              // the last < 16 rows on the fp32 MFMA
+  EpiAtomic<4> e{dWc, H};
+  return launch_gemm<CfgBig>(Kc, H, (int)(K - K1), 1, a, b, e, stream);
+}

@@ -558,8 +558,11 @@ using CfgB11 = GemmCfg<4, 1, 2, 16, 0, 4, 41984>;
 using CfgFbf16 = GemmCfg<4, 1, 4, 32, 0, 3, 0, 1>;  // bf16 operands (opt-in), BK = 32 = two 32x32x16 MFMAs per tile
 using CfgBbf16 = GemmCfg<4, 1, 2, 32, 0, 3, 0, 1>;
 // bf16 pass with shadows: the LDS-DMA pipeline of the fp32 step kernels over bf16 rows (h / da shadows, bf16 weight copies)
-using CfgF9bf16 = GemmCfg<4, 1, 4, 16, 0, 4, 41984, 1>;
-using CfgB11bf16 = GemmCfg<4, 1, 2, 16, 0, 4, 41984, 1>;
+#ifndef VD_C16_LDS
+#define VD_C16_LDS 41984     // (`make variant NAME=c16lds DEFS=-DVD_C16_LDS=32768`: four workgroups per CU for the bf16 pass's step kernels)
+#endif
+using CfgF9bf16 = GemmCfg<4, 1, 4, 16, 0, 4, VD_C16_LDS, 1>;
+using CfgB11bf16 = GemmCfg<4, 1, 2, 16, 0, 4, VD_C16_LDS, 1>;
 using CfgFwdSmallA = GemmCfg<1, 4, 4, 8, 0, 3>;   // 32 x (32 j x 4 gates), BK = 32, 23 KB LDS
 using CfgFwdSmallC = GemmCfg<1, 4, 4, 8, 0, 4>;   // as A, <=128 VGPR: fits beside 3 padded throughput workgroups
 using CfgBwdSmallD = GemmCfg<1, 4, 1, 32, 2, 4>;

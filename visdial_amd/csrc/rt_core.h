@@ -26,6 +26,16 @@
 int vd_lstm2_forward_p(const vd_lstm2_fwd_t* st, int nstacks, int H, int flags, hipStream_t stream);
 int vd_lstm2_backward_p(const vd_lstm2_bwd_t* st, int nstacks, int H, int flags, hipStream_t stream);
 
+// attention.hip: the image attention's dense products with a pass's arithmetic (flags & VD_FLAG_SPLIT9: on the exact split, from the
+// materialised dropped image tensor `xdrop`; else the C-ABI entry points)
+int vd_img_drop_gather(const float* pre, const uint8_t* mask1, float* xdrop, int N, int R, int S2, int H, float scale, hipStream_t stream);
+int vd_img_common_forward_p(const float* pre, const uint8_t* mask1, const float* xdrop, const float* Wc, const float* bc, const float* qc,
+                            const uint8_t* mask2, float* iqc, int N, int R, int S2, int H, int Kc, float scale, int flags, hipStream_t stream);
+int vd_img_tr_backward_p(const float* dz, const float* Wc, const float* p, const float* datt, const uint8_t* mask1, float* dpre, int N, int R,
+                         int S2, int H, int Kc, float scale, int flags, hipStream_t stream);
+int vd_img_common_wgrad_p(const float* dz, const float* pre, const uint8_t* mask1, const float* xdrop, float* dWc, int N, int R, int S2, int H,
+                          int Kc, float scale, int flags, hipStream_t stream);
+
 #define VD_TRY(expr)                  \
   do {                                \
     const int rc__ = (expr);          \

@@ -276,6 +276,8 @@ struct SANBlock {
   std::vector<const float*> u_in;
   std::vector<float*> iqc, patt;
   float sc = 1.f;
+  float* xdrop = nullptr;   // split9 pass: dropout1(gather(pre)) [N*S2 x H], materialised once per step
+  int iflags = 0;
   static void declare(vd_model* m) {
     const long H = m->p.rnnHiddenSize, C = m->p.imgFeatureSize, K = m->p.commonEmbeddingSize;
     add_linear(m, "img_proj", C, H);
@@ -303,6 +305,14 @@ struct SANBlock {
     m2.assign(L, nullptr);
     for (int i = 0; i < L; ++i) VD_TRY(drop_mask(m, "iqc" + hop_sfx(i), (size_t)N * S2 * K, 0.5f, si, &m2[i]));
     sc = m1 ? 2.f : 1.f;
+    // split9 pass: the attention's dense products run on the exact split, from the materialised per-round image tensor (attention.hip)
+    static const int img_split_on = [] { const char* e = getenv("VD_SPLIT_IMG"); return e ? atoi(e) : 1; }();     // (A/B switch)
+    iflags = (m->p.lstmBf16 == 9 && img_split_on && (long)N * S2 >= 128 && H % 16 == 0 && K % 16 == 0) ? VD_FLAG_SPLIT9 : 0;
+    xdrop = nullptr;
+    if (iflags) {
+      VD_TRY(ws_get(m, "att.xdrop", (size_t)N * S2 * H, &xdrop));
+      VD_TRY(vd_img_drop_gather(pre, m1, xdrop, N, R, S2, (int)H, sc, si));
+    }
     return VD_OK;
   }
   int forward(vd_model* m, hipStream_t s, const float* u0, float** y) {
@@ -316,8 +326,8 @@ struct SANBlock {
       VD_TRY(ws_get(m, "att.iqc" + sf, (size_t)N * S2 * K, &iqc[i]));
       VD_TRY(ws_get(m, "att.p" + sf, (size_t)N * S2, &patt[i]));
       VD_TRY(ws_get(m, "att.u1" + sf, (size_t)N * H, &u1));
-      VD_TRY(vd_img_common_forward(pre, m1, Wp(m, "img_common" + sf + ".W"), Wp(m, "img_common" + sf + ".b"), qc, m2[i], iqc[i], N, R,
-                                   S2, (int)H, (int)K, sc, s));                   // mn-att:83-92
+      VD_TRY(vd_img_common_forward_p(pre, m1, xdrop, Wp(m, "img_common" + sf + ".W"), Wp(m, "img_common" + sf + ".b"), qc, m2[i], iqc[i], N, R,
+                                     S2, (int)H, (int)K, sc, iflags, s));         // mn-att:83-92
       VD_TRY(vd_img_att_forward(iqc[i], Wp(m, "att" + sf + ".W"), Wp(m, "att" + sf + ".b"), pre, m1, u, patt[i], u1, N, R, S2, (int)H,
                                 (int)K, sc, s));                                  // mn-att:93-102
       u_in[i] = u;
@@ -348,8 +358,8 @@ struct SANBlock {
       hipStream_t sw;
       VD_TRY(wg_fork(m, s, &sw));
       VD_TRY(vd_colsum_acc(iqc[i], K, N * S2, (int)K, Gp(m, "img_common" + sf + ".b"), sw));
-      VD_TRY(vd_img_common_wgrad(iqc[i], pre, m1, Gp(m, "img_common" + sf + ".W"), N, R, S2, (int)H, (int)K, sc, sw));
-      VD_TRY(vd_img_tr_backward(iqc[i], Wp(m, "img_common" + sf + ".W"), patt[i], dcur, m1, dpre, N, R, S2, (int)H, (int)K, sc, sw));
+      VD_TRY(vd_img_common_wgrad_p(iqc[i], pre, m1, xdrop, Gp(m, "img_common" + sf + ".W"), N, R, S2, (int)H, (int)K, sc, iflags, sw));
+      VD_TRY(vd_img_tr_backward_p(iqc[i], Wp(m, "img_common" + sf + ".W"), patt[i], dcur, m1, dpre, N, R, S2, (int)H, (int)K, sc, iflags, sw));
       VD_TRY(ques_common[i].backward(m, s, dqc, true, &duq));
       VD_TRY(vd_axpby(duq, dcur, dun, (long)N * H, 1.f, 1.f, s));                 // residual CAddTable (mn-att:102)
       dcur = dun;
