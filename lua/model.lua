@@ -44,9 +44,10 @@ function Model:__init(params)
     p.maxQuesCount = params.maxQuesCount;     p.numOptions = params.numOptions or 100
     p.learningRate = params.learningRate;     p.lrDecayRate = params.lrDecayRate
     p.minLRate = params.minLRate;             p.seed = 1234
-    -- recurrence arithmetic (-lstmPrecision, new relative to the reference): fp32 (default) | split9 (option recurrence, exact) | bf16 (option
+    -- recurrence arithmetic (-lstmPrecision, new relative to the reference): split9 (default: option recurrence on the exact 3 x bf16 split,
+    -- fp32-grade) | fp32 (v_mfma_f32) | bf16 (option
     -- recurrence on the compact bf16 state + bf16 operands in the encoder's recurrent products and dense weight gradients: BASELINE configs[4])
-    p.lstmBf16 = ({fp32 = 0, bf16 = 1, split9 = 9, split6 = 6, split3 = 3})[params.lstmPrecision or 'fp32']
+    p.lstmBf16 = ({fp32 = 0, bf16 = 1, split9 = 9, split6 = 6, split3 = 3})[params.lstmPrecision or 'split9']
     p.useStreams = 1
     p.numLayers = params.numLayers or 2;      p.imgEmbedSize = params.imgEmbedSize or 300
     p.dropout = params.dropout or 0.5

@@ -108,4 +108,4 @@ def test_startup_deadline_exits_instead_of_hanging(tmp_path):
 def test_bench_configs_name_the_baseline_workloads(bench):
     assert bench.config_params(3)['encoder'] == 'mn-att-ques-im-hist' and bench.config_params(3)['decoder'] == 'disc'
     assert bench.config_params(1)['decoder'] == 'gen' and bench.config_params(4)['lstmPrecision'] == 'bf16'
-    assert bench.config_params(2)['lstmPrecision'] == 'split9' and bench.config_params(3).get('lstmPrecision', 'fp32') == 'fp32'   # the headline sets it from --recurrence
+    assert bench.config_params(2)['lstmPrecision'] == 'split9' and bench.config_params(3)['lstmPrecision'] == 'split9'   # the library default; bench.py sets it again from --recurrence

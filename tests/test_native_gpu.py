@@ -278,8 +278,7 @@ def test_native_full_size_other_configs_are_additive_over_dialogs(gpu, config):
     kw = {1: dict(encoder='lf-ques-im-hist', decoder='gen', imgFeatureSize=4096),
           2: dict(encoder='hre-ques-im-hist', decoder='disc', imgFeatureSize=4096),
           4: dict(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=2048, imgSpatialSize=7)}[cfg]
-    if '-' in config:
-        kw['lstmPrecision'] = config.split('-')[1]
+    kw['lstmPrecision'] = config.split('-')[1] if '-' in config else 'fp32'        # ('2' pins the fp32-MFMA recurrence: split9 is the library default)
     p = default_params(batchSize=20, vocabSize=11322, gpuid=0, maxHistoryLenPerRound=40, **kw)
     full = SyntheticDataloader(p, seed=77, fast=True).getTrainBatch(p)
     if cfg == 1:

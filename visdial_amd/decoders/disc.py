@@ -28,8 +28,8 @@ class Decoder(object):
         self.Wx, self.Wh, self.b = W[:self.E], W[self.E:], fp.w['opt.b']
         self.dWx, self.dWh, self.db = dW[:self.E], dW[self.E:], fp.g['opt.b']
         self.streams = StreamPool(ws.device, enabled=False)     # Model attaches its own pool
-        # opt-in reduced precision of the option recurrence (BASELINE.json configs[4]); default = exact fp32
-        self.flags = ops.PRECISION_FLAGS[params.get('lstmPrecision', 'fp32')]
+        # arithmetic of the option recurrence (opts.py): default = the exact 3 x bf16 split (fp32-grade), 'fp32' = v_mfma_f32, 'bf16' = configs[4]
+        self.flags = ops.PRECISION_FLAGS[params.get('lstmPrecision', 'split9')]
 
     def forward(self, inputs):
         """inputs = {options [To x N*O] int32 time-major, encOut [N x H]} -> scores [N x O]"""

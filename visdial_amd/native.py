@@ -62,7 +62,7 @@ class NativeModel(SplitEval):
             maxQuesCount=p['maxQuesCount'], numOptions=p.get('numOptions', 100),
             learningRate=p.get('learningRate', 1e-3), lrDecayRate=p.get('lrDecayRate', 0.9997592083),
             minLRate=p.get('minLRate', 5e-5), seed=int(p.get('seed', 1234)) + 7919 * int(p.get('rank', 0)),
-            lstmBf16={'fp32': 0, 'bf16': 1, 'split9': 9, 'split6': 6, 'split3': 3}[p.get('lstmPrecision', 'fp32')], useStreams=int(p.get('useStreams', 1)),
+            lstmBf16={'fp32': 0, 'bf16': 1, 'split9': 9, 'split6': 6, 'split3': 3}[p.get('lstmPrecision', 'split9')], useStreams=int(p.get('useStreams', 1)),
             numLayers=int(p.get('numLayers', 2)), imgEmbedSize=int(p.get('imgEmbedSize', 300)),
             dropout=float(p.get('dropout', 0.5)))
         self.params = p

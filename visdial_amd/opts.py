@@ -33,8 +33,10 @@ OPTIONS = [
     ('minLRate', 5e-5, 'Minimum learning rate'),
     ('gpuid', 0, 'GPU id to use'),
     ('backend', 'cudnn', 'accepted for CLI compatibility; ignored'),
-    # not a reference flag: the bf16 LSTM step of BASELINE.json configs[4] (option recurrence only; default exact fp32)
-    ('lstmPrecision', 'fp32', "arithmetic of the option-LSTM recurrence GEMMs: 'fp32' (default, v_mfma_f32) | 'split9' (exact 3-way bf16 split of both operands, 9 bf16 MFMAs per fp32 one: fp32-grade) | 'bf16' (BASELINE configs[4]: bf16 operands, fp32 accumulation; through the native host also the encoder's recurrent products and dense weight gradients) | 'split6' / 'split3' (fewer products: data only)"),
+    # not a reference flag: the arithmetic of the option recurrence.  DEFAULT = split9 (fp32-grade: every fp32 operand as the exact sum of three
+    # bf16 values, all nine products, fp32 accumulate -- what bench.py's headline measures; it applies at throughput shapes, >= 2 048 option rows,
+    # smaller recurrences run the fp32 MFMA either way)
+    ('lstmPrecision', 'split9', "arithmetic of the option-LSTM recurrence GEMMs: 'split9' (default: exact 3-way bf16 split of both operands, 9 bf16 MFMAs per fp32 one, fp32-grade) | 'fp32' (v_mfma_f32_32x32x2_f32) | 'bf16' (BASELINE configs[4]: bf16 operands, fp32 accumulation; through the native host also the encoder's recurrent products and dense weight gradients) | 'split6' / 'split3' (fewer products: data only)"),
     ('saveFormat', 't7', "checkpoint files: 't7' = model_epoch_%d.t7 / model_final.t7 in the Torch7 binary format "
                          "(train.lua:99-102,120-121) | 'pt' = torch.save of the same three fields"),
     ('host', 'python', "which host drives the library: 'python' (operator-level C ABI, visdial_amd/model.py) | 'native' "
