@@ -8,7 +8,7 @@
 #   3. three separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | MFMA busy + clocks) over scripts/pmc_target.py, once per
 #      arithmetic of the option recurrence (fp32 MFMA, split9)
 #   4. non-GEMM kernels: alone GB/s + in-step averages (scripts/hbm_kernels.py)
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$PWD/gpurun_out
 ROOT=$PWD
 mkdir -p "$OUT"
