@@ -151,9 +151,6 @@ __device__ __forceinline__ void tile_to_rows(const f32x16& a, float* scr, int la
 // Epilogue functors may declare `struct Pre` + `preload(Pre&, row0, lane, M)`: state fetched before the K loop of the
 // LDS-DMA pipeline and handed to operator() as a trailing `const Pre*` (nullptr from the other pipelines).
 struct EpiNoPre {};
-#ifndef VD_LATENCY_PRIO
-#define VD_LATENCY_PRIO 3      // wave priority of the split-K latency shapes (encoder ticks, per-step kernels); `make variant DEFS=-DVD_LATENCY_PRIO=0`
-#endif
 template <class Epi, class = void>
 struct EpiPreOf {
   static constexpr bool value = false;
@@ -532,7 +529,7 @@ gemm_f32_kernel(int M, int N, int K, int kchunk, int tiles_m, int tiles_n, int r
   // Latency shapes (intra-block split-K configs) are the short dependent launches of the encoder
   // recurrences; they share CUs with throughput-shape workgroups of other streams.  Raising their wave
   // priority lets them win MFMA/VALU issue arbitration on the SIMD (priority outranks age).
-  if constexpr (Cfg::WK > 1) __builtin_amdgcn_s_setprio(VD_LATENCY_PRIO);
+  if constexpr (Cfg::WK > 1) __builtin_amdgcn_s_setprio(3);
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = wg % tiles_n;
   const int tile_m = (wg / tiles_n) % tiles_m;
@@ -839,7 +836,7 @@ template <class Cfg, class Prob, int MAXP>
 __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW)
 gemm_f32_grouped_kernel(GroupArgs<Prob, MAXP> g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if constexpr (Cfg::WK > 1) __builtin_amdgcn_s_setprio(VD_LATENCY_PRIO);
+  if constexpr (Cfg::WK > 1) __builtin_amdgcn_s_setprio(3);
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   int pi = 0;
 #pragma unroll
