@@ -644,7 +644,8 @@ def main():
         print(json.dumps(out))
     if lib_comm:
         from visdial_amd.parallel import destroy_library_comm
-        model.synchronize()
+        if getattr(model, 'h', None):            # (a world-1 run under torch.distributed.run has closed its model before the extra legs)
+            model.synchronize()
         destroy_library_comm()
     if dist.is_initialized():
         dist.destroy_process_group()
