@@ -112,7 +112,8 @@ def config_params(config, rank=0, batch=20):
           2: dict(encoder='hre-ques-im-hist', decoder='disc', imgFeatureSize=4096, lstmPrecision='split9'),
           3: dict(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=512, imgSpatialSize=14),
           4: dict(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=2048, imgSpatialSize=7, lstmPrecision='bf16')}[config]
-    return default_params(batchSize=batch, vocabSize=11322, gpuid=int(os.environ.get('LOCAL_RANK', 0)), rank=rank,
+    gpuid = 0 if os.environ.get('VD_BENCH_SHARE_GPU') == '1' else int(os.environ.get('LOCAL_RANK', 0))
+    return default_params(batchSize=batch, vocabSize=11322, gpuid=gpuid, rank=rank,
                           maxHistoryLenPerRound=40, **kw)
 
 
@@ -472,6 +473,12 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    # VD_BENCH_SHARE_GPU=1: DRY RUN of the multi-rank path on a one-GPU box -- every rank on cuda:0, gloo process group, gradients staged
+    # through host memory (RCCL refuses duplicate devices).  Exercises sharding, barriers, the max-over-ranks clock and the JSON line;
+    # its number means nothing.
+    share_gpu = os.environ.get('VD_BENCH_SHARE_GPU') == '1'
+    if share_gpu:
+        local = 0
     deadline.phase = 'rendezvous / communicator'
     if world > 1:
         print('[rank %d] hardware queues: %s' % (rank, QUEUE_CHOICE), file=sys.stderr, flush=True)
@@ -483,7 +490,11 @@ def main():
     if 'RANK' in os.environ:      # launched by torch.distributed.run (any world size, incl. 1)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        if args.host == 'native' and args.collective == 'library':
+        if share_gpu:
+            dist.init_process_group(backend='gloo')
+            group = dist.group.WORLD
+            collective = 'gloo, gradients staged through host memory (VD_BENCH_SHARE_GPU dry run: not a measurement)'
+        elif args.host == 'native' and args.collective == 'library':
             # The gradient all-reduce is the LIBRARY's: RCCL communicator + communication stream behind the C ABI
             # (csrc/comm.hip, vd_model_allreduce_grads).  torch.distributed (gloo) is only the courier of the 128-byte
             # rendezvous token, the barriers and the max-over-ranks of the wall time.

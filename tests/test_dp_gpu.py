@@ -78,3 +78,34 @@ def test_native_host_library_rccl_world2_two_devices(capsys):
     out = _run(2, 'gloo', dict(VD_TEST_HOST='native-lib', VD_TEST_DISTINCT_DEVICES='1', NCCL_DEBUG='VERSION'))
     assert 'world=2' in out and 'host=native-lib' in out and 'devices=distinct' in out
     assert "'overlapped': True" in out                     # the encoder bucket went out early
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_line_under_torchrun(world):
+    """bench.py exactly as the driver launches it for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N --steps K --warmup W`): one JSON
+    line from rank 0, exit code 0 on every rank, no probe jobs.  World 1 runs the library's RCCL communicator; world 2 on a one-GPU box is the
+    VD_BENCH_SHARE_GPU dry run (every rank on cuda:0, gloo, gradients through host memory: the sharding, the barriers, the max-over-ranks clock
+    and the line are exercised, the number means nothing)."""
+    import json
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if world > 1 and torch.cuda.device_count() < world:
+        env['VD_BENCH_SHARE_GPU'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps', '4', '--warmup', '2',
+           '--no-alt', '--no-other-configs', '--no-cpu-baseline']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-8000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == world and d['steps'] == 4 and d['scaling'] == 'weak' and d['unit'] == 'QA-rounds/s' and d['higher_is_better'] is True
+    assert d['config']['global_batch_dialogs'] == 20 * world and d['config']['parallelism'] == 'dp%d' % world
+    assert abs(d['value'] - world * 200 * 4 / (d['ms_per_step'] * 4e-3)) < 0.01 * d['value']          # whole-job rate = all ranks' rounds / max-over-ranks time
+    assert d['roofline']['frac'] > 0.05 and d['cpu_baseline'] is None
+    assert ('hardware queues: HIP default' in out.stderr) == (world > 1)
