@@ -253,7 +253,7 @@ typedef struct vd_model_params {   /* the `params` keys Model() consumes: opts.l
           numAttentionLayers, maxQuesCount, numOptions;
   float learningRate, lrDecayRate, minLRate;     /* opts.lua:35-38 */
   uint64_t seed;                                 /* dropout noise stream */
-  int32_t lstmBf16;                              /* option recurrence: 0 = fp32 (default); 1 = bf16 operands and compact bf16 state, plus bf16 operands in the encoder's recurrent products and dense weight gradients (configs[4] "bf16 LSTM step"); 9 = exact 3-way bf16 split of both operands, 9 products, in the two step kernels AND the dWh contraction (fp32-grade; what bench.py measures); 6 / 3 = fewer products (data only) */
+  int32_t lstmBf16;                              /* option recurrence: 0 = fp32 MFMA (a zeroed struct; the hosts' own default is 9); 1 = bf16 operands and compact bf16 state, plus bf16 operands in the encoder's recurrent products and dense weight gradients (configs[4] "bf16 LSTM step"); 9 = exact 3-way bf16 split of both operands, 9 products, in the two step kernels, the dWh contraction and the image attention's three dense products (fp32-grade; what bench.py measures and what -lstmPrecision defaults to in opts.py / lua/model.lua); 6 / 3 = fewer products (data only) */
   int32_t useStreams;                            /* 0 = everything on one stream (debug) */
   int32_t numLayers;                             /* -numLayers (opts.lua:27): lf-*, hre-* encoders and the gen decoder; <1 = 2 */
   int32_t imgEmbedSize;                          /* -imgEmbedSize (opts.lua:24): hre-ques-im-hist, hrea-ques-im-hist */
