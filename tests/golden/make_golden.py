@@ -67,6 +67,8 @@ FULL_CASES = {
     'mn-att': (FULL_NAME, dict(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=512, imgSpatialSize=14)),
     'hre': ('full__hre-ques-im-hist__disc.npz', dict(encoder='hre-ques-im-hist', decoder='disc', imgFeatureSize=4096)),
     'mn-att-7x7': ('full__mn-att-7x7x2048__disc.npz', dict(encoder='mn-att-ques-im-hist', decoder='disc', imgFeatureSize=2048, imgSpatialSize=7)),
+    # configs[1]: the generative decoder over the concatenated history (250 steps at this seed); no option scores: loss + gradients only
+    'lf-gen': ('full__lf-ques-im-hist__gen.npz', dict(encoder='lf-ques-im-hist', decoder='gen', imgFeatureSize=4096)),
 }
 
 
@@ -112,10 +114,12 @@ def full_outputs(name='mn-att'):
     out = {'digest.params': np.array(digest(P)), 'digest.batch': np.array(digest(batch)),
            'digest.masks': np.array(digest(masks or {}))}
     r = vo.forward_backward(p['encoder'], p['decoder'], P64, p, batch, drop)
-    gt = batch['answer_ind'].reshape(-1) - 1
+    disc = r['scores'] is not None
+    gt = batch['answer_ind'].reshape(-1) - 1 if disc else None
     out['loss'] = np.float64(r['loss'])
-    out['scores'] = r['scores']
-    out['gt_ranks'] = vo.compute_ranks(r['scores'], gt)
+    if disc:
+        out['scores'] = r['scores']
+        out['gt_ranks'] = vo.compute_ranks(r['scores'], gt)
     for k, g in r['grads'].items():
         f = g.reshape(-1)
         out['gnorm.' + k] = np.float64(np.linalg.norm(f))
@@ -125,6 +129,8 @@ def full_outputs(name='mn-att'):
     del r
     ev = vo.forward_backward(p['encoder'], p['decoder'], P64, p, batch, None, only_forward=True)   # evaluate(): no dropout
     out['eval.loss'] = np.float64(ev['loss'])
+    if not disc:
+        return out
     out['eval.scores'] = ev['scores']
     out['eval.ranks'] = vo.compute_ranks(ev['scores']).astype(np.int16)
     out['eval.gt_ranks'] = vo.compute_ranks(ev['scores'], gt)

@@ -53,6 +53,9 @@ def test_full_size_fixture_inputs_are_reproducible(name):
     assert str(z['digest.masks']) == mg.digest(masks or {})
     spec = vo.param_spec(p['encoder'], p['decoder'], p)
     assert {'gnorm.' + e[0] for e in spec} == {k for k in z.files if k.startswith('gnorm.')}
+    if p['decoder'] == 'gen':                       # loss + gradients only (no option scores in training)
+        assert 'scores' not in z.files and float(z['loss']) > 0 and float(z['eval.loss']) > 0
+        return
     assert z['scores'].shape == (200, 100) and z['eval.ranks'].shape == (200, 100)
     # internal consistency of the stored outputs (oracle-side, fp64)
     gt = batch['answer_ind'].reshape(-1) - 1
@@ -135,6 +138,46 @@ def check_step_bf16(z, loss, scores, grads, gt):
     agree = float((vo.compute_ranks(scores, gt) == z['gt_ranks']).mean())
     assert agree >= 0.9, agree
     return worst[0], agree
+
+
+@pytest.mark.gpu
+def test_full_size_gen_step_matches_fp64_golden():
+    """BASELINE.json configs[1] (lf-ques-im-hist + gen, fc7 features, history concatenated to 250 steps at this seed, dropout pinned) at full
+    size through the model-level ABI: summed NLL and every gradient tensor against the fp64 oracle's, at 1e-4 (relative to the loss of
+    ~4 000 answer tokens); the evaluate-mode loss too."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from visdial_amd.native import NativeModel
+    z, p, batch, masks, P = load_case('lf-gen')
+    assert batch['hist'].shape[2] >= 150 and 'scores' not in z.files
+    model = NativeModel(dict(p))
+    model.set_parameters_dict(P)
+    model.set_dropout_masks(masks)
+    loss = model.forwardBackward(batch)
+    grads = model.get_gradients_dict()
+    ref = float(z['loss'])
+    assert abs(loss - ref) < TOL * max(1.0, abs(ref)), (loss, ref)
+    worst = []
+    for key in [k for k in z.files if k.startswith('gnorm.')]:
+        name = key[len('gnorm.'):]
+        g = np.asarray(grads[name], np.float64).reshape(-1)
+        norm = float(z[key])
+        if norm < 1e-12:
+            assert np.abs(g).max() < 1e-6, name
+            continue
+        d = mg.sketch(name, g) - z['gsketch.' + name]
+        est = float(np.sqrt(np.mean(d * d))) / norm
+        s_ref = z['gsample.' + name]
+        s_err = rel(g[mg.sample_index(g.size)], s_ref) if np.linalg.norm(s_ref) > 1e-9 * norm else 0.0
+        worst.append((max(est, s_err, abs(float(np.linalg.norm(g)) - norm) / norm), name, est, s_err))
+    worst.sort(reverse=True)
+    assert worst[0][0] < TOL, worst[:5]
+    model.training(False)
+    ev = model.forwardBackward(batch)
+    assert abs(ev - float(z['eval.loss'])) < TOL * max(1.0, abs(float(z['eval.loss'])))
+    model.close()
+    print('full-size fp64 golden (lf-gen, native host): loss %.4f |dloss| %.2e (rel %.1e)  worst gradient tensor %s (sketch %.2e, sample %.2e)' % (
+        ref, abs(loss - ref), abs(loss - ref) / abs(ref), worst[0][1], worst[0][2], worst[0][3]))
 
 
 @pytest.mark.gpu
